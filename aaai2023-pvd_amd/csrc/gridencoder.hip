@@ -1,0 +1,408 @@
+// gridencoder.hip -- multiresolution hash / tiled grid encoder for gfx950 (MI355X).
+//
+// Replaces the reference's _gridencoder module (gridencoder/src/gridencoder.cu).
+// Layout in HBM: embeddings [sum_l size_l, C] (T = f32 or f16), level l owns rows
+// [offsets[l], offsets[l+1]); outputs [L, B, C]; dy_dx [B, L, D, C]; grad [L, B, C].
+//
+// Work decomposition: workgroup = 256 consecutive points of ONE level (blockIdx.y = level),
+// so everything that depends only on the level (table base, size, strides, hash-or-dense,
+// per-level scale) is wave-uniform and lives in SGPRs, a level's table stays hot in the
+// XCD-local L2 (2 MiB per hashed level in f16) while neighbouring workgroups sweep it, and
+// the [L,B,C] store is a fully coalesced C*sizeof(T)-per-lane write.  One feature vector
+// (C elements) is one global load / one packed atomic.
+#include "pvd_device.h"
+
+#include <math.h>
+
+namespace pvd {
+
+constexpr uint32_t kGridBlock = 256;
+constexpr uint32_t kMaxLevels = 32;
+
+struct LevelScales {
+    float scale[kMaxLevels];
+};
+
+// C consecutive table elements moved as one naturally aligned access
+template <typename T, uint32_t C>
+struct alignas(sizeof(T) * C) FeatVec {
+    T v[C];
+};
+
+typedef _Float16 half_t;
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+
+// level-uniform indexing state (reference: get_grid_index, gridencoder.cu:54-72)
+template <uint32_t D>
+struct LevelIndex {
+    uint32_t size;       // hashmap_size = offsets[l+1] - offsets[l]
+    uint32_t stride[D];  // 0 for dimensions the dense loop never reaches
+    bool hashed;
+    bool pow2;
+
+    __device__ __forceinline__ void init(uint32_t size_, uint32_t resolution, uint32_t gridtype, bool align_corners) {
+        size = size_;
+        uint32_t s = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if (s <= size) {
+                stride[d] = s;
+                s *= align_corners ? resolution : (resolution + 1);
+            } else {
+                stride[d] = 0;
+            }
+        }
+        hashed = (gridtype == 0) && (s > size);
+        pow2 = (size & (size - 1)) == 0;
+    }
+
+    __device__ __forceinline__ uint32_t operator()(const uint32_t (&pg)[D]) const {
+        uint32_t index;
+        if (hashed) {
+            constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+            index = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) index ^= pg[d] * primes[d];
+            index = pow2 ? (index & (size - 1)) : (index % size);
+        } else {
+            index = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) index += pg[d] * stride[d];
+            if (index >= size) index %= size;  // only when the table was sized smaller than the kernel's resolution
+        }
+        return index;
+    }
+};
+
+template <uint32_t D>
+__device__ __forceinline__ bool locate(const float *__restrict__ in, float scale, bool align_corners, float (&frac)[D], uint32_t (&cell)[D]) {
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = in[d];
+        oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
+    }
+    if (oob) return false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float p = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);  // canonical fused form
+        const float fl = floorf(p);
+        cell[d] = (uint32_t)fl;
+        frac[d] = p - (float)cell[d];
+    }
+    return true;
+}
+
+// accumulate one weighted feature vector with the reference's scalar_t arithmetic:
+//   f32: acc = fma(w, v, acc);   f16: acc = half(acc + half(w * float(v)))  (gridencoder.cu:166)
+template <typename T>
+__device__ __forceinline__ void axpy(T &acc, float w, T v);
+template <>
+__device__ __forceinline__ void axpy<float>(float &acc, float w, float v) { acc = fmaf(w, v, acc); }
+template <>
+__device__ __forceinline__ void axpy<half_t>(half_t &acc, float w, half_t v) { acc = acc + (half_t)(w * (float)v); }
+
+// reference: kernel_grid, gridencoder.cu:75-224
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid,
+                                                         const int32_t *__restrict__ offsets, T *__restrict__ outputs,
+                                                         uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
+                                                         bool align_corners, bool calc_grad_inputs, T *__restrict__ dy_dx) {
+    using Vec = FeatVec<T, C>;
+    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+    const Vec *__restrict__ table = reinterpret_cast<const Vec *>(grid) + off0;
+    Vec *__restrict__ out = reinterpret_cast<Vec *>(outputs) + ((size_t)level * B + b);
+    T *__restrict__ dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;  // [B, L, D, C]
+
+    float frac[D];
+    uint32_t cell[D];
+    if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell)) {
+        Vec zero;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) zero.v[c] = (T)0;
+        *out = zero;
+        if (calc_grad_inputs) {
+#pragma unroll
+            for (uint32_t k = 0; k < D * C; k++) dd[k] = (T)0;
+        }
+        return;
+    }
+
+    // issue all 2^D gathers first (independent loads), then blend in the reference's corner order
+    Vec corner[1u << D];
+    float w[1u << D];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wi = 1;
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx >> d) & 1u) { wi *= frac[d]; pg[d] = cell[d] + 1; }
+            else { wi *= 1 - frac[d]; pg[d] = cell[d]; }
+        }
+        w[idx] = wi;
+        corner[idx] = table[index(pg)];
+    }
+    Vec acc;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) acc.v[c] = (T)0;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) axpy<T>(acc.v[c], w[idx], corner[idx].v[c]);
+    }
+    *out = acc;
+
+    if (calc_grad_inputs) {  // d out / d x, gridencoder.cu:180-223
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            T g[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) g[c] = (T)0;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float wi = scale;
+                uint32_t pg[D];
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? nd + 1 : nd;
+                    if ((idx >> nd) & 1u) { wi *= frac[d]; pg[d] = cell[d] + 1; }
+                    else { wi *= 1 - frac[d]; pg[d] = cell[d]; }
+                }
+                pg[gd] = cell[gd];
+                const Vec lo = table[index(pg)];
+                pg[gd] = cell[gd] + 1;
+                const Vec hi = table[index(pg)];
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) axpy<T>(g[c], wi, (T)(hi.v[c] - lo.v[c]));
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) dd[gd * C + c] = g[c];
+        }
+    }
+}
+
+// packed / scalar atomic accumulate of one weighted gradient vector
+template <typename T, uint32_t C>
+__device__ __forceinline__ void scatter_add(T *__restrict__ dst, float w, const FeatVec<T, C> &g);
+
+template <uint32_t C>
+__device__ __forceinline__ void scatter_add_f32(float *__restrict__ dst, float w, const FeatVec<float, C> &g) {
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++)
+        __hip_atomic_fetch_add(dst + c, w * g.v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_atomic_add_f32
+}
+
+template <uint32_t C>
+__device__ __forceinline__ void scatter_add_f16(half_t *__restrict__ dst, float w, const FeatVec<half_t, C> &g) {
+    if constexpr (C % 2 == 0) {
+        // (half)(w*g) pairs -> global_atomic_pk_add_f16 (reference: __half2 atomicAdd, gridencoder.cu:303-304)
+#pragma unroll
+        for (uint32_t c = 0; c < C; c += 2) {
+            half2_t v;
+            v.x = (half_t)(w * (float)g.v[c]);
+            v.y = (half_t)(w * (float)g.v[c + 1]);
+            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t *)(dst + c), v);
+        }
+    } else {
+        // C == 1 in half: the reference's at::Half atomicAdd is an empty stub (:22-26), i.e. the
+        // gradient is silently dropped.  We accumulate it instead with a 32-bit CAS on the
+        // containing word (documented deviation).
+        const half_t add = (half_t)(w * (float)g.v[0]);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(dst);
+        uint32_t *word = reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3);
+        const uint32_t shift = (a & 2u) ? 16u : 0u;
+        uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), assumed;
+        do {
+            assumed = old;
+            const uint16_t cur_bits = (uint16_t)(assumed >> shift);
+            half_t cur;
+            __builtin_memcpy(&cur, &cur_bits, 2);
+            const half_t sum = cur + add;
+            uint16_t sum_bits;
+            __builtin_memcpy(&sum_bits, &sum, 2);
+            const uint32_t next = (assumed & ~(0xffffu << shift)) | ((uint32_t)sum_bits << shift);
+            old = assumed;
+            __hip_atomic_compare_exchange_strong(word, &old, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (old != assumed);
+    }
+}
+
+template <>
+__device__ __forceinline__ void scatter_add<float, 1>(float *d, float w, const FeatVec<float, 1> &g) { scatter_add_f32<1>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<float, 2>(float *d, float w, const FeatVec<float, 2> &g) { scatter_add_f32<2>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<float, 4>(float *d, float w, const FeatVec<float, 4> &g) { scatter_add_f32<4>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<float, 8>(float *d, float w, const FeatVec<float, 8> &g) { scatter_add_f32<8>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<half_t, 1>(half_t *d, float w, const FeatVec<half_t, 1> &g) { scatter_add_f16<1>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<half_t, 2>(half_t *d, float w, const FeatVec<half_t, 2> &g) { scatter_add_f16<2>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<half_t, 4>(half_t *d, float w, const FeatVec<half_t, 4> &g) { scatter_add_f16<4>(d, w, g); }
+template <>
+__device__ __forceinline__ void scatter_add<half_t, 8>(half_t *d, float w, const FeatVec<half_t, 8> &g) { scatter_add_f16<8>(d, w, g); }
+
+// reference: kernel_grid_backward, gridencoder.cu:227-314
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs,
+                                                         const int32_t *__restrict__ offsets, T *__restrict__ grad_grid,
+                                                         uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
+                                                         bool align_corners) {
+    using Vec = FeatVec<T, C>;
+    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+
+    float frac[D];
+    uint32_t cell[D];
+    if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell)) return;  // grad stays 0 (:254-259)
+    const Vec g = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
+    T *__restrict__ table = grad_grid + (size_t)off0 * C;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wi = 1;
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx >> d) & 1u) { wi *= frac[d]; pg[d] = cell[d] + 1; }
+            else { wi *= 1 - frac[d]; pg[d] = cell[d]; }
+        }
+        scatter_add<T, C>(table + (size_t)index(pg) * C, wi, g);
+    }
+}
+
+// reference: kernel_input_backward, gridencoder.cu:317-343
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx,
+                                                               T *__restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * kGridBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T *__restrict__ dd = dy_dx + (size_t)b * L * D * C;
+    T r = (T)0;
+    for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const T gv = grad[((size_t)l * B + b) * C + c];
+            const T dv = dd[(size_t)l * D * C + d * C + c];
+            if constexpr (sizeof(T) == 4) r = fmaf(gv, dv, r);
+            else r = r + (T)(gv * dv);  // half: product rounded, then half add
+        }
+    }
+    grad_inputs[t] = r;
+}
+
+static LevelScales make_scales(uint32_t L, float S, uint32_t H) {
+    LevelScales s;
+    for (uint32_t l = 0; l < kMaxLevels; l++) s.scale[l] = 0.f;
+    // per-level scale on the HOST with libm exp2f: device exp2 differs from libm/CUDA by an ulp or
+    // two, which would move knife-edge samples across cells (SURVEY.md section 7 "hard parts").
+    for (uint32_t l = 0; l < L; l++) s.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:126
+    return s;
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static int launch_fwd(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L, float S,
+                      uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
+    hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(div_up(B, kGridBlock), L), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets,
+                       (T *)outputs, B, L, make_scales(L, S, H), gridtype, align, calc, (T *)dy_dx);
+    return check_launch();
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static int launch_bwd(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, float S,
+                      uint32_t H, bool calc, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool align, hipStream_t s) {
+    hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(div_up(B, kGridBlock), L), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
+                       (T *)grad_emb, B, L, make_scales(L, S, H), gridtype, align);
+    if (calc)
+        hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(div_up(B * D, kGridBlock)), dim3(kGridBlock), 0, s, (const T *)grad,
+                           (const T *)dy_dx, (T *)grad_inputs, B, L);
+    return check_launch();
+}
+
+#define PVD_GRID_DISPATCH(FN, ...)                                              \
+    do {                                                                        \
+        if (D == 3) {                                                           \
+            switch (C) {                                                        \
+                case 1: return FN<T, 3, 1>(__VA_ARGS__);                        \
+                case 2: return FN<T, 3, 2>(__VA_ARGS__);                        \
+                case 4: return FN<T, 3, 4>(__VA_ARGS__);                        \
+                case 8: return FN<T, 3, 8>(__VA_ARGS__);                        \
+            }                                                                   \
+        } else if (D == 2) {                                                    \
+            switch (C) {                                                        \
+                case 1: return FN<T, 2, 1>(__VA_ARGS__);                        \
+                case 2: return FN<T, 2, 2>(__VA_ARGS__);                        \
+                case 4: return FN<T, 2, 4>(__VA_ARGS__);                        \
+                case 8: return FN<T, 2, 8>(__VA_ARGS__);                        \
+            }                                                                   \
+        }                                                                       \
+        return PVD_ERR_UNSUPPORTED; /* gridencoder.cu:355,370 */               \
+    } while (0)
+
+template <typename T>
+static int fwd_t(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C,
+                 uint32_t L, float S, uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
+    PVD_GRID_DISPATCH(launch_fwd, inputs, emb, offsets, outputs, B, L, S, H, calc, dy_dx, gridtype, align, s);
+}
+
+template <typename T>
+static int bwd_t(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t D, uint32_t C,
+                 uint32_t L, float S, uint32_t H, bool calc, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool align,
+                 hipStream_t s) {
+    PVD_GRID_DISPATCH(launch_bwd, grad, inputs, offsets, grad_emb, B, L, S, H, calc, dy_dx, grad_inputs, gridtype, align, s);
+}
+
+}  // namespace pvd
+
+using namespace pvd;
+
+extern "C" {
+
+int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void *dy_dx,
+                            uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream) {
+    if (L == 0 || L > kMaxLevels) return PVD_ERR_UNSUPPORTED;
+    if (B == 0) return PVD_OK;
+    if (!inputs || !embeddings || !offsets || !outputs || (calc_grad_inputs && !dy_dx)) return PVD_ERR_INVALID;
+    if (dtype == PVD_F32)
+        return fwd_t<float>(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, gridtype,
+                            align_corners != 0, (hipStream_t)stream);
+    if (dtype == PVD_F16)
+        return fwd_t<half_t>(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, gridtype,
+                             align_corners != 0, (hipStream_t)stream);
+    return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
+                             void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
+                             int dtype, pvd_stream_t stream) {
+    (void)embeddings;
+    if (L == 0 || L > kMaxLevels) return PVD_ERR_UNSUPPORTED;
+    if (B == 0) return PVD_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings || (calc_grad_inputs && (!dy_dx || !grad_inputs))) return PVD_ERR_INVALID;
+    if (dtype == PVD_F32)
+        return bwd_t<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, grad_inputs,
+                            gridtype, align_corners != 0, (hipStream_t)stream);
+    if (dtype == PVD_F16)
+        return bwd_t<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, grad_inputs,
+                             gridtype, align_corners != 0, (hipStream_t)stream);
+    return PVD_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

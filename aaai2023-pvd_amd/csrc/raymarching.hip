@@ -1,0 +1,556 @@
+// raymarching.hip -- occupancy-grid ray marching and compositing for gfx950 (MI355X).
+//
+// Replaces the reference's _raymarching module (raymarching/src/raymarching.cu); every
+// entry point cites the reference function it stands in for.  Written for CDNA4:
+// 64-wide wavefronts, 256-thread workgroups, ballot/scan compaction instead of
+// per-ray global atomics, and a deterministic prefix-sum slot allocator.
+#include "pvd_device.h"
+
+#include <float.h>
+
+namespace pvd {
+
+constexpr uint32_t kBlock = 256;
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+
+// ------------------------------------------------------------------ utils
+
+// reference: kernel_near_far_from_aabb, raymarching.cu:93-147
+__global__ void __launch_bounds__(kBlock) k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     const float *__restrict__ aabb, uint32_t N, float min_near,
+                                                     float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    float tn = 0.f, tf = 0.f;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float o = rays_o[3 * (size_t)n + a];
+        const float rd = 1.0f / rays_d[3 * (size_t)n + a];
+        float lo = (aabb[a] - o) * rd;
+        float hi = (aabb[a + 3] - o) * rd;
+        if (lo > hi) { const float s = lo; lo = hi; hi = s; }
+        if (a == 0) {
+            tn = lo; tf = hi;
+        } else if (!miss) {
+            if (tn > hi || lo > tf) miss = true;
+            else {
+                if (lo > tn) tn = lo;
+                if (hi < tf) tf = hi;
+            }
+        }
+    }
+    if (miss) {
+        nears[n] = FLT_MAX; fars[n] = FLT_MAX;
+    } else {
+        nears[n] = tn < min_near ? min_near : tn;
+        fars[n] = tf;
+    }
+}
+
+// reference: kernel_polar_from_ray, raymarching.cu:164-200
+__global__ void __launch_bounds__(kBlock) k_polar(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                  float radius, uint32_t N, float *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
+    const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float Bh = ox * dx + oy * dy + oz * dz;
+    const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    coords[2 * (size_t)n] = 2 * theta * kRPi - 1;
+    coords[2 * (size_t)n + 1] = phi * kRPi;
+}
+
+// reference: kernel_morton3D / kernel_morton3D_invert, raymarching.cu:216-256
+__global__ void __launch_bounds__(kBlock) k_morton3D(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3((uint32_t)coords[3 * (size_t)n], (uint32_t)coords[3 * (size_t)n + 1], (uint32_t)coords[3 * (size_t)n + 2]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_morton3D_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int32_t ind = indices[n];  // signed shifts, as the reference does
+    coords[3 * (size_t)n] = (int32_t)gather3((uint32_t)(ind >> 0));
+    coords[3 * (size_t)n + 1] = (int32_t)gather3((uint32_t)(ind >> 1));
+    coords[3 * (size_t)n + 2] = (int32_t)gather3((uint32_t)(ind >> 2));
+}
+
+// reference: kernel_packbits, raymarching.cu:269-291.  One thread per output byte; the
+// eight cells are fetched as two 16-byte loads (the grid is 32-byte aligned per byte).
+__global__ void __launch_bounds__(kBlock) k_packbits(const float *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4 *>(grid)[2 * (size_t)n];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[2 * (size_t)n + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;   bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;   bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;  bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;  bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------ DDA
+
+struct Dda {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max, rH, Cf, Hf, cell_hi;
+    uint32_t H, H3;
+    const uint8_t *grid;
+
+    __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_, uint32_t max_steps,
+                                         uint32_t C, uint32_t H_, const uint8_t *grid_) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
+        bound = bound_; dt_gamma = dt_gamma_;
+        dt_min = 2 * kSqrt3 / (float)max_steps;
+        dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H_;
+        rH = 1.0f / (float)H_;
+        Cf = (float)C; Hf = (float)H_; cell_hi = (float)(H_ - 1);
+        H = H_; H3 = H_ * H_ * H_;
+        grid = grid_;
+    }
+
+    // One probe at parameter t (reference: the loop bodies at raymarching.cu:362-403,
+    // 430-482, 756-810).  Returns true when the cell is occupied; otherwise t_next is the
+    // first t, advanced in whole dt steps, at or past the cell's exit face.
+    __device__ __forceinline__ bool probe(float t, float &x, float &y, float &z, float &dt, float &t_next) const {
+        x = clampf(fmaf(t, dx, ox), -bound, bound);
+        y = clampf(fmaf(t, dy, oy), -bound, bound);
+        z = clampf(fmaf(t, dz, oz), -bound, bound);
+        dt = clampf(t * dt_gamma, dt_min, dt_max);
+
+        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        int e_pos, e_dt;
+        (void)frexpf(mx, &e_pos);
+        const float dmx = (float)((double)(dt * Hf) * 0.5);  // double literal in the reference (:52)
+        (void)frexpf(dmx, &e_dt);
+        const int lvl_pos = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_pos));
+        const int lvl_dt = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_dt));
+        const int level = lvl_pos > lvl_dt ? lvl_pos : lvl_dt;
+
+        const float mip_bound = fminf((float)(1 << level), bound);
+        const float mip_rbound = 1.0f / mip_bound;
+
+        // nearest cell via fp64 temporaries, as the reference source promotes (:377-379)
+        const double Hd = (double)H;
+        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+
+        const uint32_t index = (uint32_t)level * H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        const bool occ = (grid[index >> 3] >> (index & 7u)) & 1u;
+        if (occ) return true;
+
+        const float tx = (((nx + 0.5f + 0.5f * sign1f(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+        const float ty = (((ny + 0.5f + 0.5f * sign1f(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+        const float tz = (((nz + 0.5f + 0.5f * sign1f(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += clampf(t * dt_gamma, dt_min, dt_max);
+        } while (t < tt);
+        t_next = t;
+        return false;
+    }
+};
+
+__device__ __forceinline__ float ray_t0(float near, float dt_min, uint32_t perturb, uint64_t seed, uint32_t n) {
+    if (!perturb) return near;
+    Pcg32 g;
+    g.seed(seed);
+    g.advance(n);
+    return near + dt_min * g.next_float();
+}
+
+// ------------------------------------------------------------------ march_rays_train
+// Three launches: count -> scan -> write.  The `rays` table itself is the scratch between
+// them (column 2 = count after pass 1, column 1 = offset after the scan), so the ABI needs
+// no workspace.  reference: kernel_march_rays_train, raymarching.cu:313-483.
+
+__global__ void __launch_bounds__(kBlock) k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                        const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                        const float *__restrict__ nears, const float *__restrict__ fars,
+                                                        int32_t *__restrict__ rays, uint32_t ray_base_unused, uint32_t perturb) {
+    (void)ray_base_unused;
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    Dda r;
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = ray_t0(nears[n], r.dt_min, perturb, 42u, n);  // rng = pcg32{42} (:488), advance(n) (:352)
+    uint32_t num = 0;
+    while (t < far && num < max_steps) {
+        float x, y, z, dt, tn;
+        if (r.probe(t, x, y, z, dt, tn)) { num++; t += dt; }
+        else t = tn;
+    }
+    rays[3 * (size_t)n + 2] = (int32_t)num;
+}
+
+// Single-workgroup exclusive scan of the per-ray counts (N is 4096 in training; a
+// 640k-ray full image is 625 trips of a 1024-wide scan).  Also bumps the caller's counter
+// the way the reference's two atomics do (:408-409).
+constexpr uint32_t kScanBlock = 1024;
+__global__ void __launch_bounds__(kScanBlock) k_march_scan(int32_t *__restrict__ rays, uint32_t N, int32_t *__restrict__ counter) {
+    __shared__ uint32_t wave_sums[kScanBlock / kWave];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    if (tid == 0) carry_s = (uint32_t)counter[0];
+    __syncthreads();
+    for (uint32_t base = 0; base < N; base += kScanBlock) {
+        const uint32_t n = base + tid;
+        const uint32_t v = (n < N) ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
+        // inclusive wave scan
+        uint32_t s = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t up = __shfl_up(s, off, kWave);
+            if ((int)lane >= off) s += up;
+        }
+        if (lane == 63) wave_sums[wid] = s;
+        __syncthreads();
+        uint32_t wave_prefix = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanBlock / kWave; w++) {
+            const uint32_t ws = wave_sums[w];
+            if (w < wid) wave_prefix += ws;
+            total += ws;
+        }
+        const uint32_t carry = carry_s;
+        if (n < N) {
+            rays[3 * (size_t)n] = (int32_t)n;
+            rays[3 * (size_t)n + 1] = (int32_t)(carry + wave_prefix + s - v);
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counter[0] = (int32_t)carry_s;
+        counter[1] += (int32_t)N;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                        const uint8_t *__restrict__ grid, float bound, float dt_gamma,
+                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                        const float *__restrict__ nears, const float *__restrict__ fars,
+                                                        float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                        const int32_t *__restrict__ rays, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num == 0) return;
+    if (off + num >= M) return;  // strict (:419)
+    Dda r;
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[n];
+    float t = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
+    float last_t = t;
+    float *px = xyzs + 3 * (size_t)off, *pd = dirs + 3 * (size_t)off, *pl = deltas + 2 * (size_t)off;
+    uint32_t step = 0;
+    while (t < far && step < num) {
+        float x, y, z, dt, tn;
+        if (r.probe(t, x, y, z, dt, tn)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;  // skipped gaps included (:463-465)
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else {
+            t = tn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ composite (train)
+
+// reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
+__global__ void __launch_bounds__(kBlock) k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                          const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                          uint32_t M, uint32_t N, float *__restrict__ weights_sum,
+                                                          float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n];
+    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
+    float r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0, T = 1.0f;
+    if (!(num == 0 || offset + num >= M)) {
+        for (uint32_t s = 0; s < num; s++) {
+            const size_t i = (size_t)offset + s;
+            const float2 dl = reinterpret_cast<const float2 *>(deltas)[i];
+            const float alpha = 1.0f - __expf(-sigmas[i] * dl.x);
+            const float w = alpha * T;
+            r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
+            t += dl.y;
+            d += w * t;
+            ws += w;
+            T *= 1.0f - alpha;
+        }
+    }
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+// reference: kernel_composite_rays_train_backward, raymarching.cu:606-686
+__global__ void __launch_bounds__(kBlock) k_composite_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
+                                                          const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                          const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                          const float *__restrict__ weights_sum, const float *__restrict__ image,
+                                                          uint32_t M, uint32_t N, float *__restrict__ grad_sigmas,
+                                                          float *__restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n];
+    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num == 0 || offset + num >= M) return;
+    const float gws = grad_ws[index];
+    const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
+    const float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
+    const float wsF = weights_sum[index];
+    float r = 0, g = 0, b = 0, ws = 0, T = 1.0f;
+    for (uint32_t s = 0; s < num; s++) {
+        const size_t i = (size_t)offset + s;
+        const float dl0 = deltas[2 * i];
+        const float c0 = rgbs[3 * i], c1 = rgbs[3 * i + 1], c2 = rgbs[3 * i + 2];
+        const float alpha = 1.0f - __expf(-sigmas[i] * dl0);
+        const float w = alpha * T;
+        r += w * c0; g += w * c1; b += w * c2;
+        ws += w;
+        T *= 1.0f - alpha;  // post-update T enters the sigma gradient (:668-673)
+        grad_rgbs[3 * i] = g0 * w; grad_rgbs[3 * i + 1] = g1 * w; grad_rgbs[3 * i + 2] = g2 * w;
+        grad_sigmas[i] = dl0 * (g0 * (T * c0 - (rF - r)) + g1 * (T * c1 - (gF - g)) + g2 * (T * c2 - (bF - b)) + gws * (T - (wsF - ws)));
+    }
+}
+
+// ------------------------------------------------------------------ inference trio
+
+// reference: kernel_march_rays, raymarching.cu:704-811
+__global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                       const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                       const float *__restrict__ rays_d, float bound, float dt_gamma,
+                                                       uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *__restrict__ grid,
+                                                       const float *__restrict__ fars, float *__restrict__ xyzs,
+                                                       float *__restrict__ dirs, float *__restrict__ deltas, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    Dda r;
+    r.init(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, bound, dt_gamma, max_steps, C, H, grid);
+    const float far = fars[index];
+    float t = ray_t0(rays_t[n], r.dt_min, perturb, (uint64_t)perturb, n);  // seed = perturb (:816), advance(n) (:750)
+    float last_t = t;
+    float *px = xyzs + 3 * (size_t)n * n_step, *pd = dirs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        float x, y, z, dt, tn;
+        if (r.probe(t, x, y, z, dt, tn)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last_t; last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else {
+            t = tn;
+        }
+    }
+}
+
+// reference: kernel_composite_rays, raymarching.cu:825-909
+__global__ void __launch_bounds__(kBlock) k_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                           float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                           const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                           float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                           float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    float t = rays_t[n];
+    float ws = weights_sum[index], d = depth[index];
+    float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const size_t i = (size_t)n * n_step + step;
+        const float dl0 = deltas[2 * i];
+        if (dl0 == 0) break;  // end-of-ray marker (:862)
+        const float alpha = 1.0f - __expf(-sigmas[i] * dl0);
+        const float T = 1 - ws;  // (:872)
+        const float w = alpha * T;
+        ws += w;
+        t += deltas[2 * i + 1];
+        d += w * t;
+        r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
+        if ((double)T < 1e-4) break;  // after accumulating this sample (:886)
+        step++;
+    }
+    rays_t[n] = (step < n_step) ? -1.0f : t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+// reference: kernel_compact_rays, raymarching.cu:921-939.  Wave-ballot compaction: one
+// global atomic per workgroup instead of one per surviving ray; order inside a workgroup is
+// preserved, order of workgroups is whatever the atomic gives (as in the reference).
+__global__ void __launch_bounds__(kBlock) k_compact_rays(uint32_t n_alive, int32_t *__restrict__ rays_alive,
+                                                         const int32_t *__restrict__ rays_alive_old, float *__restrict__ rays_t,
+                                                         const float *__restrict__ rays_t_old, int32_t *__restrict__ alive_counter) {
+    __shared__ uint32_t wave_cnt[kBlock / kWave];
+    __shared__ uint32_t block_base;
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    float t = -1.0f;
+    int32_t id = 0;
+    if (n < n_alive) { t = rays_t_old[n]; id = rays_alive_old[n]; }
+    const bool keep = (n < n_alive) && (t >= 0);
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wid] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / kWave; w++) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+        block_base = tot ? (uint32_t)atomicAdd(alive_counter, (int32_t)tot) : 0u;
+    }
+    __syncthreads();
+    if (keep) {
+        const uint32_t dst = block_base + wave_cnt[wid] + rank;
+        rays_alive[dst] = id;
+        rays_t[dst] = t;
+    }
+}
+
+}  // namespace pvd
+
+// ====================================================================== C ABI
+using namespace pvd;
+
+#define PVD_REQUIRE(cond) \
+    do { if (!(cond)) return PVD_ERR_INVALID; } while (0)
+
+extern "C" {
+
+int pvd_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                           float *nears, float *fars, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(rays_o && rays_d && aabb && nears && fars);
+    hipLaunchKernelGGL(k_near_far, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch();
+}
+
+int pvd_polar_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(rays_o && rays_d && coords);
+    hipLaunchKernelGGL(k_polar, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
+    return check_launch();
+}
+
+int pvd_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(coords && indices);
+    hipLaunchKernelGGL(k_morton3D, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coords, N, indices);
+    return check_launch();
+}
+
+int pvd_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(coords && indices);
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, indices, N, coords);
+    return check_launch();
+}
+
+int pvd_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(grid && bitfield);
+    PVD_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15u) == 0);
+    hipLaunchKernelGGL(k_packbits, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grid, N, density_thresh, bitfield);
+    return check_launch();
+}
+
+int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                         const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                         uint32_t perturb, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter);
+    PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_march_count, dim3(div_up(N, kBlock)), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
+                       nears, fars, rays, 0u, perturb);
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
+    hipLaunchKernelGGL(k_march_write, dim3(div_up(N, kBlock)), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
+                       nears, fars, xyzs, dirs, deltas, rays, perturb);
+    return check_launch();
+}
+
+int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                     uint32_t M, uint32_t N, float *weights_sum, float *depth, float *image,
+                                     pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image);
+    hipLaunchKernelGGL(k_composite_fwd, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
+                       weights_sum, depth, image);
+    return check_launch();
+}
+
+int pvd_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                      const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
+                                      const float *image, uint32_t M, uint32_t N, float *grad_sigmas, float *grad_rgbs,
+                                      pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum, grad_image, sigmas,
+                       rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    return check_launch();
+}
+
+int pvd_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                   const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                   const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                   uint32_t perturb, pvd_stream_t stream) {
+    (void)nears;
+    if (n_alive == 0) return PVD_OK;
+    PVD_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas);
+    PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
+    hipLaunchKernelGGL(k_march_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    return check_launch();
+}
+
+int pvd_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, float *rays_t, const float *sigmas,
+                       const float *rgbs, const float *deltas, float *weights_sum, float *depth, float *image,
+                       pvd_stream_t stream) {
+    if (n_alive == 0) return PVD_OK;
+    PVD_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image);
+    hipLaunchKernelGGL(k_composite_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+                       rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return check_launch();
+}
+
+int pvd_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_alive_old, float *rays_t,
+                     const float *rays_t_old, int32_t *alive_counter, pvd_stream_t stream) {
+    if (n_alive == 0) return PVD_OK;
+    PVD_REQUIRE(rays_alive && rays_alive_old && rays_t && rays_t_old && alive_counter);
+    hipLaunchKernelGGL(k_compact_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, rays_alive,
+                       rays_alive_old, rays_t, rays_t_old, alive_counter);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+"""Radiance-field models: the harness counterpart of the reference's ``NeRFNetwork``
+(distill_mutual/network.py:13-683): one class, four representations (``hash`` INGP, ``mlp``
+NeRF, ``vm`` TensoRF, ``tensors`` Plenoxels), identical parameter names and shapes so that
+reference checkpoints line up (``encoder.embeddings``, ``sigma_net.N.weight``,
+``color_net.N.weight``, ``sigma_mat.N`` ...).
+"""
+import ast
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .activation import make_trunc_exp
+from .encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+def _mlp(dims):
+    """bias-free Linear stack (network.py:103-152)."""
+    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, ops, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1, model_type="hash", args=None, is_teacher=False, **kwargs):
+        super().__init__(ops, bound, **kwargs)
+        assert model_type in ["hash", "mlp", "vm", "tensors"]
+        self.is_teacher = is_teacher
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.geo_feat_dim = geo_feat_dim
+        self.args = args
+        self.opt = args
+        self.model_type = model_type
+        self.trunc_exp = make_trunc_exp(ops.device_type)
+        self.plenoxel_degree = args.plenoxel_degree
+        self.plenoxel_res = ast.literal_eval(args.plenoxel_res) if isinstance(args.plenoxel_res, str) else list(args.plenoxel_res)
+        assert len(self.plenoxel_res) == 3
+
+        # 14 levels, 2 features, finest resolution 2048*bound (network.py:47-51)
+        self.in_dim = 14 * 2
+        self.encoder = None
+        if model_type == "hash":
+            self.encoder, self.in_dim = get_encoder(ops, encoding, desired_resolution=2048 * bound, num_levels=14)
+        elif model_type == "mlp":
+            self.encoder_nerf_pe, self.in_dim_nerf = get_encoder(ops, "frequency", multires=args.PE)
+            self.skips = args.skip
+            self.nerf_layer_num = args.nerf_layer_num
+            W = args.nerf_layer_wide
+            layers = [nn.Linear(self.in_dim_nerf, W)]
+            for i in range(self.nerf_layer_num - 2):
+                layers.append(nn.Linear(W + self.in_dim_nerf if i == self.skips else W, W))  # skip feeds the NEXT layer
+            layers.append(nn.Linear(W, self.in_dim))
+            self.nerf_mlp = nn.ModuleList(layers)
+        elif model_type == "vm":
+            self.sigma_rank = [16] * 3
+            self.color_rank = [48] * 3
+            self.color_feat_dim = 15
+            self.mat_ids = [[0, 1], [0, 2], [1, 2]]
+            self.vec_ids = [2, 1, 0]
+            self.resolution = [args.resolution0] * 3
+            self.sigma_mat, self.sigma_vec = self.init_one_vm(self.sigma_rank, self.resolution)
+            self.color_mat, self.color_vec = self.init_one_vm(self.color_rank, self.resolution)
+            self.basis_mat = nn.Linear(sum(self.color_rank), self.color_feat_dim, bias=False)
+        elif model_type == "tensors":
+            s, fea_dim = 0.02, self.plenoxel_degree ** 2 * 3 + 1  # network.py:92-96
+            self.tensor_volume = nn.ParameterList([nn.Parameter(s * torch.randn((1, fea_dim, *self.plenoxel_res)))])
+
+        if model_type in ("hash", "mlp"):
+            dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
+            self.sigma_net = _mlp(dims)
+
+        self.num_layers_color = num_layers_color
+        self.hidden_dim_color = hidden_dim_color
+        if model_type == "tensors":
+            self.encoder_dir, self.in_dim_dir = get_encoder(ops, "sphere_harmonics", degree=self.plenoxel_degree)
+        else:
+            self.encoder_dir, self.in_dim_dir = get_encoder(ops, encoding_dir, input_dim=3, multires=2)
+            dims = [self.in_dim_dir + geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3]
+            self.color_net = _mlp(dims)
+        self.bg_net = None
+
+        self.feature_sigma_color = None
+        self.sigma_l = None
+        self.color_l = None
+
+    # ------------------------------------------------------------------ VM (TensoRF) tables
+    def init_one_vm(self, n_component, resolution, scale=0.1):
+        """plane [1,R,res,res] + line [1,R,res,1] factors per axis triple (network.py:193-214)."""
+        mat, vec = [], []
+        for i in range(3):
+            m0, m1 = self.mat_ids[i]
+            mat.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[m1], resolution[m0]))))
+            vec.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[self.vec_ids[i]], 1))))
+        return nn.ParameterList(mat), nn.ParameterList(vec)
+
+    def _vm_coords(self, x):
+        mat_coord = torch.stack([x[..., self.mat_ids[i]] for i in range(3)]).detach().view(3, -1, 1, 2)
+        vec = torch.stack([x[..., self.vec_ids[i]] for i in range(3)])
+        vec_coord = torch.stack((torch.zeros_like(vec), vec), dim=-1).detach().view(3, -1, 1, 2)
+        return mat_coord, vec_coord
+
+    def get_sigma_feat(self, x):
+        """sum_r plane_r(u,v) * line_r(w) over the 3 axis triples (network.py:216-262)."""
+        N = x.shape[0]
+        mat_coord, vec_coord = self._vm_coords(x)
+        sigma_feat = torch.zeros([N], device=x.device)
+        for i in range(3):
+            m = F.grid_sample(self.sigma_mat[i], mat_coord[[i]], align_corners=True).view(-1, N)
+            v = F.grid_sample(self.sigma_vec[i], vec_coord[[i]], align_corners=True).view(-1, N)
+            sigma_feat = sigma_feat + torch.sum(m * v, dim=0)
+        return sigma_feat
+
+    def get_color_feat(self, x):
+        """144 plane*line products -> basis_mat -> 15 colour features (network.py:264-309)."""
+        N = x.shape[0]
+        mat_coord, vec_coord = self._vm_coords(x)
+        m = torch.cat([F.grid_sample(self.color_mat[i], mat_coord[[i]], align_corners=True).view(-1, N) for i in range(3)], dim=0)
+        v = torch.cat([F.grid_sample(self.color_vec[i], vec_coord[[i]], align_corners=True).view(-1, N) for i in range(3)], dim=0)
+        return self.basis_mat((m * v).T)
+
+    def density_loss(self):
+        """L1 on the sigma factors (network.py:549-557)."""
+        loss = 0
+        for i in range(3):
+            loss = loss + torch.mean(torch.abs(self.sigma_mat[i])) + torch.mean(torch.abs(self.sigma_vec[i]))
+        return loss
+
+    # ------------------------------------------------------------------ Plenoxels / NeRF-MLP
+    def compute_plenoxel_fea(self, x):
+        vol = self.tensor_volume[0]
+        return F.grid_sample(vol, x.view(1, 1, -1, 1, 3), align_corners=True).view(-1, x.shape[0]).permute(1, 0)
+
+    def forward_nerf_mlp(self, x):
+        x = self.encoder_nerf_pe(x)
+        pts = x
+        last = len(self.nerf_mlp) - 1
+        for i, layer in enumerate(self.nerf_mlp):
+            x = layer(x)
+            if i != last:
+                x = F.relu(x, inplace=True)
+            if i == self.skips:
+                x = torch.cat([pts, x], -1)
+        return x
+
+    def _unit_cube(self, x):
+        return 2 * (x - self.aabb_train[:3]) / (self.aabb_train[3:] - self.aabb_train[:3]) - 1
+
+    def _in_stage1(self):
+        return self.training and self.args.global_step < self.args.stage_iters["stage1"]
+
+    def _color_head(self, enc_d, feat):
+        h = torch.cat([enc_d, feat], dim=-1)
+        for l in range(self.num_layers_color):
+            h = self.color_net[l](h)
+            if l != self.num_layers_color - 1:
+                h = F.relu(h, inplace=True)
+        return torch.sigmoid(h)
+
+    # ------------------------------------------------------------------ forward / density
+    def forward(self, x, d):
+        """x [N,3] in [-bound,bound], d [N,3] unit -> (sigma [N], rgb [N,3]); reference network.py:335-437.
+        Side outputs kept for the distillation losses: feature_sigma_color, sigma_l, color_l."""
+        a = self.args
+        if self.model_type == "vm":
+            x = self._unit_cube(x)
+            sigma_feat = torch.clamp(self.get_sigma_feat(x), -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)
+            color_feat = torch.clamp(self.get_color_feat(x), a.sigma_clip_min, a.sigma_clip_max)
+            self.feature_sigma_color = torch.cat([sigma_feat.unsqueeze(-1), color_feat], dim=-1)
+            if self._in_stage1():
+                return None, None
+            self.sigma_l = sigma_feat
+            sigma = self.trunc_exp(sigma_feat)
+            color = self._color_head(self.encoder_dir(d), color_feat)
+            self.color_l = color
+            return sigma, color
+
+        if self.model_type == "tensors":
+            h = self.compute_plenoxel_fea(self._unit_cube(x))
+            sigma = torch.clamp(h[..., 0], -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)
+            self.sigma_l = sigma
+            sigma = self.trunc_exp(sigma)
+            sh = h[..., 1:].view(-1, 3, self.plenoxel_degree ** 2)
+            color = torch.sigmoid((sh * self.encoder_dir(d).unsqueeze(1)).sum(-1))
+            self.feature_sigma_color = None
+            self.color_l = color
+            return sigma, color
+
+        h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)
+        for l in range(self.num_layers):
+            h = self.sigma_net[l](h)
+            if l != self.num_layers - 1:
+                h = F.relu(h, inplace=True)
+        # channel 0 is log-density, clamped; written in place like the reference (network.py:418-420)
+        h[..., 0] = torch.clamp(h[..., 0].clone(), a.sigma_clip_min, a.sigma_clip_max)
+        self.feature_sigma_color = h
+        if self._in_stage1():
+            return None, None
+        self.sigma_l = h[..., 0]
+        sigma = self.trunc_exp(h[..., 0])
+        color = self._color_head(self.encoder_dir(d), h[..., 1:])
+        self.color_l = color
+        return sigma, color
+
+    def density(self, x):
+        """reference: network.py:439-494 (used by update_extra_state)."""
+        a = self.args
+        if self.model_type == "vm":
+            s = torch.clamp(self.get_sigma_feat(self._unit_cube(x)), a.sigma_clip_min, a.sigma_clip_max)
+            return {"sigma": self.trunc_exp(s)}
+        if self.model_type == "tensors":
+            h = self.compute_plenoxel_fea(self._unit_cube(x))
+            return {"sigma": self.trunc_exp(h[..., 0])}  # the reference's second, unclamped assignment wins (:481)
+        h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)
+        for l in range(self.num_layers):
+            h = self.sigma_net[l](h)
+            if l != self.num_layers - 1:
+                h = F.relu(h, inplace=True)
+        h = torch.clamp(h, a.sigma_clip_min, a.sigma_clip_max)
+        return {"sigma": self.trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def get_params(self, lr, lr2=1e-3):
+        """optimizer groups (network.py:646-683)."""
+        if self.model_type == "hash":
+            return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                    {"params": self.color_net.parameters(), "lr": lr}]
+        if self.model_type == "mlp":
+            return [{"params": self.sigma_net.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr},
+                    {"params": self.nerf_mlp.parameters(), "lr": lr}]
+        if self.model_type == "vm":
+            return [{"params": self.color_net.parameters(), "lr": lr2}, {"params": self.sigma_mat, "lr": lr},
+                    {"params": self.sigma_vec, "lr": lr}, {"params": self.color_mat, "lr": lr},
+                    {"params": self.color_vec, "lr": lr}, {"params": self.basis_mat.parameters(), "lr": lr2}]
+        return [{"params": self.tensor_volume.parameters(), "lr": lr}]

@@ -1,0 +1,13 @@
+"""Operator set used by the harness.  ``hip_ops()`` binds the product's HIP packages; the
+test-suite builds the same namespace around the CPU oracle (tests/oracle_ops.py).  The product
+never constructs anything but the HIP set."""
+import types
+
+
+def hip_ops():
+    import gridencoder
+    import raymarching
+    import shencoder
+
+    return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
+                                 device_type="cuda", name="hip")

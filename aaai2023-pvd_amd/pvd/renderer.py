@@ -1,0 +1,251 @@
+"""Occupancy-grid volume renderer: the harness counterpart of the reference's
+``NeRFRenderer`` (distill_mutual/renderer.py:66-814; teacher variant just_train_tea/renderer.py).
+
+Only the live path is reproduced -- ``run_cuda`` (train and inference branches),
+``update_extra_state``, ``mark_untrained_grid`` and ``render`` -- with the reference's buffer names
+(``density_grid``, ``density_bitfield``, ``step_counter``, ``aabb_train``, ``aabb_infer``) so that
+state-dicts line up (checkpoint row).  The dead pure-torch ``run`` is not.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, ops, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1,
+                 grid_size=128, teacher_variant=False):
+        super().__init__()
+        self.ops = ops
+        self.rm = ops.raymarching
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))  # renderer.py:81
+        self.grid_size = grid_size
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        # just_train_tea/renderer.py differs in two places (depth normalisation, no stage gating)
+        self.teacher_variant = teacher_variant
+
+        aabb = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer("density_grid", torch.zeros([self.cascade, grid_size ** 3]))
+            self.register_buffer("density_bitfield", torch.zeros(self.cascade * grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))  # ring of 16 (renderer.py:108-113)
+            self.mean_count = 0
+            self.local_step = 0
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # ------------------------------------------------------------------ run_cuda
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+                 inherited_params=(), **kwargs):
+        """reference: run_cuda, distill_mutual/renderer.py:319-559.  rays_o/rays_d [B, N, 3] with B == 1."""
+        rm = self.rm
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+
+        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+
+        if self.bg_radius > 0:
+            polar = rm.polar_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(polar, rays_d)
+        elif bg_color is None:
+            bg_color = 1
+
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+
+            # whoever renders first marches; the other model inherits the very same samples
+            # (renderer.py:365-411): student first when args.render_stu_first, else teacher first.
+            stu_first = bool(getattr(self.args, "render_stu_first", True))
+            i_march = (not self.is_teacher) if stu_first else self.is_teacher
+            if self.teacher_variant:
+                i_march = True
+            if i_march:
+                xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                               self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                               force_all_rays, dt_gamma, max_steps)
+                inherited_params = [xyzs, dirs, deltas, rays]
+            else:
+                xyzs, dirs, deltas, rays = inherited_params
+
+            sigmas, rgbs = self(xyzs, dirs)
+
+            if not self.teacher_variant:  # stage gating, renderer.py:421-438
+                gs, st = self.args.global_step, self.args.stage_iters
+                if gs < st["stage1"]:
+                    return {"stage1": gs, "depth": None, "image": None, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}
+                if gs < st["stage2"]:
+                    return {"stage2": gs, "depth": None, "image": None, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}
+
+            sigmas = self.density_scale * sigmas
+            weights_sum, depth, image = rm.composite_rays_train(sigmas, rgbs, deltas, rays)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears + eps)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}
+
+        # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
+        dtype = torch.float32
+        weights_sum = torch.zeros(N, dtype=dtype, device=device)
+        depth = torch.zeros(N, dtype=dtype, device=device)
+        image = torch.zeros(N, 3, dtype=dtype, device=device)
+        n_alive = N
+        alive_counter = torch.zeros([1], dtype=torch.int32, device=device)
+        rays_alive = torch.zeros(2, n_alive, dtype=torch.int32, device=device)  # ping-pong
+        rays_t = torch.zeros(2, n_alive, dtype=dtype, device=device)
+        step, i = 0, 0
+        while step < max_steps:
+            if step == 0:
+                rays_alive[0] = torch.arange(n_alive, dtype=torch.int32, device=device)
+                rays_t[0] = nears
+            else:
+                alive_counter.zero_()
+                rm.compact_rays(n_alive, rays_alive[i % 2], rays_alive[(i + 1) % 2], rays_t[i % 2], rays_t[(i + 1) % 2], alive_counter)
+                n_alive = alive_counter.item()  # D2H sync per round, as in the reference (:488)
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = rm.march_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], rays_o, rays_d, self.bound,
+                                               self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128, perturb,
+                                               dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            rm.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas, rgbs, deltas, weights_sum, depth, image)
+            step += n_step
+            i += 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
+
+    # ------------------------------------------------------------------ occupancy grid upkeep
+    def _cell_centres(self, coords, cas, jitter):
+        """Grid coords [n,3] in [0,H) -> world positions of cascade `cas` (renderer.py:680-693)."""
+        H = self.grid_size
+        xyzs = 2 * coords.float() / (H - 1) - 1
+        bound = min(2 ** cas, self.bound)
+        hgs = bound / H
+        p = xyzs * (bound - hgs)
+        if jitter:
+            p = p + (torch.rand_like(p) * 2 - 1) * hgs
+        return p, hgs
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """Cells seen by no training camera get density -1 and are never updated
+        (reference: renderer.py:561-645)."""
+        if not self.cuda_ray:
+            return
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        dev = self.density_grid.device
+        poses = poses.to(dev)
+        B = poses.shape[0]
+        fx, fy, cx, cy = intrinsic
+        H = self.grid_size
+        axis = torch.arange(H, dtype=torch.int32, device=dev)
+        count = torch.zeros_like(self.density_grid)
+        for xs in axis.split(S):
+            for ys in axis.split(S):
+                for zs in axis.split(S):
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+                    indices = self.rm.morton3D(coords).long()
+                    for cas in range(self.cascade):
+                        world, hgs = self._cell_centres(coords, cas, jitter=False)
+                        for head in range(0, B, S):
+                            P = poses[head:head + S]
+                            cam = (world.unsqueeze(0) - P[:, :3, 3].unsqueeze(1)) @ P[:, :3, :3]  # world -> camera
+                            seen = (cam[..., 2] > 0) \
+                                & (cam[..., 0].abs() < cx / fx * cam[..., 2] + hgs * 2) \
+                                & (cam[..., 1].abs() < cy / fy * cam[..., 2] + hgs * 2)
+                            count[cas, indices] += seen.sum(0).reshape(-1)
+        self.density_grid[count == 0] = -1
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """EMA-max update of the density grid, re-pack of the bitfield, refresh of mean_count
+        (reference: renderer.py:647-775)."""
+        if not self.cuda_ray:
+            return
+        rm = self.rm
+        dev = self.density_grid.device
+        H = self.grid_size
+        tmp_grid = -torch.ones_like(self.density_grid)
+
+        def query(coords, indices, cas):
+            p, _ = self._cell_centres(coords, cas, jitter=True)
+            sig = self.density(p)["sigma"].reshape(-1).detach().float() * self.density_scale
+            tmp_grid[cas, indices] = sig
+
+        if self.iter_density < 16:  # full sweep
+            axis = torch.arange(H, dtype=torch.int32, device=dev)
+            for xs in axis.split(S):
+                for ys in axis.split(S):
+                    for zs in axis.split(S):
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+                        indices = rm.morton3D(coords).long()
+                        for cas in range(self.cascade):
+                            query(coords, indices, cas)
+        else:  # H^3/4 uniform cells + H^3/4 currently occupied cells
+            n = H ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, H, (n, 3), device=dev)
+                indices = rm.morton3D(coords).long()
+                occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ.shape[0] > 0:
+                    occ = occ[torch.randint(0, occ.shape[0], [n], dtype=torch.long, device=dev)]
+                    occ_coords = rm.morton3D_invert(occ)
+                    indices = torch.cat([indices, occ], dim=0)
+                    coords = torch.cat([coords, occ_coords], dim=0)
+                query(coords, indices, cas)
+
+        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+
+        thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = rm.packbits(self.density_grid, thresh, self.density_bitfield)
+
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """reference: render, renderer.py:777-814 (`staged` is ignored on the cuda_ray path)."""
+        if not self.cuda_ray:
+            raise RuntimeError("only the cuda_ray path exists (the reference forces it on, main_distill_mutual.py:251-254)")
+        return self.run_cuda(rays_o, rays_d, **kwargs)

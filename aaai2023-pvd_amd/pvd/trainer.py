@@ -1,0 +1,230 @@
+"""Training steps the metric is defined on: the distillation step (student vs frozen teacher on the
+SAME samples) and the teacher step (L2 against ground-truth pixels).
+
+Counterparts of ``Trainer.train_step`` / ``train_one_epoch`` in the reference
+(distill_mutual/utils.py:753-934, 954-1189; just_train_tea/utils.py:540-640, 760-850) reduced to
+what `train rays/s` and PSNR need: loss formulas, stage gating, AMP + GradScaler, AdamW, cosine
+(student) / exponential (teacher) LR.  Data loading, logging, checkpoints, SSIM/LPIPS are out of scope.
+
+Ray data parallelism (new work, the reference has none -- tools/details.md:24): every rank renders
+its own rays against replicated models; one flat-bucket all-reduce (SUM) of the student gradient per
+step over RCCL/xGMI; norm-type losses are made global by all-reducing the sum of squares first.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def psnr(pred, truth):
+    """-10 log10(mean squared error) (reference: PSNRMeter.update, utils.py:500-507)."""
+    mse = torch.mean((pred.float() - truth.float()) ** 2)
+    return -10.0 * torch.log10(mse)
+
+
+class RayDP:
+    """Ray-level data parallel context.  world_size == 1 -> every collective is a no-op."""
+
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world_size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def all_reduce_sum_(self, t):
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def global_sum(self, local):
+        """Value = sum over ranks, gradient = gradient of the local term (d total / d local = 1)."""
+        if not self.enabled:
+            return local
+        tot = self.all_reduce_sum_(local.detach().clone())
+        return tot + (local - local.detach())
+
+    def global_norm_l2(self, diff):
+        """|| concat_r diff_r ||_2 with the right gradient on every shard (torch.norm over the whole
+        batch is not a sum of per-shard norms)."""
+        s_local = (diff.float() ** 2).sum()
+        if not self.enabled:
+            return torch.sqrt(s_local)
+        s_tot = self.all_reduce_sum_(s_local.detach().clone())
+        n = torch.sqrt(s_tot)
+        return n + (s_local - s_local.detach()) / (2 * n.clamp_min(1e-20))
+
+    def global_norm_l1(self, diff):
+        return self.global_sum(diff.float().abs().sum())
+
+    def global_mean(self, x):
+        """mean over the global batch (equal shard sizes are not assumed)."""
+        if not self.enabled:
+            return x.float().mean()
+        cnt = self.all_reduce_sum_(torch.tensor(float(x.numel()), device=x.device))
+        return self.global_sum(x.float().sum()) / cnt
+
+
+class FlatGrads:
+    """All trainable parameters' gradients as views into ONE flat fp32 buffer, so the step's
+    gradient exchange is a single all-reduce with no packing copies (autograd accumulates in place
+    into pre-set .grad views)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            assert p.dtype == torch.float32
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+        # re-attach: optimizers / zero_grad(set_to_none) may have dropped the views
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + 1].data_ptr():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+
+def _make_loss(kind, dp):
+    """reference: Trainer.get_loss, utils.py:941-952 (normL2 is a Frobenius norm, NOT a mean)."""
+    if kind == "L2":
+        return lambda pred, gt: dp.global_mean((gt.float() - pred.float()) ** 2)
+    if kind == "normL2":
+        return lambda pred, gt: dp.global_norm_l2(pred - gt)
+    if kind == "normL1":
+        return lambda pred, gt: dp.global_norm_l1(pred - gt)
+    raise ValueError("error loss_type")
+
+
+class _TrainerBase:
+    def __init__(self, opt, model, lr, device, fp16=True, dp=None, eta_min=None, exp_decay=False):
+        self.opt = opt
+        self.device = torch.device(device)
+        self.device_type = self.device.type
+        self.fp16 = bool(fp16)
+        self.dp = dp or RayDP()
+        self.model = model
+        params = model.get_params(lr)
+        fused = self.device_type == "cuda"
+        # reference: AdamW(betas=(0.9, 0.99), eps=1e-15), default weight decay (main_distill_mutual.py:334-339)
+        self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused)
+        if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
+            self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
+        else:  # student: cosine to eta_min (main_distill_mutual.py:346-348)
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
+        self.scaler = torch.amp.GradScaler(self.device_type, enabled=self.fp16 and self.device_type == "cuda")
+        self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
+        self.global_step = 0
+
+    def _backward_and_step(self, loss):
+        self.scaler.scale(loss).backward()
+        if self.dp.enabled:
+            self.dp.all_reduce_sum_(self.flat.flat)  # one bucket, SUM (losses are already global objectives)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.scheduler.step()
+        self.global_step += 1
+
+
+class DistillTrainer(_TrainerBase):
+    """One distillation step = student render (marches, grads on) -> teacher render on the inherited
+    samples (no grad) -> staged loss -> backward -> AdamW (reference: utils.py:804-824, 954-1189)."""
+
+    def __init__(self, opt, model_tea, model_stu, device, fp16=True, dp=None):
+        for p in model_tea.parameters():
+            p.requires_grad = False
+        lr = opt.lr * (0.1 if opt.model_type == "mlp" else 1.0)  # main_distill_mutual.py:241-242
+        super().__init__(opt, model_stu, lr, device, fp16, dp, eta_min=5e-5)
+        self.model_tea = model_tea.train()  # `training` selects the train branch of run_cuda; teacher is frozen
+        self.model_stu = model_stu.train()
+        self.loss = _make_loss(opt.loss_type, self.dp)
+        self.loss_rate_fea_sc = opt.loss_rate_fea_sc
+
+    def render_kwargs(self):
+        o = self.opt
+        return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps)
+
+    def compute_loss(self, rays_o, rays_d, bg_color):
+        o, stu, tea = self.opt, self.model_stu, self.model_tea
+        o.global_step = self.global_step
+        kw = self.render_kwargs()
+        out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw)
+        with torch.no_grad():
+            out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                                 inherited_params=out_stu["inherited_params"], **kw)
+        self.loss_rate_fea_sc *= 0.995  # decays every step (utils.py:1044)
+        have_fea = stu.feature_sigma_color is not None and tea.feature_sigma_color is not None
+        info = {}
+        loss = 0.0
+        if "stage1" in out_stu and self.loss_rate_fea_sc > 0.0 and have_fea:
+            l_fea = self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
+            info["fea"] = l_fea.detach()
+            return loss + self.loss_rate_fea_sc * l_fea, info, None, None
+        if "stage2" in out_stu:
+            l_col = self.loss(stu.color_l, tea.color_l)
+            l_sig = self.loss(stu.sigma_l, tea.sigma_l)
+            if o.loss_rate_color > 0.0:
+                loss = loss + o.loss_rate_color * l_col
+            if o.loss_rate_sigma > 0.0:
+                loss = loss + o.loss_rate_sigma * l_sig
+            if self.loss_rate_fea_sc > 0.0 and have_fea:
+                loss = loss + self.loss_rate_fea_sc * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
+            info.update(color=l_col.detach(), sigma=l_sig.detach())
+            return loss, info, None, None
+
+        pred_stu, pred_tea = out_stu["image"], out_tea["image"]
+        if o.loss_type == "normL2":
+            l_rgb = self.dp.global_norm_l2(pred_tea - pred_stu)
+        elif o.loss_type == "normL1":
+            l_rgb = self.dp.global_norm_l1(pred_tea - pred_stu)
+        else:
+            l_rgb = self.dp.global_mean((pred_tea.float() - pred_stu.float()) ** 2)
+        loss = loss + l_rgb * o.loss_rate_rgb
+        if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+            loss = loss + stu.density_loss() * (o.l1_reg_weight / self.dp.world_size)  # parameter-only term: not per shard
+        if self.loss_rate_fea_sc > 0.0 and have_fea:
+            loss = loss + self.loss_rate_fea_sc * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
+        if o.loss_rate_color > 0.0:
+            loss = loss + o.loss_rate_color * self.loss(stu.color_l, tea.color_l)
+        if o.loss_rate_sigma > 0.0:
+            loss = loss + o.loss_rate_sigma * self.loss(stu.sigma_l, tea.sigma_l)
+        info["rgb"] = l_rgb.detach()
+        return loss, info, pred_stu, pred_tea
+
+    def train_step(self, rays_o, rays_d, bg_color):
+        self.flat.zero_()
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+            loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color)
+        self._backward_and_step(loss)
+        return loss.detach(), info, pred_stu, pred_tea
+
+
+class TeacherTrainer(_TrainerBase):
+    """Teacher step: render, MSE against ground-truth pixels (+ VM L1 reg), occupancy update every
+    `update_extra_interval` steps (reference: just_train_tea/utils.py:573-581, 841-846)."""
+
+    def __init__(self, opt, model, device, fp16=True, dp=None):
+        lr = opt.lr * (0.1 if opt.model_type == "mlp" else 1.0)
+        super().__init__(opt, model, lr, device, fp16, dp, exp_decay=True)
+        self.model.train()
+
+    def train_step(self, rays_o, rays_d, gt_rgb, bg_color):
+        o, m = self.opt, self.model
+        if m.cuda_ray and self.global_step % o.update_extra_interval == 0:
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+                m.update_extra_state()
+        self.flat.zero_()
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+            out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                           dt_gamma=o.dt_gamma, max_steps=o.max_steps)
+            pred = out["image"]
+            loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
+            if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+                loss = loss + m.density_loss() * (o.l1_reg_weight / self.dp.world_size)
+        self._backward_and_step(loss)
+        return loss.detach(), pred

@@ -1,0 +1,300 @@
+"""ctypes binding of ``libpvd_hip.so`` (the C ABI in ``include/pvd_hip.h``).
+
+Exposes three namespaces with exactly the function names and positional
+signatures of the reference's pybind11 modules (caller-allocated, contiguous
+tensors written in place; scalars by value):
+
+* ``raymarching_backend``  <->  ``_raymarching`` (raymarching/src/bindings.cpp:5-20)
+* ``gridencoder_backend``  <->  ``_gridencoder`` (gridencoder/src/bindings.cpp:5-8)
+* ``shencoder_backend``    <->  ``_shencoder``   (shencoder/src/bindings.cpp:5-8)
+
+There is NO CPU path and no fallback: if the shared library is missing the import
+fails loudly, and every call validates that its tensors live on a HIP device.
+Kernels are enqueued on torch's *current* stream of the tensor's device.
+"""
+import ctypes
+import os
+import types
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libpvd_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libpvd_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C aaai2023-pvd_amd/csrc` (there is no CPU fallback)" % LIB_PATH
+    )
+
+_lib = ctypes.CDLL(LIB_PATH)
+_lib.pvd_status_string.restype = ctypes.c_char_p
+_lib.pvd_last_hip_error.restype = ctypes.c_char_p
+_lib.pvd_abi_version.restype = ctypes.c_int
+
+ABI_VERSION = int(_lib.pvd_abi_version())
+
+_u32, _f32, _int, _vp = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_void_p
+
+PVD_F32, PVD_F16 = 0, 1
+
+# every exported entry point, for the symbol test (tests/test_abi_symbols.py)
+ENTRY_POINTS = (
+    "pvd_abi_version", "pvd_status_string", "pvd_last_hip_error",
+    "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
+    "pvd_march_rays_train", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
+    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
+    "pvd_grid_encode_forward", "pvd_grid_encode_backward",
+    "pvd_sh_encode_forward", "pvd_sh_encode_backward",
+)
+for _name in ENTRY_POINTS:
+    if _name not in ("pvd_status_string", "pvd_last_hip_error"):
+        getattr(_lib, _name).restype = ctypes.c_int
+
+
+class PvdHipError(RuntimeError):
+    pass
+
+
+def _check(status, what):
+    if status != 0:
+        msg = _lib.pvd_status_string(status).decode()
+        hip = _lib.pvd_last_hip_error().decode()
+        raise PvdHipError("%s: %s%s" % (what, msg, (" [%s]" % hip) if hip else ""))
+
+
+def _dev(*tensors):
+    """Validate (the reference's CHECK_CUDA / CHECK_CONTIGUOUS, gridencoder.cu:420-436) and return the device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise PvdHipError("tensor must be a CUDA(HIP) tensor -- libpvd_hip has no CPU path")
+        if not t.is_contiguous():
+            raise PvdHipError("tensor must be contiguous")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise PvdHipError("all tensors must be on the same device")
+    return dev
+
+
+def _want(t, dtype, name):
+    if t.dtype != dtype:
+        raise PvdHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _stream(dev):
+    return _vp(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class KernelTimer:
+    """HIP-event timer around every launch of the named entry points, on the stream the kernels are
+    enqueued on (torch's current stream).  Used by bench.py for the live roofline measurement:
+
+        with pvd_hip.KernelTimer({"pvd_grid_encode_forward"}) as kt: ...timed region...
+        ms_per_launch = kt.mean_ms("pvd_grid_encode_forward")
+    """
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in self.names}
+        self.meta = {n: [] for n in self.names}
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+
+    def launches(self, name):
+        return len(self.events[name])
+
+    def total_ms(self, name):
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self.events[name]))
+
+    def mean_ms(self, name):
+        n = self.launches(name)
+        return self.total_ms(name) / n if n else float("nan")
+
+
+_timer = None
+
+
+def _invoke(fn_name, dev, *args, meta=None):
+    with torch.cuda.device(dev):
+        t = _timer
+        if t is not None and fn_name in t.names:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            status = getattr(_lib, fn_name)(*args, _stream(dev))
+            b.record()
+            t.events[fn_name].append((a, b))
+            t.meta[fn_name].append(meta)
+            return status
+        return getattr(_lib, fn_name)(*args, _stream(dev))
+
+
+def _call(fn_name, dev, *args):
+    _check(_invoke(fn_name, dev, *args), fn_name)
+
+
+def _f32_all(**named):
+    for k, v in named.items():
+        _want(v, torch.float32, k)
+
+
+# --------------------------------------------------------------------------- _raymarching
+def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+    dev = _dev(rays_o, rays_d, aabb, nears, fars)
+    _f32_all(rays_o=rays_o, rays_d=rays_d, aabb=aabb, nears=nears, fars=fars)
+    _call("pvd_near_far_from_aabb", dev, _p(rays_o), _p(rays_d), _p(aabb), _u32(N), _f32(min_near), _p(nears), _p(fars))
+
+
+def polar_from_ray(rays_o, rays_d, radius, N, coords):
+    dev = _dev(rays_o, rays_d, coords)
+    _f32_all(rays_o=rays_o, rays_d=rays_d, coords=coords)
+    _call("pvd_polar_from_ray", dev, _p(rays_o), _p(rays_d), _f32(radius), _u32(N), _p(coords))
+
+
+def morton3D(coords, N, indices):
+    dev = _dev(coords, indices)
+    _want(coords, torch.int32, "coords"), _want(indices, torch.int32, "indices")
+    _call("pvd_morton3D", dev, _p(coords), _u32(N), _p(indices))
+
+
+def morton3D_invert(indices, N, coords):
+    dev = _dev(coords, indices)
+    _want(coords, torch.int32, "coords"), _want(indices, torch.int32, "indices")
+    _call("pvd_morton3D_invert", dev, _p(indices), _u32(N), _p(coords))
+
+
+def packbits(grid, N, density_thresh, bitfield):
+    dev = _dev(grid, bitfield)
+    _want(grid, torch.float32, "grid"), _want(bitfield, torch.uint8, "bitfield")
+    _call("pvd_packbits", dev, _p(grid), _u32(N), _f32(density_thresh), _p(bitfield))
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
+                     xyzs, dirs, deltas, rays, counter, perturb):
+    dev = _dev(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter)
+    _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
+    _want(grid, torch.uint8, "grid"), _want(rays, torch.int32, "rays"), _want(counter, torch.int32, "counter")
+    _call("pvd_march_rays_train", dev, _p(rays_o), _p(rays_d), _p(grid), _f32(bound), _f32(dt_gamma), _u32(max_steps),
+          _u32(N), _u32(C), _u32(H), _u32(M), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter),
+          _u32(int(perturb)))
+
+
+def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image):
+    dev = _dev(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+    _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, depth=depth, image=image)
+    _want(rays, torch.int32, "rays")
+    _call("pvd_composite_rays_train_forward", dev, _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u32(M), _u32(N),
+          _p(weights_sum), _p(depth), _p(image))
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                  grad_sigmas, grad_rgbs):
+    dev = _dev(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, grad_sigmas, grad_rgbs)
+    _f32_all(grad_weights_sum=grad_weights_sum, grad_image=grad_image, sigmas=sigmas, rgbs=rgbs, deltas=deltas,
+             weights_sum=weights_sum, image=image, grad_sigmas=grad_sigmas, grad_rgbs=grad_rgbs)
+    _want(rays, torch.int32, "rays")
+    _call("pvd_composite_rays_train_backward", dev, _p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(deltas),
+          _p(rays), _p(weights_sum), _p(image), _u32(M), _u32(N), _p(grad_sigmas), _p(grad_rgbs))
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+               xyzs, dirs, deltas, perturb):
+    dev = _dev(rays_alive, rays_t, rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas)
+    _f32_all(rays_t=rays_t, rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
+    _want(rays_alive, torch.int32, "rays_alive"), _want(grid, torch.uint8, "grid")
+    _call("pvd_march_rays", dev, _u32(n_alive), _u32(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d), _f32(bound),
+          _f32(dt_gamma), _u32(max_steps), _u32(C), _u32(H), _p(grid), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas),
+          _u32(int(perturb)))
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    dev = _dev(rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+    _f32_all(rays_t=rays_t, sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, depth=depth, image=image)
+    _want(rays_alive, torch.int32, "rays_alive")
+    _call("pvd_composite_rays", dev, _u32(n_alive), _u32(n_step), _p(rays_alive), _p(rays_t), _p(sigmas), _p(rgbs), _p(deltas),
+          _p(weights_sum), _p(depth), _p(image))
+
+
+def compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter):
+    dev = _dev(rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter)
+    _f32_all(rays_t=rays_t, rays_t_old=rays_t_old)
+    for n, t in (("rays_alive", rays_alive), ("rays_alive_old", rays_alive_old), ("alive_counter", alive_counter)):
+        _want(t, torch.int32, n)
+    _call("pvd_compact_rays", dev, _u32(n_alive), _p(rays_alive), _p(rays_alive_old), _p(rays_t), _p(rays_t_old), _p(alive_counter))
+
+
+# --------------------------------------------------------------------------- _gridencoder
+def _table_dtype(t, name):
+    if t.dtype == torch.float32:
+        return PVD_F32
+    if t.dtype == torch.float16:
+        return PVD_F16
+    raise PvdHipError("%s must be float32 or float16, got %s" % (name, t.dtype))
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners):
+    dev = _dev(inputs, embeddings, offsets, outputs, dy_dx)
+    _want(inputs, torch.float32, "inputs"), _want(offsets, torch.int32, "offsets")
+    dt = _table_dtype(embeddings, "embeddings")
+    _want(outputs, embeddings.dtype, "outputs")
+    if calc_grad_inputs:
+        _want(dy_dx, embeddings.dtype, "dy_dx")
+    status = _invoke("pvd_grid_encode_forward", dev, _p(inputs), _p(embeddings), _p(offsets), _p(outputs), _u32(B), _u32(D), _u32(C), _u32(L),
+                     _f32(S), _u32(H), _int(int(bool(calc_grad_inputs))), _p(dy_dx), _u32(gridtype),
+                     _int(int(bool(align_corners))), _int(dt), meta=(B, D, C, L, dt))
+    if status == -2:
+        raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")  # the reference's message, gridencoder.cu:355
+    _check(status, "pvd_grid_encode_forward")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx,
+                         grad_inputs, gridtype, align_corners):
+    dev = _dev(grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
+    _want(inputs, torch.float32, "inputs"), _want(offsets, torch.int32, "offsets")
+    dt = _table_dtype(grad_embeddings, "grad_embeddings")
+    _want(grad, grad_embeddings.dtype, "grad")
+    status = _invoke("pvd_grid_encode_backward", dev, _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), _u32(B), _u32(D),
+                     _u32(C), _u32(L), _f32(S), _u32(H), _int(int(bool(calc_grad_inputs))), _p(dy_dx),
+                     _p(grad_inputs), _u32(gridtype), _int(int(bool(align_corners))), _int(dt), meta=(B, D, C, L, dt))
+    if status == -2:
+        raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")
+    _check(status, "pvd_grid_encode_backward")
+
+
+# --------------------------------------------------------------------------- _shencoder
+def sh_encode_forward(inputs, outputs, B, D, C, calc_grad_inputs, dy_dx):
+    dev = _dev(inputs, outputs, dy_dx)
+    _f32_all(inputs=inputs, outputs=outputs)
+    _call("pvd_sh_encode_forward", dev, _p(inputs), _p(outputs), _u32(B), _u32(D), _u32(C), _int(int(bool(calc_grad_inputs))), _p(dy_dx))
+
+
+def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+    dev = _dev(grad, inputs, dy_dx, grad_inputs)
+    _f32_all(grad=grad, inputs=inputs, dy_dx=dy_dx, grad_inputs=grad_inputs)
+    _call("pvd_sh_encode_backward", dev, _p(grad), _p(inputs), _u32(B), _u32(D), _u32(C), _p(dy_dx), _p(grad_inputs))
+
+
+raymarching_backend = types.SimpleNamespace(
+    near_far_from_aabb=near_far_from_aabb, polar_from_ray=polar_from_ray, morton3D=morton3D,
+    morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
+    composite_rays_train_forward=composite_rays_train_forward,
+    composite_rays_train_backward=composite_rays_train_backward,
+    march_rays=march_rays, composite_rays=composite_rays, compact_rays=compact_rays,
+)
+gridencoder_backend = types.SimpleNamespace(grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward)
+shencoder_backend = types.SimpleNamespace(sh_encode_forward=sh_encode_forward, sh_encode_backward=sh_encode_backward)

@@ -1,0 +1,17 @@
+"""Drop-in for the reference's ``raymarching`` package (raymarching/__init__.py:1), HIP backend only."""
+from pvd_hip import raymarching_backend as _backend
+
+from .raymarching import make_ops
+
+_ops = make_ops(_backend, device_type="cuda")
+
+near_far_from_aabb = _ops.near_far_from_aabb
+polar_from_ray = _ops.polar_from_ray
+morton3D = _ops.morton3D
+morton3D_invert = _ops.morton3D_invert
+packbits = _ops.packbits
+march_rays_train = _ops.march_rays_train
+composite_rays_train = _ops.composite_rays_train
+march_rays = _ops.march_rays
+composite_rays = _ops.composite_rays
+compact_rays = _ops.compact_rays

@@ -1,0 +1,205 @@
+"""``raymarching`` -- the Python operator surface of the reference's raymarching package
+(raymarching/raymarching.py), re-hosted on libpvd_hip.so.
+
+Same names, positional signatures, return values and allocation rules as the reference
+(cited per function), so ``renderer.py``-style callers run unchanged:
+
+    near_far_from_aabb, polar_from_ray, morton3D, morton3D_invert, packbits,
+    march_rays_train, composite_rays_train, march_rays, composite_rays, compact_rays
+
+The autograd Functions are built by :func:`make_ops` around a *backend* object that has the
+reference's ``_backend`` function set.  The module-level operators are bound to the HIP
+backend only (``pvd_hip.raymarching_backend``); there is no CPU fallback.  ``make_ops`` exists
+so the test-suite can drive the same host logic with the CPU oracle.
+"""
+import types
+
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+
+def make_ops(backend, device_type="cuda"):
+    """Build the ten operators on top of ``backend``.
+
+    device_type="cuda": inputs that are not on the GPU are moved there, as the reference
+    does (raymarching.py:35-38, 225-230).  The test-suite passes "cpu" with the oracle.
+    """
+    fwd32 = custom_fwd(device_type=device_type, cast_inputs=torch.float32)
+    bwd = custom_bwd(device_type=device_type)
+
+    def _to_dev(t):
+        if device_type == "cuda" and not t.is_cuda:
+            return t.cuda()
+        return t
+
+    class _NearFar(Function):
+        # reference: _near_far_from_aabb, raymarching.py:20-53
+        @staticmethod
+        @fwd32
+        def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+            rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
+            rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
+            N = rays_o.shape[0]
+            nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+            fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+            backend.near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
+            return nears, fars
+
+    class _Polar(Function):
+        # reference: _polar_from_ray, raymarching.py:56-87
+        @staticmethod
+        @fwd32
+        def forward(ctx, rays_o, rays_d, radius):
+            rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
+            rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
+            N = rays_o.shape[0]
+            coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+            backend.polar_from_ray(rays_o, rays_d, radius, N, coords)
+            return coords
+
+    class _Morton(Function):
+        # reference: _morton3D, raymarching.py:90-113
+        @staticmethod
+        def forward(ctx, coords):
+            coords = _to_dev(coords)
+            N = coords.shape[0]
+            indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+            backend.morton3D(coords.int().contiguous(), N, indices)
+            return indices
+
+    class _MortonInvert(Function):
+        # reference: _morton3D_invert, raymarching.py:116-138
+        @staticmethod
+        def forward(ctx, indices):
+            indices = _to_dev(indices)
+            N = indices.shape[0]
+            coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+            backend.morton3D_invert(indices.int().contiguous(), N, coords)
+            return coords
+
+    class _Packbits(Function):
+        # reference: _packbits, raymarching.py:141-169
+        @staticmethod
+        @fwd32
+        def forward(ctx, grid, thresh, bitfield=None):
+            grid = _to_dev(grid).contiguous()
+            C, H3 = grid.shape[0], grid.shape[1]
+            N = C * H3 // 8
+            if bitfield is None:
+                bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+            backend.packbits(grid, N, thresh, bitfield)
+            return bitfield
+
+    class _MarchTrain(Function):
+        # reference: _march_rays_train, raymarching.py:176-289
+        @staticmethod
+        @fwd32
+        def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                    perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+            rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
+            rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
+            density_bitfield = _to_dev(density_bitfield).contiguous()
+            N = rays_o.shape[0]
+            M = N * max_steps  # worst case (:232)
+            # running-average sample budget; overflowing rays are dropped (:234-238)
+            if not force_all_rays and mean_count > 0:
+                if align > 0:
+                    mean_count += align - mean_count % align
+                M = mean_count
+            dev, dt = rays_o.device, rays_o.dtype
+            xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+            dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+            deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+            rays = torch.empty(N, 3, dtype=torch.int32, device=dev)  # id, offset, num_steps
+            if step_counter is None:
+                step_counter = torch.zeros(2, dtype=torch.int32, device=dev)  # point counter, ray counter
+            backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
+                                     xyzs, dirs, deltas, rays, step_counter, perturb)
+            # warm-up only: trim to the real count (D2H sync, :276-284)
+            if force_all_rays or mean_count <= 0:
+                m = step_counter[0].item()
+                if align > 0:
+                    m += align - m % align
+                xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+                if device_type == "cuda":
+                    torch.cuda.empty_cache()
+            return xyzs, dirs, deltas, rays
+
+    class _CompositeTrain(Function):
+        # reference: _composite_rays_train, raymarching.py:292-357
+        @staticmethod
+        @fwd32
+        def forward(ctx, sigmas, rgbs, deltas, rays):
+            sigmas = sigmas.contiguous()
+            rgbs = rgbs.contiguous()
+            M, N = sigmas.shape[0], rays.shape[0]
+            weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+            depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+            image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+            backend.composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image)
+            ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+            ctx.dims = [M, N]
+            return weights_sum, depth, image
+
+        @staticmethod
+        @bwd
+        def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+            # grad_depth is ignored, exactly like the reference (:330)
+            grad_weights_sum = grad_weights_sum.contiguous()
+            grad_image = grad_image.contiguous()
+            sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+            M, N = ctx.dims
+            grad_sigmas = torch.zeros_like(sigmas)
+            grad_rgbs = torch.zeros_like(rgbs)
+            backend.composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
+                                                  M, N, grad_sigmas, grad_rgbs)
+            return grad_sigmas, grad_rgbs, None, None
+
+    class _March(Function):
+        # reference: _march_rays, raymarching.py:367-454
+        @staticmethod
+        @fwd32
+        def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+                    align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+            rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
+            rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
+            M = n_alive * n_step
+            if align > 0:
+                M += align - (M % align)
+            dev, dt = rays_o.device, rays_o.dtype
+            xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+            dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+            deltas = torch.zeros(M, 2, dtype=dt, device=dev)  # (for alpha, for depth)
+            backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                               density_bitfield, near, far, xyzs, dirs, deltas, perturb)
+            return xyzs, dirs, deltas
+
+    class _Composite(Function):
+        # reference: _composite_rays, raymarching.py:457-502 (in place on weights_sum / depth / image / rays_t)
+        @staticmethod
+        @fwd32
+        def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+            backend.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+            return tuple()
+
+    class _Compact(Function):
+        # reference: _compact_rays, raymarching.py:505-527 (in place on rays_alive / rays_t / alive_counter)
+        @staticmethod
+        @fwd32
+        def forward(ctx, n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter):
+            backend.compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter)
+            return tuple()
+
+    return types.SimpleNamespace(
+        near_far_from_aabb=_NearFar.apply,
+        polar_from_ray=_Polar.apply,
+        morton3D=_Morton.apply,
+        morton3D_invert=_MortonInvert.apply,
+        packbits=_Packbits.apply,
+        march_rays_train=_MarchTrain.apply,
+        composite_rays_train=_CompositeTrain.apply,
+        march_rays=_March.apply,
+        composite_rays=_Composite.apply,
+        compact_rays=_Compact.apply,
+    )

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/s of the hash->vm distillation step on the synthetic chair (BASELINE.json
+metric "train rays/s + PSNR, hash->vm chair distill", configs[2]) on N MI355X.
+
+One "step" = one full optimisation step of the student on one batch of 4096 rays per GPU:
+ray generation -> occupancy-grid march -> student (VM) forward -> teacher (hash) forward on the
+inherited samples -> compositing x2 -> distillation losses -> backward -> AdamW.  Inputs (poses,
+tables, occupancy bitfield) are resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 5
+
+Multi-GPU = ray data parallel, weak scaling (4096 rays per GPU), one RCCL all-reduce of the flat
+student gradient per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+# algorithmic bytes per sample of the grid-encoder forward (SURVEY.md section 8d / BASELINE.md section 2.4):
+#   4*D (position) + L*2^D*C*T (corner gathers) + L*C*T (output)
+def grid_fwd_bytes_per_sample(D, C, L, T):
+    return 4 * D + L * (2 ** D) * C * T + L * C * T
+
+
+def cpu_baseline(workload, steps, num_rays):
+    """The same distillation step on the host cores through the CPU oracle (fp32), on a bounded
+    sample: `steps` steps of `num_rays` rays with the GPU run's weights and occupancy grid."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.workload import DistillWorkload
+
+    opt = PVDConfig(**{**workload.opt.__dict__, "fp16": False, "num_rays": num_rays})
+    torch.set_num_threads(os.cpu_count() or 1)
+    cw = DistillWorkload(oracle_ops(), "cpu", opt, teacher_pretrain_steps=0, seed=0)
+    cw.tea.load_state_dict({k: v.detach().float().cpu() for k, v in workload.tea.state_dict().items()})
+    cw.stu.load_state_dict({k: v.detach().float().cpu() for k, v in workload.stu.state_dict().items()})
+    cw.tea.mean_count = cw.stu.mean_count = int(workload.stu.mean_count * num_rays / workload.opt.num_rays)
+    cw.step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cw.step()
+    dt = time.perf_counter() - t0
+    return {"value": steps * num_rays / dt, "unit": "rays/s", "cores": int(oracle.num_threads()), "kind": "port",
+            "sample": "%d distillation steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, "
+                      "same weights and occupancy grid as the GPU run" % (steps, num_rays)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--student", type=str, default="vm")
+    ap.add_argument("--teacher-pretrain", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--fp32", action="store_true", help="disable AMP (the reference forces fp16 on)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    assert world == args.gpus, "--gpus must match WORLD_SIZE"
+
+    import pvd_hip
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.trainer import RayDP, psnr
+    from pvd.workload import DistillWorkload
+
+    opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type="hash", fp16=not args.fp32)
+    dp = RayDP()
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp)
+    if world > 1:  # replicas must start bit-identical (teacher pre-training uses float atomics)
+        for m in (w.tea, w.stu):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    for _ in range(args.warmup):
+        w.step()
+
+    timed = {"pvd_grid_encode_forward"}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with pvd_hip.KernelTimer(timed) as kt:
+        for _ in range(args.steps):
+            loss, info, pred_stu, pred_tea = w.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- roofline of the hash-grid lookup (dominant native kernel named by north_star)
+    name = "pvd_grid_encode_forward"
+    n_launch = kt.launches(name)
+    roof = None
+    if n_launch:
+        mean_ms = kt.mean_ms(name)
+        metas = kt.meta[name]
+        B, D, C, L, dt_code = metas[-1]
+        T = 2 if dt_code == 1 else 4
+        mean_B = float(np.mean([m[0] for m in metas]))
+        bytes_per_launch = grid_fwd_bytes_per_sample(D, C, L, T) * mean_B
+        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        roof = {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward)" % ("f16" if T == 2 else "f32"), "bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_sample": grid_fwd_bytes_per_sample(D, C, L, T), "samples_per_launch": mean_B,
+                "us_per_launch": mean_ms * 1e3, "launches": n_launch}
+
+    samples = int(w.stu.step_counter[:, 0].float().mean().item())
+    total_rays = args.steps * args.rays * world
+    out = {
+        "metric": "train rays/s (hash->vm chair distillation step)",
+        "value": total_rays / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP, as the reference forces) / f32 marcher+compositor",
+        "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
+        "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
+                               "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps" % (args.student, args.rays, args.teacher_pretrain),
+                   "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "samples_per_step_per_gpu": samples,
+                   "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
+                   "teacher_psnr_db": w.teacher_psnr,
+                   "psnr_student_vs_teacher_db": float(psnr(pred_stu.detach(), pred_tea.detach())) if pred_stu is not None else None,
+                   "loss": float(loss)},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * pvd_hip.h -- C ABI of libpvd_hip.so, the MI355X (gfx950) native volume-rendering
+ * inner loop for PVD's distillation trainer.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one
+ * function of the reference's three pybind11 modules; the reference interface it
+ * replaces is cited as <file>:<line> under /root/reference.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch types; every pointer is a DEVICE
+ *     pointer on the current HIP device unless stated otherwise;
+ *   - the caller allocates everything; the library never allocates, frees or
+ *     synchronises (reference: "Python allocates everything",
+ *     raymarching/raymarching.py:240-250, gridencoder/grid.py:55-64);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  The
+ *     reference launches on the legacy default stream with no device guard
+ *     (raymarching.cu:156); here the caller passes torch's current stream;
+ *   - returns PVD_OK (0) or a negative pvd_status; no exceptions cross the ABI.
+ *     PVD_ERR_UNSUPPORTED corresponds to the reference's
+ *     `throw std::runtime_error{"GridEncoding: C must be 1, 2, 4, or 8."}`
+ *     (gridencoder.cu:355,370);
+ *   - re-entrant, no global mutable state (the reference constructs its RNG per
+ *     call, raymarching.cu:488,816 -- so do we, on the device).
+ *
+ * Buffers that the reference's Python zero-fills before the call (xyzs, dirs,
+ * deltas, grad_sigmas, grad_rgbs, grad_embeddings, grad_inputs) must arrive
+ * zero-filled here too; `rays`, `nears`, `fars`, `outputs` may be uninitialised.
+ */
+#ifndef PVD_HIP_H
+#define PVD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pvd_stream_t; /* hipStream_t */
+
+typedef enum {
+    PVD_OK = 0,
+    PVD_ERR_INVALID = -1,     /* null pointer / bad size */
+    PVD_ERR_UNSUPPORTED = -2, /* D, C, L, degree or dtype outside what the reference dispatches */
+    PVD_ERR_LAUNCH = -3       /* hipGetLastError() != hipSuccess after a launch */
+} pvd_status;
+
+/* table / activation element type of the grid encoder (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * gridencoder.cu:438; double is never used on this path and is not provided) */
+typedef enum { PVD_F32 = 0, PVD_F16 = 1 } pvd_dtype;
+
+int pvd_abi_version(void);
+const char *pvd_status_string(int status);
+/* last hipError_t name seen by this thread after a failed launch ("" if none) */
+const char *pvd_last_hip_error(void);
+
+/* ------------------------------------------------------------------------
+ * _raymarching  (raymarching/src/raymarching.h:7-19, bindings.cpp:5-20)
+ * ---------------------------------------------------------------------- */
+
+/* near_far_from_aabb -- raymarching.cu:150-158 (kernel :93-147).
+ * rays_o, rays_d [N,3] f32; aabb [6] f32; nears, fars [N] f32. */
+int pvd_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                           uint32_t N, float min_near, float *nears, float *fars, pvd_stream_t stream);
+
+/* polar_from_ray -- raymarching.cu:203-211 (kernel :164-200).  coords [N,2]. */
+int pvd_polar_from_ray(const float *rays_o, const float *rays_d, float radius,
+                       uint32_t N, float *coords, pvd_stream_t stream);
+
+/* morton3D / morton3D_invert -- raymarching.cu:231-234, 259-262.  coords [N,3] i32, indices [N] i32. */
+int pvd_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, pvd_stream_t stream);
+int pvd_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, pvd_stream_t stream);
+
+/* packbits -- raymarching.cu:294-302.  grid [N*8] f32 -> bitfield [N] u8, bit i = grid[8n+i] > thresh. */
+int pvd_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, pvd_stream_t stream);
+
+/* march_rays_train -- raymarching.cu:485-494 (kernel :313-483).
+ * grid: density bitfield [C*H^3/8] u8.  xyzs/dirs [M,3], deltas [M,2] f32 (zero-filled by caller),
+ * rays [N,3] i32 (id, offset, count), counter [2] i32 (points, rays; accumulated like the
+ * reference's atomicAdd, so the caller zeroes it).
+ * Slot allocation is a deterministic exclusive prefix sum in ray order (row n of `rays`
+ * is ray n): one of the orders the reference's atomics (:408-409) can produce.
+ * A ray is written only if offset + count < M (strict, :419). */
+int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid,
+                         float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars,
+                         float *xyzs, float *dirs, float *deltas,
+                         int32_t *rays, int32_t *counter, uint32_t perturb, pvd_stream_t stream);
+
+/* composite_rays_train_forward -- raymarching.cu:585-593 (kernel :504-582). */
+int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                     const int32_t *rays, uint32_t M, uint32_t N,
+                                     float *weights_sum, float *depth, float *image, pvd_stream_t stream);
+
+/* composite_rays_train_backward -- raymarching.cu:689-697 (kernel :606-686).
+ * grad_sigmas [M], grad_rgbs [M,3] zero-filled by caller. */
+int pvd_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                      const float *sigmas, const float *rgbs, const float *deltas,
+                                      const int32_t *rays, const float *weights_sum, const float *image,
+                                      uint32_t M, uint32_t N, float *grad_sigmas, float *grad_rgbs,
+                                      pvd_stream_t stream);
+
+/* march_rays -- raymarching.cu:814-822 (kernel :704-811).  xyzs/dirs [n_alive*n_step(+pad),3],
+ * deltas [..,2] zero-filled by caller.  perturb doubles as the RNG seed (:816). */
+int pvd_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                   const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars,
+                   float *xyzs, float *dirs, float *deltas, uint32_t perturb, pvd_stream_t stream);
+
+/* composite_rays -- raymarching.cu:912-918 (kernel :825-909).  In place on rays_t, weights_sum, depth, image. */
+int pvd_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, float *rays_t,
+                       const float *sigmas, const float *rgbs, const float *deltas,
+                       float *weights_sum, float *depth, float *image, pvd_stream_t stream);
+
+/* compact_rays -- raymarching.cu:942-948 (kernel :921-939).  alive_counter [1] i32 (caller zeroes).
+ * One atomic per workgroup (wave ballot + scan inside it): survivors keep their relative order inside a
+ * 256-ray workgroup; the order of workgroups is whatever the atomic gives, as in the reference. */
+int pvd_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_alive_old,
+                     float *rays_t, const float *rays_t_old, int32_t *alive_counter, pvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * _gridencoder  (gridencoder/src/gridencoder.h:12-13, bindings.cpp:5-8)
+ * ---------------------------------------------------------------------- */
+
+/* grid_encode_forward -- gridencoder.cu:419-442 (kernel :75-224).
+ * inputs [B,D] f32 in [0,1]; embeddings [offsets[L],C] dtype; offsets [L+1] i32;
+ * outputs [L,B,C] dtype; dy_dx [B,L,D,C] dtype when calc_grad_inputs (else ignored).
+ * S = log2(per_level_scale), H = base resolution; gridtype 0 = hash, 1 = tiled. */
+int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets,
+                            void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            float S, uint32_t H, int calc_grad_inputs, void *dy_dx,
+                            uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream);
+
+/* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
+ * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
+ * when calc_grad_inputs.  `embeddings` is unused by the arithmetic (as in the reference) and may be null. */
+int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,
+                             const int32_t *offsets, void *grad_embeddings,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const void *dy_dx, void *grad_inputs,
+                             uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * _shencoder  (shencoder/src/shencoder.h:9-12, bindings.cpp:5-8)
+ * ---------------------------------------------------------------------- */
+
+/* sh_encode_forward -- shencoder.cu:402-419 (kernel :27-356).  inputs [B,3] f32, outputs [B,C*C] f32,
+ * dy_dx [B,3,C*C] f32 when calc_grad_inputs.  C = degree in [1,8]. */
+int pvd_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t C,
+                          int calc_grad_inputs, float *dy_dx, pvd_stream_t stream);
+
+/* sh_encode_backward -- shencoder.cu:421-440 (kernel :359-383).  grad_inputs [B,3] += sum grad*dy_dx. */
+int pvd_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t C,
+                           const float *dy_dx, float *grad_inputs, pvd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVD_HIP_H */

@@ -1,0 +1,315 @@
+"""GPU parity: every entry point of libpvd_hip.so against the CPU oracle on the same seeded inputs.
+
+Bars (DESIGN.md "Parity contract"):
+  * integer / index work and everything deterministic that feeds it -- near/far, Morton, packbits,
+    the whole marcher output (rays table, xyz, dirs, deltas), grid-encoder forward in f32 AND f16 --
+    is BIT-EXACT;
+  * floating point with a different evaluation order (SH polynomials, __expf in the compositor,
+    atomics in the encoder backward) is within the tolerance written next to each assert;
+    north_star's bar is RGB/sigma within 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import pvd_hip
+    return pvd_hip
+
+
+def _scene_rays(n_rays, seed, bound=1.0, thicken=0.08):
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    rng = np.random.RandomState(seed)
+    poses = torch.from_numpy(synthetic_poses(rng))
+    g = torch.Generator().manual_seed(seed)
+    r = get_rays(poses[seed % 300][None], BLENDER_INTRINSICS, 800, 800, n_rays, generator=g)
+    C = 1 + int(np.ceil(np.log2(bound)))
+    grid = ChairScene(thicken=thicken).density_grid(128, bound, C)
+    bits = packbits_torch(grid, 10.0)
+    o = (r["rays_o"].reshape(-1, 3) * (bound if bound > 1 else 1.0)).contiguous()
+    return o.numpy(), r["rays_d"].reshape(-1, 3).contiguous().numpy(), bits.numpy(), C
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def test_near_far_bit_exact(hip, dev):
+    o, d, _, _ = _scene_rays(4096, 1)
+    d[:7] = [[1, 0, 0], [0, 1, 0], [0, 0, -1], [1e-30, 1, 0], [0, 0, 1], [-1, 0, 0], [0.6, 0.8, 0]]  # axis-parallel / misses
+    o[7:9] = [[0.5, 0.5, 5.0], [3.0, 3.0, 3.0]]
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    nears, fars = torch.empty(4096, device=dev), torch.empty(4096, device=dev)
+    hip.near_far_from_aabb(t(o, dev), t(d, dev), t(aabb, dev), 4096, 0.2, nears, fars)
+    assert np.array_equal(n_ref, nears.cpu().numpy()) and np.array_equal(f_ref, fars.cpu().numpy())
+
+
+def test_morton_packbits_bit_exact(hip, dev):
+    rng = np.random.RandomState(0)
+    c = rng.randint(0, 1024, (100000, 3)).astype(np.int32)
+    idx = torch.empty(c.shape[0], dtype=torch.int32, device=dev)
+    hip.morton3D(t(c, dev), c.shape[0], idx)
+    assert np.array_equal(oracle.morton3D(c), idx.cpu().numpy())
+    back = torch.empty(c.shape[0], 3, dtype=torch.int32, device=dev)
+    hip.morton3D_invert(idx, c.shape[0], back)
+    assert np.array_equal(back.cpu().numpy(), c)
+    g = rng.randn(2 * 128 ** 3).astype(np.float32)
+    g[::97] = 0.25
+    bf = torch.empty(g.size // 8, dtype=torch.uint8, device=dev)
+    hip.packbits(t(g, dev), g.size // 8, 0.25, bf)
+    assert np.array_equal(oracle.packbits(g, 0.25), bf.cpu().numpy())
+
+
+@pytest.mark.parametrize("perturb", [0, 1])
+@pytest.mark.parametrize("bound,dt_gamma", [(1.0, 0.0), (2.0, 1.0 / 256)])
+def test_march_rays_train_bit_exact(hip, dev, perturb, bound, dt_gamma):
+    N = 4096
+    o, d, bits, C = _scene_rays(N, 3, bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    M = N * 64
+    ref = oracle.march_rays_train(o, d, bits, bound, C, 128, n_ref, f_ref, M, perturb=perturb, dt_gamma=dt_gamma)
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    hip.march_rays_train(t(o, dev), t(d, dev), t(bits, dev), bound, dt_gamma, 1024, N, C, 128, M, t(n_ref, dev), t(f_ref, dev),
+                         xyzs, dirs, deltas, rays, counter, perturb)
+    assert ref[4][0] > 1000, "scene produced too few samples to be a test"
+    assert np.array_equal(ref[4], counter.cpu().numpy())
+    assert np.array_equal(ref[3], rays.cpu().numpy()), "rays table (id, offset, count) must be bit-exact"
+    assert np.array_equal(ref[0], xyzs.cpu().numpy())
+    assert np.array_equal(ref[1], dirs.cpu().numpy())
+    assert np.array_equal(ref[2], deltas.cpu().numpy())
+
+
+def test_march_overflow_drops_trailing_rays(hip, dev):
+    N = 2048
+    o, d, bits, C = _scene_rays(N, 5)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    full = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n_ref, f_ref, N * 64)
+    M = int(full[4][0]) // 2 // 128 * 128  # budget for about half the samples
+    ref = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n_ref, f_ref, M)
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    hip.march_rays_train(t(o, dev), t(d, dev), t(bits, dev), 1.0, 0.0, 1024, N, 1, 128, M, t(n_ref, dev), t(f_ref, dev),
+                         xyzs, dirs, deltas, rays, counter, 0)
+    assert np.array_equal(ref[3], rays.cpu().numpy()) and np.array_equal(ref[0], xyzs.cpu().numpy())
+    r = rays.cpu().numpy()
+    dropped = (r[:, 2] > 0) & (r[:, 1] + r[:, 2] >= M)
+    assert dropped.any() and not dropped[: np.argmax(dropped)].any()  # strictly the tail
+
+
+def _samples(N, seed, dev):
+    o, d, bits, C = _scene_rays(N, seed)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    M = N * 48
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n_ref, f_ref, M, perturb=1)
+    m = int(counter[0])
+    m += 128 - m % 128
+    return xyzs[:m], dirs[:m], deltas[:m], rays
+
+
+def test_composite_train_fwd_bwd(hip, dev):
+    N = 4096
+    xyzs, dirs, deltas, rays = _samples(N, 7, dev)
+    M = xyzs.shape[0]
+    rng = np.random.RandomState(0)
+    sig = np.exp(rng.uniform(-2, 7, M)).astype(np.float32)
+    rgb = rng.uniform(0, 1, (M, 3)).astype(np.float32)
+    ws_r, dep_r, img_r = oracle.composite_rays_train_forward(sig, rgb, deltas, rays)
+    ws, dep, img = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+    hip.composite_rays_train_forward(t(sig, dev), t(rgb, dev), t(deltas, dev), t(rays, dev), M, N, ws, dep, img)
+    # __expf vs libm expf and fp32 accumulation: well inside north_star's 1e-4
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_r, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(img.cpu().numpy(), img_r, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(dep.cpu().numpy(), dep_r, atol=1e-5, rtol=1e-5)
+    gws = rng.randn(N).astype(np.float32)
+    gim = rng.randn(N, 3).astype(np.float32)
+    gs_r, gr_r = oracle.composite_rays_train_backward(gws, gim, sig, rgb, deltas, rays, ws_r, img_r)
+    gs, gr = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev)
+    hip.composite_rays_train_backward(t(gws, dev), t(gim, dev), t(sig, dev), t(rgb, dev), t(deltas, dev), t(rays, dev),
+                                      t(ws_r, dev), t(img_r, dev), M, N, gs, gr)
+    np.testing.assert_allclose(gr.cpu().numpy(), gr_r, atol=2e-6, rtol=1e-5)
+    scale = np.abs(gs_r).max()
+    assert np.abs(gs.cpu().numpy() - gs_r).max() <= 1e-5 * scale
+
+
+def _table(L_off, C, rng, dtype):
+    emb = rng.uniform(-1, 1, (L_off, C)).astype(np.float32) * 0.1
+    return emb.astype(dtype)
+
+
+def _offsets(D, L, per_level_scale, H, log2_hash, align=False):
+    from gridencoder.grid import level_offsets
+    return np.array(level_offsets(D, L, per_level_scale, H, log2_hash, align), np.int32)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("D,C,gridtype,align", [(3, 2, 0, False), (3, 2, 1, False), (2, 2, 0, False), (3, 4, 0, True), (3, 1, 0, False), (3, 8, 0, False)])
+def test_grid_encode_forward_bit_exact(hip, dev, dtype, D, C, gridtype, align):
+    rng = np.random.RandomState(1)
+    L, H = 14, 16
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19, align)
+    emb = _table(offs[-1], C, rng, dtype)
+    B = 20000
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:8] = [[0.0] * D, [1.0] * D, [0.5] * D, [-0.1] + [0.5] * (D - 1), [1.0001] + [0.5] * (D - 1), [1.0] + [0.0] * (D - 1), [0.25] * D, [0.999999] * D]
+    ref, dref = oracle.grid_encode_forward(x, emb, offs, S, H, calc_grad_inputs=True, gridtype=gridtype, align_corners=align)
+    td = torch.float32 if dtype == np.float32 else torch.float16
+    out = torch.empty(L, B, C, dtype=td, device=dev)
+    dy = torch.empty(B, L * D * C, dtype=td, device=dev)
+    hip.grid_encode_forward(t(x, dev), t(emb, dev), t(offs, dev), out, B, D, C, L, S, H, True, dy, gridtype, align)
+    assert np.array_equal(ref.view(np.uint32 if dtype == np.float32 else np.uint16), out.cpu().numpy().view(np.uint32 if dtype == np.float32 else np.uint16))
+    assert np.array_equal(dref, dy.cpu().numpy())
+    assert np.all(out[:, 3].cpu().numpy() == 0) and np.all(out[:, 4].cpu().numpy() == 0)  # out-of-range inputs -> zeros
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("D,C", [(3, 2), (2, 4), (3, 1)])
+def test_grid_encode_backward(hip, dev, dtype, D, C):
+    rng = np.random.RandomState(2)
+    L, H = 14, 16
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19)
+    emb = _table(offs[-1], C, rng, dtype)
+    B = 30000
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    g = (rng.randn(L, B, C) * (1.0 if dtype == np.float32 else 0.01)).astype(dtype)
+    _, dref = oracle.grid_encode_forward(x, emb, offs, S, H, calc_grad_inputs=True)
+    ge_ref, gi_ref = oracle.grid_encode_backward(g, x, emb, offs, S, H, dy_dx=dref)
+    td = torch.float32 if dtype == np.float32 else torch.float16
+    ge = torch.zeros(offs[-1], C, dtype=td, device=dev)
+    gi = torch.zeros(B, D, dtype=td, device=dev)
+    hip.grid_encode_backward(t(g, dev), t(x, dev), t(emb, dev), t(offs, dev), ge, B, D, C, L, S, H, True, t(dref, dev), gi, 0, False)
+    a, b = ge.float().cpu().numpy(), ge_ref.astype(np.float32)
+    # order of the atomic adds differs from the oracle's ascending-b order: rounding-level differences only
+    tol = 2e-5 if dtype == np.float32 else 2e-2
+    assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-6), (np.abs(a - b).max(), np.abs(b).max())
+    # conservation: sum of scattered weights == sum of incoming grads of in-range points (per level, channel)
+    np.testing.assert_allclose(a.sum(), g.astype(np.float32).sum(), rtol=2e-3 if dtype == np.float32 else 5e-2, atol=1e-2)
+    assert np.array_equal(gi.cpu().numpy(), gi_ref)  # input gradient is deterministic -> bit-exact
+
+
+@pytest.mark.parametrize("degree", list(range(1, 9)))
+def test_sh_encode(hip, dev, degree):
+    rng = np.random.RandomState(degree)
+    B = 5000
+    d = rng.randn(B, 3).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:3] = [[0, 0, 0], [0, 0, 1], [0.3, -0.2, 0.1]]  # padding rows (d = 0) and non-unit input see the same polynomials
+    ref, dref = oracle.sh_encode_forward(d, degree, calc_grad_inputs=True)
+    out = torch.empty(B, degree ** 2, device=dev)
+    dy = torch.empty(B, 3 * degree ** 2, device=dev)
+    hip.sh_encode_forward(t(d, dev), out, B, 3, degree, True, dy)
+    # fp32 Horner vs the oracle's fp64 evaluation rounded once
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=3e-6, rtol=0)
+    np.testing.assert_allclose(dy.cpu().numpy(), dref, atol=5e-5, rtol=1e-5)
+    g = rng.randn(B, degree ** 2).astype(np.float32)
+    gi = torch.zeros(B, 3, device=dev)
+    hip.sh_encode_backward(t(g, dev), t(d, dev), B, 3, degree, t(dref, dev), gi)
+    np.testing.assert_allclose(gi.cpu().numpy(), oracle.sh_encode_backward(g, d, degree, dref), atol=1e-4, rtol=1e-5)
+
+
+def test_inference_trio(hip, dev):
+    """Full march -> composite -> compact rounds, HIP vs oracle, comparing the final image per ray."""
+    N = 4096
+    o, d, bits, C = _scene_rays(N, 11)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.RandomState(0)
+
+    def shade(xyzs):  # deterministic stand-in for the network
+        s = 30.0 * (np.sin(xyzs * 9.0).sum(-1) > 0.2).astype(np.float32) + 0.5
+        c = 0.5 + 0.5 * np.sin(xyzs * 5.0 + 1.0)
+        return s.astype(np.float32), c.astype(np.float32)
+
+    def run(backend):
+        ws, dep, img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+        alive = np.arange(N, dtype=np.int32)
+        rt = nears.copy()
+        n_alive, step = N, 0
+        while step < 1024 and n_alive > 0:
+            n_step = max(min(N // n_alive, 8), 1)
+            if backend == "oracle":
+                xyzs, dirs, deltas = oracle.march_rays(n_alive, n_step, alive, rt, o, d, 1.0, bits, 1, 128, nears, fars, align=128)
+                s, c = shade(xyzs)
+                oracle.composite_rays(n_alive, n_step, alive, rt, s, c, deltas, ws, dep, img)
+                alive, rt, n_alive = oracle.compact_rays(n_alive, alive, rt)
+            else:
+                M = n_alive * n_step
+                M += 128 - M % 128
+                xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+                ta, tt = t(alive, dev), t(rt, dev)
+                hip.march_rays(n_alive, n_step, ta, tt, t(o, dev), t(d, dev), 1.0, 0.0, 1024, 1, 128, t(bits, dev), t(nears, dev), t(fars, dev),
+                               xyzs, dirs, deltas, 0)
+                s, c = shade(xyzs.cpu().numpy())
+                tws, tdep, timg = t(ws, dev), t(dep, dev), t(img, dev)
+                hip.composite_rays(n_alive, n_step, ta, tt, t(s, dev), t(c, dev), deltas, tws, tdep, timg)
+                ws, dep, img = tws.cpu().numpy(), tdep.cpu().numpy(), timg.cpu().numpy()
+                na, nt = torch.zeros_like(ta), torch.zeros_like(tt)
+                cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+                hip.compact_rays(n_alive, na, ta, nt, tt, cnt)
+                n_new = int(cnt.item())
+                # canonicalise the (legal) cross-workgroup order by ray id
+                a, r = na[:n_new].cpu().numpy(), nt[:n_new].cpu().numpy()
+                order = np.argsort(a, kind="stable")
+                alive, rt, n_alive = np.ascontiguousarray(a[order]), np.ascontiguousarray(r[order]), n_new
+            step += n_step
+        return ws, dep, img
+
+    ws_r, dep_r, img_r = run("oracle")
+    ws_h, dep_h, img_h = run("hip")
+    assert ws_r.max() > 0.5
+    np.testing.assert_allclose(ws_h, ws_r, atol=1e-5)
+    np.testing.assert_allclose(img_h, img_r, atol=1e-5)
+    np.testing.assert_allclose(dep_h, dep_r, atol=1e-4, rtol=1e-5)
+
+
+def test_full_size_properties(hip, dev):
+    """BASELINE-size run through the Python operators: size-independent properties."""
+    import raymarching
+    N = 4096 * 4
+    o, d, bits, C = _scene_rays(N, 13)
+    to, td_, tb = t(o, dev), t(d, dev), t(bits, dev)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev)
+    nears, fars = raymarching.near_far_from_aabb(to, td_, aabb, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(to, td_, 1.0, tb, 1, 128, nears, fars, counter, -1, True, 128, True, 0, 1024)
+    r = rays.cpu().numpy()
+    assert np.array_equal(r[:, 0], np.arange(N))
+    assert np.array_equal(r[:, 1], np.concatenate([[0], np.cumsum(r[:-1, 2])]))  # offsets are the exclusive prefix sum
+    assert int(counter[0]) == r[:, 2].sum() and int(counter[1]) == N and xyzs.shape[0] % 128 == 0
+    m = int(counter[0])
+    x = xyzs[:m]
+    assert bool((x.abs() <= 1).all()) and bool((deltas[:m, 0] > 0).all()) and bool((deltas[m:] == 0).all())
+    # every emitted sample sits in an occupied cell of the bitfield
+    cell = ((x + 1) * 64).clamp(0, 127).int()
+    idx = raymarching.morton3D(cell).long()
+    occ = (tb[idx // 8].int() >> (idx % 8).int()) & 1
+    assert bool(occ.all())
+    # compositing: an opaque constant-colour field reproduces the colour with weights_sum -> 1
+    sig = torch.full((xyzs.shape[0],), 1e4, device=dev)
+    rgb = torch.full((xyzs.shape[0], 3), 0.25, device=dev)
+    ws, depth, img = raymarching.composite_rays_train(sig, rgb, deltas, rays)
+    hit = torch.from_numpy(r[:, 2] > 0).to(dev)
+    assert torch.allclose(ws[hit], torch.ones_like(ws[hit]), atol=1e-6) and torch.allclose(img[hit], torch.full_like(img[hit], 0.25), atol=1e-6)
+    assert bool((ws[~hit] == 0).all())
