@@ -100,8 +100,17 @@ template <typename T>
 __device__ __forceinline__ void axpy(T &acc, float w, T v);
 template <>
 __device__ __forceinline__ void axpy<float>(float &acc, float w, float v) { acc = fmaf(w, v, acc); }
+// (half)(float product): the product must be rounded to f32 FIRST and then to f16, as c10::Half /
+// __half conversions of a float expression do (gridencoder.cu:166,303).  hipcc otherwise selects
+// v_fma_mixlo_f16 (one rounding of the exact product), which differs in the last half-ulp for
+// about 1 value in 10^4; the empty asm pins the f32 intermediate.
+__device__ __forceinline__ half_t half_of_product(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return (half_t)p;
+}
 template <>
-__device__ __forceinline__ void axpy<half_t>(half_t &acc, float w, half_t v) { acc = acc + (half_t)(w * (float)v); }
+__device__ __forceinline__ void axpy<half_t>(half_t &acc, float w, half_t v) { acc = acc + half_of_product(w, (float)v); }
 
 // reference: kernel_grid, gridencoder.cu:75-224
 template <typename T, uint32_t D, uint32_t C>
@@ -207,15 +216,15 @@ __device__ __forceinline__ void scatter_add_f16(half_t *__restrict__ dst, float 
 #pragma unroll
         for (uint32_t c = 0; c < C; c += 2) {
             half2_t v;
-            v.x = (half_t)(w * (float)g.v[c]);
-            v.y = (half_t)(w * (float)g.v[c + 1]);
+            v.x = half_of_product(w, (float)g.v[c]);
+            v.y = half_of_product(w, (float)g.v[c + 1]);
             __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t *)(dst + c), v);
         }
     } else {
         // C == 1 in half: the reference's at::Half atomicAdd is an empty stub (:22-26), i.e. the
         // gradient is silently dropped.  We accumulate it instead with a 32-bit CAS on the
         // containing word (documented deviation).
-        const half_t add = (half_t)(w * (float)g.v[0]);
+        const half_t add = half_of_product(w, (float)g.v[0]);
         const uintptr_t a = reinterpret_cast<uintptr_t>(dst);
         uint32_t *word = reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3);
         const uint32_t shift = (a & 2u) ? 16u : 0u;

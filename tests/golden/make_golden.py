@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE's Python (read-only, /root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden.py
+
+What can be pinned this way: everything in the reference that runs on CPU
+without its CUDA extensions --
+  * GridEncoder's level-offset table / parameter count / per_level_scale   (gridencoder/grid.py:142-205)
+  * trunc_exp forward + backward                                           (tools/activation.py)
+  * FreqEncoder                                                            (tools/encoding.py:6-49)
+  * NeRFNetwork parameter names and shapes for mlp / hash / vm             (distill_mutual/network.py)
+  * pose_spherical / nerf_matrix_to_ngp / get_rays                         (distill_mutual/utils.py:53-98, 324-404)
+  * the reference's GridEncoder / SHEncoder *Python wrappers* (input mapping, [L,B,C]->[B,L*C]
+    permute, backward reshapes) driven with the CPU oracle standing in for `_gridencoder` /
+    `_shencoder`: pins this repo's wrappers against the reference's wrapper logic (the kernel
+    arithmetic in those fixtures is the oracle's, not the reference's).
+The reference's kernels themselves cannot be built here (no cuda.h, stand-ins are not allowed), so
+kernel arithmetic is NOT pinned by these fixtures ("parity unpinned", see oracle/pvd_oracle.h).
+Only data (inputs + expected outputs) is written; no reference source is copied.
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import oracle_backend as ob  # the CPU oracle dressed as the three _backend modules
+
+# stand-ins for the reference's native modules and for python deps missing from this image
+for name, be in (("_raymarching", ob.raymarching_backend), ("_gridencoder", ob.gridencoder_backend), ("_shencoder", ob.shencoder_backend)):
+    m = types.ModuleType(name)
+    m.__dict__.update(be.__dict__)
+    sys.modules[name] = m
+for name in ("cv2", "trimesh", "mcubes", "lpips", "tensorboardX", "torch_ema", "imageio", "IPython", "torch_efficient_distloss"):
+    sys.modules[name] = MagicMock()
+
+# import the reference under an alias package path so its `gridencoder` etc. do not shadow ours
+our = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in ("gridencoder", "shencoder", "raymarching")}
+sys.path.insert(0, REF)
+import gridencoder as ref_grid  # noqa: E402
+import shencoder as ref_sh  # noqa: E402
+from tools.activation import trunc_exp as ref_trunc_exp  # noqa: E402
+from tools.encoding import FreqEncoder as RefFreq  # noqa: E402
+
+out = {}
+
+# ---- GridEncoder tables
+cfgs = [
+    dict(input_dim=3, num_levels=14, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048),
+    dict(input_dim=3, num_levels=14, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096),
+    dict(input_dim=2, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048),
+    dict(input_dim=3, num_levels=16, level_dim=4, base_resolution=16, log2_hashmap_size=15, per_level_scale=2, align_corners=True),
+    dict(input_dim=3, num_levels=8, level_dim=1, base_resolution=8, log2_hashmap_size=12, per_level_scale=1.5, gridtype="tiled"),
+]
+for i, c in enumerate(cfgs):
+    e = ref_grid.GridEncoder(**c)
+    out["grid%d_offsets" % i] = e.offsets.numpy().copy()
+    out["grid%d_pls" % i] = np.float64(e.per_level_scale)
+    out["grid%d_shape" % i] = np.array(e.embeddings.shape)
+out["grid_cfgs"] = np.array([repr(c) for c in cfgs])
+
+# ---- reference wrapper logic over the oracle backend (forward + backward through autograd)
+torch.manual_seed(0)
+wcfg = dict(input_dim=3, num_levels=8, level_dim=2, base_resolution=8, log2_hashmap_size=12, desired_resolution=256)  # small table
+enc = ref_grid.GridEncoder(**wcfg)
+out['gw_cfg'] = np.array(repr(wcfg))
+emb = (torch.rand_like(enc.embeddings) * 2 - 1) * 0.1
+enc.embeddings.data.copy_(emb)
+x = (torch.rand(257, 3) * 2 - 1) * 1.0
+x[0] = torch.tensor([1.0, -1.0, 0.0]); x[1] = torch.tensor([1.5, 0.0, 0.0])
+y = enc(x, bound=1)
+g = torch.randn_like(y)
+y.backward(g)
+out.update(gw_emb=emb.numpy(), gw_x=x.numpy(), gw_y=y.detach().numpy(), gw_g=g.numpy(), gw_gemb=enc.embeddings.grad.numpy())
+xb = x.clone() * 2
+yb = enc(xb, bound=2)
+out.update(gw_xb=xb.numpy(), gw_yb=yb.detach().numpy())
+
+sh = ref_sh.SHEncoder(input_dim=3, degree=4)
+d = torch.randn(129, 3); d = d / d.norm(dim=-1, keepdim=True)
+d.requires_grad_(True)
+ys = sh(d)
+gs = torch.randn_like(ys)
+ys.backward(gs)
+out.update(sh_d=d.detach().numpy(), sh_y=ys.detach().numpy(), sh_g=gs.numpy(), sh_gd=d.grad.numpy())
+
+# ---- trunc_exp
+xs = torch.linspace(-20, 20, 401, requires_grad=True)
+ys = ref_trunc_exp(xs)
+gg = torch.linspace(-1, 2, 401)
+ys.backward(gg)
+out.update(te_x=xs.detach().numpy(), te_y=ys.detach().numpy(), te_g=gg.numpy(), te_gx=xs.grad.numpy())
+
+# ---- FreqEncoder
+for mr in (10, 2, 6):
+    fe = RefFreq(input_dim=3, max_freq_log2=mr - 1, N_freqs=mr, log_sampling=True)
+    xi = torch.linspace(-1, 1, 3 * 17).view(17, 3)
+    out["freq%d_x" % mr] = xi.numpy()
+    out["freq%d_y" % mr] = fe(xi).numpy()
+    out["freq%d_dim" % mr] = np.int64(fe.output_dim)
+
+# ---- network parameter names / shapes
+sys.modules.pop("raymarching", None)
+from distill_mutual.network import NeRFNetwork as RefNet  # noqa: E402
+from distill_mutual import utils as ref_utils  # noqa: E402
+
+args = types.SimpleNamespace(plenoxel_degree=3, plenoxel_res="[128,128,128]", PE=10, skip=3, nerf_layer_num=8, nerf_layer_wide=256,
+                             resolution0=300, sigma_clip_min=-2, sigma_clip_max=7, global_step=0,
+                             stage_iters={"stage1": 2000, "stage2": 5000}, enable_edit_plenoxel=False, render_stu_first=True)
+for mt in ("hash", "mlp", "vm"):
+    net = RefNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=128, model_type=mt, args=args, is_teacher=False)
+    sd = net.state_dict()
+    out["net_%s_keys" % mt] = np.array(sorted(sd.keys()))
+    out["net_%s_shapes" % mt] = np.array([repr(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+    out["net_%s_dtypes" % mt] = np.array([str(sd[k].dtype) for k in sorted(sd.keys())])
+
+# ---- cameras and rays
+out["pose_sph"] = np.stack([ref_utils.pose_spherical(th, ph, r) for th, ph, r in ((30.0, -20.0, 4.0), (-170.0, -5.0, 4.0), (0.0, -89.0, 3.0))])
+out["pose_ngp"] = np.stack([ref_utils.nerf_matrix_to_ngp(p, scale=0.8) for p in out["pose_sph"]])
+poses = torch.from_numpy(out["pose_ngp"])
+r = ref_utils.get_rays(poses, np.array([1111.1, 1111.1, 24.0, 20.0]), 40, 48, -1)
+out.update(rays_o=r["rays_o"].numpy(), rays_d=r["rays_d"].numpy())
+torch.manual_seed(3)
+r = ref_utils.get_rays(poses[:1], np.array([1111.1, 1111.1, 400.0, 400.0]), 800, 800, 64)
+out.update(rays_n_inds=r["inds"].numpy(), rays_n_o=r["rays_o"].numpy(), rays_n_d=r["rays_d"].numpy())
+
+np.savez_compressed(os.path.join(HERE, "reference_python.npz"), **out)
+print("wrote", os.path.join(HERE, "reference_python.npz"), "with", len(out), "arrays")

@@ -1,0 +1,95 @@
+"""Fixtures generated from the reference's own Python (tests/golden/make_golden.py) vs this repo's
+host-side restatements.  CPU only."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_python.npz"), allow_pickle=False)
+
+
+def test_grid_offsets_tables():
+    from oracle_ops import OracleGridEncoder
+    cfgs = [eval(c) for c in G["grid_cfgs"]]
+    for i, c in enumerate(cfgs):
+        e = OracleGridEncoder(**c)
+        assert np.array_equal(e.offsets.numpy(), G["grid%d_offsets" % i]), c
+        assert float(e.per_level_scale) == float(G["grid%d_pls" % i])
+        assert tuple(e.embeddings.shape) == tuple(G["grid%d_shape" % i])
+    # the table the whole benchmark runs on
+    assert G["grid0_offsets"].tolist()[:7] == [0, 4920, 20552, 63432, 196088, 585112, 1109400] and G["grid0_offsets"][-1] == 5303704
+
+
+def test_grid_wrapper_logic_matches_reference_wrapper():
+    from oracle_ops import OracleGridEncoder
+    e = OracleGridEncoder(**eval(str(G["gw_cfg"])))
+    e.embeddings.data.copy_(torch.from_numpy(G["gw_emb"]))
+    y = e(torch.from_numpy(G["gw_x"]), bound=1)
+    assert np.array_equal(y.detach().numpy(), G["gw_y"])
+    y.backward(torch.from_numpy(G["gw_g"]))
+    assert np.array_equal(e.embeddings.grad.numpy(), G["gw_gemb"])
+    assert np.array_equal(e(torch.from_numpy(G["gw_xb"]), bound=2).detach().numpy(), G["gw_yb"])
+
+
+def test_sh_wrapper_logic_matches_reference_wrapper():
+    from oracle_ops import OracleSHEncoder
+    sh = OracleSHEncoder(input_dim=3, degree=4)
+    d = torch.from_numpy(G["sh_d"]).requires_grad_(True)
+    y = sh(d)
+    assert np.array_equal(y.detach().numpy(), G["sh_y"])
+    y.backward(torch.from_numpy(G["sh_g"]))
+    assert np.array_equal(d.grad.numpy(), G["sh_gd"])
+
+
+def test_trunc_exp():
+    from pvd.activation import make_trunc_exp
+    te = make_trunc_exp("cpu")
+    x = torch.from_numpy(G["te_x"]).requires_grad_(True)
+    y = te(x)
+    assert np.array_equal(y.detach().numpy(), G["te_y"])
+    y.backward(torch.from_numpy(G["te_g"]))
+    assert np.array_equal(x.grad.numpy(), G["te_gx"])
+
+
+@pytest.mark.parametrize("mr", [10, 2, 6])
+def test_freq_encoder(mr):
+    from pvd.encoding import FreqEncoder
+    fe = FreqEncoder(input_dim=3, max_freq_log2=mr - 1, N_freqs=mr)
+    assert fe.output_dim == int(G["freq%d_dim" % mr])
+    assert np.array_equal(fe(torch.from_numpy(G["freq%d_x" % mr])).numpy(), G["freq%d_y" % mr])
+
+
+@pytest.mark.parametrize("mt", ["hash", "mlp", "vm"])
+def test_network_state_dict_layout(mt):
+    """Reference checkpoints must load: same keys, shapes and dtypes (SURVEY.md section 5 checkpoint row)."""
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.network import NeRFNetwork
+    opt = PVDConfig(model_type=mt)
+    net = NeRFNetwork(oracle_ops(), model_type=mt, args=opt, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10,
+                      bg_radius=-1, grid_size=128)
+    sd = net.state_dict()
+    keys = sorted(sd.keys())
+    assert keys == list(G["net_%s_keys" % mt])
+    assert [repr(tuple(sd[k].shape)) for k in keys] == list(G["net_%s_shapes" % mt])
+    assert [str(sd[k].dtype) for k in keys] == list(G["net_%s_dtypes" % mt])
+
+
+def test_cameras_and_rays():
+    from pvd.scene import get_rays, nerf_matrix_to_ngp, pose_spherical
+    sph = np.stack([pose_spherical(th, ph, r) for th, ph, r in ((30.0, -20.0, 4.0), (-170.0, -5.0, 4.0), (0.0, -89.0, 3.0))])
+    np.testing.assert_allclose(sph, G["pose_sph"], atol=1e-6)
+    ngp = np.stack([nerf_matrix_to_ngp(p, 0.8) for p in G["pose_sph"]])
+    assert np.array_equal(ngp, G["pose_ngp"])
+    poses = torch.from_numpy(G["pose_ngp"])
+    r = get_rays(poses, (1111.1, 1111.1, 24.0, 20.0), 40, 48, -1)
+    np.testing.assert_allclose(r["rays_d"].numpy(), G["rays_d"], atol=1e-7)
+    assert np.array_equal(r["rays_o"].numpy(), G["rays_o"])
+    r = get_rays(poses[:1], (1111.1, 1111.1, 400.0, 400.0), 800, 800, 64, inds=torch.from_numpy(G["rays_n_inds"][0]))
+    np.testing.assert_allclose(r["rays_d"].numpy(), G["rays_n_d"], atol=1e-7)
+    # and the un-seeded draw is the same torch.randint call
+    torch.manual_seed(3)
+    r2 = get_rays(poses[:1], (1111.1, 1111.1, 400.0, 400.0), 800, 800, 64)
+    assert np.array_equal(r2["inds"].numpy(), G["rays_n_inds"])
