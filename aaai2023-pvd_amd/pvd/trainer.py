@@ -46,9 +46,9 @@ class RayDP:
     def global_norm_l2(self, diff):
         """|| concat_r diff_r ||_2 with the right gradient on every shard (torch.norm over the whole
         batch is not a sum of per-shard norms)."""
-        s_local = (diff.float() ** 2).sum()
         if not self.enabled:
-            return torch.sqrt(s_local)
+            return torch.norm(diff.float())  # zero-safe subgradient, as the reference's torch.norm (utils.py:947)
+        s_local = (diff.float() ** 2).sum()
         s_tot = self.all_reduce_sum_(s_local.detach().clone())
         n = torch.sqrt(s_tot)
         return n + (s_local - s_local.detach()) / (2 * n.clamp_min(1e-20))

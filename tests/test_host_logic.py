@@ -1,0 +1,184 @@
+"""Host-side logic of the product (autograd Functions, renderer, network, trainer) driven through the
+CPU oracle backend.  CPU only; the same code paths run on the HIP backend in test_hip_*.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_ops import oracle_ops
+from pvd.config import PVDConfig
+from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+from pvd.workload import DistillWorkload, install_occupancy, make_model
+
+OPS = oracle_ops()
+RM = OPS.raymarching
+
+
+def _rays(n, seed=0):
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(seed)))
+    r = get_rays(poses[7][None], BLENDER_INTRINSICS, 800, 800, n, generator=torch.Generator().manual_seed(seed))
+    grid = ChairScene().density_grid(128, 1.0, 1)
+    return r["rays_o"], r["rays_d"], packbits_torch(grid, 10.0)
+
+
+def test_march_rays_train_sizing_rules():
+    o, d, bits = _rays(512)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0])
+    nears, fars = RM.near_far_from_aabb(o, d, aabb, 0.2)
+    assert nears.shape == (512,)
+    # mean_count <= 0: trimmed to the real count rounded UP to `align`, +align when already aligned (raymarching.py:276-284)
+    counter = torch.zeros(2, dtype=torch.int32)
+    xyzs, dirs, deltas, rays = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, counter, -1, False, 128, False, 0, 1024)
+    m = int(counter[0])
+    assert xyzs.shape[0] == m + 128 - m % 128 and dirs.shape == xyzs.shape and deltas.shape == (xyzs.shape[0], 2)
+    assert rays.shape == (512, 3) and rays.dtype == torch.int32
+    # mean_count > 0: M = mean_count rounded up by align, no trimming, overflowing rays dropped
+    mc = m // 2
+    counter.zero_()
+    x2, _, _, r2 = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, counter, mc, False, 128, False, 0, 1024)
+    assert x2.shape[0] == mc + 128 - mc % 128
+    assert torch.equal(r2, rays)
+    # force_all_rays ignores mean_count
+    counter.zero_()
+    x3, _, _, _ = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, counter, mc, False, 128, True, 0, 1024)
+    assert x3.shape[0] == xyzs.shape[0]
+    # step_counter=None allocates its own
+    x4, _, _, _ = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars)
+    assert x4.shape[0] == m  # align = -1: no rounding
+
+
+def test_composite_autograd_matches_torch_restatement():
+    o, d, bits = _rays(256, 1)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0])
+    nears, fars = RM.near_far_from_aabb(o, d, aabb, 0.2)
+    xyzs, dirs, deltas, rays = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)
+    M = xyzs.shape[0]
+    g = torch.Generator().manual_seed(0)
+    sig = torch.exp(torch.rand(M, generator=g) * 6 - 2).requires_grad_(True)
+    rgb = torch.rand(M, 3, generator=g).requires_grad_(True)
+    ws, depth, img = RM.composite_rays_train(sig, rgb, deltas, rays)
+    tgt = torch.rand(256, 3, generator=g)
+    loss = ((img + (1 - ws)[:, None] * 0.3 - tgt) ** 2).sum() + depth.sum() * 0.0
+    loss.backward()
+    s2, r2 = sig.detach().double().requires_grad_(True), rgb.detach().double().requires_grad_(True)
+    ws_l, img_l = [], []
+    for n in range(256):
+        a, c = int(rays[n, 1]), int(rays[n, 2])
+        al = 1 - torch.exp(-s2[a:a + c] * deltas[a:a + c, 0].double())
+        T = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.float64), 1 - al]), 0)[:-1]
+        ws_l.append((al * T).sum()); img_l.append(((al * T)[:, None] * r2[a:a + c]).sum(0))
+    ws_t, img_t = torch.stack(ws_l), torch.stack(img_l)
+    ((img_t + (1 - ws_t)[:, None] * 0.3 - tgt.double()) ** 2).sum().backward()
+    assert torch.allclose(img.double(), img_t, atol=2e-6)
+    assert (sig.grad.double() - s2.grad).abs().max() <= 2e-5 * s2.grad.abs().max()
+    assert torch.allclose(rgb.grad.double(), r2.grad, atol=1e-5)
+
+
+def _hash_model(training=True, seed=0):
+    torch.manual_seed(seed)
+    opt = PVDConfig(model_type="hash", num_rays=512)
+    opt.stage_iters = {"stage1": -1, "stage2": -1}
+    m = make_model(OPS, opt, "hash", False, "cpu")
+    install_occupancy(m, ChairScene(), opt)
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)  # something to see
+    return m.train(training), opt
+
+
+def test_run_cuda_train_and_inference_branches_agree():
+    m, opt = _hash_model()
+    o, d, _ = _rays(512, 2)
+    with torch.no_grad():
+        tr = m.render(o, d, staged=False, bg_color=1, perturb=False, force_all_rays=True, max_steps=1024)
+        m.eval()
+        ev = m.render(o, d, staged=False, bg_color=1, perturb=False, max_steps=1024)
+    assert tr["image"].shape == (1, 512, 3) and ev["depth"].shape == (1, 512)
+    # same samples, same network; inference stops a ray once T < 1e-4 (raymarching.cu:886) -> <= 1e-4 apart
+    assert (tr["image"] - ev["image"]).abs().max() < 2e-4
+    assert "inherited_params" in tr and len(tr["inherited_params"]) == 4 and tr["rays"].shape == (512, 3)
+
+
+def test_update_extra_state_and_mark_untrained_grid():
+    torch.manual_seed(0)
+    m, opt = _hash_model()
+    scene = ChairScene()
+    m.density = lambda x: {"sigma": scene.sigma(x)}  # analytic field instead of the network
+    m.density_grid.zero_(); m.density_bitfield.zero_(); m.iter_density = 0
+    m.step_counter[:4, 0] = torch.tensor([100, 200, 300, 400], dtype=torch.int32); m.local_step = 4
+    m.update_extra_state()
+    assert m.mean_count == 250 and m.local_step == 0 and m.iter_density == 1
+    occ = m.density_grid[0] > 0
+    ref = scene.density_grid(128, 1.0, 1)[0] > 0
+    assert (occ & ~ref).sum() == 0 and occ.sum() > 0.5 * ref.sum()  # jittered point samples: subset of the conservative grid
+    thresh = min(m.mean_density, opt.density_thresh)
+    assert torch.equal(m.density_bitfield, packbits_torch(m.density_grid, thresh))
+    g1 = m.density_grid.clone()
+    m.iter_density = 16  # partial branch
+    m.update_extra_state()
+    assert (m.density_grid >= g1 * 0.95 - 1e-6).all()  # EMA-max never drops a cell by more than the decay
+    # cells outside every camera frustum are marked -1 and stay untouched
+    poses = synthetic_poses(np.random.RandomState(0))[:4]
+    m.density_grid.zero_()
+    m.mark_untrained_grid(poses, BLENDER_INTRINSICS)
+    frac = (m.density_grid < 0).float().mean().item()
+    assert 0.0 < frac < 0.9
+    before = m.density_grid.clone()
+    m.iter_density = 0
+    m.update_extra_state()
+    assert torch.equal(m.density_grid[before < 0], before[before < 0])
+
+
+@pytest.mark.parametrize("student", ["vm", "hash", "mlp", "tensors"])
+def test_distillation_stages_and_loss_decrease(student):
+    opt = PVDConfig(num_rays=256, resolution0=32, iters=50, fp16=False, model_type=student, plenoxel_res="[32,32,32]",
+                    nerf_layer_wide=32, nerf_layer_num=4, skip=1)
+    opt.stage_iters = {"stage1": 2 if student != "tensors" else -1, "stage2": 4}
+    w = DistillWorkload(OPS, "cpu", opt, teacher_pretrain_steps=3, start_stage="stage1")
+    w.trainer.global_step = 0
+    kinds, losses = [], []
+    for it in range(7):
+        loss, info, ps, pt = w.step()
+        kinds.append(tuple(sorted(info)))
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1])
+        if "rgb" in info:
+            assert ps.shape == (1, 256, 3) and pt.shape == (1, 256, 3)
+    if student != "tensors":
+        assert kinds[:2] == [("fea",), ("fea",)]
+    assert kinds[2:4] == [("color", "sigma")] * 2 if student != "tensors" else True
+    assert all(k == ("rgb",) for k in kinds[4:])
+    # the student inherits occupancy + same-shaped weights from the teacher (utils.py:1536-1545)
+    assert torch.equal(w.stu.density_bitfield, w.tea.density_bitfield)
+    if student in ("vm", "hash", "mlp"):
+        assert all(torch.equal(a, b) for a, b in zip(w.tea.color_net.parameters(), w.stu.color_net.parameters())) is False  # trained since
+    # teacher never changes
+    t0 = [p.clone() for p in w.tea.parameters()]
+    w.step()
+    assert all(torch.equal(a, b) for a, b in zip(t0, w.tea.parameters()))
+
+
+def test_stage3_loss_decreases_for_vm_student():
+    opt = PVDConfig(num_rays=512, resolution0=48, iters=200, fp16=False, model_type="vm")
+    w = DistillWorkload(OPS, "cpu", opt, teacher_pretrain_steps=20)
+    first = np.mean([float(w.step()[1]["rgb"]) for _ in range(3)])
+    for _ in range(25):
+        w.step()
+    last = np.mean([float(w.step()[1]["rgb"]) for _ in range(3)])
+    assert last < 0.8 * first, (first, last)
+
+
+def test_teacher_training_improves_psnr():
+    opt = PVDConfig(num_rays=512, iters=100, fp16=False)
+    w0 = DistillWorkload(OPS, "cpu", opt, teacher_pretrain_steps=2)
+    w1 = DistillWorkload(OPS, "cpu", opt, teacher_pretrain_steps=40)
+    assert w1.teacher_psnr > w0.teacher_psnr + 0.5
+
+
+def test_flat_gradient_views_survive_training():
+    opt = PVDConfig(num_rays=128, resolution0=16, iters=10, fp16=False)
+    w = DistillWorkload(OPS, "cpu", opt, teacher_pretrain_steps=0)
+    w.step(); w.step()
+    flat = w.trainer.flat
+    off = 0
+    for p in flat.params:
+        assert p.grad.data_ptr() == flat.flat[off:off + 1].data_ptr()
+        off += p.numel()
+    assert flat.flat.abs().sum() > 0
