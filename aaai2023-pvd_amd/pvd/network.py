@@ -15,6 +15,11 @@ from .encoding import get_encoder
 from .renderer import NeRFRenderer
 
 
+def _channels_last(t):
+    out = torch.empty_strided(t.shape, (t.shape[1] * t.shape[2] * t.shape[3], 1, t.shape[3] * t.shape[1], t.shape[1]), dtype=t.dtype)
+    return out.copy_(t)
+
+
 def _mlp(dims):
     """bias-free Linear stack (network.py:103-152)."""
     return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
@@ -90,8 +95,9 @@ class NeRFNetwork(NeRFRenderer):
         mat, vec = [], []
         for i in range(3):
             m0, m1 = self.mat_ids[i]
-            mat.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[m1], resolution[m0]))))
-            vec.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[self.vec_ids[i]], 1))))
+            # same logical shapes as the reference, stored channels-last ([H][W][R]) for the fused lookup
+            mat.append(nn.Parameter(_channels_last(scale * torch.randn((1, n_component[i], resolution[m1], resolution[m0])))))
+            vec.append(nn.Parameter(_channels_last(scale * torch.randn((1, n_component[i], resolution[self.vec_ids[i]], 1)))))
         return nn.ParameterList(mat), nn.ParameterList(vec)
 
     def _vm_coords(self, x):
@@ -118,6 +124,18 @@ class NeRFNetwork(NeRFRenderer):
         m = torch.cat([F.grid_sample(self.color_mat[i], mat_coord[[i]], align_corners=True).view(-1, N) for i in range(3)], dim=0)
         v = torch.cat([F.grid_sample(self.color_vec[i], vec_coord[[i]], align_corners=True).view(-1, N) for i in range(3)], dim=0)
         return self.basis_mat((m * v).T)
+
+    def vm_features(self, x):
+        """(sigma_feat [N], color_feat [N,15]) for world positions x.  HIP: one fused plane x line lookup
+        (vmencoder) + basis_mat; oracle / reference formulation: the twelve grid_samples above."""
+        vm_encode = getattr(self.ops, "vm_encode", None)
+        if vm_encode is None:
+            xn = self._unit_cube(x)
+            return self.get_sigma_feat(xn), self.get_color_feat(xn)
+        if not hasattr(self, "_aabb_host"):
+            self._aabb_host = tuple(float(v) for v in self.aabb_train.tolist())
+        sigma_feat, prod = vm_encode(x, self._aabb_host, *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+        return sigma_feat, self.basis_mat(prod)
 
     def density_loss(self):
         """L1 on the sigma factors (network.py:549-557)."""
@@ -163,9 +181,9 @@ class NeRFNetwork(NeRFRenderer):
         Side outputs kept for the distillation losses: feature_sigma_color, sigma_l, color_l."""
         a = self.args
         if self.model_type == "vm":
-            x = self._unit_cube(x)
-            sigma_feat = torch.clamp(self.get_sigma_feat(x), -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)
-            color_feat = torch.clamp(self.get_color_feat(x), a.sigma_clip_min, a.sigma_clip_max)
+            sigma_raw, color_raw = self.vm_features(x)
+            sigma_feat = torch.clamp(sigma_raw, -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)
+            color_feat = torch.clamp(color_raw, a.sigma_clip_min, a.sigma_clip_max)
             self.feature_sigma_color = torch.cat([sigma_feat.unsqueeze(-1), color_feat], dim=-1)
             if self._in_stage1():
                 return None, None
@@ -206,7 +224,7 @@ class NeRFNetwork(NeRFRenderer):
         """reference: network.py:439-494 (used by update_extra_state)."""
         a = self.args
         if self.model_type == "vm":
-            s = torch.clamp(self.get_sigma_feat(self._unit_cube(x)), a.sigma_clip_min, a.sigma_clip_max)
+            s = torch.clamp(self.vm_features(x)[0], a.sigma_clip_min, a.sigma_clip_max)
             return {"sigma": self.trunc_exp(s)}
         if self.model_type == "tensors":
             h = self.compute_plenoxel_fea(self._unit_cube(x))

@@ -8,6 +8,7 @@ def hip_ops():
     import gridencoder
     import raymarching
     import shencoder
+    import vmencoder
 
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, device_type="cuda", name="hip")

@@ -77,8 +77,13 @@ class FlatGrads:
         off = 0
         for p in self.params:
             assert p.dtype == torch.float32
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = self._view(p, off)
             off += p.numel()
+
+    def _view(self, p, off):
+        # same strides as the parameter (VM factors are channels-last): fused AdamW requires params and
+        # grads to share one memory layout, and autograd then accumulates without a re-layout
+        return torch.as_strided(self.flat, p.size(), p.stride(), storage_offset=off)
 
     def zero_(self):
         self.flat.zero_()
@@ -86,7 +91,7 @@ class FlatGrads:
         off = 0
         for p in self.params:
             if p.grad is None or p.grad.data_ptr() != self.flat[off:off + 1].data_ptr():
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                p.grad = self._view(p, off)
             off += p.numel()
 
 

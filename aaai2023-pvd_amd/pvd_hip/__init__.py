@@ -46,6 +46,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
+    "pvd_vm_forward", "pvd_vm_backward",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -287,6 +288,52 @@ def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
     dev = _dev(grad, inputs, dy_dx, grad_inputs)
     _f32_all(grad=grad, inputs=inputs, dy_dx=dy_dx, grad_inputs=grad_inputs)
     _call("pvd_sh_encode_backward", dev, _p(grad), _p(inputs), _u32(B), _u32(D), _u32(C), _p(dy_dx), _p(grad_inputs))
+
+
+# --------------------------------------------------------------------------- VM plane x line lookup
+def _host_ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _vm_common(xyz, aabb_host, tables, res):
+    if len(tables) != 12:
+        raise PvdHipError("expected 12 factor tensors: sigma_mat[3], sigma_vec[3], color_mat[3], color_vec[3]")
+    dev = _dev(xyz)
+    _want(xyz, torch.float32, "xyz")
+    for t in tables:
+        if not t.is_cuda or t.device != dev or t.dtype != torch.float32:
+            raise PvdHipError("VM factors must be float32 tensors on the same HIP device")
+    aabb = (ctypes.c_float * 6)(*[float(v) for v in aabb_host])
+    resa = (ctypes.c_uint32 * 3)(*[int(v) for v in res])
+    return dev, aabb, resa
+
+
+def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod):
+    """tables: 12 channels-last factor tensors (physical [H][W][R] / [L][R]); see include/pvd_hip.h."""
+    dev, aabb, resa = _vm_common(xyz, aabb_host, tables, res)
+    _dev(sigma_feat, color_prod)
+    _want(sigma_feat, torch.float32, "sigma_feat")
+    dt = _table_dtype(color_prod, "color_prod")
+    _check(_invoke("pvd_vm_forward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat), _p(color_prod),
+                   _int(dt), meta=(xyz.shape[0], dt)), "pvd_vm_forward")
+
+
+def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, grad_tables):
+    dev, aabb, resa = _vm_common(xyz, aabb_host, tables, res)
+    _dev(grad_sigma_feat, grad_color_prod)
+    _want(grad_sigma_feat, torch.float32, "grad_sigma_feat")
+    dt = _table_dtype(grad_color_prod, "grad_color_prod")
+    for t in grad_tables:
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise PvdHipError("VM gradient buffers must be float32 HIP tensors")
+    _check(_invoke("pvd_vm_backward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
+                   _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), meta=(xyz.shape[0], dt)), "pvd_vm_backward")
+
+
+vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_backward)
 
 
 raymarching_backend = types.SimpleNamespace(

@@ -1,0 +1,51 @@
+"""Autograd wrapper of the fused VM lookup (reference formulation: network.py:216-309)."""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+
+def is_channels_last(t):
+    """[1,R,H,W] stored as [H][W][R] (for lines [1,R,L,1]: [L][R])."""
+    return t.dim() == 4 and t.shape[0] == 1 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_channels_last_param(t):
+    """Same logical shape (state-dict compatible), channels-last storage."""
+    out = torch.empty_strided(t.shape, (t.shape[1] * t.shape[2] * t.shape[3], 1, t.shape[3] * t.shape[1], t.shape[1]),
+                              dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
+
+
+def make_vm_encode(backend, device_type="cuda"):
+    class _VMEncode(Function):
+        """(xyz [M,3], aabb [6], sigma_mat x3, sigma_vec x3, color_mat x3, color_vec x3)
+        -> sigma_feat [M] (f32), color_prod [M,144] (f16 under autocast, else f32)."""
+
+        @staticmethod
+        @custom_fwd(device_type=device_type)
+        def forward(ctx, xyz, aabb_host, *tables):
+            xyz = xyz.contiguous().float()
+            tabs = [t if is_channels_last(t) else to_channels_last_param(t.detach()) for t in tables]
+            res = [0, 0, 0]
+            # mat_i is [1,R,res[m1],res[m0]], vec_i [1,R,res[vec_id],1] (network.py:199-212)
+            res[0], res[1] = tabs[0].shape[3], tabs[0].shape[2]
+            res[2] = tabs[1].shape[2]
+            M = xyz.shape[0]
+            half = torch.is_autocast_enabled(device_type)
+            sigma_feat = torch.empty(M, dtype=torch.float32, device=xyz.device)
+            color_prod = torch.empty(M, 144, dtype=torch.float16 if half else torch.float32, device=xyz.device)
+            backend.vm_forward(xyz, aabb_host, tabs, res, sigma_feat, color_prod)
+            ctx.save_for_backward(xyz, *tabs)
+            ctx.aabb_host, ctx.res = aabb_host, res
+            return sigma_feat, color_prod
+
+        @staticmethod
+        @custom_bwd(device_type=device_type)
+        def backward(ctx, g_sigma, g_prod):
+            xyz, *tabs = ctx.saved_tensors
+            grads = [torch.zeros_like(t) for t in tabs]  # preserves the channels-last strides
+            backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(), grads)
+            return (None, None, *grads)
+
+    return _VMEncode.apply

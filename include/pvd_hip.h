@@ -153,6 +153,29 @@ int pvd_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint3
 int pvd_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float *dy_dx, float *grad_inputs, pvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * VM (TensoRF plane x line) feature lookup -- in the reference this is torch code, not a native
+ * module: NeRFNetwork.get_sigma_feat / get_color_feat (distill_mutual/network.py:216-309), i.e.
+ * 12 F.grid_sample(align_corners=True) calls + products; tables from init_one_vm (:193-214).
+ *
+ * xyz [M,3] f32 device, un-normalised; aabb_host[6] HOST floats (aabb_train; x_n = 2(x-lo)/(hi-lo)-1,
+ * network.py:345-350).  tables_host[12]: HOST array of DEVICE pointers
+ *   {sigma_mat[0..2], sigma_vec[0..2], color_mat[0..2], color_vec[0..2]},
+ * each factor in CHANNELS-LAST order: plane i is [H_i][W_i][R], line i is [L_i][R] with
+ * R = 16 (sigma) / 48 (colour), W_i = res[m0_i], H_i = res[m1_i], L_i = res[vec_id_i],
+ * mat_ids = {{0,1},{0,2},{1,2}}, vec_ids = {2,1,0}; res_host[3] HOST uint32.
+ * sigma_feat [M] f32; color_prod [M,144] prod_dtype (f32, or f16 when the caller runs under AMP:
+ * the products feed basis_mat, an autocast-to-half Linear).
+ * ---------------------------------------------------------------------- */
+int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
+                   const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, pvd_stream_t stream);
+
+/* grad_tables_host[12]: HOST array of DEVICE pointers laid out like tables_host, f32, accumulated into
+ * with atomics (zero-filled by the caller, or a gradient buffer to accumulate into). */
+int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
+                    const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
+                    void *const *grad_tables_host, pvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
