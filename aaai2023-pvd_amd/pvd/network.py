@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from .activation import make_trunc_exp
 from .encoding import get_encoder
+from .linear import make_skinny_linear
 from .renderer import NeRFRenderer
 
 
@@ -38,6 +39,7 @@ class NeRFNetwork(NeRFRenderer):
         self.opt = args
         self.model_type = model_type
         self.trunc_exp = make_trunc_exp(ops.device_type)
+        self.linear = make_skinny_linear(ops.device_type)  # F.linear with a split-K weight gradient
         self.plenoxel_degree = args.plenoxel_degree
         self.plenoxel_res = ast.literal_eval(args.plenoxel_res) if isinstance(args.plenoxel_res, str) else list(args.plenoxel_res)
         assert len(self.plenoxel_res) == 3
@@ -135,7 +137,7 @@ class NeRFNetwork(NeRFRenderer):
         if not hasattr(self, "_aabb_host"):
             self._aabb_host = tuple(float(v) for v in self.aabb_train.tolist())
         sigma_feat, prod = vm_encode(x, self._aabb_host, *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
-        return sigma_feat, self.basis_mat(prod)
+        return sigma_feat, self.linear(prod, self.basis_mat.weight)
 
     def density_loss(self):
         """L1 on the sigma factors (network.py:549-557)."""
@@ -170,7 +172,7 @@ class NeRFNetwork(NeRFRenderer):
     def _color_head(self, enc_d, feat):
         h = torch.cat([enc_d, feat], dim=-1)
         for l in range(self.num_layers_color):
-            h = self.color_net[l](h)
+            h = self.linear(h, self.color_net[l].weight)
             if l != self.num_layers_color - 1:
                 h = F.relu(h, inplace=True)
         return torch.sigmoid(h)
@@ -206,7 +208,7 @@ class NeRFNetwork(NeRFRenderer):
 
         h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)
         for l in range(self.num_layers):
-            h = self.sigma_net[l](h)
+            h = self.linear(h, self.sigma_net[l].weight)
             if l != self.num_layers - 1:
                 h = F.relu(h, inplace=True)
         # channel 0 is log-density, clamped; written in place like the reference (network.py:418-420)
@@ -231,7 +233,7 @@ class NeRFNetwork(NeRFRenderer):
             return {"sigma": self.trunc_exp(h[..., 0])}  # the reference's second, unclamped assignment wins (:481)
         h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)
         for l in range(self.num_layers):
-            h = self.sigma_net[l](h)
+            h = self.linear(h, self.sigma_net[l].weight)
             if l != self.num_layers - 1:
                 h = F.relu(h, inplace=True)
         h = torch.clamp(h, a.sigma_clip_min, a.sigma_clip_max)

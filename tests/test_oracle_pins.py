@@ -402,3 +402,55 @@ def test_inference_composite_matches_train_composite_when_nothing_terminates():
     # the training one t relative to the first sample (:542,557): they differ by weights_sum * near
     hit = rays[:, 2] > 0
     np.testing.assert_allclose(dep[hit], dep_t[hit] + ws_t[hit] * n[hit], atol=3e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ model of the HIP marcher's exact lattice jump
+def _lattice_advance_model(t, dt, n):
+    """numpy-float32 transcription of lattice_advance() in aaai2023-pvd_amd/csrc/raymarching.hip."""
+    f32 = np.float32
+    bits = lambda v: int(np.array(v, dtype=np.float32).view(np.uint32))
+    fb = lambda b: np.array(b, dtype=np.uint32).view(np.float32)[()]
+    t, dt = f32(t), f32(dt)
+    while n > 0:
+        t1 = f32(t + dt); n -= 1
+        if n == 0:
+            return t1
+        t2 = f32(t1 + dt)
+        b1, b2 = bits(t1), bits(t2)
+        if (b1 >> 23) != (b2 >> 23):
+            t = t1
+            continue
+        n -= 1
+        if n == 0:
+            return t2
+        t3 = f32(t2 + dt)
+        b3 = bits(t3)
+        if (b3 >> 23) != (b2 >> 23):
+            t = t2
+            continue
+        c = b3 - b2
+        if c == 0:
+            return t2
+        kmax = ((((b2 >> 23) + 1) << 23) - 1 - b2) // c
+        k = min(n, kmax)
+        t = fb(b2 + k * c)
+        n -= k
+    return t
+
+
+def test_lattice_advance_model():
+    """The wave-parallel marcher evaluates t_k = fl(...fl(fl(t0+dt)+dt)...) for all lanes at once with an
+    integer jump; this pins the jump rule against serial float32 accumulation (incl. ties, crossings)."""
+    f32 = np.float32
+    rng = np.random.RandomState(0)
+    bits = lambda v: int(np.array(v, dtype=np.float32).view(np.uint32))
+    for trial in range(4000):
+        t0 = f32(rng.uniform(0.0, 8.0)) if trial % 3 else f32(2.0 ** rng.randint(-3, 4) - rng.uniform(0, 0.05))
+        dt = f32(2 * f32(1.7320508075688772) / f32(rng.choice([1024, 512, 256, 1000, 777, 4096, 64])))
+        if trial % 7 == 0:  # dt whose remainder is exactly half an ulp two binades up: forces the tie rule
+            dt = np.array((bits(dt) & ~0x3ff) | 0x200, dtype=np.uint32).view(np.float32)[()]
+        n = int(rng.randint(0, 300))
+        t = t0
+        for _ in range(n):
+            t = f32(t + dt)
+        assert bits(_lattice_advance_model(t0, dt, n)) == bits(t), (t0, dt, n)
