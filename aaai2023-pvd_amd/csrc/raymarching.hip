@@ -327,6 +327,10 @@ __device__ __forceinline__ float lattice_advance(float t, float dt, uint32_t n) 
 }
 
 __device__ __forceinline__ uint64_t lanes_from(uint32_t lane) { return lane >= 64 ? 0ull : (~0ull << lane); }
+// __builtin_amdgcn_readlane is an INT builtin: a float argument would be value-converted (truncated)
+__device__ __forceinline__ float readlane_f(float v, uint32_t lane) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)lane));
+}
 
 template <bool WRITE>
 __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float far, uint32_t limit, uint32_t lane,
@@ -373,7 +377,7 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
                 emitted += run;
                 cur = e;
             } else {
-                const float tt_cur = __builtin_amdgcn_readlane(tt, cur);
+                const float tt_cur = readlane_f(tt, cur);
                 const uint64_t ge = __ballot(!(t < tt_cur)) & lanes_from(cur + 1);
                 if (ge == 0) {
                     pending = true;
@@ -398,10 +402,10 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
                 deltas[2 * k] = dtp;
                 deltas[2 * k + 1] = t_after - (below ? prev_after : last_t);
             }
-            last_t = __builtin_amdgcn_readlane(t_after, 63 - __clzll((long long)emit_mask));
+            last_t = readlane_f(t_after, 63u - (uint32_t)__clzll((long long)emit_mask));
         }
         if (done) break;
-        t_base = __builtin_amdgcn_readlane(t_after, 63);
+        t_base = readlane_f(t_after, 63);
     }
     return emitted;
 }

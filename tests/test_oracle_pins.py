@@ -454,3 +454,95 @@ def test_lattice_advance_model():
         for _ in range(n):
             t = f32(t + dt)
         assert bits(_lattice_advance_model(t0, dt, n)) == bits(t), (t0, dt, n)
+
+
+def _probe_model(t, o, d, rd, bits):
+    """float32 transcription of Dda::probe_impl<true> for bound = 1, C = 1, H = 128 (raymarching.hip)."""
+    f32 = np.float32
+    p = np.clip((np.float64(t) * d.astype(np.float64) + o).astype(np.float32), -1, 1)  # fmaf
+    cell = np.clip((0.5 * (p + f32(1)).astype(np.float64) * 128).astype(np.float32), 0, 127).astype(np.int32)
+    m = int(oracle.morton3D(cell[None])[0])
+    occ = bool((bits[m // 8] >> (m % 8)) & 1)
+    sgn = np.copysign(f32(1), d).astype(np.float32)
+    face = ((cell.astype(np.float32) + f32(0.5) + f32(0.5) * sgn) * f32(1 / 128) * f32(2) - f32(1)).astype(np.float32)
+    tt = f32(t + max(f32(0), ((face - p).astype(np.float32) * rd).astype(np.float32).min()))
+    return occ, tt, p
+
+
+def _march_ray_wave_model(t0, far, limit, o, d, bits, dt):
+    """Python model of march_ray_wave<WRITE> in raymarching.hip: 64 lattice points per round, control flow
+    replayed on the occupancy / skip-target 'ballots'.  Returns [(xyz, dt, t_after - last_t)]."""
+    f32 = np.float32
+    rd = (f32(1) / d).astype(np.float32)
+    out, emitted, last_t, t_base = [], 0, t0, t0
+    pending, pending_tt = False, f32(0)
+    if limit == 0:
+        return out
+    while True:
+        ts = [_lattice_advance_model(t_base, dt, k) for k in range(64)]
+        after = [f32(t + dt) for t in ts]
+        valid = [bool(t < far) for t in ts]
+        pr = [_probe_model(t, o, d, rd, bits) if v else (False, f32(0), None) for t, v in zip(ts, valid)]
+        occ = [v and p[0] for v, p in zip(valid, pr)]
+        cur, done, emit = 0, False, []
+        if pending:
+            ge = [k for k in range(64) if not (ts[k] < pending_tt)]
+            if not ge:
+                cur = 64
+                done = not valid[63]
+            else:
+                cur, pending = ge[0], False
+        while cur < 64 and not done:
+            if not valid[cur]:
+                done = True
+                break
+            if occ[cur]:
+                e = cur
+                while e < 64 and occ[e]:
+                    e += 1
+                run, room = e - cur, limit - emitted
+                if run >= room:
+                    run, done = room, True
+                emit += list(range(cur, cur + run))
+                emitted += run
+                cur = e
+            else:
+                tt = pr[cur][1]
+                ge = [k for k in range(cur + 1, 64) if not (ts[k] < tt)]
+                if not ge:
+                    pending, pending_tt, cur = True, tt, 64
+                    done = not valid[63]
+                else:
+                    cur = ge[0]
+        for k in emit:
+            out.append((pr[k][2], dt, f32(after[k] - last_t)))
+            last_t = after[k]
+        if done:
+            return out
+        t_base = after[63]
+
+
+def test_wave_marcher_model_equals_serial_oracle():
+    """The HIP marcher's wave-parallel formulation (lattice + ballot replay) selects exactly the samples the
+    serial reference loop does -- checked here in a float32 Python model against the C oracle, ray by ray."""
+    o, d, bits, _ = _scene(96, 6)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n, f = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n, f, 96 * 1024, perturb=1)
+    _, t0f = oracle.pcg32_stream(42, 0, 1)
+    dt = np.float32(2) * np.float32(1.7320508075688772) / np.float32(1024)
+    checked = 0
+    for ray in range(96):
+        if f[ray] == np.finfo(np.float32).max:
+            assert rays[ray, 2] == 0
+            continue
+        noise = oracle.pcg32_stream(42, ray, 1)[1][0]
+        t0 = np.float32(n[ray] + dt * noise)
+        for limit in (1024, 5):
+            got = _march_ray_wave_model(t0, f[ray], limit, o[ray], d[ray], bits, dt)
+            s, c = rays[ray, 1], min(rays[ray, 2], limit)
+            assert len(got) == c, (ray, len(got), c)
+            for k, (p, dtk, dl1) in enumerate(got):
+                assert np.array_equal(p, xyzs[s + k]) and dtk == deltas[s + k, 0] and dl1 == deltas[s + k, 1], (ray, k)
+        checked += 1
+    assert checked > 10 and counter[0] > 500
