@@ -117,6 +117,9 @@ class _TrainerBase:
         params = model.get_params(lr)
         fused = self.device_type == "cuda"
         # reference: AdamW(betas=(0.9, 0.99), eps=1e-15), default weight decay (main_distill_mutual.py:334-339)
+        if fused:  # device-side lr so that a captured step sees the schedule (LRScheduler fills tensor lrs in place)
+            for g in params:
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
         self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused)
         if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
             self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
@@ -126,14 +129,68 @@ class _TrainerBase:
         self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
         self.global_step = 0
 
-    def _backward_and_step(self, loss):
+    def _backward(self, loss):
         self.scaler.scale(loss).backward()
+
+    def _exchange(self):
         if self.dp.enabled:
             self.dp.all_reduce_sum_(self.flat.flat)  # one bucket, SUM (losses are already global objectives)
+
+    def _optimize(self):
         self.scaler.step(self.optimizer)
         self.scaler.update()
+
+    def _backward_and_step(self, loss):
+        self._backward(loss)
+        self._exchange()
+        self._optimize()
         self.scheduler.step()
         self.global_step += 1
+
+    # ---- hipGraph capture of the step (launch-bound otherwise: ~330 kernels of a few us each)
+    def capture(self, body, warmup=3):
+        """Capture `body()` (forward + loss + backward [+ optimizer]) into HIP graphs.  Single GPU: one graph
+        for the whole step.  Ray-DP: forward/backward graph, eager RCCL all-reduce, optimizer graph.
+        Everything that changes per step lives on the device (lr tensors, loss-rate tensor, pose index,
+        RNG state), so a replay is a faithful step."""
+        assert self.device_type == "cuda"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.flat.zero_()
+                out = body()
+                self._backward(out[0])
+                self._exchange()
+                self._optimize()
+                self.scheduler.step()
+                self.global_step += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fwd = torch.cuda.CUDAGraph()
+        self._g_opt = None
+        with torch.cuda.graph(self._g_fwd):
+            self.flat.zero_()
+            self._static_out = body()
+            self._backward(self._static_out[0])
+            if not self.dp.enabled:
+                self._optimize()
+        if self.dp.enabled:
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=self._g_fwd.pool()):
+                self._optimize()
+        self.scheduler.step()
+        self.global_step += 1
+        return self._static_out
+
+    def replay(self):
+        self._g_fwd.replay()
+        if self._g_opt is not None:
+            self._exchange()
+            self._g_opt.replay()
+        self.scheduler.step()
+        self.global_step += 1
+        return self._static_out
 
 
 class DistillTrainer(_TrainerBase):
@@ -148,7 +205,8 @@ class DistillTrainer(_TrainerBase):
         self.model_tea = model_tea.train()  # `training` selects the train branch of run_cuda; teacher is frozen
         self.model_stu = model_stu.train()
         self.loss = _make_loss(opt.loss_type, self.dp)
-        self.loss_rate_fea_sc = opt.loss_rate_fea_sc
+        self.loss_rate_fea_sc = opt.loss_rate_fea_sc  # host shadow (only used for the > 0 tests)
+        self.fea_rate = torch.tensor(float(opt.loss_rate_fea_sc), dtype=torch.float32, device=self.device)  # decays on device
 
     def render_kwargs(self):
         o = self.opt
@@ -163,13 +221,14 @@ class DistillTrainer(_TrainerBase):
             out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                                  inherited_params=out_stu["inherited_params"], **kw)
         self.loss_rate_fea_sc *= 0.995  # decays every step (utils.py:1044)
+        self.fea_rate.mul_(0.995)
         have_fea = stu.feature_sigma_color is not None and tea.feature_sigma_color is not None
         info = {}
         loss = 0.0
         if "stage1" in out_stu and self.loss_rate_fea_sc > 0.0 and have_fea:
             l_fea = self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
             info["fea"] = l_fea.detach()
-            return loss + self.loss_rate_fea_sc * l_fea, info, None, None
+            return loss + self.fea_rate * l_fea, info, None, None
         if "stage2" in out_stu:
             l_col = self.loss(stu.color_l, tea.color_l)
             l_sig = self.loss(stu.sigma_l, tea.sigma_l)
@@ -178,7 +237,7 @@ class DistillTrainer(_TrainerBase):
             if o.loss_rate_sigma > 0.0:
                 loss = loss + o.loss_rate_sigma * l_sig
             if self.loss_rate_fea_sc > 0.0 and have_fea:
-                loss = loss + self.loss_rate_fea_sc * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
+                loss = loss + self.fea_rate * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
             info.update(color=l_col.detach(), sigma=l_sig.detach())
             return loss, info, None, None
 
@@ -193,7 +252,7 @@ class DistillTrainer(_TrainerBase):
         if o.l1_reg_weight > 0.0 and o.model_type == "vm":
             loss = loss + stu.density_loss() * (o.l1_reg_weight / self.dp.world_size)  # parameter-only term: not per shard
         if self.loss_rate_fea_sc > 0.0 and have_fea:
-            loss = loss + self.loss_rate_fea_sc * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
+            loss = loss + self.fea_rate * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
         if o.loss_rate_color > 0.0:
             loss = loss + o.loss_rate_color * self.loss(stu.color_l, tea.color_l)
         if o.loss_rate_sigma > 0.0:
@@ -206,6 +265,25 @@ class DistillTrainer(_TrainerBase):
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color)
         self._backward_and_step(loss)
+        return loss.detach(), info, pred_stu, pred_tea
+
+    def capture_step(self, batch_fn):
+        """Capture `batch_fn() -> (rays_o, rays_d, bg)` + the whole step into HIP graph(s); the stage
+        (which loss terms exist) is frozen at capture time, so re-capture when the stage changes."""
+        def body():
+            rays_o, rays_d, bg = batch_fn()
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                return self.compute_loss(rays_o, rays_d, bg)
+        self._captured_stage = self._stage_of(self.global_step)
+        return self.capture(body)
+
+    def _stage_of(self, step):
+        st = self.opt.stage_iters
+        return 1 if step < st["stage1"] else (2 if step < st["stage2"] else 3)
+
+    def replay_step(self):
+        assert self._stage_of(self.global_step) == self._captured_stage, "stage changed: capture_step() again"
+        loss, info, pred_stu, pred_tea = self.replay()
         return loss.detach(), info, pred_stu, pred_tea
 
 

@@ -135,5 +135,24 @@ class DistillWorkload:
         bg = torch.rand(1, opt.num_rays, 3, device=self.device, generator=self.gen)
         return r["rays_o"], r["rays_d"], bg
 
+    def device_batch(self):
+        """next_batch() with nothing on the host: pose index and RNG state live on the device, so the batch
+        generation can sit inside a captured HIP graph (default CUDA generator, graph-safe)."""
+        opt = self.opt
+        if not hasattr(self, "_pose_idx"):
+            self._pose_idx = torch.zeros(1, dtype=torch.long, device=self.device)
+        pose = self.poses.index_select(0, self._pose_idx)
+        self._pose_idx.add_(1).remainder_(len(self.poses))
+        r = get_rays(pose, BLENDER_INTRINSICS, 800, 800, opt.num_rays)
+        bg = torch.rand(1, opt.num_rays, 3, device=self.device)
+        return r["rays_o"], r["rays_d"], bg
+
+    def enable_graph(self):
+        """Whole-step hipGraph capture (GPU only)."""
+        self.trainer.capture_step(self.device_batch)
+        self._graph = True
+
     def step(self):
+        if getattr(self, "_graph", False):
+            return self.trainer.replay_step()
         return self.trainer.train_step(*self.next_batch())
