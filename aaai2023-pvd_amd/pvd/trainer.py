@@ -120,7 +120,7 @@ class _TrainerBase:
         if fused:  # device-side lr so that a captured step sees the schedule (LRScheduler fills tensor lrs in place)
             for g in params:
                 g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
-        self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused)
+        self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused, capturable=fused)
         if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
             self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
         else:  # student: cosine to eta_min (main_distill_mutual.py:346-348)
@@ -165,6 +165,7 @@ class _TrainerBase:
                 self._optimize()
                 self.scheduler.step()
                 self.global_step += 1
+                del out  # drop the autograd graph of the warm-up pass before capturing
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g_fwd = torch.cuda.CUDAGraph()
