@@ -180,9 +180,7 @@ class _TrainerBase:
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=self._g_fwd.pool()):
                 self._optimize()
-        self.scheduler.step()
-        self.global_step += 1
-        return self._static_out
+        return self._static_out  # capturing records, it does not run: no step was consumed
 
     def replay(self):
         self._g_fwd.replay()

@@ -43,11 +43,11 @@ def test_graph_and_eager_agree_on_the_same_batches():
     wb.stu.load_state_dict(wa.stu.state_dict()); wb.tea.load_state_dict(wa.tea.state_dict())
     wb.stu.mean_count = wa.stu.mean_count
     torch.cuda.manual_seed(11)
-    wa.enable_graph()          # consumes 3 warm-up steps + 1 captured step
+    wa.enable_graph()          # runs 3 warm-up steps; the capture pass itself only records
     la = [float(wa.step()[0]) for _ in range(3)]
     torch.cuda.manual_seed(11)
     lb = []
-    for _ in range(4 + 3):
+    for _ in range(3 + 3):
         lb.append(float(wb.trainer.train_step(*wb.device_batch())[0]))
-    # the first captured replay corresponds to eager step index 4 (3 warm-up + capture pass)
-    assert np.allclose(la, lb[4:7], rtol=5e-2), (la, lb)
+    # the first replay corresponds to eager step index 3 (after the 3 warm-up steps)
+    assert np.allclose(la, lb[3:6], rtol=1e-3), (la, lb)
