@@ -67,6 +67,26 @@ __global__ void __launch_bounds__(kBlock) k_polar(const float *__restrict__ rays
     coords[2 * (size_t)n + 1] = phi * kRPi;
 }
 
+
+// reference: get_rays, distill_mutual/utils.py:324-404 (pixel-centre directions through K^-1, normalise,
+// rotate by the camera-to-world pose).  One thread per ray instead of ~20 elementwise launches.
+__global__ void __launch_bounds__(kBlock) k_get_rays(const float *__restrict__ pose, float fx, float fy, float cx, float cy,
+                                                     const int64_t *__restrict__ inds, uint32_t W, uint32_t N,
+                                                     float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int64_t k = inds ? inds[n] : (int64_t)n;
+    const float i = (float)(k % W) + 0.5f, j = (float)(k / W) + 0.5f;
+    const float x = (i - cx) / fx, y = (j - cy) / fy, z = 1.0f;
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+    const float dx = x * inv, dy = y * inv, dz = z * inv;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        rays_d[3 * (size_t)n + r] = dx * pose[4 * r] + dy * pose[4 * r + 1] + dz * pose[4 * r + 2];
+        rays_o[3 * (size_t)n + r] = pose[4 * r + 3];
+    }
+}
+
 // reference: kernel_morton3D / kernel_morton3D_invert, raymarching.cu:216-256
 __global__ void __launch_bounds__(kBlock) k_morton3D(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
@@ -773,6 +793,14 @@ int pvd_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(rays_o && rays_d && aabb && nears && fars);
     hipLaunchKernelGGL(k_near_far, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch();
+}
+
+int pvd_get_rays(const float *pose, float fx, float fy, float cx, float cy, const int64_t *inds, uint32_t W, uint32_t N,
+                 float *rays_o, float *rays_d, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(pose && rays_o && rays_d && W > 0);
+    hipLaunchKernelGGL(k_get_rays, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, inds, W, N, rays_o, rays_d);
     return check_launch();
 }
 

@@ -3,12 +3,25 @@ test-suite builds the same namespace around the CPU oracle (tests/oracle_ops.py)
 never constructs anything but the HIP set."""
 import types
 
+import torch
+
 
 def hip_ops():
     import gridencoder
     import raymarching
+    import pvd_hip
     import shencoder
     import vmencoder
 
+    def get_rays_fused(pose, intrinsics, H, W, N):
+        """reference: get_rays (utils.py:324-404) for one pose: randint pixel ids + one HIP kernel."""
+        dev = pose.device
+        inds = torch.randint(0, H * W, size=[N], device=dev)  # may duplicate, like the reference
+        rays_o = torch.empty(1, N, 3, device=dev)
+        rays_d = torch.empty(1, N, 3, device=dev)
+        fx, fy, cx, cy = intrinsics
+        pvd_hip.get_rays(pose.reshape(4, 4).contiguous(), fx, fy, cx, cy, inds, W, N, rays_o, rays_d)
+        return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
+
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, device_type="cuda", name="hip")

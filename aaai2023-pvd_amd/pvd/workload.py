@@ -143,7 +143,8 @@ class DistillWorkload:
             self._pose_idx = torch.zeros(1, dtype=torch.long, device=self.device)
         pose = self.poses.index_select(0, self._pose_idx)
         self._pose_idx.add_(1).remainder_(len(self.poses))
-        r = get_rays(pose, BLENDER_INTRINSICS, 800, 800, opt.num_rays)
+        fused = getattr(self.ops, "get_rays", None)
+        r = fused(pose, BLENDER_INTRINSICS, 800, 800, opt.num_rays) if fused else get_rays(pose, BLENDER_INTRINSICS, 800, 800, opt.num_rays)
         bg = torch.rand(1, opt.num_rays, 3, device=self.device)
         return r["rays_o"], r["rays_d"], bg
 

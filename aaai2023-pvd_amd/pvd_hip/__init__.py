@@ -46,7 +46,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -159,6 +159,14 @@ def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
     dev = _dev(rays_o, rays_d, aabb, nears, fars)
     _f32_all(rays_o=rays_o, rays_d=rays_d, aabb=aabb, nears=nears, fars=fars)
     _call("pvd_near_far_from_aabb", dev, _p(rays_o), _p(rays_d), _p(aabb), _u32(N), _f32(min_near), _p(nears), _p(fars))
+
+
+def get_rays(pose, fx, fy, cx, cy, inds, W, N, rays_o, rays_d):
+    dev = _dev(pose, inds, rays_o, rays_d)
+    _f32_all(pose=pose, rays_o=rays_o, rays_d=rays_d)
+    if inds is not None:
+        _want(inds, torch.int64, "inds")
+    _call("pvd_get_rays", dev, _p(pose), _f32(fx), _f32(fy), _f32(cx), _f32(cy), _p(inds), _u32(W), _u32(N), _p(rays_o), _p(rays_d))
 
 
 def polar_from_ray(rays_o, rays_d, radius, N, coords):
@@ -337,7 +345,7 @@ vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_
 
 
 raymarching_backend = types.SimpleNamespace(
-    near_far_from_aabb=near_far_from_aabb, polar_from_ray=polar_from_ray, morton3D=morton3D,
+    get_rays=get_rays, near_far_from_aabb=near_far_from_aabb, polar_from_ray=polar_from_ray, morton3D=morton3D,
     morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
     composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward,

@@ -62,6 +62,12 @@ const char *pvd_last_hip_error(void);
 int pvd_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
                            uint32_t N, float min_near, float *nears, float *fars, pvd_stream_t stream);
 
+/* get_rays -- torch code in the reference: distill_mutual/utils.py:324-404.  pose [4,4] f32 row-major cam2world
+ * (device), intrinsics by value, inds [N] i64 flat pixel ids (k = row*W + col) or NULL for k = n.
+ * rays_o, rays_d [N,3] f32.  d = normalise(((i+.5-cx)/fx, (j+.5-cy)/fy, 1)) rotated by pose[:3,:3]. */
+int pvd_get_rays(const float *pose, float fx, float fy, float cx, float cy, const int64_t *inds, uint32_t W, uint32_t N,
+                 float *rays_o, float *rays_d, pvd_stream_t stream);
+
 /* polar_from_ray -- raymarching.cu:203-211 (kernel :164-200).  coords [N,2]. */
 int pvd_polar_from_ray(const float *rays_o, const float *rays_d, float radius,
                        uint32_t N, float *coords, pvd_stream_t stream);

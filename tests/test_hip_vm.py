@@ -81,3 +81,16 @@ def test_vm_layout_is_channels_last_and_state_dict_compatible():
     sd = {k: v.contiguous() for k, v in hip.state_dict().items()}  # a reference-style (channel-major) checkpoint
     hip.load_state_dict(sd)
     assert hip.sigma_mat[0].permute(0, 2, 3, 1).is_contiguous()  # load_state_dict copies in place: layout survives
+
+
+def test_fused_get_rays_matches_torch_formulation():
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    dev = torch.device("cuda:0")
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
+    torch.manual_seed(0)
+    r = hip_ops().get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, 4096)
+    ref = get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, 4096, inds=r["inds"][0])
+    assert torch.equal(r["rays_o"], ref["rays_o"].contiguous())
+    assert (r["rays_d"] - ref["rays_d"]).abs().max().item() < 3e-7
+    assert torch.allclose(r["rays_d"].norm(dim=-1), torch.ones(1, 4096, device=dev), atol=1e-6)
