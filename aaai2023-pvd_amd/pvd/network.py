@@ -22,11 +22,17 @@ def _channels_last(t):
 
 
 class _L1MeanSum(torch.autograd.Function):
+    _inv_cache = {}
+
     @staticmethod
     def forward(ctx, *tensors):
         ctx.save_for_backward(*tensors)
         norms = torch._foreach_norm(list(tensors), 1)
-        inv = torch.tensor([1.0 / t.numel() for t in tensors], dtype=torch.float32, device=tensors[0].device)
+        key = (tensors[0].device, tuple(t.numel() for t in tensors))
+        inv = _L1MeanSum._inv_cache.get(key)
+        if inv is None:  # created once, outside any graph capture (no H2D copy inside a captured step)
+            inv = torch.tensor([1.0 / t.numel() for t in tensors], dtype=torch.float32, device=tensors[0].device)
+            _L1MeanSum._inv_cache[key] = inv
         ctx.inv = inv
         return (torch.stack(norms).float() * inv).sum()
 
