@@ -1,0 +1,131 @@
+"""Ray data parallelism on 2 CPU processes (gloo): the N > 1 path of bench.py / DistillTrainer.
+
+What must hold for "shard the rays, all-reduce the flat gradient bucket (SUM)" to be the same
+optimisation as one process on all rays:
+  * norm-type losses are global norms (sum of squares all-reduced before the sqrt) with the right
+    per-shard gradient; mean-type losses are global means; parameter-only terms are not multiplied by G;
+  * after the all-reduce every rank holds the full-batch gradient, and replicas stay bit-identical.
+Runs the real trainer on the CPU oracle operators (no GPU here); RCCL replaces gloo on the GPU box.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_paths():
+    for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _make(opt_kw, dp=None):
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.workload import DistillWorkload
+    opt = PVDConfig(**opt_kw)
+    torch.manual_seed(0)
+    return DistillWorkload(oracle_ops(), "cpu", opt, teacher_pretrain_steps=0, seed=0, dp=dp)
+
+
+OPT = dict(num_rays=256, resolution0=24, iters=50, fp16=False, model_type="vm",
+           loss_rate_fea_sc=0.0, loss_rate_color=0.0, loss_rate_sigma=0.0)  # rgb norm + L1 reg: independent of row padding
+
+
+def _worker(rank, world, port, out_path):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from pvd.trainer import RayDP
+    dp = RayDP()
+    assert dp.enabled and dp.world_size == world and dp.rank == rank
+
+    # --- collective helpers against closed forms
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(world * 100, 7, generator=g)
+    mine = full[rank * 100:(rank + 1) * 100].clone().requires_grad_(True)
+    n = dp.global_norm_l2(mine)
+    assert torch.allclose(n, full.norm(), rtol=1e-6)
+    n.backward()
+    assert torch.allclose(mine.grad, (full / full.norm())[rank * 100:(rank + 1) * 100], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(dp.global_mean(mine.detach()), full.mean(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(dp.global_norm_l1(mine.detach()), full.abs().sum(), rtol=1e-5)
+
+    # --- the real trainer: every rank renders its half of the rays
+    w = _make(OPT, dp=dp)
+    base = _make(OPT)  # only for the shared batch (same seed on every rank)
+    rays_o, rays_d, bg = base.next_batch()
+    half = OPT["num_rays"] // world
+    sl = slice(rank * half, (rank + 1) * half)
+    p0 = [p.detach().clone() for p in w.stu.parameters()]
+    loss, info, _, _ = w.trainer.train_step(rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous())
+    flat = w.trainer.flat.flat.clone()
+    # replicas identical after the step
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    params = torch.cat([p.detach().reshape(-1) for p in w.stu.parameters()])
+    gp = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gp, params)
+    assert all(torch.equal(gp[0], t) for t in gp)
+    if rank == 0:
+        torch.save({"loss": float(loss), "flat": flat, "rgb": float(info["rgb"])}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ray_dp_two_ranks_equals_single_process(tmp_path):
+    _setup_paths()
+    port = _free_port()
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    dp_res = torch.load(out)
+
+    # single process, same two shards (the marcher's perturbation is a function of the ray's index INSIDE a
+    # launch, raymarching.cu:352, so the shards -- not the concatenated batch -- are the comparable unit):
+    # one autograd graph over both shards with the loss written on the concatenation
+    w = _make(OPT)
+    base = _make(OPT)
+    rays_o, rays_d, bg = base.next_batch()
+    tr, stu, tea = w.trainer, w.stu, w.tea
+    tr.opt.global_step = tr.global_step
+    tr.flat.zero_()
+    diffs = []
+    half = OPT["num_rays"] // 2
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        o, d, b = rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous()
+        out_s = stu.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024)
+        with torch.no_grad():
+            out_t = tea.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False,
+                               inherited_params=out_s["inherited_params"], dt_gamma=0, max_steps=1024)
+        diffs.append(out_t["image"] - out_s["image"])
+    l_rgb = torch.norm(torch.cat(diffs, dim=1))
+    loss = l_rgb * tr.opt.loss_rate_rgb + stu.density_loss() * tr.opt.l1_reg_weight
+    loss.backward()
+    flat = tr.flat.flat
+    assert abs(float(l_rgb.detach()) - dp_res["rgb"]) <= 1e-5 * abs(dp_res["rgb"]), (float(l_rgb), dp_res["rgb"])
+    # a rank's reported loss carries 1/G of the parameter-only L1 term (its gradients are summed over ranks)
+    l1 = float(stu.density_loss().detach()) * tr.opt.l1_reg_weight
+    assert abs((float(loss.detach()) - l1 / 2) - dp_res["loss"]) <= 1e-5 * abs(dp_res["loss"])
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
