@@ -1,0 +1,331 @@
+// fusedhead.hip -- the sigma / colour head as ONE MFMA kernel per direction (gfx950, MI355X).
+//
+// Replaces, per sample, the chain the reference runs as ~5 cuBLAS GEMMs + ~15 elementwise launches
+// (distill_mutual/network.py:335-437 under autocast):
+//   hash model : enc[28] -> sigma_net (28->64 relu ->16) -> clamp h0 -> feature_sigma_color[16]
+//   VM model   : prod[144] -> basis_mat (144->15) -> clamp ; sigma_feat clamp -> feature_sigma_color[16]
+//   both       : sigma = exp(h0);  rgb = sigmoid(color_net([SH_4(d) (16), h1..15] : 31->64 relu->64 relu->3))
+//
+// MFMA formulation.  v_mfma_f32_16x16x16_f16 computes D = A.B + C with per-lane fragments
+//   A[16x16]: lane l holds A[row = l&15][k = 4*(l>>4)+j]      (4 halfs)
+//   B[16x16]: lane l holds B[k = 4*(l>>4)+j][col = l&15]      (4 halfs)
+//   D[16x16]: lane l holds D[row = 4*(l>>4)+j][col = l&15]    (4 floats)
+// We compute Y^T = W . X^T: A = a 16x16 tile of the weight matrix (rows = output neurons), B = 16
+// features x 16 SAMPLES, so a D tile holds 4 consecutive neurons of one sample per lane -- which is
+// exactly the B fragment the NEXT layer needs for its k-step.  Activations therefore never leave
+// registers between layers: no LDS round trip, no shuffles.  A wavefront owns 16 samples at a time.
+// Weights are read from the fp32 masters, rounded to f16 exactly like autocast's cast, and kept in LDS
+// (<= 22 KB per workgroup) with +4 halfs of row padding (conflict-free 8-byte fragment reads).
+// Layer outputs are rounded to f16 between layers (what a chain of autocast Linear layers does).
+//
+// Index bookkeeping that keeps the layers lane-aligned:
+//   * the colour layer's input is [SH(16) | h1..h15]; we feed k-step 1 with the whole 16-row feature tile
+//     (h0 = log-sigma included) and give column 16 a ZERO weight, columns 17..31 the weights of h1..h15;
+//   * the VM basis layer (144->15) is stored with a zero ROW 0, so its output tile is [0, cf0..cf14] and
+//     row 0 is then replaced by the clamped sigma feature: same tile shape as the hash model's h.
+//
+// The backward kernel (student) recomputes the forward in registers, chains W^T . dY the same way, and
+// forms the weight gradients dW = dY . X^T with MFMAs whose operands are 16x16 transposes of the
+// register tiles (through a 512-byte LDS scratch per wave); dW tiles live in accumulators for the whole
+// launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
+#include "pvd_device.h"
+
+namespace pvd {
+
+#include "sh_basis.inc"
+
+typedef _Float16 half_t;
+typedef half_t h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kHeadBlock = 256;  // 4 independent waves sharing the weights in LDS
+constexpr int kPad = 4;               // halfs of LDS row padding
+
+__device__ __forceinline__ f4 mfma(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ h4 to_h4(f4 v) {
+    h4 r;
+    r.x = (half_t)v.x; r.y = (half_t)v.y; r.z = (half_t)v.z; r.w = (half_t)v.w;
+    return r;
+}
+__device__ __forceinline__ h4 relu_h4(h4 v) {
+    const half_t z = (half_t)0.0f;
+    h4 r;
+    r.x = v.x > z ? v.x : z; r.y = v.y > z ? v.y : z; r.z = v.z > z ? v.z : z; r.w = v.w > z ? v.w : z;
+    return r;
+}
+
+// ---- weights in LDS: row-major [rows_pad][cols_pad + kPad] halfs, built from fp32 masters
+struct LdsMat {
+    half_t *p;
+    int stride;  // cols_pad + kPad
+    __device__ __forceinline__ h4 afrag(int tile, int kstep, uint32_t lane) const {  // A fragment of W
+        return *reinterpret_cast<const h4 *>(p + (16 * tile + (lane & 15)) * stride + 16 * kstep + 4 * (lane >> 4));
+    }
+};
+
+// dst[r][c] = (r in [r0, r0+rows) and mapped col valid) ? half(src[r-r0][col_map(c)]) : 0
+// col_shift: columns >= col_split of dst take src column (c - 1)   (the colour layer's zero column 16)
+__device__ __forceinline__ void load_weight(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
+                                            int row0, int col_split, uint32_t tid, uint32_t nthreads) {
+    for (int i = tid; i < rows_pad * cols_pad; i += nthreads) {
+        const int r = i / cols_pad, c = i - r * cols_pad;
+        float v = 0.f;
+        const int sr = r - row0;
+        int sc = c;
+        bool ok = sr >= 0 && sr < rows;
+        if (col_split >= 0) {
+            if (c == col_split) ok = false;
+            else if (c > col_split) sc = c - 1;
+        }
+        if (ok && sc < cols) v = src[(size_t)sr * cols + sc];
+        m.p[r * m.stride + c] = (half_t)v;
+    }
+}
+// transposed copy: dst[c][r] (for the backward's W^T . dY)
+__device__ __forceinline__ void load_weight_T(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
+                                              int row0, int col_split, uint32_t tid, uint32_t nthreads) {
+    for (int i = tid; i < rows_pad * cols_pad; i += nthreads) {
+        const int r = i / cols_pad, c = i - r * cols_pad;
+        float v = 0.f;
+        const int sr = r - row0;
+        int sc = c;
+        bool ok = sr >= 0 && sr < rows;
+        if (col_split >= 0) {
+            if (c == col_split) ok = false;
+            else if (c > col_split) sc = c - 1;
+        }
+        if (ok && sc < cols) v = src[(size_t)sr * cols + sc];
+        m.p[c * m.stride + r] = (half_t)v;
+    }
+}
+
+struct HeadArgs {
+    // inputs
+    const half_t *x0;        // hash: encoder output [14][M][2] f16 (level-major);  VM: products [M][144] f16
+    const float *sigma_raw;  // VM: [M] raw sigma feature
+    const float *dirs;       // [M][3]
+    uint32_t M;
+    // fp32 master weights, row-major [out][in]
+    const float *Wa1;  // hash: sigma_net.0 [64][28]   VM: basis_mat [15][144]
+    const float *Wa2;  // hash: sigma_net.1 [16][64]   VM: unused
+    const float *Wc1;  // color_net.0 [64][31]
+    const float *Wc2;  // color_net.1 [64][64]
+    const float *Wc3;  // color_net.2 [3][64]
+    float clip_sigma_min, clip_feat_min, clip_max;
+    // outputs
+    float *sigma;   // [M]
+    float *rgb;     // [M][3]
+    float *feat16;  // [M][16]  feature_sigma_color
+};
+
+constexpr int KIND_HASH = 0, KIND_VM = 1;
+
+// the 4 SH values k = 4*hi + j of a degree-4 basis for direction d (all 16 computed, 4 kept)
+__device__ __forceinline__ h4 sh_frag(const float *__restrict__ dirs, size_t b, bool valid, uint32_t hi) {
+    float o[16];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) { x = dirs[3 * b]; y = dirs[3 * b + 1]; z = dirs[3 * b + 2]; }
+    pvd_sh_basis<4, false>(x, y, z, [&](int i, float v) { o[i] = v; }, [&](int, float, float, float) {});
+    h4 r;
+    r.x = (half_t)(hi == 0 ? o[0] : hi == 1 ? o[4] : hi == 2 ? o[8] : o[12]);
+    r.y = (half_t)(hi == 0 ? o[1] : hi == 1 ? o[5] : hi == 2 ? o[9] : o[13]);
+    r.z = (half_t)(hi == 0 ? o[2] : hi == 1 ? o[6] : hi == 2 ? o[10] : o[14]);
+    r.w = (half_t)(hi == 0 ? o[3] : hi == 1 ? o[7] : hi == 2 ? o[11] : o[15]);
+    return r;
+}
+
+// everything the forward produces for one 16-sample tile, in registers
+struct TileFwd {
+    f4 F;        // feature tile rows 4hi..4hi+3 (row 0 = clamped log-sigma), fp32 copy for the output
+    h4 Fh;       // same as the next layer's B fragment
+    f4 raw;      // VM: pre-clamp basis output (for the clamp's backward mask)
+    float sig_raw;
+    h4 sh;       // SH fragment
+    h4 H1[4], H2[4];
+    f4 out;      // colour layer 3 pre-activation (rows 0..2 valid)
+};
+
+template <int KIND>
+struct HeadLds {
+    LdsMat Wa1, Wa2, Wc1, Wc2, Wc3;
+    static constexpr int a1_rows = KIND == KIND_HASH ? 64 : 16, a1_cols = KIND == KIND_HASH ? 32 : 144;
+    static constexpr int halfs = a1_rows * (a1_cols + kPad) + (KIND == KIND_HASH ? 16 * (64 + kPad) : 0) + 64 * (32 + kPad) +
+                                 64 * (64 + kPad) + 16 * (64 + kPad);
+    __device__ __forceinline__ void carve(half_t *base) {
+        Wa1 = {base, a1_cols + kPad}; base += a1_rows * (a1_cols + kPad);
+        if (KIND == KIND_HASH) { Wa2 = {base, 64 + kPad}; base += 16 * (64 + kPad); }
+        else Wa2 = {base, 0};
+        Wc1 = {base, 32 + kPad}; base += 64 * (32 + kPad);
+        Wc2 = {base, 64 + kPad}; base += 64 * (64 + kPad);
+        Wc3 = {base, 64 + kPad};
+    }
+    __device__ __forceinline__ void load(const HeadArgs &a, uint32_t tid, uint32_t n) {
+        if (KIND == KIND_HASH) {
+            load_weight(Wa1, a.Wa1, 64, 28, 64, 32, 0, -1, tid, n);
+            load_weight(Wa2, a.Wa2, 16, 64, 16, 64, 0, -1, tid, n);
+        } else {
+            load_weight(Wa1, a.Wa1, 15, 144, 16, 144, /*row0=*/1, -1, tid, n);  // zero row 0
+        }
+        load_weight(Wc1, a.Wc1, 64, 31, 64, 32, 0, /*zero column*/ 16, tid, n);
+        load_weight(Wc2, a.Wc2, 64, 64, 64, 64, 0, -1, tid, n);
+        load_weight(Wc3, a.Wc3, 3, 64, 16, 64, 0, -1, tid, n);
+    }
+};
+
+template <int KIND>
+__device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, size_t b, bool valid, uint32_t lane, TileFwd &t) {
+    const uint32_t hi = lane >> 4;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    // ---- stage A: features -> 16-row feature tile
+    if (KIND == KIND_HASH) {
+        h4 X[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            X[s] = (h4){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+            const int k0 = 16 * s + 4 * hi;  // features k0..k0+3 = levels k0/2, k0/2+1 (2 channels each)
+            if (valid && k0 < 28) {
+                const uint32_t lv = k0 >> 1;
+                const uint32_t u0 = *reinterpret_cast<const uint32_t *>(a.x0 + ((size_t)lv * a.M + b) * 2);
+                const uint32_t u1 = *reinterpret_cast<const uint32_t *>(a.x0 + ((size_t)(lv + 1) * a.M + b) * 2);
+                uint32_t w[2] = {u0, u1};
+                __builtin_memcpy(&X[s], w, 8);
+            }
+        }
+        h4 Ha[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            f4 acc = zero;
+#pragma unroll
+            for (int s = 0; s < 2; s++) acc = mfma(W.Wa1.afrag(n, s, lane), X[s], acc);
+            Ha[n] = relu_h4(to_h4(acc));
+        }
+        f4 acc = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = mfma(W.Wa2.afrag(0, s, lane), Ha[s], acc);
+        h4 Fh = to_h4(acc);  // Linear output is f16
+        if (hi == 0) {
+            const float c = fminf(a.clip_max, fmaxf(a.clip_sigma_min, (float)Fh.x));
+            Fh.x = (half_t)c;
+        }
+        t.Fh = Fh;
+        t.F = (f4){(float)Fh.x, (float)Fh.y, (float)Fh.z, (float)Fh.w};
+        t.raw = zero;
+        t.sig_raw = 0.f;
+    } else {
+        f4 acc = zero;
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            h4 x = (h4){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+            if (valid) x = *reinterpret_cast<const h4 *>(a.x0 + b * 144 + 16 * s + 4 * hi);
+            acc = mfma(W.Wa1.afrag(0, s, lane), x, acc);
+        }
+        const h4 rawh = to_h4(acc);  // basis_mat output, f16
+        t.raw = (f4){(float)rawh.x, (float)rawh.y, (float)rawh.z, (float)rawh.w};
+        f4 F;
+        F.x = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.x));
+        F.y = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.y));
+        F.z = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.z));
+        F.w = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.w));
+        t.sig_raw = 0.f;
+        if (hi == 0) {
+            t.sig_raw = valid ? a.sigma_raw[b] : 0.f;
+            F.x = fminf(a.clip_max, fmaxf(a.clip_sigma_min, t.sig_raw));  // row 0 := clamped sigma feature (fp32)
+        }
+        t.F = F;
+        t.Fh = to_h4(F);
+    }
+    // ---- stage B: colour head
+    t.sh = sh_frag(a.dirs, b, valid, hi);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        f4 acc = zero;
+        acc = mfma(W.Wc1.afrag(n, 0, lane), t.sh, acc);
+        acc = mfma(W.Wc1.afrag(n, 1, lane), t.Fh, acc);  // column 16 (log-sigma) has zero weight
+        t.H1[n] = relu_h4(to_h4(acc));
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        f4 acc = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = mfma(W.Wc2.afrag(n, s, lane), t.H1[s], acc);
+        t.H2[n] = relu_h4(to_h4(acc));
+    }
+    f4 acc = zero;
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = mfma(W.Wc3.afrag(0, s, lane), t.H2[s], acc);
+    t.out = acc;
+}
+
+__device__ __forceinline__ float sigmoid_h(float pre) {
+    // Linear output rounded to f16, sigmoid evaluated in fp32, result rounded to f16 (torch.sigmoid on a half tensor)
+    const float x = (float)(half_t)pre;
+    return (float)(half_t)(1.0f / (1.0f + __expf(-x)));
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(kHeadBlock) k_head_fwd(HeadArgs a) {
+    extern __shared__ __align__(16) half_t lds[];
+    HeadLds<KIND> W;
+    W.carve(lds);
+    W.load(a, threadIdx.x, kHeadBlock);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
+    const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
+    const uint32_t nwaves = gridDim.x * (kHeadBlock / 64);
+    const uint32_t ntiles = div_up(a.M, 16u);
+    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t b = (size_t)tile * 16 + (lane & 15);
+        const bool valid = b < a.M;
+        TileFwd t;
+        head_forward_tile<KIND>(a, W, b, valid, lane, t);
+        if (valid) {
+            *reinterpret_cast<f4 *>(a.feat16 + b * 16 + 4 * hi) = t.F;
+            if (hi == 0) {
+                a.sigma[b] = __expf(t.F.x);
+                a.rgb[3 * b] = sigmoid_h(t.out.x);
+                a.rgb[3 * b + 1] = sigmoid_h(t.out.y);
+                a.rgb[3 * b + 2] = sigmoid_h(t.out.z);
+            }
+        }
+    }
+}
+
+template <int KIND>
+static int launch_head_fwd(const HeadArgs &a, hipStream_t s) {
+    const uint32_t ntiles = div_up(a.M, 16u);
+    uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
+    if (blocks > 1024) blocks = 1024;  // 256 CUs x 4; every workgroup pays one weight load
+    const size_t lds_bytes = HeadLds<KIND>::halfs * sizeof(half_t);
+    hipLaunchKernelGGL((k_head_fwd<KIND>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a);
+    return check_launch();
+}
+
+}  // namespace pvd
+
+using namespace pvd;
+
+extern "C" {
+
+int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1,
+                     const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, float clip_sigma_min,
+                     float clip_feat_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
+    if (M == 0) return PVD_OK;
+    if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
+    HeadArgs a;
+    a.x0 = (const half_t *)x0; a.sigma_raw = sigma_raw; a.dirs = dirs; a.M = M;
+    a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_feat_min; a.clip_max = clip_max;
+    a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16;
+    if (kind == KIND_HASH) {
+        if (!Wa2) return PVD_ERR_INVALID;
+        return launch_head_fwd<KIND_HASH>(a, (hipStream_t)stream);
+    }
+    if (kind == KIND_VM) {
+        if (!sigma_raw) return PVD_ERR_INVALID;
+        return launch_head_fwd<KIND_VM>(a, (hipStream_t)stream);
+    }
+    return PVD_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

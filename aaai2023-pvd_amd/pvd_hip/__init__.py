@@ -46,7 +46,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -342,6 +342,15 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
 
 
 vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_backward)
+
+
+# --------------------------------------------------------------------------- fused sigma / colour head
+def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, sigma, rgb, feat16):
+    dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16)
+    _want(x0, torch.float16, "x0")
+    _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
+    _call("pvd_head_forward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
+          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
 
 
 raymarching_backend = types.SimpleNamespace(

@@ -182,6 +182,24 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
                     const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
                     void *const *grad_tables_host, pvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused sigma / colour head (MFMA).  Torch code in the reference: NeRFNetwork.forward,
+ * distill_mutual/network.py:335-437 (sigma_net :103-118, color_net :135-152, basis_mat :88-90, trunc_exp,
+ * SH degree 4) evaluated under autocast(fp16).  kind 0 = hash model, 1 = VM model.
+ *   x0: kind 0: grid-encoder output [14][M][2] f16 (the level-major layout pvd_grid_encode_forward writes);
+ *       kind 1: plane x line products [M][144] f16 (pvd_vm_forward).
+ *   sigma_raw [M] f32 (kind 1 only), dirs [M][3] f32.
+ *   Wa1/Wa2: kind 0: sigma_net.0 [64][28], sigma_net.1 [16][64]; kind 1: basis_mat [15][144], NULL.
+ *   Wc1 [64][31], Wc2 [64][64], Wc3 [3][64]: color_net.  All weights fp32 masters, row-major [out][in];
+ *   they are rounded to f16 inside the kernel exactly like autocast's cast.
+ *   clip_*: args.sigma_clip_min / sigma_clip_max (network.py:353-362, 418-420).
+ * Outputs: sigma [M] = exp(clamped log-sigma), rgb [M][3], feat16 [M][16] = feature_sigma_color (all f32).
+ * ---------------------------------------------------------------------- */
+int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
+                     const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
+                     float clip_sigma_min, float clip_feat_min, float clip_max,
+                     float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
