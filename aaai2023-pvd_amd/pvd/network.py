@@ -162,10 +162,13 @@ class NeRFNetwork(NeRFRenderer):
         if vm_encode is None:
             xn = self._unit_cube(x)
             return self.get_sigma_feat(xn), self.get_color_feat(xn)
-        if not hasattr(self, "_aabb_host"):
-            self._aabb_host = tuple(float(v) for v in self.aabb_train.tolist())
-        sigma_feat, prod = vm_encode(x, self._aabb_host, *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+        sigma_feat, prod = vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
         return sigma_feat, self.linear(prod, self.basis_mat.weight)
+
+    def _aabb(self):
+        if not hasattr(self, "_aabb_host"):
+            self._aabb_host = tuple(float(v) for v in self.aabb_train.tolist())  # one D2H copy, cached
+        return self._aabb_host
 
     def density_loss(self):
         """L1 on the sigma factors: sum_i mean|sigma_mat_i| + mean|sigma_vec_i| (network.py:549-557), as two
@@ -204,10 +207,33 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(h)
 
     # ------------------------------------------------------------------ forward / density
+    def _fused_ok(self, x):
+        fh = getattr(self.ops, "fused_head", None)
+        return fh is not None and x.is_cuda and torch.is_autocast_enabled("cuda") and self.bg_net is None
+
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] unit -> (sigma [N], rgb [N,3]); reference network.py:335-437.
         Side outputs kept for the distillation losses: feature_sigma_color, sigma_l, color_l."""
         a = self.args
+        if self._fused_ok(x):
+            fh = self.ops.fused_head
+            out = None
+            if self.model_type == "hash" and not torch.is_grad_enabled():
+                out = fh.hash_head_infer(self, x, d)  # frozen teacher / inference: encoder + whole head, 2 launches
+            elif self.model_type == "vm" and not torch.is_grad_enabled():
+                sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+                out = fh.vm_head_infer(self, sraw, prod, d)
+            elif self.model_type == "vm" and hasattr(fh, "vm_head_train"):
+                sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+                out = fh.vm_head_train(self, sraw, prod, d)
+            if out is not None:
+                sigma, color, feat = out
+                self.feature_sigma_color = feat
+                if self._in_stage1():
+                    return None, None
+                self.sigma_l = feat[..., 0]
+                self.color_l = color
+                return sigma, color
         if self.model_type == "vm":
             sigma_raw, color_raw = self.vm_features(x)
             sigma_feat = torch.clamp(sigma_raw, -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)

@@ -9,6 +9,7 @@ import torch
 def hip_ops():
     import gridencoder
     import raymarching
+    import fusedhead
     import pvd_hip
     import shencoder
     import vmencoder
@@ -24,4 +25,4 @@ def hip_ops():
         return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
 
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, device_type="cuda", name="hip")

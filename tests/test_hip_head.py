@@ -68,6 +68,6 @@ def test_vm_head_matches_layerwise_autocast(M):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         sig_r, rgb_r = m(x, d)
         feat_r = m.feature_sigma_color
-        sraw, prod = m.ops.vm_encode(x, m._aabb_host, *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
+        sraw, prod = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
     sig, rgb, feat = fusedhead.vm_head_infer(m, sraw, prod, d)
     _check(sig, rgb, feat, sig_r, rgb_r, feat_r)

@@ -17,9 +17,12 @@ def _models(res, seed=0):
     torch.manual_seed(seed)
     opt = PVDConfig(model_type="vm", resolution0=res)
     dev = torch.device("cuda:0")
-    hip = make_model(hip_ops(), opt, "vm", False, dev)
+    h_ops = hip_ops()
+    h_ops.fused_head = None  # this file tests the lookup kernel, not the fused head
+    hip = make_model(h_ops, opt, "vm", False, dev)
     ref_ops = hip_ops()
     ref_ops.vm_encode = None  # reference formulation (torch grid_sample) on the same weights
+    ref_ops.fused_head = None
     ref = make_model(ref_ops, opt, "vm", False, dev)
     ref.load_state_dict(hip.state_dict())
     return hip, ref
