@@ -301,6 +301,215 @@ static int launch_head_fwd(const HeadArgs &a, hipStream_t s) {
     return check_launch();
 }
 
+
+// ====================================================================== backward (VM student)
+
+constexpr int kDwTilesB = 9, kDwTilesC1 = 8, kDwTilesC2 = 16, kDwTilesC3 = 4;
+constexpr int kDwTiles = kDwTilesB + kDwTilesC1 + kDwTilesC2 + kDwTilesC3;  // 37 accumulator tiles per wave
+constexpr int kDwFloats = kDwTiles * 256;
+
+struct HeadBwdArgs {
+    HeadArgs f;
+    const float *g_sigma;   // [M]      d loss / d sigma
+    const float *g_rgb;     // [M][3]
+    const float *g_feat16;  // [M][16]
+    float *g_sigma_raw;     // [M]
+    half_t *g_prod;         // [M][144]
+    float *partials;        // [nwaves][kDwFloats]
+};
+
+// 16x16 transpose of a register tile through LDS: in = X[row 4hi+j][col l&15]  ->  out = X[row l&15][col 4hi+j]
+__device__ __forceinline__ h4 transpose_tile(h4 v, half_t *__restrict__ scratch, uint32_t lane) {
+    const uint32_t c = lane & 15, hi = lane >> 4;
+    scratch[(4 * hi + 0) * 16 + c] = v.x;
+    scratch[(4 * hi + 1) * 16 + c] = v.y;
+    scratch[(4 * hi + 2) * 16 + c] = v.z;
+    scratch[(4 * hi + 3) * 16 + c] = v.w;
+    __builtin_amdgcn_wave_barrier();
+    const h4 r = *reinterpret_cast<const h4 *>(scratch + c * 16 + 4 * hi);
+    __builtin_amdgcn_wave_barrier();
+    return r;
+}
+
+__device__ __forceinline__ h4 mask_relu(f4 g, h4 act) {  // dPre = dAct * (act > 0), rounded to f16
+    const half_t z = (half_t)0.0f;
+    h4 r;
+    r.x = act.x > z ? (half_t)g.x : z; r.y = act.y > z ? (half_t)g.y : z;
+    r.z = act.z > z ? (half_t)g.z : z; r.w = act.w > z ? (half_t)g.w : z;
+    return r;
+}
+
+__global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
+    extern __shared__ __align__(16) half_t lds[];
+    HeadLds<KIND_VM> W;
+    W.carve(lds);
+    half_t *p = lds + HeadLds<KIND_VM>::halfs;
+    // transposed copies for dX = W^T . dY  (A fragments must be contiguous along the contracted index)
+    LdsMat WbT = {p, 16 + kPad};  p += 144 * (16 + kPad);   // [144][16]
+    LdsMat Wc1T = {p, 64 + kPad}; p += 32 * (64 + kPad);    // [32][64]
+    LdsMat Wc2T = {p, 64 + kPad}; p += 64 * (64 + kPad);    // [64][64]
+    LdsMat Wc3T = {p, 16 + kPad}; p += 64 * (16 + kPad);    // [64][16]
+    half_t *scratch = p + (threadIdx.x >> 6) * 256;          // 512 B per wave
+    W.load(a.f, threadIdx.x, kHeadBlock);
+    load_weight_T(WbT, a.f.Wa1, 15, 144, 16, 144, 1, -1, threadIdx.x, kHeadBlock);
+    load_weight_T(Wc1T, a.f.Wc1, 64, 31, 64, 32, 0, 16, threadIdx.x, kHeadBlock);
+    load_weight_T(Wc2T, a.f.Wc2, 64, 64, 64, 64, 0, -1, threadIdx.x, kHeadBlock);
+    load_weight_T(Wc3T, a.f.Wc3, 3, 64, 16, 64, 0, -1, threadIdx.x, kHeadBlock);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
+    const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
+    const uint32_t nwaves = gridDim.x * (kHeadBlock / 64);
+    const uint32_t ntiles = div_up(a.f.M, 16u);
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const h4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+
+    f4 dWb[kDwTilesB], dW1[kDwTilesC1], dW2[kDwTilesC2], dW3[kDwTilesC3];
+#pragma unroll
+    for (int i = 0; i < kDwTilesB; i++) dWb[i] = zero;
+#pragma unroll
+    for (int i = 0; i < kDwTilesC1; i++) dW1[i] = zero;
+#pragma unroll
+    for (int i = 0; i < kDwTilesC2; i++) dW2[i] = zero;
+#pragma unroll
+    for (int i = 0; i < kDwTilesC3; i++) dW3[i] = zero;
+
+    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t b = (size_t)tile * 16 + (lane & 15);
+        const bool valid = b < a.f.M;
+        TileFwd t;
+        head_forward_tile<KIND_VM>(a.f, W, b, valid, lane, t);
+
+        // ---- d loss / d (colour layer 3 pre-activation): rows 0..2 live in the hi == 0 lanes
+        h4 D3 = hzero;
+        if (valid && hi == 0) {
+            const float s0 = sigmoid_h(t.out.x), s1 = sigmoid_h(t.out.y), s2 = sigmoid_h(t.out.z);
+            D3.x = (half_t)(a.g_rgb[3 * b] * s0 * (1.0f - s0));
+            D3.y = (half_t)(a.g_rgb[3 * b + 1] * s1 * (1.0f - s1));
+            D3.z = (half_t)(a.g_rgb[3 * b + 2] * s2 * (1.0f - s2));
+        }
+        h4 D2[4], D1[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) D2[n] = mask_relu(mfma(Wc3T.afrag(n, 0, lane), D3, zero), t.H2[n]);
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            f4 acc = zero;
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc = mfma(Wc2T.afrag(n, s, lane), D2[s], acc);
+            D1[n] = mask_relu(acc, t.H1[n]);
+        }
+        f4 dF = zero;  // rows 16..31 of the colour layer's input = the feature tile (row 16 has zero weights)
+#pragma unroll
+        for (int s = 0; s < 4; s++) dF = mfma(Wc1T.afrag(1, s, lane), D1[s], dF);
+        if (valid) {
+            const f4 gf = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
+            dF.x += gf.x; dF.y += gf.y; dF.z += gf.z; dF.w += gf.w;
+        }
+        // clamp backward: gradient passes where the raw value is inside [min, max]
+        const float lo = a.f.clip_feat_min, hi_c = a.f.clip_max;
+        f4 dcf;
+        dcf.x = (t.raw.x >= lo && t.raw.x <= hi_c) ? dF.x : 0.f;
+        dcf.y = (t.raw.y >= lo && t.raw.y <= hi_c) ? dF.y : 0.f;
+        dcf.z = (t.raw.z >= lo && t.raw.z <= hi_c) ? dF.z : 0.f;
+        dcf.w = (t.raw.w >= lo && t.raw.w <= hi_c) ? dF.w : 0.f;
+        if (hi == 0) {
+            // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
+            // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
+            if (valid) {
+                const float g0 = dF.x + a.g_sigma[b] * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
+                a.g_sigma_raw[b] = (t.sig_raw >= a.f.clip_sigma_min && t.sig_raw <= a.f.clip_max) ? g0 : 0.f;
+            }
+            dcf.x = 0.f;
+        }
+        const h4 Dcf = to_h4(dcf);
+        // ---- d loss / d products = Wb'^T . Dcf, written as the f16 [M][144] the VM backward reads
+#pragma unroll
+        for (int tk = 0; tk < 9; tk++) {
+            const h4 g = to_h4(mfma(WbT.afrag(tk, 0, lane), Dcf, zero));
+            if (valid) *reinterpret_cast<h4 *>(a.g_prod + b * 144 + 16 * tk + 4 * hi) = g;
+        }
+        // ---- weight gradients: dW[n][k] += sum_samples dY[n][s] X[k][s]  (both operands transposed tiles)
+        {
+            const h4 TD3 = transpose_tile(D3, scratch, lane);
+#pragma unroll
+            for (int tk = 0; tk < 4; tk++) dW3[tk] = mfma(TD3, transpose_tile(t.H2[tk], scratch, lane), dW3[tk]);
+        }
+        {
+            h4 TH1[4];
+#pragma unroll
+            for (int tk = 0; tk < 4; tk++) TH1[tk] = transpose_tile(t.H1[tk], scratch, lane);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const h4 TD = transpose_tile(D2[tn], scratch, lane);
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++) dW2[tn * 4 + tk] = mfma(TD, TH1[tk], dW2[tn * 4 + tk]);
+            }
+        }
+        {
+            const h4 TSH = transpose_tile(t.sh, scratch, lane), TF = transpose_tile(t.Fh, scratch, lane);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const h4 TD = transpose_tile(D1[tn], scratch, lane);
+                dW1[tn * 2] = mfma(TD, TSH, dW1[tn * 2]);
+                dW1[tn * 2 + 1] = mfma(TD, TF, dW1[tn * 2 + 1]);
+            }
+        }
+        {
+            const h4 TD = transpose_tile(Dcf, scratch, lane);
+#pragma unroll
+            for (int tk = 0; tk < 9; tk++) {
+                h4 x = hzero;
+                if (valid) x = *reinterpret_cast<const h4 *>(a.f.x0 + b * 144 + 16 * tk + 4 * hi);
+                dWb[tk] = mfma(TD, transpose_tile(x, scratch, lane), dWb[tk]);
+            }
+        }
+    }
+
+    // ---- one partial per wave: [tile][reg j][lane]
+    float *__restrict__ out = a.partials + (size_t)wave * kDwFloats;
+    auto put = [&](int tile, f4 v) {
+        out[(tile * 4 + 0) * 64 + lane] = v.x; out[(tile * 4 + 1) * 64 + lane] = v.y;
+        out[(tile * 4 + 2) * 64 + lane] = v.z; out[(tile * 4 + 3) * 64 + lane] = v.w;
+    };
+#pragma unroll
+    for (int i = 0; i < kDwTilesB; i++) put(i, dWb[i]);
+#pragma unroll
+    for (int i = 0; i < kDwTilesC1; i++) put(kDwTilesB + i, dW1[i]);
+#pragma unroll
+    for (int i = 0; i < kDwTilesC2; i++) put(kDwTilesB + kDwTilesC1 + i, dW2[i]);
+#pragma unroll
+    for (int i = 0; i < kDwTilesC3; i++) put(kDwTilesB + kDwTilesC1 + kDwTilesC2 + i, dW3[i]);
+}
+
+// Sum the per-wave partials and ACCUMULATE into the fp32 gradient buffers (real, un-padded layouts).
+// One thread per real weight element; consecutive threads read consecutive lanes of a tile (coalesced).
+__global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWb,
+                                                       float *__restrict__ gW1, float *__restrict__ gW2, float *__restrict__ gW3) {
+    const uint32_t nB = 15 * 144, n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float *dst;
+    uint32_t tile, n16, k;  // accumulator tile, row inside the 16-row tile, padded column
+    if (i < nB) {
+        const uint32_t r = i / 144, c = i - r * 144;
+        dst = gWb + i; n16 = r + 1; k = c; tile = k >> 4;
+    } else if ((i -= nB) < n1) {
+        const uint32_t r = i / 31, c = i - r * 31;
+        dst = gW1 + i; n16 = r & 15; k = c < 16 ? c : c + 1; tile = kDwTilesB + (r >> 4) * 2 + (k >> 4);
+    } else if ((i -= n1) < n2) {
+        const uint32_t r = i >> 6, c = i & 63;
+        dst = gW2 + i; n16 = r & 15; k = c; tile = kDwTilesB + kDwTilesC1 + (r >> 4) * 4 + (k >> 4);
+    } else if ((i -= n2) < n3) {
+        const uint32_t r = i >> 6, c = i & 63;
+        dst = gW3 + i; n16 = r; k = c; tile = kDwTilesB + kDwTilesC1 + kDwTilesC2 + (k >> 4);
+    } else {
+        return;
+    }
+    const uint32_t off = (tile * 4 + (n16 & 3)) * 64 + (k & 15) + 16 * (n16 >> 2);
+    float acc = 0.f;
+    for (uint32_t w = 0; w < nwaves; w++) acc += partials[(size_t)w * kDwFloats + off];
+    *dst += acc;
+}
+
 }  // namespace pvd
 
 using namespace pvd;
@@ -326,6 +535,40 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
         return launch_head_fwd<KIND_VM>(a, (hipStream_t)stream);
     }
     return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_head_backward_vm_workspace_floats(uint32_t M, uint32_t *nwaves_out) {
+    const uint32_t ntiles = div_up(M, 16u);
+    uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
+    if (blocks > 128) blocks = 128;
+    if (blocks < 1) blocks = 1;
+    if (nwaves_out) *nwaves_out = blocks * (kHeadBlock / 64);
+    return (int)(blocks * (kHeadBlock / 64) * kDwFloats);
+}
+
+int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wb, const float *Wc1,
+                         const float *Wc2, const float *Wc3, float clip_sigma_min, float clip_feat_min, float clip_max,
+                         const float *g_sigma, const float *g_rgb, const float *g_feat16, float *g_sigma_raw, void *g_prod,
+                         float *gWb, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
+    if (M == 0) return PVD_OK;
+    if (!prod || !sigma_raw || !dirs || !Wb || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_sigma_raw || !g_prod ||
+        !gWb || !gWc1 || !gWc2 || !gWc3 || !workspace)
+        return PVD_ERR_INVALID;
+    HeadBwdArgs a;
+    a.f.x0 = (const half_t *)prod; a.f.sigma_raw = sigma_raw; a.f.dirs = dirs; a.f.M = M;
+    a.f.Wa1 = Wb; a.f.Wa2 = nullptr; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
+    a.f.clip_sigma_min = clip_sigma_min; a.f.clip_feat_min = clip_feat_min; a.f.clip_max = clip_max;
+    a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr;
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_prod = (half_t *)g_prod;
+    a.partials = workspace;
+    uint32_t nwaves = 0;
+    (void)pvd_head_backward_vm_workspace_floats(M, &nwaves);
+    const size_t lds_halfs = HeadLds<KIND_VM>::halfs + 144 * (16 + kPad) + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad) +
+                             (kHeadBlock / 64) * 256;
+    hipLaunchKernelGGL(k_head_bwd_vm, dim3(nwaves / (kHeadBlock / 64)), dim3(kHeadBlock), lds_halfs * sizeof(half_t), (hipStream_t)stream, a);
+    const uint32_t nreal = 15 * 144 + 64 * 31 + 64 * 64 + 3 * 64;
+    hipLaunchKernelGGL(k_head_reduce_dw, dim3(div_up(nreal, 256u)), dim3(256), 0, (hipStream_t)stream, workspace, nwaves, gWb, gWc1, gWc2, gWc3);
+    return check_launch();
 }
 
 }  // extern "C"

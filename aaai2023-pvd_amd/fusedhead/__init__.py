@@ -59,3 +59,47 @@ def vm_head_infer(model, sigma_raw, prod, d):
                          _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2]),
                          smin, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat)
     return sigma, rgb, feat
+
+
+class _VMHeadTrain(torch.autograd.Function):
+    """(sigma_raw [M], prod [M,144] f16, dirs, basis_mat.weight, color_net.{0,1,2}.weight) ->
+    (sigma [M], rgb [M,3], feature_sigma_color [M,16]), all f32; one MFMA kernel each way."""
+
+    @staticmethod
+    def forward(ctx, sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3, smin, fmin, cmax):
+        M = prod.shape[0]
+        sigma_raw, prod, dirs = sigma_raw.float().contiguous(), prod.contiguous(), dirs.float().contiguous()
+        sigma, rgb, feat = _outputs(M, prod.device)
+        pvd_hip.head_forward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(),
+                             smin, fmin, cmax, sigma, rgb, feat)
+        ctx.save_for_backward(sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3)
+        ctx.clips = (smin, fmin, cmax)
+        ctx.leaves = (Wb, Wc1, Wc2, Wc3)
+        return sigma, rgb, feat
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb, g_feat):
+        sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3 = ctx.saved_tensors
+        M = prod.shape[0]
+        dev = prod.device
+        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        g_sigma = g_sigma.float().contiguous() if g_sigma is not None else zeros(M)
+        g_rgb = g_rgb.float().contiguous() if g_rgb is not None else zeros(M, 3)
+        g_feat = g_feat.float().contiguous() if g_feat is not None else zeros(M, 16)
+        g_sraw = torch.empty(M, dtype=torch.float32, device=dev)
+        g_prod = torch.empty(M, 144, dtype=torch.float16, device=dev)
+        ws = torch.empty(pvd_hip.head_backward_vm_workspace_floats(M), dtype=torch.float32, device=dev)
+        # accumulate straight into the leaves' gradient buffers when they exist (the trainer's flat bucket)
+        direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
+        grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
+        pvd_hip.head_backward_vm(prod, sigma_raw, dirs, M, Wb.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
+                                 g_sigma, g_rgb, g_feat, g_sraw, g_prod, *grads, ws)
+        gw = (None, None, None, None) if direct else tuple(grads)
+        return (g_sraw, g_prod, None) + gw + (None, None, None)
+
+
+def vm_head_train(model, sigma_raw, prod, d):
+    a = model.args
+    smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
+    return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
+                              model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max)

@@ -47,6 +47,7 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
+    "pvd_head_backward_vm", "pvd_head_backward_vm_workspace_floats",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -351,6 +352,26 @@ def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sig
     _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
     _call("pvd_head_forward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
           _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+
+
+def head_backward_vm_workspace_floats(M):
+    return int(_lib.pvd_head_backward_vm_workspace_floats(_u32(M), ctypes.c_void_p(0)))
+
+
+def head_backward_vm(prod, sigma_raw, dirs, M, Wb, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
+                     g_sigma_raw, g_prod, gWb, gWc1, gWc2, gWc3, workspace):
+    dev = _dev(prod, sigma_raw, dirs, Wb, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_prod, workspace)
+    _want(prod, torch.float16, "prod"), _want(g_prod, torch.float16, "g_prod")
+    _f32_all(sigma_raw=sigma_raw, dirs=dirs, Wb=Wb, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb, g_feat16=g_feat16,
+             g_sigma_raw=g_sigma_raw, gWb=gWb, gWc1=gWc1, gWc2=gWc2, gWc3=gWc3, workspace=workspace)
+    for t in (gWb, gWc1, gWc2, gWc3):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise PvdHipError("weight gradient buffers must be contiguous HIP tensors")
+    if workspace.numel() < head_backward_vm_workspace_floats(M):
+        raise PvdHipError("workspace too small")
+    _call("pvd_head_backward_vm", dev, _p(prod), _p(sigma_raw), _p(dirs), _u32(M), _p(Wb), _p(Wc1), _p(Wc2), _p(Wc3),
+          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_prod),
+          _p(gWb), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
 
 
 raymarching_backend = types.SimpleNamespace(

@@ -200,6 +200,19 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
                      float clip_sigma_min, float clip_feat_min, float clip_max,
                      float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
 
+/* Backward of the VM head (student).  Recomputes the forward from (prod, sigma_raw, dirs), then
+ *   g_sigma_raw [M] f32, g_prod [M][144] f16 (the layout pvd_vm_backward reads), and ACCUMULATES the weight
+ *   gradients into gWb [15][144], gWc1 [64][31], gWc2 [64][64], gWc3 [3][64] (f32, += ).
+ * g_sigma [M], g_rgb [M][3], g_feat16 [M][16]: incoming gradients (f32) of pvd_head_forward's three outputs.
+ * workspace: pvd_head_backward_vm_workspace_floats(M, &nwaves) floats of scratch (per-wave dW partials). */
+int pvd_head_backward_vm_workspace_floats(uint32_t M, uint32_t *nwaves_out);
+int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *dirs, uint32_t M,
+                         const float *Wb, const float *Wc1, const float *Wc2, const float *Wc3,
+                         float clip_sigma_min, float clip_feat_min, float clip_max,
+                         const float *g_sigma, const float *g_rgb, const float *g_feat16,
+                         float *g_sigma_raw, void *g_prod, float *gWb, float *gWc1, float *gWc2, float *gWc3,
+                         float *workspace, pvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,3 +71,72 @@ def test_vm_head_matches_layerwise_autocast(M):
         sraw, prod = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
     sig, rgb, feat = fusedhead.vm_head_infer(m, sraw, prod, d)
     _check(sig, rgb, feat, sig_r, rgb_r, feat_r)
+
+
+def test_vm_head_backward_matches_layerwise_autograd():
+    """Gradients of the fused head (prod, sigma_raw, all four weight matrices) vs autograd through the
+    layer-by-layer autocast formulation on the same inputs."""
+    import fusedhead
+    from pvd.ops import hip_ops
+    m = _model("vm", seed=3).train()
+    M = 16 * 700 + 5
+    x, d = _inputs(M, seed=4)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        sraw0, prod0 = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
+    w_sig = torch.randn(M, device="cuda", generator=g) * 1e-3
+    w_rgb = torch.randn(M, 3, device="cuda", generator=g)
+    w_fea = torch.randn(M, 16, device="cuda", generator=g) * 0.1
+    names = ["basis_mat.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight"]
+    params = dict(m.named_parameters())
+
+    def run(fused):
+        sraw = sraw0.clone().requires_grad_(True)
+        prod = prod0.clone().requires_grad_(True)
+        for n in names:
+            params[n].grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            if fused:
+                sig, rgb, feat = fusedhead.vm_head_train(m, sraw, prod, d)
+            else:
+                a = m.args
+                cf = torch.clamp(m.linear(prod, m.basis_mat.weight), a.sigma_clip_min, a.sigma_clip_max)
+                sf = torch.clamp(sraw, a.sigma_clip_min, a.sigma_clip_max)
+                feat = torch.cat([sf.unsqueeze(-1), cf], dim=-1)
+                sig = m.trunc_exp(sf)
+                rgb = m._color_head(m.encoder_dir(d), cf)
+        loss = (sig.float() * w_sig).sum() + (rgb.float() * w_rgb).sum() + (feat.float() * w_fea).sum()
+        loss.backward()
+        return sraw.grad.clone(), prod.grad.float().clone(), [params[n].grad.clone() for n in names]
+
+    gs_r, gp_r, gw_r = run(False)
+    gs_f, gp_f, gw_f = run(True)
+    assert torch.isfinite(gp_f).all()
+    assert torch.allclose(gs_f, gs_r, rtol=2e-3, atol=1e-6)
+    scale = gp_r.abs().max().item()
+    assert (gp_f - gp_r).abs().max().item() <= 2e-2 * scale, ((gp_f - gp_r).abs().max().item(), scale)
+    assert (gp_f - gp_r).abs().mean().item() <= 2e-3 * gp_r.abs().mean().item() + 1e-8
+    for n, a, b in zip(names, gw_f, gw_r):
+        s = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-2 * s, (n, (a - b).abs().max().item(), s)
+        assert (a - b).abs().mean().item() <= 5e-3 * b.abs().mean().item(), n
+
+
+def test_vm_head_backward_accumulates_into_existing_grads():
+    import fusedhead
+    m = _model("vm", seed=5).train()
+    M = 4096
+    x, d = _inputs(M, seed=6)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        sraw, prod = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
+    ps = [m.basis_mat.weight, m.color_net[0].weight, m.color_net[1].weight, m.color_net[2].weight]
+    outs = []
+    for pre in (0.0, 1.0):
+        for p in ps:
+            p.grad = torch.full_like(p, pre)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sig, rgb, feat = fusedhead.vm_head_train(m, sraw.clone().requires_grad_(True), prod.clone().requires_grad_(True), d)
+        (rgb.sum() + feat.sum()).backward()
+        outs.append([p.grad.clone() for p in ps])
+    for a, b in zip(*outs):
+        assert torch.allclose(b - 1.0, a, rtol=1e-4, atol=1e-3)
