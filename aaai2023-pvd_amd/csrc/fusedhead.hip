@@ -482,7 +482,9 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
 }
 
 // Sum the per-wave partials and ACCUMULATE into the fp32 gradient buffers (real, un-padded layouts).
-// One thread per real weight element; consecutive threads read consecutive lanes of a tile (coalesced).
+// blockIdx.x walks the real weight elements (consecutive threads read consecutive lanes of a tile:
+// coalesced), blockIdx.y a slice of the waves; every slice adds its sum with one atomic per element.
+constexpr uint32_t kReduceSlices = 16;
 __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWb,
                                                        float *__restrict__ gW1, float *__restrict__ gW2, float *__restrict__ gW3) {
     const uint32_t nB = 15 * 144, n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
@@ -505,9 +507,12 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
         return;
     }
     const uint32_t off = (tile * 4 + (n16 & 3)) * 64 + (k & 15) + 16 * (n16 >> 2);
+    const uint32_t per = div_up(nwaves, kReduceSlices);
+    const uint32_t w0 = blockIdx.y * per, w1 = min(nwaves, w0 + per);
     float acc = 0.f;
-    for (uint32_t w = 0; w < nwaves; w++) acc += partials[(size_t)w * kDwFloats + off];
-    *dst += acc;
+#pragma unroll 4
+    for (uint32_t w = w0; w < w1; w++) acc += partials[(size_t)w * kDwFloats + off];
+    if (w1 > w0) __hip_atomic_fetch_add(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace pvd
@@ -567,7 +572,8 @@ int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *
                              (kHeadBlock / 64) * 256;
     hipLaunchKernelGGL(k_head_bwd_vm, dim3(nwaves / (kHeadBlock / 64)), dim3(kHeadBlock), lds_halfs * sizeof(half_t), (hipStream_t)stream, a);
     const uint32_t nreal = 15 * 144 + 64 * 31 + 64 * 64 + 3 * 64;
-    hipLaunchKernelGGL(k_head_reduce_dw, dim3(div_up(nreal, 256u)), dim3(256), 0, (hipStream_t)stream, workspace, nwaves, gWb, gWc1, gWc2, gWc3);
+    hipLaunchKernelGGL(k_head_reduce_dw, dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, (hipStream_t)stream, workspace, nwaves, gWb, gWc1, gWc2,
+                       gWc3);
     return check_launch();
 }
 

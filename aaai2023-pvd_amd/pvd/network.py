@@ -27,6 +27,7 @@ class _L1MeanSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *tensors):
         ctx.save_for_backward(*tensors)
+        ctx.leaves = tensors
         norms = torch._foreach_norm(list(tensors), 1)
         key = (tensors[0].device, tuple(t.numel() for t in tensors))
         inv = _L1MeanSum._inv_cache.get(key)
@@ -42,6 +43,12 @@ class _L1MeanSum(torch.autograd.Function):
         signs = torch._foreach_sign(list(tensors))
         scales = (g.float() * ctx.inv).unbind(0)
         torch._foreach_mul_(signs, list(scales))
+        # leaves that already own a gradient buffer with their own strides (the trainer's flat bucket):
+        # one multi-tensor add instead of one AccumulateGrad launch per factor
+        leaves = ctx.leaves
+        if all(p.is_leaf and p.grad is not None and p.grad.stride() == s.stride() for p, s in zip(leaves, signs)):
+            torch._foreach_add_([p.grad for p in leaves], signs)
+            return (None,) * len(signs)
         return tuple(signs)
 
 

@@ -170,7 +170,8 @@ class _TrainerBase:
         torch.cuda.synchronize()
         self._g_fwd = torch.cuda.CUDAGraph()
         self._g_opt = None
-        with torch.cuda.graph(self._g_fwd):
+        # thread_local: RCCL's watchdog thread may touch the device while we capture
+        with torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
             self.flat.zero_()
             self._static_out = body()
             self._backward(self._static_out[0])
@@ -178,7 +179,7 @@ class _TrainerBase:
                 self._optimize()
         if self.dp.enabled:
             self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, pool=self._g_fwd.pool()):
+            with torch.cuda.graph(self._g_opt, pool=self._g_fwd.pool(), capture_error_mode="thread_local"):
                 self._optimize()
         return self._static_out  # capturing records, it does not run: no step was consumed
 

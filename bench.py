@@ -116,11 +116,22 @@ def main():
     if world > 1:  # replicas must start bit-identical (teacher pre-training uses float atomics)
         for m in (w.tea, w.stu):
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src=0)
+                d = t.data
+                if not d.is_contiguous():  # channels-last VM factors: broadcast the dense [H][W][R] view
+                    d = d.permute(0, 2, 3, 1)
+                    assert d.is_contiguous()
+                dist.broadcast(d, src=0)
 
     torch.cuda.manual_seed(1234 + rank)  # in-graph ray / background sampling: different rays on every rank
+    launch_mode = "eager"
     if not args.eager:
-        w.enable_graph()  # the step is launch-bound eagerly (~330 kernels of a few us): replay it as HIP graph(s)
+        try:
+            w.enable_graph()  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
+            launch_mode = "hipGraph replay"
+        except Exception as e:  # never lose the measurement to a capture problem: fall back to eager launches
+            torch.cuda.synchronize()
+            w._graph = False
+            launch_mode = "eager (graph capture failed: %s)" % type(e).__name__
     for _ in range(args.warmup):
         w.step()
 
@@ -182,7 +193,7 @@ def main():
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
         "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
                                "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps" % (args.student, args.rays, args.teacher_pretrain),
-                   "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": "eager" if args.eager else "hipGraph replay", "samples_per_step_per_gpu": samples,
+                   "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode, "samples_per_step_per_gpu": samples,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
                    "teacher_psnr_db": w.teacher_psnr,
                    "psnr_student_vs_teacher_db": float(psnr(pred_stu.detach(), pred_tea.detach())) if pred_stu is not None else None,
