@@ -1,0 +1,124 @@
+// distill.hip -- the distillation objective of stage 3 as three launches instead of ~45.
+//
+// Reference (torch code): Trainer.train_step / get_loss, distill_mutual/utils.py:941-952, 1044-1189 with
+// loss_type = "normL2":  loss = r_rgb ||I_tea - I_stu|| + r_fea ||F_stu - F_tea|| + r_sig ||s_stu - s_tea||
+//                               + r_col ||c_stu - c_tea||       (Frobenius norms over ALL rows, padding included)
+// where F = feature_sigma_color [M,16], s = F[:,0] (sigma_l), c = color_l [M,3], I = composited image [N,3].
+//   k_sumsq4      : S[0..3] = the four sums of squares (one pass over the six tensors)
+//   (all-reduce of S[4] under ray data parallelism happens between the two kernels, on the host side)
+//   k_loss_final  : loss = sum_i r_i sqrt(S_i);  coef_i = r_i / sqrt(S_i)   (0 where S_i = 0: torch.norm's subgradient)
+//   k_sumsq4_bwd  : the three student gradients in one pass, scaled by the upstream gradient on the device
+#include "pvd_device.h"
+
+namespace pvd {
+
+constexpr uint32_t kLossBlock = 256;
+
+__device__ __forceinline__ float block_sum(float v, float *__restrict__ sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < kLossBlock / 64; w++) r += sh[w];
+    return r;
+}
+
+__global__ void __launch_bounds__(kLossBlock) k_sumsq4(const float *__restrict__ img_s, const float *__restrict__ img_t, uint32_t n_img,
+                                                      const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
+                                                      const float *__restrict__ col_s, const float *__restrict__ col_t,
+                                                      float *__restrict__ S) {
+    __shared__ float sh[kLossBlock / 64];
+    const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
+    float s_img = 0.f, s_fea = 0.f, s_sig = 0.f, s_col = 0.f;
+    for (uint32_t i = tid; i < n_img; i += stride) { const float d = img_t[i] - img_s[i]; s_img += d * d; }
+    // feature rows as float4 quarters: quarter q of row m; column 0 (q == 0, .x) is also the sigma term
+    for (uint32_t i = tid; i < M * 4u; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        s_fea += dx * dx + dy * dy + dz * dz + dw * dw;
+        if ((i & 3u) == 0) s_sig += dx * dx;
+    }
+    for (uint32_t i = tid; i < M * 3u; i += stride) { const float d = col_s[i] - col_t[i]; s_col += d * d; }
+    s_img = block_sum(s_img, sh); s_fea = block_sum(s_fea, sh); s_sig = block_sum(s_sig, sh); s_col = block_sum(s_col, sh);
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(S + 0, s_img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(S + 1, s_fea, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(S + 2, s_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(S + 3, s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void k_loss_final(const float *__restrict__ S, const float *__restrict__ rates, float *__restrict__ loss,
+                             float *__restrict__ coef, float *__restrict__ norms) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float n = sqrtf(S[i]);
+        norms[i] = n;
+        total += rates[i] * n;
+        coef[i] = n > 0.f ? rates[i] / n : 0.f;  // d (r ||x||) / dx = r x / ||x||
+    }
+    loss[0] = total;
+}
+
+__global__ void __launch_bounds__(kLossBlock) k_sumsq4_bwd(const float *__restrict__ img_s, const float *__restrict__ img_t, uint32_t n_img,
+                                                          const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
+                                                          const float *__restrict__ col_s, const float *__restrict__ col_t,
+                                                          const float *__restrict__ coef, const float *__restrict__ upstream,
+                                                          float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col) {
+    const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
+    const float up = upstream[0];
+    const float c_img = coef[0] * up, c_fea = coef[1] * up, c_sig = coef[2] * up, c_col = coef[3] * up;
+    for (uint32_t i = tid; i < n_img; i += stride) g_img[i] = c_img * (img_s[i] - img_t[i]);
+    for (uint32_t i = tid; i < M * 4u; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+        float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
+        if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
+        reinterpret_cast<float4 *>(g_fea)[i] = g;
+    }
+    for (uint32_t i = tid; i < M * 3u; i += stride) g_col[i] = c_col * (col_s[i] - col_t[i]);
+}
+
+}  // namespace pvd
+
+using namespace pvd;
+
+extern "C" {
+
+int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea, uint32_t M,
+                      const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream) {
+    if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(S4, 0, 4 * sizeof(float), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
+    return check_launch();
+}
+
+int pvd_distill_loss_final(const float *S4, const float *rates4, float *loss, float *coef4, float *norms4, pvd_stream_t stream) {
+    if (!S4 || !rates4 || !loss || !coef4 || !norms4) return PVD_ERR_INVALID;
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, (hipStream_t)stream, S4, rates4, loss, coef4, norms4);
+    return check_launch();
+}
+
+int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
+                               uint32_t M, const float *col_stu, const float *col_tea, const float *coef4, const float *upstream,
+                               float *g_img, float *g_fea, float *g_col, pvd_stream_t stream) {
+    if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !coef4 || !upstream || !g_img || !g_fea || !g_col)
+        return PVD_ERR_INVALID;
+    uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sumsq4_bwd, dim3(blocks), dim3(kLossBlock), 0, (hipStream_t)stream, img_stu, img_tea, n_img, fea_stu, fea_tea, M,
+                       col_stu, col_tea, coef4, upstream, g_img, g_fea, g_col);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -525,11 +525,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Optional fused epilogue of run_cuda (distill_mutual/renderer.py:445-446):
+//   image += (1 - weights_sum) * bg_color ;  depth = clamp(depth - near, 0) / (far - near + eps)
+struct CompositeEpilogue {
+    const float *bg;      // [N,3] per-ray background, or null -> bg_scalar
+    float bg_scalar;
+    const float *nears, *fars;
+    float depth_eps;
+};
+
 // reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
+template <bool EPI>
 __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
                                                                uint32_t M, uint32_t N, float *__restrict__ weights_sum,
-                                                               float *__restrict__ depth, float *__restrict__ image) {
+                                                               float *__restrict__ depth, float *__restrict__ image, CompositeEpilogue ep) {
     const uint32_t n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
@@ -564,19 +574,29 @@ __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__re
         r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
     }
     if (lane == 0) {
+        if (EPI) {
+            const float t = 1.0f - ws;
+            const float b0 = ep.bg ? ep.bg[3 * (size_t)index] : ep.bg_scalar, b1 = ep.bg ? ep.bg[3 * (size_t)index + 1] : ep.bg_scalar,
+                        b2 = ep.bg ? ep.bg[3 * (size_t)index + 2] : ep.bg_scalar;
+            r = r + t * b0; g = g + t * b1; b = b + t * b2;
+            const float near = ep.nears[index], far = ep.fars[index];
+            d = fmaxf(d - near, 0.0f) / (far - near + ep.depth_eps);
+        }
         weights_sum[index] = ws;
         depth[index] = d;
         image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
     }
 }
 
-// reference: kernel_composite_rays_train_backward, raymarching.cu:606-686
+// reference: kernel_composite_rays_train_backward, raymarching.cu:606-686.  With EPI the incoming gradient is
+// w.r.t. the blended image: d blended / d ws = -bg, and `image` holds the blended colours (un-blended here).
+template <bool EPI>
 __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
                                                                const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
                                                                const float *__restrict__ weights_sum, const float *__restrict__ image,
                                                                uint32_t M, uint32_t N, float *__restrict__ grad_sigmas,
-                                                               float *__restrict__ grad_rgbs) {
+                                                               float *__restrict__ grad_rgbs, CompositeEpilogue ep) {
     const uint32_t n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
@@ -584,10 +604,17 @@ __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__re
     const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
     if (num == 0 || offset + num >= M) return;
-    const float gws = grad_ws[index];
+    float gws = grad_ws ? grad_ws[index] : 0.0f;
     const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
-    const float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
+    float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
     const float wsF = weights_sum[index];
+    if (EPI) {
+        const float b0 = ep.bg ? ep.bg[3 * (size_t)index] : ep.bg_scalar, b1 = ep.bg ? ep.bg[3 * (size_t)index + 1] : ep.bg_scalar,
+                    b2 = ep.bg ? ep.bg[3 * (size_t)index + 2] : ep.bg_scalar;
+        const float t = 1.0f - wsF;
+        rF -= t * b0; gF -= t * b1; bF -= t * b2;
+        gws -= g0 * b0 + g1 * b1 + g2 * b2;
+    }
     float T_carry = 1.0f, r_carry = 0.f, g_carry = 0.f, b_carry = 0.f, ws_carry = 0.f;
     for (uint32_t base = 0; base < num; base += 64) {
         const uint32_t s = base + lane;
@@ -863,8 +890,8 @@ int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
                                      pvd_stream_t stream) {
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image);
-    hipLaunchKernelGGL(k_composite_fwd_wave, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays,
-                       M, N, weights_sum, depth, image);
+    hipLaunchKernelGGL(k_composite_fwd_wave<false>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas,
+                       rays, M, N, weights_sum, depth, image, CompositeEpilogue{});
     return check_launch();
 }
 
@@ -874,8 +901,31 @@ int pvd_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       pvd_stream_t stream) {
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
-    hipLaunchKernelGGL(k_composite_bwd_wave, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
-                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    hipLaunchKernelGGL(k_composite_bwd_wave<false>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, CompositeEpilogue{});
+    return check_launch();
+}
+
+int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
+                                        uint32_t N, const float *bg, float bg_scalar, const float *nears, const float *fars,
+                                        float depth_eps, float *weights_sum, float *depth, float *image, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && weights_sum && depth && image);
+    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps};
+    hipLaunchKernelGGL(k_composite_fwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas,
+                       rays, M, N, weights_sum, depth, image, ep);
+    return check_launch();
+}
+
+int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
+                                         const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
+                                         uint32_t M, uint32_t N, const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs,
+                                         pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
+    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f};
+    hipLaunchKernelGGL(k_composite_bwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, ep);
     return check_launch();
 }
 

@@ -114,15 +114,14 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     }
 }
 
-// One run of identical texels being accumulated in registers by the backward.
-struct Run {
-    int x0, y0, l0;
-    float p[4], l[2];
-    bool open;
-};
+// Runs of consecutive samples that hit the same plane texel quad / the same line texel pair are
+// accumulated in registers and flushed with one atomic per tap when the texel changes.  The plane and
+// the line of an axis triple advance independently along a ray (roughly every 2/(|du|+|dv|) and 2/|dw|
+// samples at res 300), so they are tracked separately.
+struct PlaneRun { int x0, y0; float p[4]; bool open; };
+struct LineRun { int l0; float l[2]; bool open; };
 
-
-__device__ __forceinline__ void flush_run(Run &r, float *__restrict__ gm, float *__restrict__ gv, int W, int H, int L, uint32_t R) {
+__device__ __forceinline__ void flush_plane(PlaneRun &r, float *__restrict__ gm, int W, int H, uint32_t R) {
     if (!r.open) return;
     const bool x0 = r.x0 >= 0 && r.x0 < W, x1 = r.x0 + 1 >= 0 && r.x0 + 1 < W;
     const bool y0 = r.y0 >= 0 && r.y0 < H, y1 = r.y0 + 1 >= 0 && r.y0 + 1 < H;
@@ -132,6 +131,10 @@ __device__ __forceinline__ void flush_run(Run &r, float *__restrict__ gm, float 
     if (x1 && y0) __hip_atomic_fetch_add(gm + base + R, r.p[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (x0 && y1) __hip_atomic_fetch_add(gm + base + (long)W * R, r.p[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (x1 && y1) __hip_atomic_fetch_add(gm + base + (long)W * R + R, r.p[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.open = false;
+}
+__device__ __forceinline__ void flush_line(LineRun &r, float *__restrict__ gv, int L, uint32_t R) {
+    if (!r.open) return;
     if (r.l0 >= 0 && r.l0 < L) __hip_atomic_fetch_add(gv + (long)r.l0 * R, r.l[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (r.l0 + 1 >= 0 && r.l0 + 1 < L) __hip_atomic_fetch_add(gv + (long)(r.l0 + 1) * R, r.l[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.open = false;
@@ -149,9 +152,10 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     const uint32_t R = kind ? kRc : kRs;
     const uint32_t ch = kind ? lane - kRs : lane;
 
-    Run run[3];
+    PlaneRun prun[3];
+    LineRun lrun[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) run[i].open = false;
+    for (int i = 0; i < 3; i++) { prun[i].open = false; lrun[i].open = false; }
 
     for (uint32_t m = s0; m < s1; m++) {
         float xn[3];
@@ -179,31 +183,40 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
             const float gp = g * lv;  // d loss / d plane value
             const float gl = g * pv;  // d loss / d line value
 
-            Run &r = run[i];
-            if (r.open && (r.x0 != tx.i0 || r.y0 != ty.i0 || r.l0 != tl.i0))  // wave-uniform branch
-                flush_run(r, gr.mat[kind][i] + ch, gr.vec[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R);
-            if (!r.open) {
-                r.open = true;
-                r.x0 = tx.i0; r.y0 = ty.i0; r.l0 = tl.i0;
-                r.p[0] = r.p[1] = r.p[2] = r.p[3] = 0.f;
-                r.l[0] = r.l[1] = 0.f;
+            PlaneRun &pr = prun[i];
+            if (pr.open && (pr.x0 != tx.i0 || pr.y0 != ty.i0))  // wave-uniform branches
+                flush_plane(pr, gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
+            if (!pr.open) {
+                pr.open = true;
+                pr.x0 = tx.i0; pr.y0 = ty.i0;
+                pr.p[0] = pr.p[1] = pr.p[2] = pr.p[3] = 0.f;
             }
-            r.p[0] += gp * (tx.w0 * ty.w0);
-            r.p[1] += gp * (tx.w1 * ty.w0);
-            r.p[2] += gp * (tx.w0 * ty.w1);
-            r.p[3] += gp * (tx.w1 * ty.w1);
-            r.l[0] += gl * tl.w0;
-            r.l[1] += gl * tl.w1;
+            pr.p[0] += gp * (tx.w0 * ty.w0);
+            pr.p[1] += gp * (tx.w1 * ty.w0);
+            pr.p[2] += gp * (tx.w0 * ty.w1);
+            pr.p[3] += gp * (tx.w1 * ty.w1);
+            LineRun &lr = lrun[i];
+            if (lr.open && lr.l0 != tl.i0) flush_line(lr, gr.vec[kind][i] + ch, (int)tb.L[i], R);
+            if (!lr.open) {
+                lr.open = true;
+                lr.l0 = tl.i0;
+                lr.l[0] = lr.l[1] = 0.f;
+            }
+            lr.l[0] += gl * tl.w0;
+            lr.l[1] += gl * tl.w1;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) flush_run(run[i], gr.mat[kind][i] + ch, gr.vec[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R);
+    for (int i = 0; i < 3; i++) {
+        flush_plane(prun[i], gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
+        flush_line(lrun[i], gr.vec[kind][i] + ch, (int)tb.L[i], R);
+    }
 }
 
 static uint32_t pick_chunk(uint32_t M) {
     // enough waves to fill 256 CUs x 8+ waves, but runs long enough for the backward's merging to bite
     uint32_t chunk = 16;
-    while (chunk < 64 && (uint64_t)M / chunk > 256u * 32u) chunk <<= 1;
+    while (chunk < 64 && (uint64_t)M / chunk > 256u * 16u) chunk <<= 1;
     return chunk;
 }
 

@@ -1,0 +1,43 @@
+"""Stage-3 distillation objective (normL2) as three launches: sums of squares, (optional all-reduce of 4
+scalars under ray-DP), finalise; one launch backward.  Reference formulation: Trainer.get_loss and the
+loss assembly in train_step, distill_mutual/utils.py:941-952, 1109-1189 -- kept in trainer.py as the generic path
+(other loss types, CPU oracle)."""
+import torch
+from torch.autograd import Function
+
+import pvd_hip
+
+
+class _DistillNormL2(Function):
+    """(img_stu, img_tea [.,N,3], fea_stu, fea_tea [M,16], col_stu, col_tea [M,3], rates[4] device, dp)
+    -> (loss scalar, norms[4] detached: rgb, fea, sigma, colour)"""
+
+    @staticmethod
+    def forward(ctx, img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp):
+        dev = img_s.device
+        args = [t.detach().float().contiguous() for t in (img_s, img_t, fea_s, fea_t, col_s, col_t)]
+        S = torch.empty(4, dtype=torch.float32, device=dev)
+        pvd_hip.distill_sumsq(*args, S)
+        if dp is not None and dp.enabled:
+            dp.all_reduce_sum_(S)  # global norms: sum of squares over all shards
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        coef = torch.empty(4, dtype=torch.float32, device=dev)
+        norms = torch.empty(4, dtype=torch.float32, device=dev)
+        pvd_hip.distill_loss_final(S, rates, loss, coef, norms)
+        ctx.save_for_backward(*args, coef)
+        ctx.shapes = (img_s.shape, fea_s.shape, col_s.shape)
+        ctx.mark_non_differentiable(norms)
+        return loss[0], norms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_norms):
+        img_s, img_t, fea_s, fea_t, col_s, col_t, coef = ctx.saved_tensors
+        g_img, g_fea, g_col = torch.empty_like(img_s), torch.empty_like(fea_s), torch.empty_like(col_s)
+        up = g_loss.detach().float().reshape(1).contiguous()
+        pvd_hip.distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef, up, g_img, g_fea, g_col)
+        s_img, s_fea, s_col = ctx.shapes
+        return g_img.view(s_img), None, g_fea.view(s_fea), None, g_col.view(s_col), None, None, None
+
+
+def distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp=None):
+    return _DistillNormL2.apply(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp)

@@ -6,6 +6,11 @@ import types
 import torch
 
 
+def _distill_loss():
+    from .losses import distill_loss_normL2
+    return distill_loss_normL2
+
+
 def hip_ops():
     import gridencoder
     import raymarching
@@ -25,4 +30,4 @@ def hip_ops():
         return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
 
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), device_type="cuda", name="hip")

@@ -106,11 +106,11 @@ class NeRFRenderer(nn.Module):
                 if gs < st["stage2"]:
                     return {"stage2": gs, "depth": None, "image": None, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}
 
-            sigmas = self.density_scale * sigmas
-            weights_sum, depth, image = rm.composite_rays_train(sigmas, rgbs, deltas, rays)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
             eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears + eps)
+            # compositing + `image += (1 - ws) * bg` + depth normalisation (renderer.py:442-446) as one op
+            weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}

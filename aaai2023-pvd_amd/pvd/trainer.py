@@ -206,7 +206,11 @@ class DistillTrainer(_TrainerBase):
         self.model_stu = model_stu.train()
         self.loss = _make_loss(opt.loss_type, self.dp)
         self.loss_rate_fea_sc = opt.loss_rate_fea_sc  # host shadow (only used for the > 0 tests)
-        self.fea_rate = torch.tensor(float(opt.loss_rate_fea_sc), dtype=torch.float32, device=self.device)  # decays on device
+        # device-side loss rates [rgb, fea, sigma, colour]; the feature rate decays on the device every step
+        self.rates = torch.tensor([opt.loss_rate_rgb, opt.loss_rate_fea_sc, opt.loss_rate_sigma, opt.loss_rate_color],
+                                  dtype=torch.float32, device=self.device)
+        self.fea_rate = self.rates[1:2]
+        self.fused_loss = getattr(model_stu.ops, "distill_loss", None)
 
     def render_kwargs(self):
         o = self.opt
@@ -242,6 +246,17 @@ class DistillTrainer(_TrainerBase):
             return loss, info, None, None
 
         pred_stu, pred_tea = out_stu["image"], out_tea["image"]
+        if (self.fused_loss is not None and o.loss_type == "normL2" and have_fea and pred_stu.is_cuda
+                and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc, o.loss_rate_rgb) > 0.0
+                and stu.feature_sigma_color.dtype == torch.float32 and tea.feature_sigma_color.dtype == torch.float32):
+            # all four norm terms (utils.py:1109-1176) in one fused objective
+            l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
+                                        tea.color_l.float(), self.rates, self.dp)
+            loss = loss + l4
+            if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+                loss = loss + stu.density_loss() * (o.l1_reg_weight / self.dp.world_size)
+            info["rgb"] = norms[0]
+            return loss, info, pred_stu, pred_tea
         if o.loss_type == "normL2":
             l_rgb = self.dp.global_norm_l2(pred_tea - pred_stu)
         elif o.loss_type == "normL1":

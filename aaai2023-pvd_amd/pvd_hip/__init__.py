@@ -48,6 +48,8 @@ ENTRY_POINTS = (
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
     "pvd_head_backward_vm", "pvd_head_backward_vm_workspace_floats",
+    "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -374,7 +376,43 @@ def head_backward_vm(prod, sigma_raw, dirs, M, Wb, Wc1, Wc2, Wc3, clip_sigma_min
           _p(gWb), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
 
 
+# --------------------------------------------------------------------------- fused epilogue / objective
+def composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar, nears, fars, depth_eps, weights_sum, depth, image):
+    dev = _dev(sigmas, rgbs, deltas, rays, bg, nears, fars, weights_sum, depth, image)
+    _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, nears=nears, fars=fars, weights_sum=weights_sum, depth=depth, image=image)
+    _call("pvd_composite_rays_train_bg_forward", dev, _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u32(M), _u32(N), _p(bg), _f32(bg_scalar),
+          _p(nears), _p(fars), _f32(depth_eps), _p(weights_sum), _p(depth), _p(image))
+
+
+def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, bg, bg_scalar,
+                                     grad_sigmas, grad_rgbs):
+    dev = _dev(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, bg, grad_sigmas, grad_rgbs)
+    _f32_all(grad_image=grad_image, sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, image=image)
+    _call("pvd_composite_rays_train_bg_backward", dev, _p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(deltas), _p(rays),
+          _p(weights_sum), _p(image), _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs))
+
+
+def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4):
+    dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4)
+    _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4)
+    _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s), _p(col_t), _p(S4))
+
+
+def distill_loss_final(S4, rates4, loss, coef4, norms4):
+    dev = _dev(S4, rates4, loss, coef4, norms4)
+    _f32_all(S4=S4, rates4=rates4, loss=loss, coef4=coef4, norms4=norms4)
+    _call("pvd_distill_loss_final", dev, _p(S4), _p(rates4), _p(loss), _p(coef4), _p(norms4))
+
+
+def distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_img, g_fea, g_col):
+    dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_img, g_fea, g_col)
+    _f32_all(coef4=coef4, upstream=upstream, g_img=g_img, g_fea=g_fea, g_col=g_col)
+    _call("pvd_distill_sumsq_backward", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s),
+          _p(col_t), _p(coef4), _p(upstream), _p(g_img), _p(g_fea), _p(g_col))
+
+
 raymarching_backend = types.SimpleNamespace(
+    composite_rays_train_bg_forward=composite_rays_train_bg_forward, composite_rays_train_bg_backward=composite_rays_train_bg_backward,
     get_rays=get_rays, near_far_from_aabb=near_far_from_aabb, polar_from_ray=polar_from_ray, morton3D=morton3D,
     morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
     composite_rays_train_forward=composite_rays_train_forward,

@@ -12,6 +12,7 @@ morton3D_invert = _ops.morton3D_invert
 packbits = _ops.packbits
 march_rays_train = _ops.march_rays_train
 composite_rays_train = _ops.composite_rays_train
+composite_rays_train_bg = _ops.composite_rays_train_bg  # extension: + run_cuda's epilogue
 march_rays = _ops.march_rays
 composite_rays = _ops.composite_rays
 compact_rays = _ops.compact_rays

@@ -156,6 +156,52 @@ def make_ops(backend, device_type="cuda"):
                                                   M, N, grad_sigmas, grad_rgbs)
             return grad_sigmas, grad_rgbs, None, None
 
+    fused_bg = hasattr(backend, "composite_rays_train_bg_forward")
+
+    class _CompositeTrainBg(Function):
+        """composite_rays_train + run_cuda's epilogue in one launch each way (distill_mutual/renderer.py:442-446):
+        returns (weights_sum, normalised depth, background-blended image).  bg: python scalar or [.., N, 3] tensor."""
+
+        @staticmethod
+        @fwd32
+        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps):
+            sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+            M, N = sigmas.shape[0], rays.shape[0]
+            bg_t = bg.reshape(-1, 3).contiguous().float() if torch.is_tensor(bg) else None
+            bg_s = 0.0 if torch.is_tensor(bg) else float(bg)
+            weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+            depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+            image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+            backend.composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum,
+                                                    depth, image)
+            ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
+            ctx.bg = (bg_t, bg_s)
+            ctx.dims = [M, N]
+            return weights_sum, depth, image
+
+        @staticmethod
+        @bwd
+        def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+            sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
+            M, N = ctx.dims
+            grad_sigmas = torch.zeros_like(sigmas)
+            grad_rgbs = torch.zeros_like(rgbs)
+            gws = grad_weights_sum.contiguous() if grad_weights_sum is not None else None
+            backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                     ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
+            return grad_sigmas, grad_rgbs, None, None, None, None, None, None
+
+    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps):
+        if fused_bg:
+            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps)
+        # reference formulation (used with the CPU oracle backend in the test-suite)
+        weights_sum, depth, image = _CompositeTrain.apply(sigmas, rgbs, deltas, rays)
+        if torch.is_tensor(bg):
+            bg = bg.reshape(-1, 3)
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears + depth_eps)
+        return weights_sum, depth, image
+
     class _March(Function):
         # reference: _march_rays, raymarching.py:367-454
         @staticmethod
@@ -199,6 +245,7 @@ def make_ops(backend, device_type="cuda"):
         packbits=_Packbits.apply,
         march_rays_train=_MarchTrain.apply,
         composite_rays_train=_CompositeTrain.apply,
+        composite_rays_train_bg=composite_rays_train_bg,
         march_rays=_March.apply,
         composite_rays=_Composite.apply,
         compact_rays=_Compact.apply,

@@ -213,6 +213,36 @@ int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *
                          float *g_sigma_raw, void *g_prod, float *gWb, float *gWc1, float *gWc2, float *gWc3,
                          float *workspace, pvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused pieces of run_cuda / train_step that are torch code in the reference.
+ * ---------------------------------------------------------------------- */
+
+/* composite_rays_train + the epilogue of run_cuda (distill_mutual/renderer.py:442-446):
+ *   image += (1 - weights_sum) * bg ; depth = clamp(depth - near, 0) / (far - near + depth_eps).
+ * bg [N,3] f32 per-ray background or NULL (then bg_scalar).  Outputs are the blended image / normalised depth. */
+int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                        uint32_t M, uint32_t N, const float *bg, float bg_scalar, const float *nears,
+                                        const float *fars, float depth_eps, float *weights_sum, float *depth, float *image,
+                                        pvd_stream_t stream);
+/* grad_image is w.r.t. the BLENDED image; `image` is the blended image the forward returned; grad_weights_sum may be NULL. */
+int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                         const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
+                                         const float *image, uint32_t M, uint32_t N, const float *bg, float bg_scalar,
+                                         float *grad_sigmas, float *grad_rgbs, pvd_stream_t stream);
+
+/* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
+ *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
+ *   loss = sum_i rates4[i] * sqrt(S4[i]);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
+ * img [n_img] f32 (= N*3), fea [M,16] f32 (16-byte aligned), col [M,3] f32.  Under ray data parallelism the host
+ * all-reduces S4 between pvd_distill_sumsq and pvd_distill_loss_final.  rates4 / upstream are DEVICE scalars. */
+int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
+                      uint32_t M, const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream);
+int pvd_distill_loss_final(const float *S4, const float *rates4, float *loss, float *coef4, float *norms4, pvd_stream_t stream);
+int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
+                               const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea,
+                               const float *coef4, const float *upstream, float *g_img, float *g_fea, float *g_col,
+                               pvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""GPU parity of the fused host-side pieces: compositing epilogue and the stage-3 distillation objective,
+each against its reference formulation in plain PyTorch ops on the same device."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(N=2048, seed=0):
+    import raymarching
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    dev = torch.device("cuda:0")
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(seed))).to(dev)
+    r = get_rays(poses[4:5], BLENDER_INTRINSICS, 800, 800, N, generator=torch.Generator(device=dev).manual_seed(seed))
+    bits = packbits_torch(ChairScene().density_grid(128, 1.0, 1, device=dev), 10.0)
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)
+    return xyzs, deltas, rays, nears, fars
+
+
+@pytest.mark.parametrize("bg_kind", ["tensor", "scalar"])
+def test_composite_bg_matches_composition(bg_kind):
+    import raymarching
+    dev = torch.device("cuda:0")
+    xyzs, deltas, rays, nears, fars = _samples()
+    M, N = xyzs.shape[0], rays.shape[0]
+    g = torch.Generator(device=dev).manual_seed(1)
+    sig0 = torch.exp(torch.rand(M, device=dev, generator=g) * 6 - 2)
+    rgb0 = torch.rand(M, 3, device=dev, generator=g)
+    bg = torch.rand(1, N, 3, device=dev, generator=g) if bg_kind == "tensor" else 1
+    w_img = torch.randn(N, 3, device=dev, generator=g)
+    w_ws = torch.randn(N, device=dev, generator=g)
+    res = []
+    for fused in (True, False):
+        sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+        if fused:
+            ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6)
+        else:
+            ws, depth, img = raymarching.composite_rays_train(sig, rgb, deltas, rays)
+            img = img + (1 - ws).unsqueeze(-1) * (bg.reshape(-1, 3) if torch.is_tensor(bg) else bg)
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears + 1e-6)
+        ((img * w_img).sum() + (ws * w_ws).sum()).backward()
+        res.append((ws.detach(), depth.detach(), img.detach(), sig.grad, rgb.grad))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=1e-6) and torch.allclose(a[2], b[2], atol=1e-6)
+    assert torch.allclose(a[4], b[4], atol=1e-6)
+    assert (a[3] - b[3]).abs().max() <= 2e-5 * b[3].abs().max()
+
+
+def test_fused_distill_loss_matches_torch_norms():
+    from pvd.losses import distill_loss_normL2
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2)
+    N, M = 4096, 16 * 5000 + 128
+    img_t = torch.rand(1, N, 3, device=dev, generator=g)
+    fea_t = torch.randn(M, 16, device=dev, generator=g)
+    col_t = torch.rand(M, 3, device=dev, generator=g)
+    rates = torch.tensor([1.0, 0.002, 0.003, 0.004], device=dev)
+    up = 65536.0  # GradScaler-style upstream factor
+    res = []
+    for fused in (True, False):
+        img_s = (img_t + 0.1 * torch.randn(1, N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3))).requires_grad_(True)
+        fea_s = (fea_t + 0.2 * torch.randn(M, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(4))).requires_grad_(True)
+        col_s = (col_t + 0.05 * torch.randn(M, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(5))).requires_grad_(True)
+        if fused:
+            loss, norms = distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, None)
+        else:
+            norms = torch.stack([torch.norm(img_t - img_s), torch.norm(fea_s - fea_t), torch.norm(fea_s[:, 0] - fea_t[:, 0]), torch.norm(col_s - col_t)])
+            loss = (norms * rates).sum()
+        (loss * up).backward()
+        res.append((loss.detach(), norms.detach(), img_s.grad, fea_s.grad, col_s.grad))
+    a, b = res
+    assert torch.allclose(a[0], b[0], rtol=1e-5) and torch.allclose(a[1], b[1], rtol=1e-5)
+    for x, y in zip(a[2:], b[2:]):
+        assert (x - y).abs().max() <= 1e-5 * y.abs().max()
+    # identical inputs: zero loss and zero (not NaN) gradients, like torch.norm's subgradient
+    z = fea_t.clone().requires_grad_(True)
+    loss, _ = distill_loss_normL2(img_t.clone().requires_grad_(True), img_t, z, fea_t, col_t.clone().requires_grad_(True), col_t, rates, None)
+    loss.backward()
+    assert float(loss) == 0.0 and torch.count_nonzero(z.grad) == 0
