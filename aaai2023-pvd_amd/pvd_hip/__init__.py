@@ -49,7 +49,7 @@ ENTRY_POINTS = (
     "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
     "pvd_head_backward_vm", "pvd_head_backward_vm_workspace_floats",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -286,6 +286,10 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     if status == -2:
         raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")
     _check(status, "pvd_grid_encode_backward")
+
+
+def grid_set_variant(v):
+    return int(_lib.pvd_grid_set_variant(_int(int(v))))
 
 
 # --------------------------------------------------------------------------- _shencoder

@@ -137,6 +137,10 @@ int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const i
                             float S, uint32_t H, int calc_grad_inputs, void *dy_dx,
                             uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream);
 
+/* Tuning knob for A/B measurements (tools/bench_grid.py): forward kernel variant, 1 = x-paired gathers + two levels
+ * per thread (default), 0 = one (point, level) per thread.  Returns the previous value.  Results are identical. */
+int pvd_grid_set_variant(int variant);
+
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
  * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
  * when calc_grad_inputs.  `embeddings` is unused by the arithmetic (as in the reference) and may be null. */

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the hash-grid lookup (pvd_grid_encode_forward) on one MI355X: kernel variants x table dtype
+x sample coherence x batch size, timed with HIP events on the launch stream.  Prints a table of us/launch and
+algorithmic GB/s (516 B/sample f16, 1020 B/sample f32) -- the numbers DESIGN.md quotes."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "aaai2023-pvd_amd")]
+import numpy as np
+import torch
+
+import pvd_hip
+import raymarching
+from gridencoder import GridEncoder
+from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+
+dev = torch.device("cuda:0")
+enc = GridEncoder(num_levels=14, desired_resolution=2048).to(dev)
+enc.embeddings.data.uniform_(-1, 1)
+S = float(np.log2(enc.per_level_scale))
+
+
+def ray_samples(n_rays):
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
+    bits = packbits_torch(ChairScene().density_grid(128, 1.0, 1, device=dev), 10.0)
+    xs = []
+    for k in range(max(1, n_rays // 4096)):
+        r = get_rays(poses[k:k + 1], BLENDER_INTRINSICS, 800, 800, min(n_rays, 4096))
+        o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+        nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+        xyzs, _, _, _ = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)
+        xs.append(xyzs)
+    return ((torch.cat(xs) + 1) / 2).contiguous()
+
+
+def time_it(x01, emb, variant, iters=50):
+    B = x01.shape[0]
+    out = torch.empty(14, B, 2, dtype=emb.dtype, device=dev)
+    pvd_hip.grid_set_variant(variant)
+    run = lambda: pvd_hip.grid_encode_forward(x01, emb, enc.offsets, out, B, 3, 2, 14, S, 16, False, out, 0, False)
+    for _ in range(5):
+        run()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3, out
+
+
+coh = {n: ray_samples(n) for n in (4096, 16384, 65536)}
+print("%-28s %10s %6s %9s %9s %8s" % ("samples", "B", "dtype", "v0 us", "v1 us", "v1 GB/s"))
+for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("uniform random", torch.rand(1 << 18, 3, device=dev)),
+                                                                           ("uniform random", torch.rand(1 << 20, 3, device=dev))]:
+    for dt in (torch.float16, torch.float32):
+        emb = enc.embeddings.detach().to(dt)
+        t0, o0 = time_it(x, emb, 0)
+        t1, o1 = time_it(x, emb, 1)
+        assert torch.equal(o0, o1), "variants must agree bit for bit"
+        bps = 516 if dt == torch.float16 else 1020
+        print("%-28s %10d %6s %9.1f %9.1f %8.0f" % (name, x.shape[0], "f16" if dt == torch.float16 else "f32", t0, t1, bps * x.shape[0] / t1 / 1e3))
+pvd_hip.grid_set_variant(1)
