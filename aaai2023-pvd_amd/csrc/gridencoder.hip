@@ -23,6 +23,65 @@ struct LevelScales {
     float scale[kMaxLevels];
 };
 
+// XCD-aware (level, point-block) schedule.  MI355X has 8 XCDs with private 4 MiB L2s and dispatches
+// workgroup i to XCD i % 8.  With a plain (point-block, level) grid every XCD sweeps every level, so each
+// level's table (2 MiB per hashed level in f16) is pulled into all eight L2s: 8 x 21 MB of fabric traffic per
+// launch, which is what bounds the kernel at training-batch sizes (~1e5 samples).  Instead the big levels are
+// dealt out one per XCD ("exclusive": that XCD alone walks all points of that level, so the table is fetched
+// into one L2 only), and what is left (big levels that do not fill a round of 8, plus the small coarse levels)
+// is split by point-block across all XCDs.  Every XCD gets the same number of workgroups.  The mapping relies
+// on i % 8 placement for speed only; any placement gives the same results.
+struct LevelSchedule {
+    uint32_t nb;             // point blocks per level
+    uint32_t n_excl_rounds;  // exclusive levels per XCD
+    uint32_t n_shared;       // levels split across XCDs
+    uint32_t total_blocks;
+    uint8_t excl[kMaxLevels];    // [round * 8 + xcd]
+    uint8_t shared[kMaxLevels];
+
+    __device__ __forceinline__ bool locate(uint32_t id, uint32_t &level, uint32_t &pblock) const {
+        const uint32_t xcd = id & 7u, slot = id >> 3;
+        const uint32_t n_excl_slots = n_excl_rounds * nb;
+        if (slot < n_excl_slots) {
+            const uint32_t round = slot / nb;
+            level = excl[round * 8 + xcd];
+            pblock = slot - round * nb;
+            return true;
+        }
+        const uint32_t g = (slot - n_excl_slots) * 8 + xcd;
+        if (g >= n_shared * nb) return false;
+        const uint32_t k = g / nb;
+        level = shared[k];
+        pblock = g - k * nb;
+        return true;
+    }
+};
+
+static int g_grid_variant = 1;  // 1 = XCD-aware schedule (default), 0 = every level shared (plain level-major order)
+
+template <uint32_t D>
+static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t nb, size_t row_bytes) {
+    LevelSchedule s;
+    s.nb = nb;
+    uint32_t big[kMaxLevels], n_big = 0, n_shared = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        // table footprint from the level's resolution (dense (res+1)^D rows, capped by any hash size at 2^19+ rows)
+        const double res = ceil((double)sc.scale[l]) + 2.0;
+        double rows = 1.0;
+        for (uint32_t d = 0; d < D; d++) rows *= res;
+        const bool is_big = g_grid_variant == 1 && rows * (double)row_bytes >= 512.0 * 1024.0;
+        if (is_big) big[n_big++] = l;
+        else s.shared[n_shared++] = (uint8_t)l;
+    }
+    s.n_excl_rounds = n_big / 8;
+    for (uint32_t i = 0; i < s.n_excl_rounds * 8; i++) s.excl[i] = (uint8_t)big[i];
+    for (uint32_t i = s.n_excl_rounds * 8; i < n_big; i++) s.shared[n_shared++] = (uint8_t)big[i];
+    s.n_shared = n_shared;
+    const uint32_t per_xcd = s.n_excl_rounds * nb + div_up(n_shared * nb, 8u);
+    s.total_blocks = per_xcd * 8;
+    return s;
+}
+
 // C consecutive table elements moved as one naturally aligned access
 template <typename T, uint32_t C>
 struct alignas(sizeof(T) * C) FeatVec {
@@ -116,12 +175,13 @@ __device__ __forceinline__ void axpy<half_t>(half_t &acc, float w, half_t v) { a
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                          const int32_t *__restrict__ offsets, T *__restrict__ outputs,
-                                                         uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
+                                                         uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
                                                          bool align_corners, bool calc_grad_inputs, T *__restrict__ dy_dx) {
     using Vec = FeatVec<T, C>;
-    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
+    uint32_t level, pblock;
+    if (!sched.locate(blockIdx.x, level, pblock)) return;
+    const uint32_t b = pblock * kGridBlock + threadIdx.x;
     if (b >= B) return;
-    const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
     const float scale = scales.scale[level];
     LevelIndex<D> index;
@@ -199,94 +259,6 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict
 }
 
 
-// ---- forward fast path (no dy_dx): x-paired gathers, two levels per thread --------------------------------
-// The 2^D corners come in 2^(D-1) pairs that differ only in x.  With stride_x = 1 (dense levels) and hash
-// prime 1 for x (hashed levels) the two rows of a pair are neighbours in the table whenever their indices
-// differ only in bit 0 -- always for an even x0 on hashed levels, every other cell on dense ones -- and one
-// naturally aligned 2*sizeof(Vec) load then fetches both (the texture path pays per distinct cache line per
-// lane, so this removes ~25 % of the gather cost).  Each thread also walks two levels, which doubles the
-// gathers in flight and halves the re-reads of the position.  Blend order is the reference's (bit-exact).
-template <typename T, uint32_t C>
-struct alignas(sizeof(T) * C * 2) FeatPair {
-    FeatVec<T, C> v[2];
-};
-
-template <typename T, uint32_t D, uint32_t C>
-__device__ __forceinline__ void encode_level_paired(const float *__restrict__ in, const T *__restrict__ grid, const int32_t *__restrict__ offsets,
-                                                    uint32_t level, float scale, uint32_t gridtype, bool align_corners,
-                                                    FeatVec<T, C> &acc) {
-    using Vec = FeatVec<T, C>;
-    using Pair = FeatPair<T, C>;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    LevelIndex<D> index;
-    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
-    const Vec *__restrict__ table = reinterpret_cast<const Vec *>(grid) + off0;
-#pragma unroll
-    for (uint32_t c = 0; c < C; c++) acc.v[c] = (T)0;
-    float frac[D];
-    uint32_t cell[D];
-    if (!locate<D>(in, scale, align_corners, frac, cell)) return;
-    // the level's row offset must keep pair alignment: offsets are multiples of 8 rows (grid.py:186)
-    const bool base_even = (off0 & 1u) == 0;
-    Vec corner[1u << D];
-    float w[1u << D];
-#pragma unroll
-    for (uint32_t hi = 0; hi < (1u << (D - 1)); hi++) {  // the (y[,z]) combination
-        float wy = 1;
-        uint32_t pg[D];
-#pragma unroll
-        for (uint32_t d = 1; d < D; d++) {
-            if ((hi >> (d - 1)) & 1u) { wy *= frac[d]; pg[d] = cell[d] + 1; }
-            else { wy *= 1 - frac[d]; pg[d] = cell[d]; }
-        }
-        // same products, same order as the reference's w *= ... chain over d = 0..D-1
-        float w0 = 1 - frac[0], w1 = frac[0];
-#pragma unroll
-        for (uint32_t d = 1; d < D; d++) {
-            const float f = ((hi >> (d - 1)) & 1u) ? frac[d] : 1 - frac[d];
-            w0 *= f; w1 *= f;
-        }
-        (void)wy;
-        pg[0] = cell[0];
-        const uint32_t i0 = index(pg);
-        pg[0] = cell[0] + 1;
-        const uint32_t i1 = index(pg);
-        w[2 * hi] = w0; w[2 * hi + 1] = w1;
-        if (base_even && ((i0 ^ i1) == 1u)) {
-            const Pair p = *reinterpret_cast<const Pair *>(table + (i0 & ~1u));
-            corner[2 * hi] = p.v[i0 & 1u];
-            corner[2 * hi + 1] = p.v[i1 & 1u];
-        } else {
-            corner[2 * hi] = table[i0];
-            corner[2 * hi + 1] = table[i1];
-        }
-    }
-#pragma unroll
-    for (uint32_t idx = 0; idx < (1u << D); idx++) {
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) axpy<T>(acc.v[c], w[idx], corner[idx].v[c]);
-    }
-}
-
-template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(kGridBlock) k_grid_fwd_fast(const float *__restrict__ inputs, const T *__restrict__ grid,
-                                                              const int32_t *__restrict__ offsets, T *__restrict__ outputs, uint32_t B,
-                                                              uint32_t L, LevelScales scales, uint32_t gridtype, bool align_corners) {
-    using Vec = FeatVec<T, C>;
-    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
-    if (b >= B) return;
-    float x[D];
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
-    const uint32_t l0 = blockIdx.y * 2;
-    Vec a0, a1;
-    encode_level_paired<T, D, C>(x, grid, offsets, l0, scales.scale[l0], gridtype, align_corners, a0);
-    const bool two = l0 + 1 < L;
-    if (two) encode_level_paired<T, D, C>(x, grid, offsets, l0 + 1, scales.scale[l0 + 1], gridtype, align_corners, a1);
-    reinterpret_cast<Vec *>(outputs)[(size_t)l0 * B + b] = a0;
-    if (two) reinterpret_cast<Vec *>(outputs)[(size_t)(l0 + 1) * B + b] = a1;
-}
-
 // packed / scalar atomic accumulate of one weighted gradient vector
 template <typename T, uint32_t C>
 __device__ __forceinline__ void scatter_add(T *__restrict__ dst, float w, const FeatVec<T, C> &g);
@@ -354,12 +326,13 @@ __device__ __forceinline__ void scatter_add<half_t, 8>(half_t *d, float w, const
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs,
                                                          const int32_t *__restrict__ offsets, T *__restrict__ grad_grid,
-                                                         uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
+                                                         uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
                                                          bool align_corners) {
     using Vec = FeatVec<T, C>;
-    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
+    uint32_t level, pblock;
+    if (!sched.locate(blockIdx.x, level, pblock)) return;
+    const uint32_t b = pblock * kGridBlock + threadIdx.x;
     if (b >= B) return;
-    const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
     const float scale = scales.scale[level];
     LevelIndex<D> index;
@@ -404,8 +377,6 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_input_bwd(const T *__restri
     grad_inputs[t] = r;
 }
 
-static int g_grid_variant = 1;  // 1 = paired/two-level forward (default), 0 = one (point, level) per thread
-
 static LevelScales make_scales(uint32_t L, float S, uint32_t H) {
     LevelScales s;
     for (uint32_t l = 0; l < kMaxLevels; l++) s.scale[l] = 0.f;
@@ -418,21 +389,20 @@ static LevelScales make_scales(uint32_t L, float S, uint32_t H) {
 template <typename T, uint32_t D, uint32_t C>
 static int launch_fwd(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
-    if (!calc && g_grid_variant == 1 && sizeof(T) * C * 2 <= 16) {
-        hipLaunchKernelGGL((k_grid_fwd_fast<T, D, C>), dim3(div_up(B, kGridBlock), div_up(L, 2u)), dim3(kGridBlock), 0, s, inputs, (const T *)emb,
-                           offsets, (T *)outputs, B, L, make_scales(L, S, H), gridtype, align);
-        return check_launch();
-    }
-    hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(div_up(B, kGridBlock), L), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets,
-                       (T *)outputs, B, L, make_scales(L, S, H), gridtype, align, calc, (T *)dy_dx);
+    const LevelScales sc = make_scales(L, S, H);
+    const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
+    hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets, (T *)outputs, B,
+                       L, sc, sched, gridtype, align, calc, (T *)dy_dx);
     return check_launch();
 }
 
 template <typename T, uint32_t D, uint32_t C>
 static int launch_bwd(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool align, hipStream_t s) {
-    hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(div_up(B, kGridBlock), L), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
-                       (T *)grad_emb, B, L, make_scales(L, S, H), gridtype, align);
+    const LevelScales sc = make_scales(L, S, H);
+    const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
+    hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
+                       (T *)grad_emb, B, L, sc, sched, gridtype, align);
     if (calc)
         hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(div_up(B * D, kGridBlock)), dim3(kGridBlock), 0, s, (const T *)grad,
                            (const T *)dy_dx, (T *)grad_inputs, B, L);

@@ -137,8 +137,8 @@ int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const i
                             float S, uint32_t H, int calc_grad_inputs, void *dy_dx,
                             uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream);
 
-/* Tuning knob for A/B measurements (tools/bench_grid.py): forward kernel variant, 1 = x-paired gathers + two levels
- * per thread (default), 0 = one (point, level) per thread.  Returns the previous value.  Results are identical. */
+/* Tuning knob for A/B measurements (tools/bench_grid.py): workgroup schedule of the grid kernels, 1 = XCD-aware
+ * (big levels dealt out one per XCD, default), 0 = plain level-major.  Returns the previous value.  Results are identical. */
 int pvd_grid_set_variant(int variant);
 
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
