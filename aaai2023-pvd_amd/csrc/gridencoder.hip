@@ -57,7 +57,8 @@ struct LevelSchedule {
     }
 };
 
-static int g_grid_variant = 1;  // 1 = XCD-aware schedule (default), 0 = every level shared (plain level-major order)
+static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain level-major order (default: measured faster)
+static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
 
 template <uint32_t D>
 static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t nb, size_t row_bytes) {
@@ -259,6 +260,65 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict
 }
 
 
+// Forward without dy_dx, P points per thread (strided by the workgroup so every pass stays coalesced): the
+// P x 2^D gathers of a thread are independent, so more of them are in flight per wave and the launch needs
+// P x fewer workgroups (at ~1e5 samples the plain grid is ~2.4 waves of workgroups: tail-bound).
+template <typename T, uint32_t D, uint32_t C, uint32_t P>
+__global__ void __launch_bounds__(kGridBlock) k_grid_fwd_multi(const float *__restrict__ inputs, const T *__restrict__ grid,
+                                                               const int32_t *__restrict__ offsets, T *__restrict__ outputs, uint32_t B,
+                                                               uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
+                                                               bool align_corners) {
+    using Vec = FeatVec<T, C>;
+    uint32_t level, pblock;
+    if (!sched.locate(blockIdx.x, level, pblock)) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+    const Vec *__restrict__ table = reinterpret_cast<const Vec *>(grid) + off0;
+    Vec *__restrict__ out = reinterpret_cast<Vec *>(outputs) + (size_t)level * B;
+
+    Vec corner[P][1u << D];
+    float w[P][1u << D];
+    bool live[P], inside[P];
+#pragma unroll
+    for (uint32_t q = 0; q < P; q++) {
+        const uint32_t b = (pblock * P + q) * kGridBlock + threadIdx.x;
+        live[q] = b < B;
+        inside[q] = false;
+        float frac[D];
+        uint32_t cell[D];
+        if (live[q]) inside[q] = locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell);
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            float wi = 1;
+            uint32_t pg[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((idx >> d) & 1u) { wi *= frac[d]; pg[d] = cell[d] + 1; }
+                else { wi *= 1 - frac[d]; pg[d] = cell[d]; }
+            }
+            w[q][idx] = wi;
+            if (inside[q]) corner[q][idx] = table[index(pg)];
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < P; q++) {
+        if (!live[q]) continue;
+        Vec acc;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) acc.v[c] = (T)0;
+        if (inside[q]) {
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) axpy<T>(acc.v[c], w[q][idx], corner[q][idx].v[c]);
+            }
+        }
+        out[(pblock * P + q) * kGridBlock + threadIdx.x] = acc;
+    }
+}
+
 // packed / scalar atomic accumulate of one weighted gradient vector
 template <typename T, uint32_t C>
 __device__ __forceinline__ void scatter_add(T *__restrict__ dst, float w, const FeatVec<T, C> &g);
@@ -390,6 +450,17 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_fwd(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
     const LevelScales sc = make_scales(L, S, H);
+    const uint32_t P = calc ? 1u : (uint32_t)g_grid_points_per_thread;
+    if (P > 1 && sizeof(T) * C <= 8) {
+        const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock * P), sizeof(T) * C);
+        if (P == 2)
+            hipLaunchKernelGGL((k_grid_fwd_multi<T, D, C, 2>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets,
+                               (T *)outputs, B, L, sc, sched, gridtype, align);
+        else
+            hipLaunchKernelGGL((k_grid_fwd_multi<T, D, C, 4>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets,
+                               (T *)outputs, B, L, sc, sched, gridtype, align);
+        return check_launch();
+    }
     const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
     hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets, (T *)outputs, B,
                        L, sc, sched, gridtype, align, calc, (T *)dy_dx);
@@ -449,7 +520,13 @@ using namespace pvd;
 extern "C" {
 
 // tuning knob for A/B measurements (tools/bench_grid.py); not part of the drop-in surface
-int pvd_grid_set_variant(int v) { const int old = g_grid_variant; g_grid_variant = v; return old; }
+int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bits 4..7: points per thread (0 -> 1, else 2 or 4)
+    const int old = g_grid_variant | (g_grid_points_per_thread << 4);
+    g_grid_variant = v & 1;
+    const int ppt = (v >> 4) & 15;
+    g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
+    return old;
+}
 
 int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B,
                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void *dy_dx,
