@@ -114,30 +114,74 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     }
 }
 
-// Runs of consecutive samples that hit the same plane texel quad / the same line texel pair are
-// accumulated in registers and flushed with one atomic per tap when the texel changes.  The plane and
-// the line of an axis triple advance independently along a ray (roughly every 2/(|du|+|dv|) and 2/|dw|
-// samples at res 300), so they are tracked separately.
-struct PlaneRun { int x0, y0; float p[4]; bool open; };
-struct LineRun { int l0; float l[2]; bool open; };
+// Gradient accumulation windows.  Consecutive samples of a ray move by a fraction of a texel, so the 2x2
+// plane footprint (and the 2-tap line footprint) of sample k+1 usually overlaps that of sample k.  Each
+// wave keeps the current footprint's partial sums in registers; when the footprint slides by one texel
+// along one axis only the row/column that LEAVES is flushed (one contiguous 64-lane atomic per texel, lane =
+// channel), the overlapping one is shifted in registers; any other move flushes everything.  Every texel a
+// ray crosses thus receives about one atomic per contiguous visit instead of one per sample and tap --
+// the memory-side atomic rate, not bandwidth, is what bounds this kernel (rocprofv3: WRITE_SIZE 153 MB/launch).
+struct PlaneWin { int x0, y0; float a00, a01, a10, a11; bool open; };  // a[dy][dx]
+struct LineWin { int l0; float a0, a1; bool open; };
 
-__device__ __forceinline__ void flush_plane(PlaneRun &r, float *__restrict__ gm, int W, int H, uint32_t R) {
-    if (!r.open) return;
-    const bool x0 = r.x0 >= 0 && r.x0 < W, x1 = r.x0 + 1 >= 0 && r.x0 + 1 < W;
-    const bool y0 = r.y0 >= 0 && r.y0 < H, y1 = r.y0 + 1 >= 0 && r.y0 + 1 < H;
-    const long base = ((long)r.y0 * W + r.x0) * (long)R;
-    // one contiguous 64-lane atomic per tap (lane = channel): global_atomic_add_f32
-    if (x0 && y0) __hip_atomic_fetch_add(gm + base, r.p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (x1 && y0) __hip_atomic_fetch_add(gm + base + R, r.p[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (x0 && y1) __hip_atomic_fetch_add(gm + base + (long)W * R, r.p[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (x1 && y1) __hip_atomic_fetch_add(gm + base + (long)W * R + R, r.p[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.open = false;
+__device__ __forceinline__ void atom(float *__restrict__ p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void flush_texel(float *__restrict__ gm, int x, int y, int W, int H, uint32_t R, float v) {
+    if (x >= 0 && x < W && y >= 0 && y < H) atom(gm + ((long)y * W + x) * (long)R, v);
 }
-__device__ __forceinline__ void flush_line(LineRun &r, float *__restrict__ gv, int L, uint32_t R) {
-    if (!r.open) return;
-    if (r.l0 >= 0 && r.l0 < L) __hip_atomic_fetch_add(gv + (long)r.l0 * R, r.l[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (r.l0 + 1 >= 0 && r.l0 + 1 < L) __hip_atomic_fetch_add(gv + (long)(r.l0 + 1) * R, r.l[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.open = false;
+
+__device__ __forceinline__ void plane_move(PlaneWin &w, int nx, int ny, float *__restrict__ gm, int W, int H, uint32_t R) {
+    if (!w.open) {
+        w.open = true; w.x0 = nx; w.y0 = ny; w.a00 = w.a01 = w.a10 = w.a11 = 0.f;
+        return;
+    }
+    const int dx = nx - w.x0, dy = ny - w.y0;
+    if (dx == 0 && dy == 0) return;
+    if (dy == 0 && dx == 1) {          // column x0 leaves
+        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10);
+        w.a00 = w.a01; w.a10 = w.a11; w.a01 = 0.f; w.a11 = 0.f;
+    } else if (dy == 0 && dx == -1) {  // column x0+1 leaves
+        flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
+        w.a01 = w.a00; w.a11 = w.a10; w.a00 = 0.f; w.a10 = 0.f;
+    } else if (dx == 0 && dy == 1) {   // row y0 leaves
+        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
+        w.a00 = w.a10; w.a01 = w.a11; w.a10 = 0.f; w.a11 = 0.f;
+    } else if (dx == 0 && dy == -1) {  // row y0+1 leaves
+        flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
+        w.a10 = w.a00; w.a11 = w.a01; w.a00 = 0.f; w.a01 = 0.f;
+    } else {
+        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
+        flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
+        w.a00 = w.a01 = w.a10 = w.a11 = 0.f;
+    }
+    w.x0 = nx; w.y0 = ny;
+}
+__device__ __forceinline__ void plane_close(PlaneWin &w, float *__restrict__ gm, int W, int H, uint32_t R) {
+    if (!w.open) return;
+    flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
+    flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
+    w.open = false;
+}
+
+__device__ __forceinline__ void flush_line_texel(float *__restrict__ gv, int l, int L, uint32_t R, float v) {
+    if (l >= 0 && l < L) atom(gv + (long)l * R, v);
+}
+__device__ __forceinline__ void line_move(LineWin &w, int nl, float *__restrict__ gv, int L, uint32_t R) {
+    if (!w.open) {
+        w.open = true; w.l0 = nl; w.a0 = w.a1 = 0.f;
+        return;
+    }
+    const int d = nl - w.l0;
+    if (d == 0) return;
+    if (d == 1) { flush_line_texel(gv, w.l0, L, R, w.a0); w.a0 = w.a1; w.a1 = 0.f; }
+    else if (d == -1) { flush_line_texel(gv, w.l0 + 1, L, R, w.a1); w.a1 = w.a0; w.a0 = 0.f; }
+    else { flush_line_texel(gv, w.l0, L, R, w.a0); flush_line_texel(gv, w.l0 + 1, L, R, w.a1); w.a0 = w.a1 = 0.f; }
+    w.l0 = nl;
+}
+__device__ __forceinline__ void line_close(LineWin &w, float *__restrict__ gv, int L, uint32_t R) {
+    if (!w.open) return;
+    flush_line_texel(gv, w.l0, L, R, w.a0); flush_line_texel(gv, w.l0 + 1, L, R, w.a1);
+    w.open = false;
 }
 
 template <typename T>
@@ -152,10 +196,10 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     const uint32_t R = kind ? kRc : kRs;
     const uint32_t ch = kind ? lane - kRs : lane;
 
-    PlaneRun prun[3];
-    LineRun lrun[3];
+    PlaneWin pw[3];
+    LineWin lw[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { prun[i].open = false; lrun[i].open = false; }
+    for (int i = 0; i < 3; i++) { pw[i].open = false; lw[i].open = false; }
 
     for (uint32_t m = s0; m < s1; m++) {
         float xn[3];
@@ -183,33 +227,21 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
             const float gp = g * lv;  // d loss / d plane value
             const float gl = g * pv;  // d loss / d line value
 
-            PlaneRun &pr = prun[i];
-            if (pr.open && (pr.x0 != tx.i0 || pr.y0 != ty.i0))  // wave-uniform branches
-                flush_plane(pr, gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
-            if (!pr.open) {
-                pr.open = true;
-                pr.x0 = tx.i0; pr.y0 = ty.i0;
-                pr.p[0] = pr.p[1] = pr.p[2] = pr.p[3] = 0.f;
-            }
-            pr.p[0] += gp * (tx.w0 * ty.w0);
-            pr.p[1] += gp * (tx.w1 * ty.w0);
-            pr.p[2] += gp * (tx.w0 * ty.w1);
-            pr.p[3] += gp * (tx.w1 * ty.w1);
-            LineRun &lr = lrun[i];
-            if (lr.open && lr.l0 != tl.i0) flush_line(lr, gr.vec[kind][i] + ch, (int)tb.L[i], R);
-            if (!lr.open) {
-                lr.open = true;
-                lr.l0 = tl.i0;
-                lr.l[0] = lr.l[1] = 0.f;
-            }
-            lr.l[0] += gl * tl.w0;
-            lr.l[1] += gl * tl.w1;
+            // wave-uniform control flow: every lane shares the sample's texel coordinates
+            plane_move(pw[i], tx.i0, ty.i0, gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
+            pw[i].a00 += gp * (tx.w0 * ty.w0);
+            pw[i].a01 += gp * (tx.w1 * ty.w0);
+            pw[i].a10 += gp * (tx.w0 * ty.w1);
+            pw[i].a11 += gp * (tx.w1 * ty.w1);
+            line_move(lw[i], tl.i0, gr.vec[kind][i] + ch, (int)tb.L[i], R);
+            lw[i].a0 += gl * tl.w0;
+            lw[i].a1 += gl * tl.w1;
         }
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        flush_plane(prun[i], gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
-        flush_line(lrun[i], gr.vec[kind][i] + ch, (int)tb.L[i], R);
+        plane_close(pw[i], gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
+        line_close(lw[i], gr.vec[kind][i] + ch, (int)tb.L[i], R);
     }
 }
 
