@@ -13,6 +13,7 @@
 namespace pvd {
 
 constexpr uint32_t kLossBlock = 256;
+constexpr uint32_t kSumsqMaxBlocks = 1024;  // S4 is [4 + 4 * kSumsqMaxBlocks] floats: sums, then per-block partials
 
 __device__ __forceinline__ float block_sum(float v, float *__restrict__ sh) {
 #pragma unroll
@@ -44,12 +45,19 @@ __global__ void __launch_bounds__(kLossBlock) k_sumsq4(const float *__restrict__
     }
     for (uint32_t i = tid; i < M * 3u; i += stride) { const float d = col_s[i] - col_t[i]; s_col += d * d; }
     s_img = block_sum(s_img, sh); s_fea = block_sum(s_fea, sh); s_sig = block_sum(s_sig, sh); s_col = block_sum(s_col, sh);
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(S + 0, s_img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(S + 1, s_fea, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(S + 2, s_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(S + 3, s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // per-block partials (4096 same-line atomics would serialise at ~12 ns each); reduced by k_sumsq4_reduce
+    if (threadIdx.x == 0) reinterpret_cast<float4 *>(S + 4)[blockIdx.x] = make_float4(s_img, s_fea, s_sig, s_col);
+}
+
+__global__ void __launch_bounds__(kLossBlock) k_sumsq4_reduce(float *__restrict__ S, uint32_t nblocks) {
+    __shared__ float sh[kLossBlock / 64];
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += kLossBlock) {
+        const float4 v = reinterpret_cast<const float4 *>(S + 4)[i];
+        a += v.x; b += v.y; c += v.z; d += v.w;
     }
+    a = block_sum(a, sh); b = block_sum(b, sh); c = block_sum(c, sh); d = block_sum(d, sh);
+    if (threadIdx.x == 0) { S[0] = a; S[1] = b; S[2] = c; S[3] = d; }
 }
 
 __global__ void k_loss_final(const float *__restrict__ S, const float *__restrict__ rates, float *__restrict__ loss,
@@ -94,11 +102,11 @@ int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img
                       const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(S4, 0, 4 * sizeof(float), s) != hipSuccess) return PVD_ERR_LAUNCH;
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > kSumsqMaxBlocks) blocks = kSumsqMaxBlocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
+    hipLaunchKernelGGL(k_sumsq4_reduce, dim3(1), dim3(kLossBlock), 0, s, S4, blocks);
     return check_launch();
 }
 

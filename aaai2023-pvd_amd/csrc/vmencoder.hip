@@ -245,10 +245,12 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     }
 }
 
-static uint32_t pick_chunk(uint32_t M) {
-    // enough waves to fill 256 CUs x 8+ waves, but runs long enough for the backward's merging to bite
+static uint32_t pick_chunk(uint32_t M, bool backward) {
+    // forward: short runs, many waves (pure latency hiding).  backward: longer runs so the accumulation
+    // windows see more consecutive samples of a ray, while still filling 256 CUs x 16 waves.
     uint32_t chunk = 16;
-    while (chunk < 64 && (uint64_t)M / chunk > 256u * 16u) chunk <<= 1;
+    const uint32_t target_waves = backward ? 256u * 16u : 256u * 32u;
+    while (chunk < 64 && (uint64_t)M / chunk > target_waves) chunk <<= 1;
     return chunk;
 }
 
@@ -284,7 +286,7 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
     VmTables tb;
     const int rc = fill_tables(tb, tables_host, res_host, aabb_host);
     if (rc != PVD_OK) return rc;
-    const uint32_t chunk = pick_chunk(M);
+    const uint32_t chunk = pick_chunk(M, false);
     const uint32_t waves = div_up(M, chunk);
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
     if (prod_dtype == PVD_F32)
@@ -311,7 +313,7 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
             gr.vec[k][i] = (float *)grad_tables_host[k * 6 + 3 + i];
             if (!gr.mat[k][i] || !gr.vec[k][i]) return PVD_ERR_INVALID;
         }
-    const uint32_t chunk = pick_chunk(M);
+    const uint32_t chunk = pick_chunk(M, true);
     const uint32_t waves = div_up(M, chunk);
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
     if (prod_dtype == PVD_F32)

@@ -16,10 +16,10 @@ class _DistillNormL2(Function):
     def forward(ctx, img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp):
         dev = img_s.device
         args = [t.detach().float().contiguous() for t in (img_s, img_t, fea_s, fea_t, col_s, col_t)]
-        S = torch.empty(4, dtype=torch.float32, device=dev)
+        S = torch.empty(4 + 4 * 1024, dtype=torch.float32, device=dev)  # 4 sums + per-workgroup partials (scratch)
         pvd_hip.distill_sumsq(*args, S)
         if dp is not None and dp.enabled:
-            dp.all_reduce_sum_(S)  # global norms: sum of squares over all shards
+            dp.all_reduce_sum_(S[:4])  # global norms: sum of squares over all shards
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         coef = torch.empty(4, dtype=torch.float32, device=dev)
         norms = torch.empty(4, dtype=torch.float32, device=dev)

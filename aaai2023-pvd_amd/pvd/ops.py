@@ -11,6 +11,11 @@ def _distill_loss():
     return distill_loss_normL2
 
 
+def _flat_adamw():
+    from .flat_adamw import FlatAdamW
+    return FlatAdamW
+
+
 def hip_ops():
     import gridencoder
     import raymarching
@@ -30,4 +35,4 @@ def hip_ops():
         return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
 
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

@@ -95,6 +95,16 @@ class FlatGrads:
             off += p.numel()
 
 
+class _FlatOptGrads:
+    """FlatGrads interface over FlatAdamW's own gradient buffer."""
+
+    def __init__(self, opt):
+        self.opt, self.flat, self.params = opt, opt.flat_g, opt.params
+
+    def zero_(self):
+        self.opt.zero_grad()
+
+
 def _make_loss(kind, dp):
     """reference: Trainer.get_loss, utils.py:941-952 (normL2 is a Frobenius norm, NOT a mean)."""
     if kind == "L2":
@@ -117,16 +127,23 @@ class _TrainerBase:
         params = model.get_params(lr)
         fused = self.device_type == "cuda"
         # reference: AdamW(betas=(0.9, 0.99), eps=1e-15), default weight decay (main_distill_mutual.py:334-339)
-        if fused:  # device-side lr so that a captured step sees the schedule (LRScheduler fills tensor lrs in place)
-            for g in params:
-                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
-        self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused, capturable=fused)
+        self.flat_opt = fused and getattr(model.ops, "flat_adamw", None) is not None
+        if self.flat_opt:  # parameters, gradients and moments in flat buffers, one HIP kernel per step
+            self.optimizer = model.ops.flat_adamw(params, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+        else:
+            if fused:  # device-side lr so that a captured step sees the schedule (LRScheduler fills tensor lrs in place)
+                for g in params:
+                    g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+            self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused, capturable=fused)
         if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
             self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
         else:  # student: cosine to eta_min (main_distill_mutual.py:346-348)
             self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
         self.scaler = torch.amp.GradScaler(self.device_type, enabled=self.fp16 and self.device_type == "cuda")
-        self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
+        if self.flat_opt:
+            self.flat = _FlatOptGrads(self.optimizer)
+        else:
+            self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
         self.global_step = 0
 
     def _backward(self, loss):

@@ -50,6 +50,7 @@ ENTRY_POINTS = (
     "pvd_head_backward_vm", "pvd_head_backward_vm_workspace_floats",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
+    "pvd_adamw_step",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -413,6 +414,16 @@ def distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upst
     _f32_all(coef4=coef4, upstream=upstream, g_img=g_img, g_fea=g_fea, g_col=g_col)
     _call("pvd_distill_sumsq_backward", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s),
           _p(col_t), _p(coef4), _p(upstream), _p(g_img), _p(g_fea), _p(g_col))
+
+
+# --------------------------------------------------------------------------- flat AdamW
+def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None):
+    dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
+    _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
+    ends = (ctypes.c_uint64 * len(segment_ends))(*[int(e) for e in segment_ends])
+    _call("pvd_adamw_step", dev, _p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.numel()), ends, _u32(len(segment_ends)), _p(lr),
+          ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_double(weight_decay), _p(step), _p(grad_scale),
+          _p(found_inf))
 
 
 raymarching_backend = types.SimpleNamespace(

@@ -238,7 +238,8 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
  *   loss = sum_i rates4[i] * sqrt(S4[i]);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
  * img [n_img] f32 (= N*3), fea [M,16] f32 (16-byte aligned), col [M,3] f32.  Under ray data parallelism the host
- * all-reduces S4 between pvd_distill_sumsq and pvd_distill_loss_final.  rates4 / upstream are DEVICE scalars. */
+ * all-reduces S4[0..3] between pvd_distill_sumsq and pvd_distill_loss_final.  rates4 / upstream are DEVICE scalars.
+ * S4 must hold 4 + 4*1024 floats: the four sums, followed by scratch for per-workgroup partials. */
 int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
                       uint32_t M, const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream);
 int pvd_distill_loss_final(const float *S4, const float *rates4, float *loss, float *coef4, float *norms4, pvd_stream_t stream);
@@ -246,6 +247,15 @@ int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint3
                                const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea,
                                const float *coef4, const float *upstream, float *g_img, float *g_fea, float *g_col,
                                pvd_stream_t stream);
+
+/* AdamW over flat fp32 buffers (the optimiser is torch.optim.AdamW in the reference, main_distill_mutual.py:334-339;
+ * arithmetic of torch's fused kernel, ADAMW mode).  p, g, m, v: [n] device, n and every segment end multiples of 4.
+ * segment_ends_host[n_segments]: HOST array; segment k = [end[k-1], end[k]) uses the DEVICE learning rate lr[k].
+ * step: DEVICE float step count (incremented unless found_inf); grad_scale / found_inf: DEVICE scalars of a
+ * GradScaler or NULL. */
+int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
+                   uint32_t n_segments, const float *lr, double beta1, double beta2, double eps, double weight_decay,
+                   float *step, const float *grad_scale, const float *found_inf, pvd_stream_t stream);
 
 #ifdef __cplusplus
 }

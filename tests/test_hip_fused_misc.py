@@ -81,3 +81,46 @@ def test_fused_distill_loss_matches_torch_norms():
     loss, _ = distill_loss_normL2(img_t.clone().requires_grad_(True), img_t, z, fea_t, col_t.clone().requires_grad_(True), col_t, rates, None)
     loss.backward()
     assert float(loss) == 0.0 and torch.count_nonzero(z.grad) == 0
+
+
+def test_flat_adamw_matches_torch_fused_adamw():
+    """Same parameters / gradients through torch.optim.AdamW(fused) and FlatAdamW, with GradScaler-style
+    grad_scale, a skipped (found_inf) step and two learning-rate groups, over several steps."""
+    from pvd.flat_adamw import FlatAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    shapes = [(1, 16, 30, 30), (64, 31), (3, 64), (1, 48, 30, 1), (15, 144), (7,)]
+    def make():
+        ps = []
+        gg = torch.Generator(device=dev).manual_seed(1)
+        for i, s in enumerate(shapes):
+            t = torch.randn(*s, device=dev, generator=gg)
+            if len(s) == 4:
+                t = t.contiguous(memory_format=torch.channels_last) if i == 0 else t
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    pa, pb = make(), make()
+    groups = lambda ps: [{"params": ps[:3], "lr": 1e-2}, {"params": ps[3:], "lr": 1e-3}]
+    ref = torch.optim.AdamW(groups(pa), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+    mine = FlatAdamW(groups(pb), betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b) and a.stride() == b.stride()
+    scale = torch.tensor(1024.0, device=dev)
+    for it in range(6):
+        inf = torch.tensor(1.0 if it == 3 else 0.0, device=dev)
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, device=dev, generator=g) * 1024.0
+            a.grad = gr.clone().contiguous(memory_format=torch.channels_last) if a.dim() == 4 and a.stride() != a.contiguous().stride() else gr.clone()
+            mine.zero_grad() if False else None
+            b.grad.copy_(gr)
+        ref.grad_scale, ref.found_inf = scale, inf
+        mine.grad_scale, mine.found_inf = scale, inf
+        ref.step(); mine.step()
+        if it == 4:  # schedulers fill tensor lrs in place
+            for grp in mine.param_groups:
+                grp["lr"].mul_(0.5)
+            for grp in ref.param_groups:
+                grp["lr"] = grp["lr"] * 0.5 if torch.is_tensor(grp["lr"]) else grp["lr"] * 0.5
+    assert float(mine.step_count) == 5.0  # one step skipped
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (a - b).abs().max()
