@@ -48,8 +48,6 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.grad = _view(self.flat_g, p, o)
         for k, g in enumerate(self.param_groups):
             g["lr"] = self.lr_dev[k:k + 1]  # LRScheduler.step() fills tensor lrs in place
-        self.grad_scale = None
-        self.found_inf = None
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -64,4 +62,5 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         d = self.defaults
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
-                           d["eps"], d["weight_decay"], self.step_count, self.grad_scale, self.found_inf)
+                           d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None))
+        # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
