@@ -146,34 +146,42 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # per-kernel HIP events cannot sit inside a replayed graph: time the dominant kernel live, on the
-    # stream it is launched on, in a few extra eager steps on the same state right after the timed region
-    timed = {"pvd_grid_encode_forward"}
-    w._graph = False
-    with pvd_hip.KernelTimer(timed) as kt:
-        for _ in range(5):
-            w.step()
-        torch.cuda.synchronize()
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-
-    # ---- roofline of the hash-grid lookup (dominant native kernel named by north_star)
+    # ---- roofline of the hash-grid lookup (the kernel north_star names).  Per-kernel HIP events cannot sit inside a
+    # replayed graph, so right after the timed region the SAME kernel is re-launched on the samples of one more step
+    # (teacher forward = pvd_grid_encode_forward + fused head), 40 times back to back with the queue kept full, each
+    # launch bracketed by HIP events on the launch stream (torch's current stream).
+    import fusedhead
     name = "pvd_grid_encode_forward"
-    n_launch = kt.launches(name)
     roof = None
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+        rays_o, rays_d, bg = w.device_batch()
+        out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
+                               max_steps=opt.max_steps)
+        xyzs, dirs = out_stu["inherited_params"][0], out_stu["inherited_params"][1]
+        for _ in range(5):
+            fusedhead.hash_head_infer(w.tea, xyzs, dirs)
+        torch.cuda.synchronize()
+        with pvd_hip.KernelTimer({name}) as kt:
+            for _ in range(40):
+                fusedhead.hash_head_infer(w.tea, xyzs, dirs)
+            torch.cuda.synchronize()
+    n_launch = kt.launches(name)
     if n_launch:
         mean_ms = kt.mean_ms(name)
-        metas = kt.meta[name]
-        B, D, C, L, dt_code = metas[-1]
+        B, D, C, L, dt_code = kt.meta[name][-1]
         T = 2 if dt_code == 1 else 4
-        mean_B = float(np.mean([m[0] for m in metas]))
-        bytes_per_launch = grid_fwd_bytes_per_sample(D, C, L, T) * mean_B
-        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        bps = grid_fwd_bytes_per_sample(D, C, L, T)
+        achieved = bps * B / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):  # FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes, per sample
+            pmc = json.load(open(pmc_path))
+            per_sample = (pmc["k_grid_fwd"]["fetch_kb"] + pmc["k_grid_fwd"]["write_kb"]) * 1024.0 / pmc["samples_per_launch"]
+            traffic = per_sample * B
         roof = {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward)" % ("f16" if T == 2 else "f32"), "bound": "hbm",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_sample": grid_fwd_bytes_per_sample(D, C, L, T), "samples_per_launch": mean_B,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json; gather pattern, uncorrected)",
+                "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps, "samples_per_launch": B,
                 "us_per_launch": mean_ms * 1e3, "launches": n_launch}
 
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
