@@ -59,6 +59,7 @@ struct LevelSchedule {
 
 static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain level-major order (default: measured faster)
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
+static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
 
 template <uint32_t D>
 static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t nb, size_t row_bytes) {
@@ -387,10 +388,11 @@ template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs,
                                                          const int32_t *__restrict__ offsets, T *__restrict__ grad_grid,
                                                          uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
-                                                         bool align_corners) {
+                                                         bool align_corners, uint32_t level_mask) {
     using Vec = FeatVec<T, C>;
     uint32_t level, pblock;
     if (!sched.locate(blockIdx.x, level, pblock)) return;
+    if (level_mask && !((level_mask >> level) & 1u)) return;
     const uint32_t b = pblock * kGridBlock + threadIdx.x;
     if (b >= B) return;
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -473,7 +475,7 @@ static int launch_bwd(const void *grad, const float *inputs, const int32_t *offs
     const LevelScales sc = make_scales(L, S, H);
     const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
     hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
-                       (T *)grad_emb, B, L, sc, sched, gridtype, align);
+                       (T *)grad_emb, B, L, sc, sched, gridtype, align, g_grid_level_mask);
     if (calc)
         hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(div_up(B * D, kGridBlock)), dim3(kGridBlock), 0, s, (const T *)grad,
                            (const T *)dy_dx, (T *)grad_inputs, B, L);
@@ -525,6 +527,7 @@ int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bits 4..7: poin
     g_grid_variant = v & 1;
     const int ppt = (v >> 4) & 15;
     g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
+    g_grid_level_mask = ((uint32_t)v >> 8) & 0xffffffu;  // bits 8..31: backward level mask (measurement only)
     return old;
 }
 
