@@ -60,6 +60,7 @@ struct LevelSchedule {
 static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain level-major order (default: measured faster)
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
+static float g_grid_coarse_scale = 300.f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off)
 
 template <uint32_t D>
 static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t nb, size_t row_bytes) {
@@ -418,6 +419,78 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_bwd(const T *__restrict__ g
     }
 }
 
+// Coarse levels: the samples of a wave are consecutive along a ray and a coarse cell is many steps wide
+// (level 0: ~40 steps), so whole runs of lanes scatter into the SAME rows -- which is what makes the plain
+// kernel slow there (rocprof/bench_grid_bwd: level 0 alone 527 us of 806 us: same-address atomics serialise at
+// the memory side).  Here every corner's contributions are first summed across each run of equal row index
+// with a segmented wave scan (runs are identified by a ballot of head flags, so only contiguous equal keys
+// merge), and only the last lane of a run issues the atomic: one atomic per (run, corner) instead of per
+// (sample, corner).  The run sum is formed in fp32 and rounded once.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_bwd_coarse(const T *__restrict__ grad, const float *__restrict__ inputs,
+                                                                const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t B,
+                                                                uint32_t L, LevelScales scales, uint32_t level_lo, uint32_t level_hi,
+                                                                uint32_t gridtype, bool align_corners, uint32_t level_mask) {
+    using Vec = FeatVec<T, C>;
+    const uint32_t level = level_lo + blockIdx.y;
+    if (level >= level_hi) return;
+    if (level_mask && !((level_mask >> level) & 1u)) return;
+    const uint32_t b = blockIdx.x * kGridBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+    float frac[D];
+    uint32_t cell[D];
+    const bool live = b < B && locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell);
+    float g[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) g[c] = 0.f;
+    if (live) {
+        const Vec gv = reinterpret_cast<const Vec *>(grad)[(size_t)level * B + b];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) g[c] = (float)gv.v[c];
+    }
+    T *__restrict__ table = grad_grid + (size_t)off0 * C;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wi = 1;
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx >> d) & 1u) { wi *= live ? frac[d] : 0.f; pg[d] = live ? cell[d] + 1 : 0u; }
+            else { wi *= live ? 1 - frac[d] : 0.f; pg[d] = live ? cell[d] : 0u; }
+        }
+        const uint32_t key = live ? index(pg) : 0xffffffffu;
+        float v[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) v[c] = wi * g[c];
+        // runs of equal keys: head flags -> run ids
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool head = lane == 0 || prev != key;
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t r_up = __shfl_up(run, off, 64);
+            const bool same = (int)lane >= off && r_up == run;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                const float up = __shfl_up(v[c], off, 64);
+                if (same) v[c] += up;
+            }
+        }
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        if (live && tail) {
+            Vec sum;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) sum.v[c] = (T)v[c];
+            scatter_add<T, C>(table + (size_t)key * C, 1.0f, sum);
+        }
+    }
+}
+
 // reference: kernel_input_backward, gridencoder.cu:317-343
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx,
@@ -473,9 +546,22 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_bwd(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool align, hipStream_t s) {
     const LevelScales sc = make_scales(L, S, H);
+    // levels whose cells are wider than a few marching steps go through the run-merging kernel
+    uint32_t n_coarse = 0;
+    if (g_grid_coarse_scale > 0.f)
+        while (n_coarse < L && sc.scale[n_coarse] < g_grid_coarse_scale) n_coarse++;
+    if (n_coarse > 0)
+        hipLaunchKernelGGL((k_grid_bwd_coarse<T, D, C>), dim3(div_up(B, kGridBlock), n_coarse), dim3(kGridBlock), 0, s, (const T *)grad, inputs,
+                           offsets, (T *)grad_emb, B, L, sc, 0u, n_coarse, gridtype, align, g_grid_level_mask);
+    uint32_t fine_mask = g_grid_level_mask;
+    if (n_coarse > 0) {
+        const uint32_t not_coarse = ~((1u << n_coarse) - 1u) & ((L >= 32 ? 0u : (1u << L)) - 1u);
+        fine_mask = g_grid_level_mask ? (g_grid_level_mask & not_coarse) : not_coarse;
+        if (fine_mask == 0) return check_launch();
+    }
     const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
     hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
-                       (T *)grad_emb, B, L, sc, sched, gridtype, align, g_grid_level_mask);
+                       (T *)grad_emb, B, L, sc, sched, gridtype, align, fine_mask);
     if (calc)
         hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(div_up(B * D, kGridBlock)), dim3(kGridBlock), 0, s, (const T *)grad,
                            (const T *)dy_dx, (T *)grad_inputs, B, L);
@@ -527,7 +613,8 @@ int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bits 4..7: poin
     g_grid_variant = v & 1;
     const int ppt = (v >> 4) & 15;
     g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
-    g_grid_level_mask = ((uint32_t)v >> 8) & 0xffffffu;  // bits 8..31: backward level mask (measurement only)
+    g_grid_level_mask = ((uint32_t)v >> 8) & 0x3fffffu;  // bits 8..29: backward level mask (measurement only)
+    g_grid_coarse_scale = (v & (1 << 30)) ? 0.f : 300.f;   // bit 30: disable the run-merging backward
     return old;
 }
 
