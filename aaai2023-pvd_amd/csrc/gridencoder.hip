@@ -60,7 +60,8 @@ struct LevelSchedule {
 static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain level-major order (default: measured faster)
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
-static float g_grid_coarse_scale = 300.f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off)
+static float g_grid_coarse_scale = 1e30f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off);
+                                           // measured best on every level (tools/bench_grid_bwd.py: 179 vs 205 vs 850 us, f16, 9e4 samples)
 
 template <uint32_t D>
 static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t nb, size_t row_bytes) {
@@ -613,8 +614,8 @@ int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bits 4..7: poin
     g_grid_variant = v & 1;
     const int ppt = (v >> 4) & 15;
     g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
-    g_grid_level_mask = ((uint32_t)v >> 8) & 0x3fffffu;  // bits 8..29: backward level mask (measurement only)
-    g_grid_coarse_scale = (v & (1 << 30)) ? 0.f : 300.f;   // bit 30: disable the run-merging backward
+    g_grid_level_mask = ((uint32_t)v >> 8) & 0x1fffffu;  // bits 8..28: backward level mask (measurement only)
+    g_grid_coarse_scale = (v & (1 << 30)) ? 0.f : ((v & (1 << 29)) ? 300.f : 1e30f);  // bit 30: no run merging; bit 29: coarse levels only
     return old;
 }
 

@@ -33,6 +33,8 @@ for dt in (torch.float16, torch.float32):
         return a.elapsed_time(b) / iters * 1e3
 
     print("backward %s B=%d: all levels %.1f us; per level:" % (dt, B, timeit(0)), " ".join("%d:%.0f" % (l, timeit(1 << l)) for l in range(14)))
+    ALL = 1 << 21  # bit 29: run merging on the coarse levels only (scale < 300)
+    print("  (run-merging on coarse levels only) all levels %.1f us; per level:" % timeit(ALL), " ".join("%d:%.0f" % (l, timeit(ALL | (1 << l))) for l in range(14)))
     OFF = 1 << 22  # bit 30 of the knob after the << 8 below: plain kernel for every level
     print("  (run-merging off) all levels %.1f us; per level:" % timeit(OFF), " ".join("%d:%.0f" % (l, timeit(OFF | (1 << l))) for l in range(14)))
 pvd_hip.grid_set_variant(0)
