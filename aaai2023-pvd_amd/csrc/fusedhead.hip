@@ -144,6 +144,7 @@ struct TileFwd {
     h4 sh;       // SH fragment
     h4 H1[4], H2[4];
     f4 out;      // colour layer 3 pre-activation (rows 0..2 valid)
+    h4 X[2], Ha[4];  // hash: encoder-feature fragments and sigma_net hidden layer (kept for the backward)
 };
 
 template <int KIND>
@@ -204,14 +205,18 @@ __device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadL
 #pragma unroll
         for (int s = 0; s < 4; s++) acc = mfma(W.Wa2.afrag(0, s, lane), Ha[s], acc);
         h4 Fh = to_h4(acc);  // Linear output is f16
+        t.raw = zero;
+        t.sig_raw = (float)Fh.x;  // pre-clamp h0 (for the clamp's backward mask)
         if (hi == 0) {
             const float c = fminf(a.clip_max, fmaxf(a.clip_sigma_min, (float)Fh.x));
             Fh.x = (half_t)c;
         }
         t.Fh = Fh;
         t.F = (f4){(float)Fh.x, (float)Fh.y, (float)Fh.z, (float)Fh.w};
-        t.raw = zero;
-        t.sig_raw = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; s++) t.X[s] = X[s];
+#pragma unroll
+        for (int n = 0; n < 4; n++) t.Ha[n] = Ha[n];
     } else {
         f4 acc = zero;
 #pragma unroll
@@ -302,20 +307,25 @@ static int launch_head_fwd(const HeadArgs &a, hipStream_t s) {
 }
 
 
-// ====================================================================== backward (VM student)
+// ====================================================================== backward (training)
 
-constexpr int kDwTilesB = 9, kDwTilesC1 = 8, kDwTilesC2 = 16, kDwTilesC3 = 4;
-constexpr int kDwTiles = kDwTilesB + kDwTilesC1 + kDwTilesC2 + kDwTilesC3;  // 37 accumulator tiles per wave
-constexpr int kDwFloats = kDwTiles * 256;
+// accumulator tiles per wave: [stage-A weights][colour 1: 4x2][colour 2: 4x4][colour 3: 1x4]
+//   VM   stage A = basis_mat  (1 x 9 tiles);   hash stage A = sigma_net.0 (4 x 2) then sigma_net.1 (1 x 4)
+template <int KIND>
+struct DwLayout {
+    static constexpr int a = KIND == KIND_VM ? 9 : 12;
+    static constexpr int c1 = a, c2 = a + 8, c3 = a + 24, tiles = a + 28;
+    static constexpr int floats = tiles * 256;
+};
 
 struct HeadBwdArgs {
     HeadArgs f;
     const float *g_sigma;   // [M]      d loss / d sigma
     const float *g_rgb;     // [M][3]
     const float *g_feat16;  // [M][16]
-    float *g_sigma_raw;     // [M]
-    half_t *g_prod;         // [M][144]
-    float *partials;        // [nwaves][kDwFloats]
+    float *g_sigma_raw;     // VM: [M]
+    half_t *g_x0;           // VM: d loss / d products [M][144];  hash: d loss / d encoder output [14][M][2]
+    float *partials;        // [nwaves][DwLayout::floats]
 };
 
 // 16x16 transpose of a register tile through LDS: in = X[row 4hi+j][col l&15]  ->  out = X[row l&15][col 4hi+j]
@@ -339,19 +349,32 @@ __device__ __forceinline__ h4 mask_relu(f4 g, h4 act) {  // dPre = dAct * (act >
     return r;
 }
 
-__global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
+template <int KIND>
+__global__ void __launch_bounds__(kHeadBlock) k_head_bwd(HeadBwdArgs a) {
     extern __shared__ __align__(16) half_t lds[];
-    HeadLds<KIND_VM> W;
+    HeadLds<KIND> W;
     W.carve(lds);
-    half_t *p = lds + HeadLds<KIND_VM>::halfs;
+    half_t *p = lds + HeadLds<KIND>::halfs;
     // transposed copies for dX = W^T . dY  (A fragments must be contiguous along the contracted index)
-    LdsMat WbT = {p, 16 + kPad};  p += 144 * (16 + kPad);   // [144][16]
+    LdsMat Wa1T, Wa2T;
+    if (KIND == KIND_VM) {
+        Wa1T = {p, 16 + kPad}; p += 144 * (16 + kPad);  // basis^T [144][16]
+        Wa2T = {p, 0};
+    } else {
+        Wa1T = {p, 64 + kPad}; p += 32 * (64 + kPad);   // sigma_net.0^T [32][64]
+        Wa2T = {p, 16 + kPad}; p += 64 * (16 + kPad);   // sigma_net.1^T [64][16]
+    }
     LdsMat Wc1T = {p, 64 + kPad}; p += 32 * (64 + kPad);    // [32][64]
     LdsMat Wc2T = {p, 64 + kPad}; p += 64 * (64 + kPad);    // [64][64]
     LdsMat Wc3T = {p, 16 + kPad}; p += 64 * (16 + kPad);    // [64][16]
     half_t *scratch = p + (threadIdx.x >> 6) * 256;          // 512 B per wave
     W.load(a.f, threadIdx.x, kHeadBlock);
-    load_weight_T(WbT, a.f.Wa1, 15, 144, 16, 144, 1, -1, threadIdx.x, kHeadBlock);
+    if (KIND == KIND_VM) {
+        load_weight_T(Wa1T, a.f.Wa1, 15, 144, 16, 144, 1, -1, threadIdx.x, kHeadBlock);
+    } else {
+        load_weight_T(Wa1T, a.f.Wa1, 64, 28, 64, 32, 0, -1, threadIdx.x, kHeadBlock);
+        load_weight_T(Wa2T, a.f.Wa2, 16, 64, 16, 64, 0, -1, threadIdx.x, kHeadBlock);
+    }
     load_weight_T(Wc1T, a.f.Wc1, 64, 31, 64, 32, 0, 16, threadIdx.x, kHeadBlock);
     load_weight_T(Wc2T, a.f.Wc2, 64, 64, 64, 64, 0, -1, threadIdx.x, kHeadBlock);
     load_weight_T(Wc3T, a.f.Wc3, 3, 64, 16, 64, 0, -1, threadIdx.x, kHeadBlock);
@@ -364,21 +387,22 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     const h4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
 
-    f4 dWb[kDwTilesB], dW1[kDwTilesC1], dW2[kDwTilesC2], dW3[kDwTilesC3];
+    using LY = DwLayout<KIND>;
+    f4 dWa[LY::a], dW1[8], dW2[16], dW3[4];
 #pragma unroll
-    for (int i = 0; i < kDwTilesB; i++) dWb[i] = zero;
+    for (int i = 0; i < LY::a; i++) dWa[i] = zero;
 #pragma unroll
-    for (int i = 0; i < kDwTilesC1; i++) dW1[i] = zero;
+    for (int i = 0; i < 8; i++) dW1[i] = zero;
 #pragma unroll
-    for (int i = 0; i < kDwTilesC2; i++) dW2[i] = zero;
+    for (int i = 0; i < 16; i++) dW2[i] = zero;
 #pragma unroll
-    for (int i = 0; i < kDwTilesC3; i++) dW3[i] = zero;
+    for (int i = 0; i < 4; i++) dW3[i] = zero;
 
     for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
         const size_t b = (size_t)tile * 16 + (lane & 15);
         const bool valid = b < a.f.M;
         TileFwd t;
-        head_forward_tile<KIND_VM>(a.f, W, b, valid, lane, t);
+        head_forward_tile<KIND>(a.f, W, b, valid, lane, t);
 
         // ---- d loss / d (colour layer 3 pre-activation): rows 0..2 live in the hi == 0 lanes
         h4 D3 = hzero;
@@ -405,28 +429,59 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
             const f4 gf = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
             dF.x += gf.x; dF.y += gf.y; dF.z += gf.z; dF.w += gf.w;
         }
-        // clamp backward: gradient passes where the raw value is inside [min, max]
-        const float lo = a.f.clip_feat_min, hi_c = a.f.clip_max;
-        f4 dcf;
-        dcf.x = (t.raw.x >= lo && t.raw.x <= hi_c) ? dF.x : 0.f;
-        dcf.y = (t.raw.y >= lo && t.raw.y <= hi_c) ? dF.y : 0.f;
-        dcf.z = (t.raw.z >= lo && t.raw.z <= hi_c) ? dF.z : 0.f;
-        dcf.w = (t.raw.w >= lo && t.raw.w <= hi_c) ? dF.w : 0.f;
-        if (hi == 0) {
-            // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
-            // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
-            if (valid) {
-                const float g0 = dF.x + a.g_sigma[b] * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
-                a.g_sigma_raw[b] = (t.sig_raw >= a.f.clip_sigma_min && t.sig_raw <= a.f.clip_max) ? g0 : 0.f;
-            }
-            dcf.x = 0.f;
+        // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
+        // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
+        float g0 = 0.f;
+        if (hi == 0 && valid) {
+            g0 = dF.x + a.g_sigma[b] * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
+            g0 = (t.sig_raw >= a.f.clip_sigma_min && t.sig_raw <= a.f.clip_max) ? g0 : 0.f;
         }
-        const h4 Dcf = to_h4(dcf);
-        // ---- d loss / d products = Wb'^T . Dcf, written as the f16 [M][144] the VM backward reads
+        h4 Da;  // gradient of stage A's output tile
+        if (KIND == KIND_VM) {
+            // clamp backward on the colour features; row 0 leaves through g_sigma_raw
+            const float lo = a.f.clip_feat_min, hi_c = a.f.clip_max;
+            f4 dcf;
+            dcf.x = (t.raw.x >= lo && t.raw.x <= hi_c) ? dF.x : 0.f;
+            dcf.y = (t.raw.y >= lo && t.raw.y <= hi_c) ? dF.y : 0.f;
+            dcf.z = (t.raw.z >= lo && t.raw.z <= hi_c) ? dF.z : 0.f;
+            dcf.w = (t.raw.w >= lo && t.raw.w <= hi_c) ? dF.w : 0.f;
+            if (hi == 0) {
+                if (valid) a.g_sigma_raw[b] = g0;
+                dcf.x = 0.f;
+            }
+            Da = to_h4(dcf);
+            // d loss / d products = Wb'^T . Da, written as the f16 [M][144] the VM backward reads
 #pragma unroll
-        for (int tk = 0; tk < 9; tk++) {
-            const h4 g = to_h4(mfma(WbT.afrag(tk, 0, lane), Dcf, zero));
-            if (valid) *reinterpret_cast<h4 *>(a.g_prod + b * 144 + 16 * tk + 4 * hi) = g;
+            for (int tk = 0; tk < 9; tk++) {
+                const h4 g = to_h4(mfma(Wa1T.afrag(tk, 0, lane), Da, zero));
+                if (valid) *reinterpret_cast<h4 *>(a.g_x0 + b * 144 + 16 * tk + 4 * hi) = g;
+            }
+        } else {
+            // hash: only h0 is clamped (network.py:418-420); the tile is sigma_net.1's output
+            f4 dh = dF;
+            if (hi == 0) dh.x = g0;
+            Da = to_h4(dh);
+        }
+        h4 Dh[4];  // hash: gradient of sigma_net's hidden layer (pre-relu)
+        if (KIND == KIND_HASH) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) Dh[n] = mask_relu(mfma(Wa2T.afrag(n, 0, lane), Da, zero), t.Ha[n]);
+            // d loss / d encoder features = W_s0^T . Dh, stored level-major [14][M][2] (what pvd_grid_encode_backward reads)
+#pragma unroll
+            for (int tk = 0; tk < 2; tk++) {
+                f4 acc = zero;
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = mfma(Wa1T.afrag(tk, s, lane), Dh[s], acc);
+                const h4 g = to_h4(acc);
+                const int k0 = 16 * tk + 4 * hi;
+                if (valid && k0 < 28) {
+                    uint32_t w2[2];
+                    __builtin_memcpy(w2, &g, 8);
+                    const uint32_t lv = k0 >> 1;
+                    *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)lv * a.f.M + b) * 2) = w2[0];
+                    *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)(lv + 1) * a.f.M + b) * 2) = w2[1];
+                }
+            }
         }
         // ---- weight gradients: dW[n][k] += sum_samples dY[n][s] X[k][s]  (both operands transposed tiles)
         {
@@ -454,55 +509,79 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd_vm(HeadBwdArgs a) {
                 dW1[tn * 2 + 1] = mfma(TD, TF, dW1[tn * 2 + 1]);
             }
         }
-        {
-            const h4 TD = transpose_tile(Dcf, scratch, lane);
+        if (KIND == KIND_VM) {
+            const h4 TD = transpose_tile(Da, scratch, lane);
 #pragma unroll
             for (int tk = 0; tk < 9; tk++) {
                 h4 x = hzero;
                 if (valid) x = *reinterpret_cast<const h4 *>(a.f.x0 + b * 144 + 16 * tk + 4 * hi);
-                dWb[tk] = mfma(TD, transpose_tile(x, scratch, lane), dWb[tk]);
+                dWa[tk] = mfma(TD, transpose_tile(x, scratch, lane), dWa[tk]);
             }
+        } else {
+            // sigma_net.0 [64][32]: tiles tn*2+tk;  sigma_net.1 [16][64]: tiles 8+tk
+            const h4 TX0 = transpose_tile(t.X[0], scratch, lane), TX1 = transpose_tile(t.X[1], scratch, lane);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const h4 TD = transpose_tile(Dh[tn], scratch, lane);
+                dWa[tn * 2] = mfma(TD, TX0, dWa[tn * 2]);
+                dWa[tn * 2 + 1] = mfma(TD, TX1, dWa[tn * 2 + 1]);
+            }
+            const h4 TDa = transpose_tile(Da, scratch, lane);
+#pragma unroll
+            for (int tk = 0; tk < 4; tk++) dWa[8 + tk] = mfma(TDa, transpose_tile(t.Ha[tk], scratch, lane), dWa[8 + tk]);
         }
     }
 
     // ---- one partial per wave: [tile][reg j][lane]
-    float *__restrict__ out = a.partials + (size_t)wave * kDwFloats;
+    float *__restrict__ out = a.partials + (size_t)wave * LY::floats;
     auto put = [&](int tile, f4 v) {
         out[(tile * 4 + 0) * 64 + lane] = v.x; out[(tile * 4 + 1) * 64 + lane] = v.y;
         out[(tile * 4 + 2) * 64 + lane] = v.z; out[(tile * 4 + 3) * 64 + lane] = v.w;
     };
 #pragma unroll
-    for (int i = 0; i < kDwTilesB; i++) put(i, dWb[i]);
+    for (int i = 0; i < LY::a; i++) put(i, dWa[i]);
 #pragma unroll
-    for (int i = 0; i < kDwTilesC1; i++) put(kDwTilesB + i, dW1[i]);
+    for (int i = 0; i < 8; i++) put(LY::c1 + i, dW1[i]);
 #pragma unroll
-    for (int i = 0; i < kDwTilesC2; i++) put(kDwTilesB + kDwTilesC1 + i, dW2[i]);
+    for (int i = 0; i < 16; i++) put(LY::c2 + i, dW2[i]);
 #pragma unroll
-    for (int i = 0; i < kDwTilesC3; i++) put(kDwTilesB + kDwTilesC1 + kDwTilesC2 + i, dW3[i]);
+    for (int i = 0; i < 4; i++) put(LY::c3 + i, dW3[i]);
 }
 
 // Sum the per-wave partials and ACCUMULATE into the fp32 gradient buffers (real, un-padded layouts).
 // blockIdx.x walks the real weight elements (consecutive threads read consecutive lanes of a tile:
 // coalesced), blockIdx.y a slice of the waves; every slice adds its sum with one atomic per element.
 constexpr uint32_t kReduceSlices = 16;
-__global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWb,
-                                                       float *__restrict__ gW1, float *__restrict__ gW2, float *__restrict__ gW3) {
-    const uint32_t nB = 15 * 144, n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
+template <int KIND>
+__global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWa1,
+                                                       float *__restrict__ gWa2, float *__restrict__ gW1, float *__restrict__ gW2,
+                                                       float *__restrict__ gW3) {
+    using LY = DwLayout<KIND>;
+    const uint32_t nA1 = KIND == KIND_VM ? 15 * 144 : 64 * 28, nA2 = KIND == KIND_VM ? 0 : 16 * 64;
+    const uint32_t n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float *dst;
     uint32_t tile, n16, k;  // accumulator tile, row inside the 16-row tile, padded column
-    if (i < nB) {
-        const uint32_t r = i / 144, c = i - r * 144;
-        dst = gWb + i; n16 = r + 1; k = c; tile = k >> 4;
-    } else if ((i -= nB) < n1) {
+    if (i < nA1) {
+        if (KIND == KIND_VM) {
+            const uint32_t r = i / 144, c = i - r * 144;
+            dst = gWa1 + i; n16 = r + 1; k = c; tile = k >> 4;
+        } else {
+            const uint32_t r = i / 28, c = i - r * 28;
+            dst = gWa1 + i; n16 = r & 15; k = c; tile = (r >> 4) * 2 + (k >> 4);
+        }
+    } else if ((i -= nA1) < nA2) {
+        const uint32_t r = i >> 6, c = i & 63;
+        dst = gWa2 + i; n16 = r; k = c; tile = 8 + (k >> 4);
+    } else if ((i -= nA2) < n1) {
         const uint32_t r = i / 31, c = i - r * 31;
-        dst = gW1 + i; n16 = r & 15; k = c < 16 ? c : c + 1; tile = kDwTilesB + (r >> 4) * 2 + (k >> 4);
+        dst = gW1 + i; n16 = r & 15; k = c < 16 ? c : c + 1; tile = LY::c1 + (r >> 4) * 2 + (k >> 4);
     } else if ((i -= n1) < n2) {
         const uint32_t r = i >> 6, c = i & 63;
-        dst = gW2 + i; n16 = r & 15; k = c; tile = kDwTilesB + kDwTilesC1 + (r >> 4) * 4 + (k >> 4);
+        dst = gW2 + i; n16 = r & 15; k = c; tile = LY::c2 + (r >> 4) * 4 + (k >> 4);
     } else if ((i -= n2) < n3) {
         const uint32_t r = i >> 6, c = i & 63;
-        dst = gW3 + i; n16 = r; k = c; tile = kDwTilesB + kDwTilesC1 + kDwTilesC2 + (k >> 4);
+        dst = gW3 + i; n16 = r; k = c; tile = LY::c3 + (k >> 4);
     } else {
         return;
     }
@@ -511,8 +590,19 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
     const uint32_t w0 = blockIdx.y * per, w1 = min(nwaves, w0 + per);
     float acc = 0.f;
 #pragma unroll 4
-    for (uint32_t w = w0; w < w1; w++) acc += partials[(size_t)w * kDwFloats + off];
+    for (uint32_t w = w0; w < w1; w++) acc += partials[(size_t)w * LY::floats + off];
     if (w1 > w0) __hip_atomic_fetch_add(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KIND>
+static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s) {
+    size_t lds_halfs = HeadLds<KIND>::halfs + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad) + (kHeadBlock / 64) * 256;
+    lds_halfs += KIND == KIND_VM ? 144 * (16 + kPad) : 32 * (64 + kPad) + 64 * (16 + kPad);
+    hipLaunchKernelGGL((k_head_bwd<KIND>), dim3(nwaves / (kHeadBlock / 64)), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
+    const uint32_t nreal = (KIND == KIND_VM ? 15 * 144 : 64 * 28 + 16 * 64) + 64 * 31 + 64 * 64 + 3 * 64;
+    hipLaunchKernelGGL((k_head_reduce_dw<KIND>), dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, s, a.partials, nwaves, gWa1, gWa2, gW1,
+                       gW2, gW3);
+    return check_launch();
 }
 
 }  // namespace pvd
@@ -542,39 +632,43 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
     return PVD_ERR_UNSUPPORTED;
 }
 
-int pvd_head_backward_vm_workspace_floats(uint32_t M, uint32_t *nwaves_out) {
+static uint32_t head_bwd_waves(uint32_t M) {
     const uint32_t ntiles = div_up(M, 16u);
     uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
     if (blocks > 128) blocks = 128;
     if (blocks < 1) blocks = 1;
-    if (nwaves_out) *nwaves_out = blocks * (kHeadBlock / 64);
-    return (int)(blocks * (kHeadBlock / 64) * kDwFloats);
+    return blocks * (kHeadBlock / 64);
 }
 
-int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wb, const float *Wc1,
-                         const float *Wc2, const float *Wc3, float clip_sigma_min, float clip_feat_min, float clip_max,
-                         const float *g_sigma, const float *g_rgb, const float *g_feat16, float *g_sigma_raw, void *g_prod,
-                         float *gWb, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
+int pvd_head_backward_workspace_floats(int kind, uint32_t M) {
+    return (int)(head_bwd_waves(M) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
+}
+
+int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
+                      const float *Wc1, const float *Wc2, const float *Wc3, float clip_sigma_min, float clip_feat_min, float clip_max,
+                      const float *g_sigma, const float *g_rgb, const float *g_feat16, float *g_sigma_raw, void *g_x0, float *gWa1,
+                      float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
-    if (!prod || !sigma_raw || !dirs || !Wb || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_sigma_raw || !g_prod ||
-        !gWb || !gWc1 || !gWc2 || !gWc3 || !workspace)
+    if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_x0 || !gWa1 || !gWc1 || !gWc2 || !gWc3 ||
+        !workspace)
         return PVD_ERR_INVALID;
     HeadBwdArgs a;
-    a.f.x0 = (const half_t *)prod; a.f.sigma_raw = sigma_raw; a.f.dirs = dirs; a.f.M = M;
-    a.f.Wa1 = Wb; a.f.Wa2 = nullptr; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
+    a.f.x0 = (const half_t *)x0; a.f.sigma_raw = sigma_raw; a.f.dirs = dirs; a.f.M = M;
+    a.f.Wa1 = Wa1; a.f.Wa2 = Wa2; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
     a.f.clip_sigma_min = clip_sigma_min; a.f.clip_feat_min = clip_feat_min; a.f.clip_max = clip_max;
     a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr;
-    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_prod = (half_t *)g_prod;
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
     a.partials = workspace;
-    uint32_t nwaves = 0;
-    (void)pvd_head_backward_vm_workspace_floats(M, &nwaves);
-    const size_t lds_halfs = HeadLds<KIND_VM>::halfs + 144 * (16 + kPad) + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad) +
-                             (kHeadBlock / 64) * 256;
-    hipLaunchKernelGGL(k_head_bwd_vm, dim3(nwaves / (kHeadBlock / 64)), dim3(kHeadBlock), lds_halfs * sizeof(half_t), (hipStream_t)stream, a);
-    const uint32_t nreal = 15 * 144 + 64 * 31 + 64 * 64 + 3 * 64;
-    hipLaunchKernelGGL(k_head_reduce_dw, dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, (hipStream_t)stream, workspace, nwaves, gWb, gWc1, gWc2,
-                       gWc3);
-    return check_launch();
+    const uint32_t nwaves = head_bwd_waves(M);
+    if (kind == KIND_VM) {
+        if (!sigma_raw || !g_sigma_raw) return PVD_ERR_INVALID;
+        return launch_head_bwd<KIND_VM>(a, nwaves, gWa1, nullptr, gWc1, gWc2, gWc3, (hipStream_t)stream);
+    }
+    if (kind == KIND_HASH) {
+        if (!Wa2 || !gWa2) return PVD_ERR_INVALID;
+        return launch_head_bwd<KIND_HASH>(a, nwaves, gWa1, gWa2, gWc1, gWc2, gWc3, (hipStream_t)stream);
+    }
+    return PVD_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -558,11 +558,12 @@ static int launch_bwd(const void *grad, const float *inputs, const int32_t *offs
     if (n_coarse > 0) {
         const uint32_t not_coarse = ~((1u << n_coarse) - 1u) & ((L >= 32 ? 0u : (1u << L)) - 1u);
         fine_mask = g_grid_level_mask ? (g_grid_level_mask & not_coarse) : not_coarse;
-        if (fine_mask == 0) return check_launch();
     }
-    const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
-    hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
-                       (T *)grad_emb, B, L, sc, sched, gridtype, align, fine_mask);
+    if (n_coarse == 0 || fine_mask != 0) {
+        const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
+        hipLaunchKernelGGL((k_grid_bwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, (const T *)grad, inputs, offsets,
+                           (T *)grad_emb, B, L, sc, sched, gridtype, align, fine_mask);
+    }
     if (calc)
         hipLaunchKernelGGL((k_grid_input_bwd<T, D, C>), dim3(div_up(B * D, kGridBlock)), dim3(kGridBlock), 0, s, (const T *)grad,
                            (const T *)dy_dx, (T *)grad_inputs, B, L);

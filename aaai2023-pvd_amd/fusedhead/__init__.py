@@ -88,12 +88,12 @@ class _VMHeadTrain(torch.autograd.Function):
         g_feat = g_feat.float().contiguous() if g_feat is not None else zeros(M, 16)
         g_sraw = torch.empty(M, dtype=torch.float32, device=dev)
         g_prod = torch.empty(M, 144, dtype=torch.float16, device=dev)
-        ws = torch.empty(pvd_hip.head_backward_vm_workspace_floats(M), dtype=torch.float32, device=dev)
+        ws = torch.empty(pvd_hip.head_backward_workspace_floats(KIND_VM, M), dtype=torch.float32, device=dev)
         # accumulate straight into the leaves' gradient buffers when they exist (the trainer's flat bucket)
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
         grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
-        pvd_hip.head_backward_vm(prod, sigma_raw, dirs, M, Wb.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
-                                 g_sigma, g_rgb, g_feat, g_sraw, g_prod, *grads, ws)
+        pvd_hip.head_backward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
+                              g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws)
         gw = (None, None, None, None) if direct else tuple(grads)
         return (g_sraw, g_prod, None) + gw + (None, None, None)
 
@@ -103,3 +103,75 @@ def vm_head_train(model, sigma_raw, prod, d):
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
     return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
                               model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max)
+
+
+def _grid_dims(enc):
+    L = enc.offsets.shape[0] - 1
+    C = enc.embeddings.shape[1]
+    assert L == 14 and C == 2 and enc.input_dim == 3, "fused head expects the 14-level, 2-feature hash grid"
+    return L, C, float(np.log2(enc.per_level_scale))
+
+
+class _HashHeadTrain(torch.autograd.Function):
+    """(x01 [M,3] in [0,1], embeddings [rows,2] f32, dirs, sigma_net.{0,1}.weight, color_net.{0,1,2}.weight) ->
+    (sigma, rgb, feature_sigma_color): grid lookup + MFMA head forward, MFMA head + grid scatter backward.
+    Same dtype pipeline as the reference under autocast: table cast to half per call (grid.py:49-52), half
+    gradient table from the atomics (grid.py:105-123), widened to f32 when it reaches the parameter."""
+
+    @staticmethod
+    def forward(ctx, x01, emb, dirs, Ws0, Ws1, Wc1, Wc2, Wc3, offsets, S, H, gridtype, align, smin, cmax):
+        M = x01.shape[0]
+        dev = x01.device
+        x01, dirs = x01.float().contiguous(), dirs.float().contiguous()
+        emb16 = emb.detach().to(torch.float16)
+        enc = torch.empty(14, M, 2, dtype=torch.float16, device=dev)
+        pvd_hip.grid_encode_forward(x01, emb16, offsets, enc, M, 3, 2, 14, S, H, False, enc, gridtype, align)
+        sigma, rgb, feat = _outputs(M, dev)
+        pvd_hip.head_forward(KIND_HASH, enc, None, dirs, M, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(),
+                             smin, smin, cmax, sigma, rgb, feat)
+        ctx.save_for_backward(x01, enc, dirs, offsets, Ws0, Ws1, Wc1, Wc2, Wc3)
+        ctx.emb = emb
+        ctx.grid = (S, H, gridtype, align)
+        ctx.clips = (smin, smin, cmax)
+        ctx.leaves = (Ws0, Ws1, Wc1, Wc2, Wc3)
+        return sigma, rgb, feat
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb, g_feat):
+        x01, enc, dirs, offsets, Ws0, Ws1, Wc1, Wc2, Wc3 = ctx.saved_tensors
+        emb = ctx.emb
+        M = x01.shape[0]
+        dev = x01.device
+        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        g_sigma = g_sigma.float().contiguous() if g_sigma is not None else zeros(M)
+        g_rgb = g_rgb.float().contiguous() if g_rgb is not None else zeros(M, 3)
+        g_feat = g_feat.float().contiguous() if g_feat is not None else zeros(M, 16)
+        g_enc = torch.empty(14, M, 2, dtype=torch.float16, device=dev)
+        ws = torch.empty(pvd_hip.head_backward_workspace_floats(KIND_HASH, M), dtype=torch.float32, device=dev)
+        direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
+        grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
+        pvd_hip.head_backward(KIND_HASH, enc, None, dirs, M, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(),
+                              *ctx.clips, g_sigma, g_rgb, g_feat, None, g_enc, *grads, ws)
+        g_emb = None
+        if ctx.needs_input_grad[1]:
+            S, H, gridtype, align = ctx.grid
+            g16 = torch.zeros(emb.shape, dtype=torch.float16, device=dev)
+            dummy = g16[:1]
+            pvd_hip.grid_encode_backward(g_enc, x01, g16, offsets, g16, M, 3, 2, 14, S, H, False, dummy, dummy, gridtype, align)
+            if emb.is_leaf and emb.grad is not None and emb.grad.dtype == torch.float32:
+                emb.grad.add_(g16)  # widen + accumulate in one pass
+            else:
+                g_emb = g16.float()
+        gw = (None,) * 5 if direct else tuple(grads)
+        return (None, g_emb, None) + gw + (None,) * 7
+
+
+def hash_head_train(model, x, d):
+    enc = model.encoder
+    _, _, S = _grid_dims(enc)
+    a = model.args
+    bound = model.bound
+    x01 = (x.float() + bound) / (2 * bound)  # GridEncoder.forward's mapping (grid.py:211)
+    return _HashHeadTrain.apply(x01, enc.embeddings, d, model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight,
+                                model.color_net[1].weight, model.color_net[2].weight, enc.offsets, S, enc.base_resolution, enc.gridtype_id,
+                                enc.align_corners, a.sigma_clip_min, a.sigma_clip_max)

@@ -233,6 +233,8 @@ class NeRFNetwork(NeRFRenderer):
             elif self.model_type == "vm" and hasattr(fh, "vm_head_train"):
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
                 out = fh.vm_head_train(self, sraw, prod, d)
+            elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
+                out = fh.hash_head_train(self, x, d)  # teacher training / hash student
             if out is not None:
                 sigma, color, feat = out
                 self.feature_sigma_color = feat

@@ -47,7 +47,7 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
-    "pvd_head_backward_vm", "pvd_head_backward_vm_workspace_floats",
+    "pvd_head_backward", "pvd_head_backward_workspace_floats",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
     "pvd_adamw_step",
@@ -361,24 +361,28 @@ def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sig
           _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
 
 
-def head_backward_vm_workspace_floats(M):
-    return int(_lib.pvd_head_backward_vm_workspace_floats(_u32(M), ctypes.c_void_p(0)))
+def head_backward_workspace_floats(kind, M):
+    return int(_lib.pvd_head_backward_workspace_floats(_int(kind), _u32(M)))
 
 
-def head_backward_vm(prod, sigma_raw, dirs, M, Wb, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
-                     g_sigma_raw, g_prod, gWb, gWc1, gWc2, gWc3, workspace):
-    dev = _dev(prod, sigma_raw, dirs, Wb, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_prod, workspace)
-    _want(prod, torch.float16, "prod"), _want(g_prod, torch.float16, "g_prod")
-    _f32_all(sigma_raw=sigma_raw, dirs=dirs, Wb=Wb, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb, g_feat16=g_feat16,
-             g_sigma_raw=g_sigma_raw, gWb=gWb, gWc1=gWc1, gWc2=gWc2, gWc3=gWc3, workspace=workspace)
-    for t in (gWb, gWc1, gWc2, gWc3):
-        if not (t.is_cuda and t.is_contiguous()):
+def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
+                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace):
+    """kind 1 (vm): x0 = products [M,144], g_x0 same layout.  kind 0 (hash): x0 = encoder output [14,M,2], g_x0 same."""
+    dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_x0, workspace)
+    _want(x0, torch.float16, "x0"), _want(g_x0, torch.float16, "g_x0")
+    _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb, g_feat16=g_feat16,
+             gWa1=gWa1, gWc1=gWc1, gWc2=gWc2, gWc3=gWc3, workspace=workspace)
+    for t in (sigma_raw, Wa2, g_sigma_raw, gWa2):
+        if t is not None:
+            _want(t, torch.float32, "head_backward argument")
+    for t in (gWa1, gWa2, gWc1, gWc2, gWc3):
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
             raise PvdHipError("weight gradient buffers must be contiguous HIP tensors")
-    if workspace.numel() < head_backward_vm_workspace_floats(M):
+    if workspace.numel() < head_backward_workspace_floats(kind, M):
         raise PvdHipError("workspace too small")
-    _call("pvd_head_backward_vm", dev, _p(prod), _p(sigma_raw), _p(dirs), _u32(M), _p(Wb), _p(Wc1), _p(Wc2), _p(Wc3),
-          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_prod),
-          _p(gWb), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
+    _call("pvd_head_backward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
+          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
+          _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
 
 
 # --------------------------------------------------------------------------- fused epilogue / objective

@@ -204,18 +204,24 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
                      float clip_sigma_min, float clip_feat_min, float clip_max,
                      float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
 
-/* Backward of the VM head (student).  Recomputes the forward from (prod, sigma_raw, dirs), then
- *   g_sigma_raw [M] f32, g_prod [M][144] f16 (the layout pvd_vm_backward reads), and ACCUMULATES the weight
- *   gradients into gWb [15][144], gWc1 [64][31], gWc2 [64][64], gWc3 [3][64] (f32, += ).
+/* Backward of the fused head (training).  Recomputes the forward from (x0, sigma_raw, dirs), then writes the
+ * gradient of the head's input and ACCUMULATES (+=) the f32 weight gradients.
+ *   kind = PVD_HEAD_VM  : g_sigma_raw [M] f32, g_x0 = d/d products [M][144] f16 (the layout pvd_vm_backward
+ *                         reads); gWa1 = basis_mat [15][144]; Wa2/gWa2 unused (NULL).
+ *   kind = PVD_HEAD_HASH: g_x0 = d/d encoder output, level-major [14][M][2] f16 (what pvd_grid_encode_backward
+ *                         reads as `grad`); gWa1 = sigma_net.0 [64][28], gWa2 = sigma_net.1 [16][64];
+ *                         sigma_raw / g_sigma_raw unused (NULL).
+ *   gWc1 [64][31], gWc2 [64][64], gWc3 [3][64]: color_net.
  * g_sigma [M], g_rgb [M][3], g_feat16 [M][16]: incoming gradients (f32) of pvd_head_forward's three outputs.
- * workspace: pvd_head_backward_vm_workspace_floats(M, &nwaves) floats of scratch (per-wave dW partials). */
-int pvd_head_backward_vm_workspace_floats(uint32_t M, uint32_t *nwaves_out);
-int pvd_head_backward_vm(const void *prod, const float *sigma_raw, const float *dirs, uint32_t M,
-                         const float *Wb, const float *Wc1, const float *Wc2, const float *Wc3,
-                         float clip_sigma_min, float clip_feat_min, float clip_max,
-                         const float *g_sigma, const float *g_rgb, const float *g_feat16,
-                         float *g_sigma_raw, void *g_prod, float *gWb, float *gWc1, float *gWc2, float *gWc3,
-                         float *workspace, pvd_stream_t stream);
+ * workspace: pvd_head_backward_workspace_floats(kind, M) floats of scratch (per-wave dW partials).
+ * Replaces autograd through network.py:395-447 (hash) / 353-393 (vm). */
+int pvd_head_backward_workspace_floats(int kind, uint32_t M);
+int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
+                      const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
+                      float clip_sigma_min, float clip_feat_min, float clip_max,
+                      const float *g_sigma, const float *g_rgb, const float *g_feat16,
+                      float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3,
+                      float *workspace, pvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused pieces of run_cuda / train_step that are torch code in the reference.

@@ -140,3 +140,62 @@ def test_vm_head_backward_accumulates_into_existing_grads():
         outs.append([p.grad.clone() for p in ps])
     for a, b in zip(*outs):
         assert torch.allclose(b - 1.0, a, rtol=1e-4, atol=1e-3)
+
+
+def test_hash_head_backward_matches_layerwise_autograd():
+    """Fused hash path (grid lookup + MFMA head, MFMA head backward + grid scatter) vs autograd through
+    GridEncoder + the layer-by-layer autocast formulation: gradients of the embedding table, sigma_net and
+    color_net (network.py:395-437)."""
+    import fusedhead
+    m = _model("hash", seed=7).train()
+    M = 16 * 700 + 5
+    x, d = _inputs(M, seed=8)
+    g = torch.Generator(device="cuda").manual_seed(10)
+    w_sig = torch.randn(M, device="cuda", generator=g) * 1e-3
+    w_rgb = torch.randn(M, 3, device="cuda", generator=g)
+    w_fea = torch.randn(M, 16, device="cuda", generator=g) * 0.1
+    names = ["encoder.embeddings", "sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight",
+             "color_net.2.weight"]
+    params = dict(m.named_parameters())
+
+    def run(fused):
+        for n in names:
+            params[n].grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            if fused:
+                sig, rgb, feat = fusedhead.hash_head_train(m, x, d)
+            else:
+                sig, rgb = m(x, d)
+                feat = m.feature_sigma_color
+        loss = (sig.float() * w_sig).sum() + (rgb.float() * w_rgb).sum() + (feat.float() * w_fea).sum()
+        loss.backward()
+        return sig.detach().float(), rgb.detach().float(), feat.detach().float(), [params[n].grad.float().clone() for n in names]
+
+    sig_r, rgb_r, feat_r, gw_r = run(False)
+    sig_f, rgb_f, feat_f, gw_f = run(True)
+    _check(sig_f, rgb_f, feat_f, sig_r, rgb_r, feat_r)
+    for n, a, b in zip(names, gw_f, gw_r):
+        assert torch.isfinite(a).all(), n
+        s = b.abs().max().item()
+        assert s > 0, n
+        assert (a - b).abs().max().item() <= 2e-2 * s, (n, (a - b).abs().max().item(), s)
+        assert (a - b).abs().mean().item() <= 5e-3 * b.abs().mean().item() + 1e-9, n
+
+
+def test_hash_head_backward_accumulates_into_existing_grads():
+    import fusedhead
+    m = _model("hash", seed=11).train()
+    M = 4096
+    x, d = _inputs(M, seed=12)
+    ps = [m.encoder.embeddings, m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight, m.color_net[1].weight,
+          m.color_net[2].weight]
+    outs = []
+    for pre in (0.0, 1.0):
+        for p in ps:
+            p.grad = torch.full_like(p, pre)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sig, rgb, feat = fusedhead.hash_head_train(m, x, d)
+        (rgb.sum() + feat.sum()).backward()
+        outs.append([p.grad.clone() for p in ps])
+    for a, b in zip(*outs):
+        assert torch.allclose(b - 1.0, a, rtol=1e-3, atol=2e-3)
