@@ -21,6 +21,11 @@ def _channels_last(t):
     return out.copy_(t)
 
 
+def _channels_last_3d(t):
+    _, C, D, H, W = t.shape
+    return torch.empty_strided(t.shape, (C * D * H * W, 1, H * W * C, W * C, C), dtype=t.dtype).copy_(t)
+
+
 class _L1MeanSum(torch.autograd.Function):
     _inv_cache = {}
 
@@ -106,7 +111,7 @@ class NeRFNetwork(NeRFRenderer):
             self.basis_mat = nn.Linear(sum(self.color_rank), self.color_feat_dim, bias=False)
         elif model_type == "tensors":
             s, fea_dim = 0.02, self.plenoxel_degree ** 2 * 3 + 1  # network.py:92-96
-            self.tensor_volume = nn.ParameterList([nn.Parameter(s * torch.randn((1, fea_dim, *self.plenoxel_res)))])
+            self.tensor_volume = nn.ParameterList([nn.Parameter(_channels_last_3d(s * torch.randn((1, fea_dim, *self.plenoxel_res))))])
 
         if model_type in ("hash", "mlp"):
             dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
@@ -184,8 +189,14 @@ class NeRFNetwork(NeRFRenderer):
 
     # ------------------------------------------------------------------ Plenoxels / NeRF-MLP
     def compute_plenoxel_fea(self, x):
+        """x already mapped to [-1,1]^3 -> [N, fea_dim]; the reference formulation (network.py:311-322)."""
         vol = self.tensor_volume[0]
         return F.grid_sample(vol, x.view(1, 1, -1, 1, 3), align_corners=True).view(-1, x.shape[0]).permute(1, 0)
+
+    def _plenoxel_ops(self, x):
+        px = getattr(self.ops, "plenoxel", None)
+        # the editing demo rewrites the volume in place every call (network.py:313-316): keep that on the torch path
+        return px if (px is not None and x.is_cuda and not self.args.enable_edit_plenoxel) else None
 
     def forward_nerf_mlp(self, x):
         x = self.encoder_nerf_pe(x)
@@ -257,6 +268,13 @@ class NeRFNetwork(NeRFRenderer):
             return sigma, color
 
         if self.model_type == "tensors":
+            px = self._plenoxel_ops(x)
+            if px is not None:  # lookup + clamp + trunc_exp + SH colour + sigmoid: one kernel each way
+                sigma, color, self.sigma_l, _ = px.plenoxel_head(x, d, self._aabb(), self.tensor_volume[0], self.plenoxel_degree,
+                                                                 a.sigma_clip_min, a.sigma_clip_max)
+                self.feature_sigma_color = None
+                self.color_l = color
+                return sigma, color
             h = self.compute_plenoxel_fea(self._unit_cube(x))
             sigma = torch.clamp(h[..., 0], -100 if a.enable_edit_plenoxel else a.sigma_clip_min, a.sigma_clip_max)
             self.sigma_l = sigma
@@ -290,6 +308,11 @@ class NeRFNetwork(NeRFRenderer):
             s = torch.clamp(self.vm_features(x)[0], a.sigma_clip_min, a.sigma_clip_max)
             return {"sigma": self.trunc_exp(s)}
         if self.model_type == "tensors":
+            px = self._plenoxel_ops(x)
+            if px is not None and not torch.is_grad_enabled():
+                _, _, _, h0 = px.plenoxel_head(x, torch.zeros_like(x), self._aabb(), self.tensor_volume[0], self.plenoxel_degree,
+                                               a.sigma_clip_min, a.sigma_clip_max)
+                return {"sigma": torch.exp(h0)}
             h = self.compute_plenoxel_fea(self._unit_cube(x))
             return {"sigma": self.trunc_exp(h[..., 0])}  # the reference's second, unclamped assignment wins (:481)
         h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)

@@ -23,6 +23,7 @@ def hip_ops():
     import pvd_hip
     import shencoder
     import vmencoder
+    import plenoxel
 
     def get_rays_fused(pose, intrinsics, H, W, N):
         """reference: get_rays (utils.py:324-404) for one pose: randint pixel ids + one HIP kernel."""
@@ -35,4 +36,4 @@ def hip_ops():
         return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
 
     return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

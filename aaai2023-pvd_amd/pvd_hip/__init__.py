@@ -46,7 +46,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_get_rays", "pvd_head_forward",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_head_forward",
     "pvd_head_backward", "pvd_head_backward_workspace_floats",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
@@ -350,6 +350,53 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
 
 
 vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_backward)
+
+
+# --------------------------------------------------------------------------- Plenoxel dense-volume lookup + SH head
+def _is_channels_last_3d(t):
+    return t.dim() == 5 and t.shape[0] == 1 and t.permute(0, 2, 3, 4, 1).is_contiguous()
+
+
+def _px_common(xyz, dirs, aabb_host, volume, what):
+    dev = _dev(xyz, dirs)
+    if not volume.is_cuda or volume.device != dev:
+        raise PvdHipError(f"{what} must be on the same HIP device as xyz -- libpvd_hip has no CPU path")
+    _want(xyz, torch.float32, "xyz"), _want(volume, torch.float32, what)
+    if dirs is not None:
+        _want(dirs, torch.float32, "dirs")
+    if not _is_channels_last_3d(volume):
+        raise PvdHipError(f"{what} must be a [1,C,D,H,W] tensor stored channels-last ([D][H][W][C])")
+    aabb = (ctypes.c_float * 6)(*[float(v) for v in aabb_host])
+    dims = (ctypes.c_uint32 * 3)(*[int(v) for v in volume.shape[2:]])
+    return dev, aabb, dims, int(volume.shape[1])
+
+
+def plenoxel_forward(xyz, dirs, aabb_host, volume, degree, clip_min, clip_max, feat, h0_raw, sigma_l, sigma, rgb):
+    """volume: [1,C,D,H,W] f32, channels-last storage.  dirs None: raw features only (feat [M,C])."""
+    dev, aabb, dims, C = _px_common(xyz, dirs, aabb_host, volume, "volume")
+    _dev(feat, h0_raw, sigma_l, sigma, rgb)
+    for t in (feat, h0_raw, sigma_l, sigma, rgb):
+        if t is not None:
+            _want(t, torch.float32, "plenoxel output")
+    M = xyz.shape[0]
+    _check(_invoke("pvd_plenoxel_forward", dev, _p(xyz), _p(dirs), _u32(M), aabb, _p(volume), dims, _u32(C), _u32(degree), _f32(clip_min),
+                   _f32(clip_max), _p(feat), _p(h0_raw), _p(sigma_l), _p(sigma), _p(rgb), meta=(M, C)), "pvd_plenoxel_forward")
+
+
+def plenoxel_backward(xyz, dirs, aabb_host, degree, clip_min, clip_max, h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb, grad_volume):
+    """Accumulates (+=) into grad_volume ([1,C,D,H,W] f32, channels-last storage)."""
+    dev, aabb, dims, C = _px_common(xyz, dirs, aabb_host, grad_volume, "grad_volume")
+    _dev(h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb)
+    for t in (h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb):
+        if t is not None:
+            _want(t, torch.float32, "plenoxel gradient input")
+    M = xyz.shape[0]
+    _check(_invoke("pvd_plenoxel_backward", dev, _p(xyz), _p(dirs), _u32(M), aabb, dims, _u32(C), _u32(degree), _f32(clip_min), _f32(clip_max),
+                   _p(h0_raw), _p(rgb), _p(g_feat), _p(g_sigma), _p(g_sigma_l), _p(g_rgb), _p(grad_volume), meta=(M, C)),
+           "pvd_plenoxel_backward")
+
+
+plenoxel_backend = types.SimpleNamespace(plenoxel_forward=plenoxel_forward, plenoxel_backward=plenoxel_backward)
 
 
 # --------------------------------------------------------------------------- fused sigma / colour head

@@ -224,6 +224,28 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
                       float *workspace, pvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Plenoxel ("tensors") model: dense-volume lookup + SH colour head, forward and backward.
+ * Replaces compute_plenoxel_fea (3-D F.grid_sample, trilinear, align_corners=True, zero padding;
+ * distill_mutual/network.py:311-322) and the head around it (network.py:383-409):
+ *   h = sample(volume, 2*(x-lo)/(hi-lo)-1);  sigma_l = clamp(h[0], clip_min, clip_max);  sigma = exp(sigma_l);
+ *   rgb[c] = sigmoid(sum_k h[1 + c*deg^2 + k] * SH_k(d)).
+ * volume: the [1,C,D,H,W] parameter stored CHANNELS-LAST ([D][H][W][C] f32), C = 3*degree^2 + 1, degree 1..3.
+ * dims_host = {D, H, W}; aabb_host = {lo[3], hi[3]} (host memory).
+ * forward: feat [M][C] raw features (optional, NULL to skip); if dirs != NULL also h0_raw [M], sigma_l [M],
+ *   sigma [M], rgb [M][3].  dirs == NULL: feature lookup only.
+ * backward: ACCUMULATES (+=) into grad_volume (same layout).  g_feat [M][C], g_sigma [M], g_sigma_l [M],
+ *   g_rgb [M][3] are the gradients of the forward's outputs; any of them may be NULL (= zero).  With dirs the
+ *   saved h0_raw and rgb of the forward are required.
+ * ---------------------------------------------------------------------- */
+int pvd_plenoxel_forward(const float *xyz, const float *dirs, uint32_t M, const float *aabb_host, const float *volume,
+                         const uint32_t *dims_host, uint32_t C, uint32_t degree, float clip_min, float clip_max,
+                         float *feat, float *h0_raw, float *sigma_l, float *sigma, float *rgb, pvd_stream_t stream);
+int pvd_plenoxel_backward(const float *xyz, const float *dirs, uint32_t M, const float *aabb_host, const uint32_t *dims_host,
+                          uint32_t C, uint32_t degree, float clip_min, float clip_max, const float *h0_raw, const float *rgb,
+                          const float *g_feat, const float *g_sigma, const float *g_sigma_l, const float *g_rgb,
+                          float *grad_volume, pvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Fused pieces of run_cuda / train_step that are torch code in the reference.
  * ---------------------------------------------------------------------- */
 
