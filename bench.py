@@ -118,7 +118,7 @@ def main():
             for t in list(m.parameters()) + list(m.buffers()):
                 d = t.data
                 if not d.is_contiguous():  # channels-last VM factors: broadcast the dense [H][W][R] view
-                    d = d.permute(0, 2, 3, 1)
+                    d = d.permute(0, 2, 3, 1) if d.dim() == 4 else d.permute(0, 2, 3, 4, 1)
                     assert d.is_contiguous()
                 dist.broadcast(d, src=0)
 
@@ -187,7 +187,7 @@ def main():
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
     total_rays = args.steps * args.rays * world
     out = {
-        "metric": "train rays/s (hash->vm chair distillation step)",
+        "metric": "train rays/s (hash->%s chair distillation step)" % opt.model_type,
         "value": total_rays / elapsed,
         "unit": "rays/s",
         "n_gpus": world,
