@@ -180,10 +180,12 @@ template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                          const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                          uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
-                                                         bool align_corners, bool calc_grad_inputs, T *__restrict__ dy_dx) {
+                                                         bool align_corners, bool calc_grad_inputs, T *__restrict__ dy_dx,
+                                                         uint32_t level_mask) {
     using Vec = FeatVec<T, C>;
     uint32_t level, pblock;
     if (!sched.locate(blockIdx.x, level, pblock)) return;
+    if (level_mask && !((level_mask >> level) & 1u)) return;  // measurement only (pvd_grid_set_variant)
     const uint32_t b = pblock * kGridBlock + threadIdx.x;
     if (b >= B) return;
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -539,7 +541,7 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
     }
     const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
     hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets, (T *)outputs, B,
-                       L, sc, sched, gridtype, align, calc, (T *)dy_dx);
+                       L, sc, sched, gridtype, align, calc, (T *)dy_dx, g_grid_level_mask);
     return check_launch();
 }
 

@@ -20,15 +20,43 @@ struct AdamSegments {
     uint32_t count;
 };
 
-__global__ void k_adamw_count(float *__restrict__ step, const float *__restrict__ found_inf) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && !(found_inf && found_inf[0] != 0.f)) step[0] += 1.0f;
+struct AdamExtras {
+    // learning-rate schedule evaluated on the device (so a captured step sees it without host-side scheduler ops)
+    int32_t sched_kind;   // 0: lr[] used as is; 1: cosine annealing; 2: exponential decay
+    float sched_T;        // T_max (cosine) / iters (exponential)
+    float sched_param;    // eta_min (cosine) / total factor (exponential: lr = base * factor^min(t/T, 1))
+    const float *base_lr; // DEVICE [segments]
+    float *sched_step;    // DEVICE scalar: scheduler ticks so far (advanced every call, also on skipped steps)
+    // L1 regulariser folded into the update: inside range r the gradient gets coef[r] * sign(p)
+    uint32_t n_l1;
+    uint64_t l1_begin[kMaxSegments], l1_end[kMaxSegments];
+    float l1_coef[kMaxSegments];
+};
+
+// one thread: advance the step count (unless the GradScaler found an inf) and evaluate the schedule.
+//   cosine: torch.optim.lr_scheduler.CosineAnnealingLR's closed form (main_distill_mutual.py:346-348)
+//   exponential: LambdaLR(0.1 ** min(iter / iters, 1)) (main_just_train_tea.py:293-296)
+__global__ void k_adamw_count(float *__restrict__ step, const float *__restrict__ found_inf, AdamExtras ex, float *__restrict__ lr,
+                              uint32_t n_segments) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!(found_inf && found_inf[0] != 0.f)) step[0] += 1.0f;
+    if (ex.sched_kind == 0) return;
+    const double t = (double)ex.sched_step[0];
+    ex.sched_step[0] += 1.0f;
+    for (uint32_t k = 0; k < n_segments; k++) {
+        const double base = (double)ex.base_lr[k];
+        double v;
+        if (ex.sched_kind == 1) v = (double)ex.sched_param + (base - (double)ex.sched_param) * (1.0 + cos(M_PI * t / (double)ex.sched_T)) * 0.5;
+        else v = base * pow((double)ex.sched_param, fmin(t / (double)ex.sched_T, 1.0));
+        lr[k] = (float)v;
+    }
 }
 
 __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, uint64_t n, AdamSegments seg, const float *__restrict__ lr,
                                                     double beta1, double beta2, double eps, double weight_decay,
                                                     const float *__restrict__ step, const float *__restrict__ grad_scale,
-                                                    const float *__restrict__ found_inf) {
+                                                    const float *__restrict__ found_inf, AdamExtras ex) {
     if (found_inf && found_inf[0] != 0.f) return;  // GradScaler: skip the whole step
     const double t = (double)step[0];
     const double bc1 = 1.0 - pow((double)beta1, t);
@@ -38,6 +66,9 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         const uint64_t e = i << 2;
         uint32_t k = 0;
         while (k + 1 < seg.count && e >= seg.end[k]) k++;  // segments are multiples of 4 elements (see trainer)
+        float l1 = 0.f;  // ranges are multiples of 4 elements too
+        for (uint32_t r = 0; r < ex.n_l1; r++)
+            if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
         const double lrk = (double)lr[k];
         const float step_size = (float)(lrk / bc1);
         float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<const float4 *>(g)[i];
@@ -47,7 +78,8 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         for (int c = 0; c < 4; c++) {
             // torch's fused kernel keeps the hyper-parameters in double, so these expressions evaluate in fp64
             // and round once into the fp32 state (ATen fused_adam_utils.cuh: adam_math, ADAMW mode)
-            const float grad = grad_scale ? (float)((double)gg[c] / (double)grad_scale[0]) : gg[c];
+            float grad = grad_scale ? (float)((double)gg[c] / (double)grad_scale[0]) : gg[c];
+            if (l1 != 0.f) grad += l1 * (pp[c] > 0.f ? 1.0f : (pp[c] < 0.f ? -1.0f : 0.0f));  // d(l1 * |p|)/dp
             float param = (float)((double)pp[c] - lrk * (double)weight_decay * (double)pp[c]);
             const float ea = (float)((double)mm[c] + (1.0 - (double)beta1) * ((double)grad - (double)mm[c]));
             const float es = (float)((double)beta2 * (double)vv[c] + (1.0 - (double)beta2) * (double)grad * (double)grad);
@@ -61,15 +93,80 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
     }
 }
 
+// found_inf[0] = 1 if any element is inf / nan (never cleared here): the read-only half of
+// torch._amp_foreach_non_finite_check_and_unscale_, which GradScaler.step runs with a scale of 1 for optimizers
+// that unscale inside their own kernel.
+__global__ void __launch_bounds__(kOptBlock) k_check_finite(const float *__restrict__ g, uint64_t n4, float *__restrict__ found_inf) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kOptBlock) {
+        const float4 G = reinterpret_cast<const float4 *>(g)[i];
+        // finite <=> exponent field not all ones
+        const uint32_t a = __float_as_uint(G.x), b = __float_as_uint(G.y), c = __float_as_uint(G.z), d = __float_as_uint(G.w);
+        bad |= ((a & 0x7f800000u) == 0x7f800000u) | ((b & 0x7f800000u) == 0x7f800000u) | ((c & 0x7f800000u) == 0x7f800000u) |
+               ((d & 0x7f800000u) == 0x7f800000u);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+}
+
+// partials[block] = sum over the block's elements of coef[range] * |p|
+__global__ void __launch_bounds__(kOptBlock) k_l1_partial(const float *__restrict__ p, AdamExtras ex, float *__restrict__ partials) {
+    __shared__ float red[kOptBlock / 64];
+    float acc = 0.f;
+    for (uint32_t r = 0; r < ex.n_l1; r++) {
+        const uint64_t b4 = ex.l1_begin[r] >> 2, e4 = ex.l1_end[r] >> 2;
+        float a = 0.f;
+        for (uint64_t i = b4 + (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < e4; i += (uint64_t)gridDim.x * kOptBlock) {
+            const float4 P = reinterpret_cast<const float4 *>(p)[i];
+            a += (fabsf(P.x) + fabsf(P.y)) + (fabsf(P.z) + fabsf(P.w));
+        }
+        acc += ex.l1_coef[r] * a;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (uint32_t w = 0; w < kOptBlock / 64; w++) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+__global__ void __launch_bounds__(kOptBlock) k_l1_final(const float *__restrict__ partials, uint32_t n, float *__restrict__ out) {
+    __shared__ float red[kOptBlock / 64];
+    float acc = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += kOptBlock) acc += partials[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (uint32_t w = 0; w < kOptBlock / 64; w++) s += red[w];
+        out[0] = s;
+    }
+}
+
+constexpr uint32_t kL1Blocks = 1024;
+
+static int fill_l1(AdamExtras &ex, const uint64_t *begin, const uint64_t *end, const float *coef, uint32_t n) {
+    if (n > kMaxSegments || (n && (!begin || !end || !coef))) return PVD_ERR_INVALID;
+    ex.n_l1 = n;
+    for (uint32_t r = 0; r < n; r++) {
+        if ((begin[r] & 3u) || (end[r] & 3u) || end[r] < begin[r]) return PVD_ERR_UNSUPPORTED;
+        ex.l1_begin[r] = begin[r]; ex.l1_end[r] = end[r]; ex.l1_coef[r] = coef[r];
+    }
+    return PVD_OK;
+}
+
 }  // namespace pvd
 
 using namespace pvd;
 
 extern "C" {
 
-int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host, uint32_t n_segments,
-                   const float *lr, double beta1, double beta2, double eps, double weight_decay, float *step, const float *grad_scale,
-                   const float *found_inf, pvd_stream_t stream) {
+int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host, uint32_t n_segments,
+                      float *lr, double beta1, double beta2, double eps, double weight_decay, float *step, const float *grad_scale,
+                      const float *found_inf, const pvd_adamw_extras *extras_host, pvd_stream_t stream) {
     if (n == 0) return PVD_OK;
     if (!p || !g || !m || !v || !segment_ends_host || !lr || !step) return PVD_ERR_INVALID;
     if (n_segments < 1 || n_segments > kMaxSegments || (n & 3u)) return PVD_ERR_UNSUPPORTED;
@@ -79,12 +176,53 @@ int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, con
         if (segment_ends_host[k] & 3u) return PVD_ERR_UNSUPPORTED;
         seg.end[k] = segment_ends_host[k];
     }
+    AdamExtras ex;
+    ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
+    if (extras_host) {
+        const pvd_adamw_extras &h = *extras_host;
+        if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
+        if (h.sched_kind != 0 && (!h.base_lr || !h.sched_step || !(h.sched_T > 0.f))) return PVD_ERR_INVALID;
+        ex.sched_kind = h.sched_kind; ex.sched_T = h.sched_T; ex.sched_param = h.sched_param;
+        ex.base_lr = h.base_lr; ex.sched_step = h.sched_step;
+        const int rc = fill_l1(ex, h.l1_begin_host, h.l1_end_host, h.l1_coef_host, h.n_l1);
+        if (rc != PVD_OK) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adamw_count, dim3(1), dim3(64), 0, s, step, found_inf);
+    hipLaunchKernelGGL(k_adamw_count, dim3(1), dim3(64), 0, s, step, found_inf, ex, lr, n_segments);
     uint64_t blocks = (n / 4 + kOptBlock - 1) / kOptBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, lr, beta1, beta2, eps, weight_decay, step,
-                       grad_scale, found_inf);
+                       grad_scale, found_inf, ex);
+    return check_launch();
+}
+
+int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host, uint32_t n_segments,
+                   const float *lr, double beta1, double beta2, double eps, double weight_decay, float *step, const float *grad_scale,
+                   const float *found_inf, pvd_stream_t stream) {
+    return pvd_adamw_step_ex(p, g, m, v, n, segment_ends_host, n_segments, const_cast<float *>(lr), beta1, beta2, eps, weight_decay, step,
+                             grad_scale, found_inf, nullptr, stream);
+}
+
+int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream) {
+    if (n == 0) return PVD_OK;
+    if (!g || !found_inf) return PVD_ERR_INVALID;
+    if (n & 3u) return PVD_ERR_UNSUPPORTED;
+    uint64_t blocks = (n / 4 + kOptBlock - 1) / kOptBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_check_finite, dim3((uint32_t)blocks), dim3(kOptBlock), 0, (hipStream_t)stream, g, n >> 2, found_inf);
+    return check_launch();
+}
+
+int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host, uint32_t n_ranges,
+                  float *scratch, float *out, pvd_stream_t stream) {
+    if (!p || !scratch || !out) return PVD_ERR_INVALID;
+    AdamExtras ex;
+    ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
+    const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
+    if (rc != PVD_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_l1_partial, dim3(kL1Blocks), dim3(kOptBlock), 0, s, p, ex, scratch);
+    hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(kOptBlock), 0, s, scratch, kL1Blocks, out);
     return check_launch();
 }
 

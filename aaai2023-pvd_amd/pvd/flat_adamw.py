@@ -58,9 +58,63 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = _view(self.flat_g, p, o)
 
+    # ---- pieces of the training loop folded into the update kernel (pvd_adamw_step_ex)
+    def set_schedule(self, kind, T, param):
+        """Evaluate the lr schedule on the device inside step(): kind "cosine" (CosineAnnealingLR closed form,
+        T = T_max, param = eta_min) or "exp" (LambdaLR(param ** min(t / T, 1))).  Base rates = the current ones."""
+        self.base_lr = self.lr_dev.clone()
+        self.sched_step = torch.zeros(1, dtype=torch.float32, device=self.lr_dev.device)
+        self._schedule = ({"cosine": 1, "exp": 2}[kind], float(T), float(param), self.base_lr, self.sched_step)
+
+    def set_l1(self, tensors, weight):
+        """Fold weight * sum_t mean|t| (NeRFNetwork.density_loss) into the update: its gradient weight/numel * sign(p)
+        is added to the unscaled gradient inside the kernel; l1_value() returns the term's value."""
+        off = {id(p): o for p, o in zip(self.params, self.offsets)}
+        self._l1 = []
+        for t in tensors:
+            o, n = off[id(t)], t.numel()
+            assert o % 4 == 0 and n % 4 == 0, "L1 ranges must be multiples of 4 elements"
+            self._l1.append((o, o + n, weight / n))
+        self._l1_scratch = torch.empty(1024, dtype=torch.float32, device=self.flat_p.device)
+
+    @torch.no_grad()
+    def l1_value(self):
+        out = torch.empty(1, dtype=torch.float32, device=self.flat_p.device)
+        pvd_hip.l1_ranges(self.flat_p, self._l1, self._l1_scratch, out)
+        return out[0]
+
     @torch.no_grad()
     def step(self, closure=None):
         d = self.defaults
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
-                           d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None))
+                           d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
+                           schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None))
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
+
+
+class DeviceSchedule:
+    """Stand-in for a torch LR scheduler when FlatAdamW evaluates the schedule on the device: step() only counts."""
+
+    def __init__(self, optimizer, kind, T, param):
+        optimizer.set_schedule(kind, T, param)
+        self.optimizer, self.last_epoch = optimizer, 0
+
+    def step(self):
+        self.last_epoch += 1
+
+    def get_last_lr(self):
+        return [float(v) for v in self.optimizer.lr_dev.tolist()]
+
+
+class FlatGradScaler(torch.amp.GradScaler):
+    """GradScaler whose inf check for a FlatAdamW is one read-only pass over the flat gradient buffer
+    (pvd_check_finite) instead of the multi-tensor check-and-unscale-by-1 (which also rewrites every gradient)."""
+
+    def _check_inf_per_device(self, optimizer):
+        if not isinstance(optimizer, FlatAdamW):
+            return super()._check_inf_per_device(optimizer)
+        _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
+        found_inf = torch.full((), 0.0, dtype=torch.float32, device=_scale.device)
+        pvd_hip.check_finite(optimizer.flat_g, found_inf.view(1))
+        self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = {_scale.device: found_inf}
+        return self._per_optimizer_states[id(optimizer)]["found_inf_per_device"]

@@ -135,16 +135,38 @@ class _TrainerBase:
                 for g in params:
                     g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
             self.optimizer = torch.optim.AdamW(params, betas=(0.9, 0.99), eps=1e-15, fused=fused, capturable=fused)
-        if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
-            self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
-        else:  # student: cosine to eta_min (main_distill_mutual.py:346-348)
-            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
-        self.scaler = torch.amp.GradScaler(self.device_type, enabled=self.fp16 and self.device_type == "cuda")
+        amp = self.fp16 and self.device_type == "cuda"
+        if self.flat_opt:
+            # schedule evaluated inside the update kernel, inf check = one read-only pass over the flat gradient:
+            # nothing of the scheduler / scaler bookkeeping is launched from the host per step
+            from .flat_adamw import DeviceSchedule, FlatGradScaler
+            self.scheduler = (DeviceSchedule(self.optimizer, "exp", opt.iters, 0.1) if exp_decay else
+                              DeviceSchedule(self.optimizer, "cosine", opt.iters, eta_min or 5e-5))
+            self.scaler = FlatGradScaler(self.device_type, enabled=amp)
+        else:
+            if exp_decay:  # teacher: 0.1^(iter/iters) (main_just_train_tea.py:293-296)
+                self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
+            else:  # student: cosine to eta_min (main_distill_mutual.py:346-348)
+                self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
+            self.scaler = torch.amp.GradScaler(self.device_type, enabled=amp)
+        self._l1_folded = False
         if self.flat_opt:
             self.flat = _FlatOptGrads(self.optimizer)
         else:
             self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
         self.global_step = 0
+
+    def _l1_term(self):
+        """l1_reg_weight * density_loss() for the VM model (utils.py:1101-1104 / just_train_tea/utils.py:573-581).
+        A parameter-only term: under ray-DP every rank adds 1/G of it.  With the flat optimizer its gradient is
+        applied inside the update kernel (after the all-reduce, full weight) and only the value is computed here."""
+        o, m = self.opt, self.model
+        if self.flat_opt:
+            if not self._l1_folded:
+                self.optimizer.set_l1([*m.sigma_mat, *m.sigma_vec], o.l1_reg_weight)
+                self._l1_folded = True
+            return self.optimizer.l1_value() / self.dp.world_size
+        return m.density_loss() * (o.l1_reg_weight / self.dp.world_size)
 
     def _backward(self, loss):
         self.scaler.scale(loss).backward()
@@ -271,7 +293,7 @@ class DistillTrainer(_TrainerBase):
                                         tea.color_l.float(), self.rates, self.dp)
             loss = loss + l4
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
-                loss = loss + stu.density_loss() * (o.l1_reg_weight / self.dp.world_size)
+                loss = loss + self._l1_term()
             info["rgb"] = norms[0]
             return loss, info, pred_stu, pred_tea
         if o.loss_type == "normL2":
@@ -282,7 +304,7 @@ class DistillTrainer(_TrainerBase):
             l_rgb = self.dp.global_mean((pred_tea.float() - pred_stu.float()) ** 2)
         loss = loss + l_rgb * o.loss_rate_rgb
         if o.l1_reg_weight > 0.0 and o.model_type == "vm":
-            loss = loss + stu.density_loss() * (o.l1_reg_weight / self.dp.world_size)  # parameter-only term: not per shard
+            loss = loss + self._l1_term()
         if self.loss_rate_fea_sc > 0.0 and have_fea:
             loss = loss + self.fea_rate * self.loss(stu.feature_sigma_color, tea.feature_sigma_color)
         if o.loss_rate_color > 0.0:
@@ -340,6 +362,6 @@ class TeacherTrainer(_TrainerBase):
             pred = out["image"]
             loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
-                loss = loss + m.density_loss() * (o.l1_reg_weight / self.dp.world_size)
+                loss = loss + self._l1_term()
         self._backward_and_step(loss)
         return loss.detach(), pred

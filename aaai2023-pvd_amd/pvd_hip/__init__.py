@@ -50,7 +50,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
-    "pvd_adamw_step",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_l1_ranges",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -468,13 +468,60 @@ def distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upst
 
 
 # --------------------------------------------------------------------------- flat AdamW
-def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None):
+class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
+    _fields_ = [("sched_kind", ctypes.c_int32), ("sched_T", ctypes.c_float), ("sched_param", ctypes.c_float),
+                ("base_lr", ctypes.c_void_p), ("sched_step", ctypes.c_void_p), ("n_l1", ctypes.c_uint32),
+                ("l1_begin_host", ctypes.POINTER(ctypes.c_uint64)), ("l1_end_host", ctypes.POINTER(ctypes.c_uint64)),
+                ("l1_coef_host", ctypes.POINTER(ctypes.c_float))]
+
+
+def _u64_array(vals):
+    return (ctypes.c_uint64 * len(vals))(*[int(v) for v in vals])
+
+
+def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
+               l1_ranges=None):
+    """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
+    l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
-    ends = (ctypes.c_uint64 * len(segment_ends))(*[int(e) for e in segment_ends])
-    _call("pvd_adamw_step", dev, _p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.numel()), ends, _u32(len(segment_ends)), _p(lr),
+    ends = _u64_array(segment_ends)
+    ex = None
+    if schedule is not None or l1_ranges:
+        ex = _AdamwExtras()
+        if schedule is not None:
+            kind, T, param, base_lr, sched_step = schedule
+            _dev(base_lr, sched_step)
+            _f32_all(base_lr=base_lr, sched_step=sched_step)
+            if base_lr.numel() != len(segment_ends):
+                raise PvdHipError("base_lr must hold one value per segment")
+            ex.sched_kind, ex.sched_T, ex.sched_param = int(kind), float(T), float(param)
+            ex.base_lr, ex.sched_step = base_lr.data_ptr(), sched_step.data_ptr()
+        if l1_ranges:
+            b, e = _u64_array([r[0] for r in l1_ranges]), _u64_array([r[1] for r in l1_ranges])
+            c = (ctypes.c_float * len(l1_ranges))(*[float(r[2]) for r in l1_ranges])
+            ex.n_l1, ex.l1_begin_host, ex.l1_end_host, ex.l1_coef_host = len(l1_ranges), b, e, c
+    _call("pvd_adamw_step_ex", dev, _p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.numel()), ends, _u32(len(segment_ends)), _p(lr),
           ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_double(weight_decay), _p(step), _p(grad_scale),
-          _p(found_inf))
+          _p(found_inf), ctypes.byref(ex) if ex is not None else _vp(0))
+
+
+def check_finite(g, found_inf):
+    """found_inf[0] = 1 if g holds an inf / nan (not cleared otherwise)."""
+    dev = _dev(g, found_inf)
+    _f32_all(g=g, found_inf=found_inf)
+    _call("pvd_check_finite", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
+
+
+def l1_ranges(p, ranges, scratch, out):
+    """out[0] = sum_r coef_r * sum |p[begin_r:end_r]|; ranges = [(begin, end, coef)], scratch >= 1024 floats."""
+    dev = _dev(p, scratch, out)
+    _f32_all(p=p, scratch=scratch, out=out)
+    if scratch.numel() < 1024:
+        raise PvdHipError("scratch too small")
+    b, e = _u64_array([r[0] for r in ranges]), _u64_array([r[1] for r in ranges])
+    c = (ctypes.c_float * len(ranges))(*[float(r[2]) for r in ranges])
+    _call("pvd_l1_ranges", dev, _p(p), b, e, c, _u32(len(ranges)), _p(scratch), _p(out))
 
 
 raymarching_backend = types.SimpleNamespace(

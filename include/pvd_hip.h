@@ -285,6 +285,37 @@ int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, con
                    uint32_t n_segments, const float *lr, double beta1, double beta2, double eps, double weight_decay,
                    float *step, const float *grad_scale, const float *found_inf, pvd_stream_t stream);
 
+/* pvd_adamw_step with two pieces of the training loop folded in (extras_host may be NULL = plain step):
+ *  - the learning-rate schedule, evaluated on the device into lr[] before the update (so a captured HIP graph
+ *    sees it and no host-side scheduler ops run per step):
+ *      sched_kind 1: CosineAnnealingLR closed form, lr = eta_min + (base - eta_min)(1 + cos(pi t / T))/2
+ *                    (main_distill_mutual.py:346-348; sched_T = T_max, sched_param = eta_min)
+ *      sched_kind 2: LambdaLR(factor ** min(t / T, 1)) (main_just_train_tea.py:293-296; sched_param = factor)
+ *    t = sched_step[0] (DEVICE scalar, advanced by one per call, also on skipped steps, like scheduler.step()).
+ *  - an L1 regulariser on parameter ranges (NeRFNetwork.density_loss, network.py:549-557): inside range r the
+ *    unscaled gradient gets l1_coef[r] * sign(p), i.e. the gradient of l1_coef[r] * sum|p|. */
+typedef struct pvd_adamw_extras {
+    int32_t sched_kind;
+    float sched_T, sched_param;
+    const float *base_lr;  /* DEVICE [n_segments] */
+    float *sched_step;     /* DEVICE scalar */
+    uint32_t n_l1;         /* <= 16 ranges, begin/end multiples of 4 elements */
+    const uint64_t *l1_begin_host, *l1_end_host;
+    const float *l1_coef_host;
+} pvd_adamw_extras;
+int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
+                      uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,
+                      float *step, const float *grad_scale, const float *found_inf, const pvd_adamw_extras *extras_host,
+                      pvd_stream_t stream);
+
+/* found_inf[0] = 1 if any of g[0..n) is inf/nan (never cleared): the read-only inf check GradScaler.step needs
+ * for an optimizer that unscales inside its own kernel (n multiple of 4). */
+int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream);
+
+/* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats). */
+int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host,
+                  uint32_t n_ranges, float *scratch, float *out, pvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

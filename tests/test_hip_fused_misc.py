@@ -124,3 +124,76 @@ def test_flat_adamw_matches_torch_fused_adamw():
     assert float(mine.step_count) == 5.0  # one step skipped
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (a - b).abs().max()
+
+
+def test_flat_adamw_device_schedule_l1_and_finite_check():
+    """FlatAdamW with the cosine / exponential schedule evaluated inside the update kernel and the L1
+    regulariser folded into it == torch AdamW + torch LR scheduler + autograd of weight * sum mean|t|."""
+    import math
+    import pvd_hip
+    from pvd.flat_adamw import DeviceSchedule, FlatAdamW, FlatGradScaler
+    dev = torch.device("cuda:0")
+    for kind in ("cosine", "exp"):
+        def make():
+            gg = torch.Generator(device=dev).manual_seed(3)
+            return [torch.nn.Parameter(torch.randn(*s, device=dev, generator=gg)) for s in [(64, 32), (1, 16, 24, 24), (1, 16, 24, 1), (3, 64)]]
+        pa, pb = make(), make()
+        groups = lambda ps: [{"params": ps[:1], "lr": 1e-2}, {"params": ps[1:3], "lr": 2e-2}, {"params": ps[3:], "lr": 1e-3}]
+        ga = groups(pa)
+        for grp in ga:
+            grp["lr"] = torch.tensor(grp["lr"], device=dev)
+        ref = torch.optim.AdamW(ga, betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+        mine = FlatAdamW(groups(pb), betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+        T, w = 40, 3e-2
+        if kind == "cosine":
+            sched_ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=T, eta_min=5e-5)
+            sched = DeviceSchedule(mine, "cosine", T, 5e-5)
+        else:
+            sched_ref = torch.optim.lr_scheduler.LambdaLR(ref, lambda it: 0.1 ** min(it / T, 1))
+            sched = DeviceSchedule(mine, "exp", T, 0.1)
+        mine.set_l1([pb[1], pb[2]], w)
+        g = torch.Generator(device=dev).manual_seed(4)
+        for it in range(50):
+            l1_ref = w * (pa[1].abs().mean() + pa[2].abs().mean())
+            assert abs(float(mine.l1_value()) - float(l1_ref)) <= 1e-5 * abs(float(l1_ref))
+            for a, b in zip(pa, pb):
+                gr = torch.randn(a.shape, device=dev, generator=g)
+                a.grad = gr.clone()
+                b.grad.copy_(gr)
+            for a, gl in zip((pa[1], pa[2]), torch.autograd.grad(l1_ref, (pa[1], pa[2]))):
+                a.grad += gl
+            ref.step(); mine.step()
+            sched_ref.step(); sched.step()
+            lr_ref = [float(grp["lr"]) for grp in ref.param_groups]
+            # the kernel wrote the rate it used for THIS step; torch's scheduler already holds the next one
+            assert it == 0 or all(abs(a - b) <= 2e-6 * b for a, b in zip(prev_lr_mine_next, mine.lr_dev.tolist()))
+            prev_lr_mine_next = lr_ref
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), (kind, (a - b).abs().max())
+
+    # finite check: read-only, sets (never clears) the flag
+    flag = torch.zeros(1, device=dev)
+    buf = torch.randn(4 * 1000, device=dev)
+    pvd_hip.check_finite(buf, flag)
+    assert float(flag) == 0.0
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        flag.zero_()
+        b2 = buf.clone(); b2[1237] = bad
+        pvd_hip.check_finite(b2, flag)
+        assert float(flag) == 1.0
+        pvd_hip.check_finite(buf, flag)
+        assert float(flag) == 1.0
+    # FlatGradScaler: a scaled step with an inf gradient is skipped and the scale backs off
+    ps = [torch.nn.Parameter(torch.ones(8, device=dev))]
+    opt = FlatAdamW([{"params": ps, "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    scaler = FlatGradScaler("cuda", init_scale=1024.0)
+    for it, gval in enumerate((1.0, float("inf"), 1.0)):
+        opt.zero_grad()
+        ps[0].grad.fill_(gval * 1024.0)
+        before = ps[0].detach().clone()
+        scaler.scale(torch.zeros((), device=dev))  # lazily creates the device-side scale, as scale(loss) does in a step
+        scaler.step(opt)
+        scaler.update()
+        changed = not torch.equal(before, ps[0].detach())
+        assert changed == (gval == 1.0)
+    assert float(scaler.get_scale()) == 512.0 and float(opt.step_count) == 2.0
