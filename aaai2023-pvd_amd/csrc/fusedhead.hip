@@ -30,6 +30,8 @@
 // launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
 #include "pvd_device.h"
 
+#include <stdlib.h>
+
 namespace pvd {
 
 #include "sh_basis.inc"
@@ -66,38 +68,47 @@ struct LdsMat {
 
 // dst[r][c] = (r in [r0, r0+rows) and mapped col valid) ? half(src[r-r0][col_map(c)]) : 0
 // col_shift: columns >= col_split of dst take src column (c - 1)   (the colour layer's zero column 16)
-__device__ __forceinline__ void load_weight(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
-                                            int row0, int col_split, uint32_t tid, uint32_t nthreads) {
-    for (int i = tid; i < rows_pad * cols_pad; i += nthreads) {
-        const int r = i / cols_pad, c = i - r * cols_pad;
-        float v = 0.f;
-        const int sr = r - row0;
-        int sc = c;
-        bool ok = sr >= 0 && sr < rows;
-        if (col_split >= 0) {
-            if (c == col_split) ok = false;
-            else if (c > col_split) sc = c - 1;
+// f32 weight [rows][cols] in HBM -> f16 [rows_pad][cols_pad] in LDS (TRANSPOSED: stored [cols_pad][rows_pad]), with
+// `row0` zero rows in front and an optional zero column inserted at `col_split`.  The global loads of kUnroll
+// elements are issued before any of them is consumed: the weights are the kernel's fixed cost (every workgroup
+// reads all of them), and a load -> convert -> store chain per element made that cost 60 us in the backward.
+template <bool TRANSPOSED>
+__device__ __forceinline__ void load_weight_impl(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
+                                                 int row0, int col_split, uint32_t tid, uint32_t nthreads) {
+    constexpr int kUnroll = 8;
+    const int total = rows_pad * cols_pad;
+    for (int base = tid; base < total; base += nthreads * kUnroll) {
+        float v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int i = base + u * (int)nthreads;
+            const int r = i / cols_pad, c = i - r * cols_pad;
+            const int sr = r - row0;
+            int sc = c;
+            bool ok = i < total && sr >= 0 && sr < rows;
+            if (col_split >= 0) {
+                if (c == col_split) ok = false;
+                else if (c > col_split) sc = c - 1;
+            }
+            v[u] = (ok && sc < cols) ? src[(size_t)sr * cols + sc] : 0.f;
         }
-        if (ok && sc < cols) v = src[(size_t)sr * cols + sc];
-        m.p[r * m.stride + c] = (half_t)v;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int i = base + u * (int)nthreads;
+            if (i < total) {
+                const int r = i / cols_pad, c = i - r * cols_pad;
+                m.p[TRANSPOSED ? c * m.stride + r : r * m.stride + c] = (half_t)v[u];
+            }
+        }
     }
 }
-// transposed copy: dst[c][r] (for the backward's W^T . dY)
+__device__ __forceinline__ void load_weight(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
+                                            int row0, int col_split, uint32_t tid, uint32_t nthreads) {
+    load_weight_impl<false>(m, src, rows, cols, rows_pad, cols_pad, row0, col_split, tid, nthreads);
+}
 __device__ __forceinline__ void load_weight_T(LdsMat m, const float *__restrict__ src, int rows, int cols, int rows_pad, int cols_pad,
                                               int row0, int col_split, uint32_t tid, uint32_t nthreads) {
-    for (int i = tid; i < rows_pad * cols_pad; i += nthreads) {
-        const int r = i / cols_pad, c = i - r * cols_pad;
-        float v = 0.f;
-        const int sr = r - row0;
-        int sc = c;
-        bool ok = sr >= 0 && sr < rows;
-        if (col_split >= 0) {
-            if (c == col_split) ok = false;
-            else if (c > col_split) sc = c - 1;
-        }
-        if (ok && sc < cols) v = src[(size_t)sr * cols + sc];
-        m.p[c * m.stride + r] = (half_t)v;
-    }
+    load_weight_impl<true>(m, src, rows, cols, rows_pad, cols_pad, row0, col_split, tid, nthreads);
 }
 
 struct HeadArgs {
@@ -112,6 +123,7 @@ struct HeadArgs {
     const float *Wc1;  // color_net.0 [64][31]
     const float *Wc2;  // color_net.1 [64][64]
     const float *Wc3;  // color_net.2 [3][64]
+    const half_t *image;  // optional: the weights pre-packed by pvd_head_pack_weights (LDS image), else NULL
     float clip_sigma_min, clip_feat_min, clip_max;
     // outputs
     float *sigma;   // [M]
@@ -173,6 +185,59 @@ struct HeadLds {
         load_weight(Wc3, a.Wc3, 3, 64, 16, 64, 0, -1, tid, n);
     }
 };
+
+// transposed copies for dX = W^T . dY (A fragments must be contiguous along the contracted index); the backward's
+// LDS holds HeadLds followed by this
+template <int KIND>
+struct HeadLdsT {
+    LdsMat Wa1T, Wa2T, Wc1T, Wc2T, Wc3T;
+    static constexpr int halfs = (KIND == KIND_VM ? 144 * (16 + kPad) : 32 * (64 + kPad) + 64 * (16 + kPad)) + 32 * (64 + kPad) +
+                                 64 * (64 + kPad) + 64 * (16 + kPad);
+    __device__ __forceinline__ void carve(half_t *p) {
+        if (KIND == KIND_VM) {
+            Wa1T = {p, 16 + kPad}; p += 144 * (16 + kPad);  // basis^T [144][16]
+            Wa2T = {p, 0};
+        } else {
+            Wa1T = {p, 64 + kPad}; p += 32 * (64 + kPad);   // sigma_net.0^T [32][64]
+            Wa2T = {p, 16 + kPad}; p += 64 * (16 + kPad);   // sigma_net.1^T [64][16]
+        }
+        Wc1T = {p, 64 + kPad}; p += 32 * (64 + kPad);        // [32][64]
+        Wc2T = {p, 64 + kPad}; p += 64 * (64 + kPad);        // [64][64]
+        Wc3T = {p, 16 + kPad};                               // [64][16]
+    }
+    __device__ __forceinline__ void load(const HeadArgs &a, uint32_t tid, uint32_t n) {
+        if (KIND == KIND_VM) {
+            load_weight_T(Wa1T, a.Wa1, 15, 144, 16, 144, 1, -1, tid, n);
+        } else {
+            load_weight_T(Wa1T, a.Wa1, 64, 28, 64, 32, 0, -1, tid, n);
+            load_weight_T(Wa2T, a.Wa2, 16, 64, 16, 64, 0, -1, tid, n);
+        }
+        load_weight_T(Wc1T, a.Wc1, 64, 31, 64, 32, 0, 16, tid, n);
+        load_weight_T(Wc2T, a.Wc2, 64, 64, 64, 64, 0, -1, tid, n);
+        load_weight_T(Wc3T, a.Wc3, 3, 64, 16, 64, 0, -1, tid, n);
+    }
+};
+
+// every workgroup needs all the weights in LDS: with a packed image (pvd_head_pack_weights) that is ~10
+// independent 16-byte loads per thread instead of a convert-and-scatter of the fp32 masters (which was the
+// kernels' fixed cost: 11-20k cycles forward, 23-31k backward of ~50k for a single tile)
+__device__ __forceinline__ void copy_image(half_t *__restrict__ lds, const half_t *__restrict__ image, int halfs, uint32_t tid, uint32_t n) {
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(image);
+    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(lds);
+    for (int i = tid; i < halfs / 8; i += n) dst[i] = src[i];
+}
+
+// the packed image: [HeadLds<KIND>][HeadLdsT<KIND>], exactly the backward kernel's LDS contents
+template <int KIND>
+__global__ void __launch_bounds__(256) k_head_pack(HeadArgs a, half_t *__restrict__ image) {
+    HeadLds<KIND> W;
+    W.carve(image);
+    HeadLdsT<KIND> T;
+    T.carve(image + HeadLds<KIND>::halfs);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    W.load(a, tid, n);
+    T.load(a, tid, n);
+}
 
 template <int KIND>
 __device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, size_t b, bool valid, uint32_t lane, TileFwd &t) {
@@ -273,7 +338,8 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_fwd(HeadArgs a) {
     extern __shared__ __align__(16) half_t lds[];
     HeadLds<KIND> W;
     W.carve(lds);
-    W.load(a, threadIdx.x, kHeadBlock);
+    if (a.image) copy_image(lds, a.image, HeadLds<KIND>::halfs, threadIdx.x, kHeadBlock);
+    else W.load(a, threadIdx.x, kHeadBlock);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
     const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
@@ -325,7 +391,7 @@ struct HeadBwdArgs {
     const float *g_feat16;  // [M][16]
     float *g_sigma_raw;     // VM: [M]
     half_t *g_x0;           // VM: d loss / d products [M][144];  hash: d loss / d encoder output [14][M][2]
-    float *partials;        // [nwaves][DwLayout::floats]
+    float *partials;        // [blocks][DwLayout::floats]
 };
 
 // 16x16 transpose of a register tile through LDS: in = X[row 4hi+j][col l&15]  ->  out = X[row l&15][col 4hi+j]
@@ -349,36 +415,32 @@ __device__ __forceinline__ h4 mask_relu(f4 g, h4 act) {  // dPre = dAct * (act >
     return r;
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(kHeadBlock) k_head_bwd(HeadBwdArgs a) {
+template <int KIND, int OCC>
+__global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
     extern __shared__ __align__(16) half_t lds[];
     HeadLds<KIND> W;
     W.carve(lds);
-    half_t *p = lds + HeadLds<KIND>::halfs;
-    // transposed copies for dX = W^T . dY  (A fragments must be contiguous along the contracted index)
-    LdsMat Wa1T, Wa2T;
-    if (KIND == KIND_VM) {
-        Wa1T = {p, 16 + kPad}; p += 144 * (16 + kPad);  // basis^T [144][16]
-        Wa2T = {p, 0};
+    HeadLdsT<KIND> T;
+    T.carve(lds + HeadLds<KIND>::halfs);
+    const LdsMat Wa1T = T.Wa1T, Wa2T = T.Wa2T, Wc1T = T.Wc1T, Wc2T = T.Wc2T, Wc3T = T.Wc3T;
+    half_t *scratch = lds + HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (threadIdx.x >> 6) * 256;  // 512 B per wave
+#ifdef PVD_HEAD_PROFILE
+    long long *stamps = reinterpret_cast<long long *>(a.partials + (size_t)gridDim.x * DwLayout<KIND>::floats);
+    int n_stamp = 0;
+#define PVD_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 30) stamps[n_stamp] = (long long)__builtin_readcyclecounter(); n_stamp++; } while (0)
+#else
+#define PVD_STAMP() do { } while (0)
+#endif
+    PVD_STAMP();
+    if (a.f.image) {
+        copy_image(lds, a.f.image, HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs, threadIdx.x, kHeadBlock);
     } else {
-        Wa1T = {p, 64 + kPad}; p += 32 * (64 + kPad);   // sigma_net.0^T [32][64]
-        Wa2T = {p, 16 + kPad}; p += 64 * (16 + kPad);   // sigma_net.1^T [64][16]
+        W.load(a.f, threadIdx.x, kHeadBlock);
+        T.load(a.f, threadIdx.x, kHeadBlock);
     }
-    LdsMat Wc1T = {p, 64 + kPad}; p += 32 * (64 + kPad);    // [32][64]
-    LdsMat Wc2T = {p, 64 + kPad}; p += 64 * (64 + kPad);    // [64][64]
-    LdsMat Wc3T = {p, 16 + kPad}; p += 64 * (16 + kPad);    // [64][16]
-    half_t *scratch = p + (threadIdx.x >> 6) * 256;          // 512 B per wave
-    W.load(a.f, threadIdx.x, kHeadBlock);
-    if (KIND == KIND_VM) {
-        load_weight_T(Wa1T, a.f.Wa1, 15, 144, 16, 144, 1, -1, threadIdx.x, kHeadBlock);
-    } else {
-        load_weight_T(Wa1T, a.f.Wa1, 64, 28, 64, 32, 0, -1, threadIdx.x, kHeadBlock);
-        load_weight_T(Wa2T, a.f.Wa2, 16, 64, 16, 64, 0, -1, threadIdx.x, kHeadBlock);
-    }
-    load_weight_T(Wc1T, a.f.Wc1, 64, 31, 64, 32, 0, 16, threadIdx.x, kHeadBlock);
-    load_weight_T(Wc2T, a.f.Wc2, 64, 64, 64, 64, 0, -1, threadIdx.x, kHeadBlock);
-    load_weight_T(Wc3T, a.f.Wc3, 3, 64, 16, 64, 0, -1, threadIdx.x, kHeadBlock);
+    PVD_STAMP();
     __syncthreads();
+    PVD_STAMP();
 
     const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
     const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
@@ -402,7 +464,9 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd(HeadBwdArgs a) {
         const size_t b = (size_t)tile * 16 + (lane & 15);
         const bool valid = b < a.f.M;
         TileFwd t;
+        PVD_STAMP();
         head_forward_tile<KIND>(a.f, W, b, valid, lane, t);
+        PVD_STAMP();
 
         // ---- d loss / d (colour layer 3 pre-activation): rows 0..2 live in the hi == 0 lanes
         h4 D3 = hzero;
@@ -483,6 +547,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd(HeadBwdArgs a) {
                 }
             }
         }
+        PVD_STAMP();
         // ---- weight gradients: dW[n][k] += sum_samples dY[n][s] X[k][s]  (both operands transposed tiles)
         {
             const h4 TD3 = transpose_tile(D3, scratch, lane);
@@ -532,20 +597,35 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_bwd(HeadBwdArgs a) {
         }
     }
 
-    // ---- one partial per wave: [tile][reg j][lane]
-    float *__restrict__ out = a.partials + (size_t)wave * LY::floats;
-    auto put = [&](int tile, f4 v) {
-        out[(tile * 4 + 0) * 64 + lane] = v.x; out[(tile * 4 + 1) * 64 + lane] = v.y;
-        out[(tile * 4 + 2) * 64 + lane] = v.z; out[(tile * 4 + 3) * 64 + lane] = v.w;
-    };
+    PVD_STAMP();
+    // ---- one partial per WORKGROUP: the four waves add their accumulator tiles in LDS one after the other (the
+    // weights are dead by now; plain 16-byte read-modify-writes -- LDS float atomics measured 118k cycles here),
+    // then the block writes [tile][reg j][lane] coalesced.
+    __syncthreads();
+    float *__restrict__ red = reinterpret_cast<float *>(lds);
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    for (uint32_t turn = 0; turn < kHeadBlock / 64; turn++) {
+        if (wave_in_block == turn) {
+            auto put = [&](int tile, f4 v) {
+                float *q = red + tile * 256 + lane;
+                if (turn != 0) { v.x += q[0]; v.y += q[64]; v.z += q[128]; v.w += q[192]; }
+                q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
+            };
 #pragma unroll
-    for (int i = 0; i < LY::a; i++) put(i, dWa[i]);
+            for (int i = 0; i < LY::a; i++) put(i, dWa[i]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) put(LY::c1 + i, dW1[i]);
+            for (int i = 0; i < 8; i++) put(LY::c1 + i, dW1[i]);
 #pragma unroll
-    for (int i = 0; i < 16; i++) put(LY::c2 + i, dW2[i]);
+            for (int i = 0; i < 16; i++) put(LY::c2 + i, dW2[i]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) put(LY::c3 + i, dW3[i]);
+            for (int i = 0; i < 4; i++) put(LY::c3 + i, dW3[i]);
+        }
+        __syncthreads();
+    }
+    float *__restrict__ out = a.partials + (size_t)blockIdx.x * LY::floats;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)LY::floats; i += kHeadBlock) out[i] = red[i];
+    PVD_STAMP();
+#undef PVD_STAMP
 }
 
 // Sum the per-wave partials and ACCUMULATE into the fp32 gradient buffers (real, un-padded layouts).
@@ -594,13 +674,28 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
     if (w1 > w0) __hip_atomic_fetch_add(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// waves per SIMD the backward is compiled for: 1 = all accumulators in registers (> 256 VGPRs), 2 = twice the
+// workgroups with ~40-80 spilled registers.  PVD_HEAD_BWD_OCC overrides (measurement).
+static int head_bwd_occupancy() {
+    static int occ = 0;
+    if (occ == 0) {
+        const char *e = getenv("PVD_HEAD_BWD_OCC");
+        occ = (e && e[0] == '2') ? 2 : 1;
+    }
+    return occ;
+}
+
 template <int KIND>
 static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s) {
-    size_t lds_halfs = HeadLds<KIND>::halfs + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad) + (kHeadBlock / 64) * 256;
-    lds_halfs += KIND == KIND_VM ? 144 * (16 + kPad) : 32 * (64 + kPad) + 64 * (16 + kPad);
-    hipLaunchKernelGGL((k_head_bwd<KIND>), dim3(nwaves / (kHeadBlock / 64)), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
+    size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 256;
+    if (lds_halfs < 2 * (size_t)DwLayout<KIND>::floats) lds_halfs = 2 * (size_t)DwLayout<KIND>::floats;
+    const uint32_t nblocks = nwaves / (kHeadBlock / 64);
+    if (head_bwd_occupancy() == 2)
+        hipLaunchKernelGGL((k_head_bwd<KIND, 2>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
+    else
+        hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
     const uint32_t nreal = (KIND == KIND_VM ? 15 * 144 : 64 * 28 + 16 * 64) + 64 * 31 + 64 * 64 + 3 * 64;
-    hipLaunchKernelGGL((k_head_reduce_dw<KIND>), dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, s, a.partials, nwaves, gWa1, gWa2, gW1,
+    hipLaunchKernelGGL((k_head_reduce_dw<KIND>), dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, s, a.partials, nblocks, gWa1, gWa2, gW1,
                        gW2, gW3);
     return check_launch();
 }
@@ -611,8 +706,25 @@ using namespace pvd;
 
 extern "C" {
 
+int pvd_head_image_halfs(int kind) {
+    if (kind == KIND_VM) return HeadLds<KIND_VM>::halfs + HeadLdsT<KIND_VM>::halfs;
+    if (kind == KIND_HASH) return HeadLds<KIND_HASH>::halfs + HeadLdsT<KIND_HASH>::halfs;
+    return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, void *image,
+                          pvd_stream_t stream) {
+    if (!Wa1 || !Wc1 || !Wc2 || !Wc3 || !image || (kind == KIND_HASH && !Wa2)) return PVD_ERR_INVALID;
+    HeadArgs a = {};
+    a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    if (kind == KIND_VM) hipLaunchKernelGGL((k_head_pack<KIND_VM>), dim3(16), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
+    else if (kind == KIND_HASH) hipLaunchKernelGGL((k_head_pack<KIND_HASH>), dim3(16), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
+    else return PVD_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
 int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1,
-                     const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, float clip_sigma_min,
+                     const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min,
                      float clip_feat_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
@@ -620,7 +732,7 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
     a.x0 = (const half_t *)x0; a.sigma_raw = sigma_raw; a.dirs = dirs; a.M = M;
     a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
     a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_feat_min; a.clip_max = clip_max;
-    a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16;
+    a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16; a.image = (const half_t *)image;
     if (kind == KIND_HASH) {
         if (!Wa2) return PVD_ERR_INVALID;
         return launch_head_fwd<KIND_HASH>(a, (hipStream_t)stream);
@@ -635,17 +747,18 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
 static uint32_t head_bwd_waves(uint32_t M) {
     const uint32_t ntiles = div_up(M, 16u);
     uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
-    if (blocks > 128) blocks = 128;
+    if (blocks > 256u * head_bwd_occupancy()) blocks = 256u * head_bwd_occupancy();  // one workgroup per CU and occupancy slot
     if (blocks < 1) blocks = 1;
     return blocks * (kHeadBlock / 64);
 }
 
 int pvd_head_backward_workspace_floats(int kind, uint32_t M) {
-    return (int)(head_bwd_waves(M) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
+    return (int)(head_bwd_waves(M) / (kHeadBlock / 64) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
 }
 
 int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
-                      const float *Wc1, const float *Wc2, const float *Wc3, float clip_sigma_min, float clip_feat_min, float clip_max,
+                      const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
+                      float clip_max,
                       const float *g_sigma, const float *g_rgb, const float *g_feat16, float *g_sigma_raw, void *g_x0, float *gWa1,
                       float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
@@ -656,7 +769,7 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
     a.f.x0 = (const half_t *)x0; a.f.sigma_raw = sigma_raw; a.f.dirs = dirs; a.f.M = M;
     a.f.Wa1 = Wa1; a.f.Wa2 = Wa2; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
     a.f.clip_sigma_min = clip_sigma_min; a.f.clip_feat_min = clip_feat_min; a.f.clip_max = clip_max;
-    a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr;
+    a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr; a.f.image = (const half_t *)image;
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
     a.partials = workspace;
     const uint32_t nwaves = head_bwd_waves(M);

@@ -22,6 +22,21 @@ def _w(lin):
     return w if w.is_contiguous() else w.contiguous()
 
 
+def _cache_key(tensors):
+    return (pvd_hip.weight_epoch,) + tuple((t._version, t.data_ptr()) for t in tensors if t is not None)
+
+
+def _cached_image(model, kind, weights):
+    """Packed f16 weight image of a model that is not being trained right now (frozen teacher / inference)."""
+    key = _cache_key(weights)
+    cache = getattr(model, "_head_image_cache", None)
+    if cache is None or cache[0] != key:
+        w = [None if t is None else t.detach() for t in weights]
+        cache = (key, pvd_hip.head_pack_weights(kind, *w))
+        model._head_image_cache = cache
+    return cache[1]
+
+
 @torch.no_grad()
 def hash_head_infer(model, x, d):
     """(sigma, rgb, feature_sigma_color) of a hash model for positions x, directions d -- no autograd."""
@@ -32,8 +47,9 @@ def hash_head_infer(model, x, d):
     x01 = ((x.float() + bound) / (2 * bound)).contiguous()  # GridEncoder.forward's mapping (grid.py:211)
     emb = enc.embeddings
     cache = getattr(model, "_emb_half_cache", None)
-    if cache is None or cache[0] != emb._version or cache[1] != emb.data_ptr():
-        cache = (emb._version, emb.data_ptr(), emb.detach().to(torch.float16))  # frozen teacher: cast once, not per step
+    key = _cache_key([emb])
+    if cache is None or cache[0] != key:
+        cache = (key, None, emb.detach().to(torch.float16))  # frozen teacher: cast once, not per step
         model._emb_half_cache = cache
     L = enc.offsets.shape[0] - 1
     C = emb.shape[1]
@@ -43,9 +59,9 @@ def hash_head_infer(model, x, d):
                                 False, out, enc.gridtype_id, enc.align_corners)
     sigma, rgb, feat = _outputs(M, dev)
     a = model.args
-    pvd_hip.head_forward(KIND_HASH, out, None, d.float().contiguous(), M, _w(model.sigma_net[0]), _w(model.sigma_net[1]),
-                         _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2]),
-                         a.sigma_clip_min, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat)
+    ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    pvd_hip.head_forward(KIND_HASH, out, None, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_min, a.sigma_clip_max,
+                         sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws))
     return sigma, rgb, feat
 
 
@@ -55,9 +71,10 @@ def vm_head_infer(model, sigma_raw, prod, d):
     sigma, rgb, feat = _outputs(M, prod.device)
     a = model.args
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
-    pvd_hip.head_forward(KIND_VM, prod.contiguous(), sigma_raw.float().contiguous(), d.float().contiguous(), M, _w(model.basis_mat), None,
-                         _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2]),
-                         smin, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat)
+    ws = [_w(model.basis_mat), None, _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    pvd_hip.head_forward(KIND_VM, prod.contiguous(), sigma_raw.float().contiguous(), d.float().contiguous(), M, *ws,
+                         smin, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
+                         image=_cached_image(model, KIND_VM, ws))
     return sigma, rgb, feat
 
 
@@ -70,8 +87,10 @@ class _VMHeadTrain(torch.autograd.Function):
         M = prod.shape[0]
         sigma_raw, prod, dirs = sigma_raw.float().contiguous(), prod.contiguous(), dirs.float().contiguous()
         sigma, rgb, feat = _outputs(M, prod.device)
+        image = pvd_hip.head_pack_weights(KIND_VM, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach())  # serves both passes
         pvd_hip.head_forward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(),
-                             smin, fmin, cmax, sigma, rgb, feat)
+                             smin, fmin, cmax, sigma, rgb, feat, image=image)
+        ctx.image = image
         ctx.save_for_backward(sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3)
         ctx.clips = (smin, fmin, cmax)
         ctx.leaves = (Wb, Wc1, Wc2, Wc3)
@@ -93,7 +112,7 @@ class _VMHeadTrain(torch.autograd.Function):
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
         grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
         pvd_hip.head_backward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
-                              g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws)
+                              g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws, image=ctx.image)
         gw = (None, None, None, None) if direct else tuple(grads)
         return (g_sraw, g_prod, None) + gw + (None, None, None)
 
@@ -127,8 +146,10 @@ class _HashHeadTrain(torch.autograd.Function):
         enc = torch.empty(14, M, 2, dtype=torch.float16, device=dev)
         pvd_hip.grid_encode_forward(x01, emb16, offsets, enc, M, 3, 2, 14, S, H, False, enc, gridtype, align)
         sigma, rgb, feat = _outputs(M, dev)
+        image = pvd_hip.head_pack_weights(KIND_HASH, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach())
         pvd_hip.head_forward(KIND_HASH, enc, None, dirs, M, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(),
-                             smin, smin, cmax, sigma, rgb, feat)
+                             smin, smin, cmax, sigma, rgb, feat, image=image)
+        ctx.image = image
         ctx.save_for_backward(x01, enc, dirs, offsets, Ws0, Ws1, Wc1, Wc2, Wc3)
         ctx.emb = emb
         ctx.grid = (S, H, gridtype, align)
@@ -151,7 +172,7 @@ class _HashHeadTrain(torch.autograd.Function):
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
         grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
         pvd_hip.head_backward(KIND_HASH, enc, None, dirs, M, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(),
-                              *ctx.clips, g_sigma, g_rgb, g_feat, None, g_enc, *grads, ws)
+                              *ctx.clips, g_sigma, g_rgb, g_feat, None, g_enc, *grads, ws, image=ctx.image)
         g_emb = None
         if ctx.needs_input_grad[1]:
             S, H, gridtype, align = ctx.grid

@@ -223,6 +223,9 @@ class _TrainerBase:
         return self._static_out  # capturing records, it does not run: no step was consumed
 
     def replay(self):
+        if self.flat_opt:
+            import pvd_hip
+            pvd_hip.note_weights_changed()  # the captured optimizer kernel rewrites the parameters
         self._g_fwd.replay()
         if self._g_opt is not None:
             self._exchange()

@@ -47,7 +47,7 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_head_forward",
-    "pvd_head_backward", "pvd_head_backward_workspace_floats",
+    "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_l1_ranges",
@@ -400,12 +400,44 @@ plenoxel_backend = types.SimpleNamespace(plenoxel_forward=plenoxel_forward, plen
 
 
 # --------------------------------------------------------------------------- fused sigma / colour head
-def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, sigma, rgb, feat16):
-    dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16)
+def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, sigma, rgb, feat16,
+                 image=None):
+    dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
     _want(x0, torch.float16, "x0")
     _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
+    _check_image(kind, image)
     _call("pvd_head_forward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
-          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+
+
+# bumped whenever something rewrites parameters behind autograd's back (the flat optimizer kernel, a graph replay):
+# caches of derived weight data (fusedhead's packed teacher image, f16 embedding shadow) key on it
+weight_epoch = 0
+
+
+def note_weights_changed():
+    global weight_epoch
+    weight_epoch += 1
+
+
+def head_image_halfs(kind):
+    return int(_lib.pvd_head_image_halfs(_int(kind)))
+
+
+def _check_image(kind, image):
+    if image is not None and (image.dtype != torch.float16 or image.numel() < head_image_halfs(kind)):
+        raise PvdHipError("weight image must be float16 with pvd_head_image_halfs(kind) elements")
+
+
+def head_pack_weights(kind, Wa1, Wa2, Wc1, Wc2, Wc3, image=None):
+    """The head's weights as the f16 LDS image the kernels stage (forward part, then the transposed backward part)."""
+    dev = _dev(Wa1, Wa2, Wc1, Wc2, Wc3, image)
+    _f32_all(Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3)
+    if image is None:
+        image = torch.empty(head_image_halfs(kind), dtype=torch.float16, device=dev)
+    _check_image(kind, image)
+    _call("pvd_head_pack_weights", dev, _int(kind), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image))
+    return image
 
 
 def head_backward_workspace_floats(kind, M):
@@ -413,7 +445,7 @@ def head_backward_workspace_floats(kind, M):
 
 
 def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
-                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace):
+                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, image=None):
     """kind 1 (vm): x0 = products [M,144], g_x0 same layout.  kind 0 (hash): x0 = encoder output [14,M,2], g_x0 same."""
     dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_x0, workspace)
     _want(x0, torch.float16, "x0"), _want(g_x0, torch.float16, "g_x0")
@@ -427,8 +459,9 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
             raise PvdHipError("weight gradient buffers must be contiguous HIP tensors")
     if workspace.numel() < head_backward_workspace_floats(kind, M):
         raise PvdHipError("workspace too small")
+    _check_image(kind, image)
     _call("pvd_head_backward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
-          _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
+          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
           _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
 
 

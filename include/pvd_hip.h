@@ -201,8 +201,17 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
  * ---------------------------------------------------------------------- */
 int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
                      const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
-                     float clip_sigma_min, float clip_feat_min, float clip_max,
+                     const void *image, float clip_sigma_min, float clip_feat_min, float clip_max,
                      float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
+
+/* Optional weight image.  Every workgroup of the head kernels stages all weights in LDS; converting and
+ * (for the backward) transposing the fp32 masters there is the kernels' fixed cost.  pvd_head_pack_weights does it
+ * once into `image` (pvd_head_image_halfs(kind) f16 elements, device memory), and pvd_head_forward /
+ * pvd_head_backward given image != NULL copy it with 16-byte loads instead.  The image must be re-packed whenever
+ * the fp32 weights change (once per optimizer step for a student, once ever for a frozen teacher). */
+int pvd_head_image_halfs(int kind);
+int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2,
+                          const float *Wc3, void *image, pvd_stream_t stream);
 
 /* Backward of the fused head (training).  Recomputes the forward from (x0, sigma_raw, dirs), then writes the
  * gradient of the head's input and ACCUMULATES (+=) the f32 weight gradients.
@@ -218,7 +227,7 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
 int pvd_head_backward_workspace_floats(int kind, uint32_t M);
 int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
                       const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
-                      float clip_sigma_min, float clip_feat_min, float clip_max,
+                      const void *image, float clip_sigma_min, float clip_feat_min, float clip_max,
                       const float *g_sigma, const float *g_rgb, const float *g_feat16,
                       float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3,
                       float *workspace, pvd_stream_t stream);

@@ -199,3 +199,63 @@ def test_hash_head_backward_accumulates_into_existing_grads():
         outs.append([p.grad.clone() for p in ps])
     for a, b in zip(*outs):
         assert torch.allclose(b - 1.0, a, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("kind", ["vm", "hash"])
+def test_packed_weight_image_is_bit_identical(kind):
+    """pvd_head_pack_weights + image path == converting the fp32 masters inside the kernels (same f16 values, same
+    LDS layout): outputs and every gradient bit for bit."""
+    import pvd_hip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    M = 16 * 300 + 7
+    K = 1 if kind == "vm" else 0
+    f32 = lambda *s: torch.randn(*s, device=dev) * 0.3
+    if K == 1:
+        x0 = (torch.randn(M, 144, device=dev) * 0.3).half(); Wa1, Wa2 = f32(15, 144), None
+        sraw = f32(M)
+    else:
+        x0 = (torch.randn(14, M, 2, device=dev) * 0.3).half(); Wa1, Wa2 = f32(64, 28), f32(16, 64)
+        sraw = None
+    d = torch.randn(M, 3, device=dev); d = d / d.norm(dim=-1, keepdim=True)
+    Wc1, Wc2, Wc3 = f32(64, 31), f32(64, 64), f32(3, 64)
+    gs, gr, gf = f32(M), f32(M, 3), f32(M, 16)
+    image = pvd_hip.head_pack_weights(K, Wa1, Wa2, Wc1, Wc2, Wc3)
+    assert image.dtype == torch.float16 and image.numel() == pvd_hip.head_image_halfs(K)
+    res = []
+    for img in (None, image):
+        sig, rgb, feat = torch.empty(M, device=dev), torch.empty(M, 3, device=dev), torch.empty(M, 16, device=dev)
+        pvd_hip.head_forward(K, x0, sraw, d, M, Wa1, Wa2, Wc1, Wc2, Wc3, -2.0, -2.0, 7.0, sig, rgb, feat, image=img)
+        gx = torch.empty_like(x0)
+        gsraw = torch.empty(M, device=dev) if K == 1 else None
+        gWa1 = torch.zeros_like(Wa1)
+        gWa2 = torch.zeros_like(Wa2) if Wa2 is not None else None
+        gW = [torch.zeros_like(w) for w in (Wc1, Wc2, Wc3)]
+        ws = torch.empty(pvd_hip.head_backward_workspace_floats(K, M), device=dev)
+        pvd_hip.head_backward(K, x0, sraw, d, M, Wa1, Wa2, Wc1, Wc2, Wc3, -2.0, -2.0, 7.0, gs, gr, gf, gsraw, gx, gWa1, gWa2, *gW, ws, image=img)
+        res.append([sig, rgb, feat, gx, gWa1] + gW + ([gsraw] if K == 1 else [gWa2]))
+    for a, b in zip(*res):
+        # the weight gradients are summed by atomics over 16 slices: order-dependent in the last bits
+        if a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] != M:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(a, b)
+
+
+def test_teacher_image_cache_follows_weight_updates():
+    """hash_head_infer caches the packed image and the f16 table; an optimizer kernel that rewrites the parameters
+    (no autograd version bump) must invalidate both."""
+    import fusedhead
+    import pvd_hip
+    m = _model("hash", seed=13).eval()
+    x, d = _inputs(4096, seed=14)
+    s0, c0, _ = fusedhead.hash_head_infer(m, x, d)
+    s1, c1, _ = fusedhead.hash_head_infer(m, x, d)
+    assert torch.equal(c0, c1)
+    ptr = m.color_net[2].weight.data_ptr()
+    torch.ops.aten.mul_(m.color_net[2].weight.data, 0.5)  # .data: no version bump on the Parameter, like a raw kernel write
+    m.encoder.embeddings.data.mul_(0.5)
+    assert m.color_net[2].weight.data_ptr() == ptr
+    pvd_hip.note_weights_changed()
+    s2, c2, _ = fusedhead.hash_head_infer(m, x, d)
+    assert not torch.equal(c0, c2) and not torch.equal(s0, s2)
