@@ -717,8 +717,8 @@ int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const fl
     if (!Wa1 || !Wc1 || !Wc2 || !Wc3 || !image || (kind == KIND_HASH && !Wa2)) return PVD_ERR_INVALID;
     HeadArgs a = {};
     a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
-    if (kind == KIND_VM) hipLaunchKernelGGL((k_head_pack<KIND_VM>), dim3(16), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
-    else if (kind == KIND_HASH) hipLaunchKernelGGL((k_head_pack<KIND_HASH>), dim3(16), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
+    if (kind == KIND_VM) hipLaunchKernelGGL((k_head_pack<KIND_VM>), dim3(64), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
+    else if (kind == KIND_HASH) hipLaunchKernelGGL((k_head_pack<KIND_HASH>), dim3(64), dim3(256), 0, (hipStream_t)stream, a, (half_t *)image);
     else return PVD_ERR_UNSUPPORTED;
     return check_launch();
 }

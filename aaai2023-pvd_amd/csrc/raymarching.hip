@@ -125,6 +125,10 @@ struct Dda {
     float bound, dt_gamma, dt_min, dt_max, rH, Cf, Hf, cell_hi;
     uint32_t H, H3;
     const uint8_t *grid;
+    // wave-uniform fast paths with identical results: one cascade (level is always 0) and a power-of-two H
+    // (0.5 * v * H in fp64, rounded to fp32, equals the fp32 product v * (H / 2): a power-of-two scaling is exact)
+    bool one_cascade, pow2_h;
+    float mip_bound0, mip_rbound0, half_h;
 
     __device__ __forceinline__ void init(const float *o, const float *d, float bound_, float dt_gamma_, uint32_t max_steps,
                                          uint32_t C, uint32_t H_, const uint8_t *grid_) {
@@ -138,6 +142,11 @@ struct Dda {
         Cf = (float)C; Hf = (float)H_; cell_hi = (float)(H_ - 1);
         H = H_; H3 = H_ * H_ * H_;
         grid = grid_;
+        one_cascade = C == 1;
+        pow2_h = (H_ & (H_ - 1)) == 0 && H_ >= 2;
+        mip_bound0 = fminf(1.0f, bound_);
+        mip_rbound0 = 1.0f / mip_bound0;
+        half_h = 0.5f * (float)H_;
     }
 
     // One probe at parameter t (reference: the loop bodies at raymarching.cu:362-403,
@@ -150,23 +159,33 @@ struct Dda {
         z = clampf(fmaf(t, dz, oz), -bound, bound);
         dt = clampf(t * dt_gamma, dt_min, dt_max);
 
-        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-        int e_pos, e_dt;
-        (void)frexpf(mx, &e_pos);
-        const float dmx = (float)((double)(dt * Hf) * 0.5);  // double literal in the reference (:52)
-        (void)frexpf(dmx, &e_dt);
-        const int lvl_pos = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_pos));
-        const int lvl_dt = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_dt));
-        const int level = lvl_pos > lvl_dt ? lvl_pos : lvl_dt;
-
-        const float mip_bound = fminf((float)(1 << level), bound);
-        const float mip_rbound = 1.0f / mip_bound;
+        int level = 0;
+        float mip_bound = mip_bound0, mip_rbound = mip_rbound0;
+        if (!one_cascade) {
+            const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+            int e_pos, e_dt;
+            (void)frexpf(mx, &e_pos);
+            const float dmx = (float)((double)(dt * Hf) * 0.5);  // double literal in the reference (:52)
+            (void)frexpf(dmx, &e_dt);
+            const int lvl_pos = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_pos));
+            const int lvl_dt = (int)fminf(Cf - 1, fmaxf(0.0f, (float)e_dt));
+            level = lvl_pos > lvl_dt ? lvl_pos : lvl_dt;
+            mip_bound = fminf((float)(1 << level), bound);
+            mip_rbound = 1.0f / mip_bound;
+        }
 
         // nearest cell via fp64 temporaries, as the reference source promotes (:377-379)
-        const double Hd = (double)H;
-        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
-        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
-        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+        int nx, ny, nz;
+        if (pow2_h) {
+            nx = (int)clampf((x * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
+            ny = (int)clampf((y * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
+            nz = (int)clampf((z * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
+        } else {
+            const double Hd = (double)H;
+            nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+            ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+            nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+        }
 
         const uint32_t index = (uint32_t)level * H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
         const bool occ = (grid[index >> 3] >> (index & 7u)) & 1u;
@@ -352,9 +371,26 @@ __device__ __forceinline__ float readlane_f(float v, uint32_t lane) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)lane));
 }
 
+// Chunk records: the count pass keeps, for every 64-point chunk of the lattice in which samples were emitted, the
+// emit mask and the chunk's first lattice point, in a caller-provided workspace; the write pass rebuilds the samples
+// from them (positions are a function of t alone) instead of probing the occupancy grid a second time.
+constexpr uint32_t kMarchMaxRecords = 15;
+struct MarchChunk { uint64_t mask; float t_base; uint32_t pad; };
+struct MarchRayRecords {            // one per ray in the workspace: 256 bytes
+    uint32_t n, overflow, pad[2];
+    MarchChunk chunk[kMarchMaxRecords];
+};
+struct MarchRecord {                // register-side view while marching
+    MarchChunk *chunk;
+    uint32_t n;
+    bool overflow;
+};
+static_assert(sizeof(MarchRayRecords) == 256, "workspace stride");
+
 template <bool WRITE>
 __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float far, uint32_t limit, uint32_t lane,
-                                                  float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+                                                  float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                  uint32_t *n_chunks = nullptr, MarchRecord *__restrict__ rec = nullptr) {
     const float dt = r.dt_min;
     float t_base = t0;
     bool pending = false;
@@ -362,8 +398,14 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
     uint32_t emitted = 0;
     float last_t = t0;
     if (limit == 0) return 0;
+    // steady increment (in units of the bit pattern) of the binade t_base lies in, 0 = unknown: while the whole chunk
+    // (and the next base) stays inside the binade, lane k's lattice point is bits(t_base) + k * lat_c (see lattice_advance)
+    uint32_t lat_c = 0;
     for (;;) {
-        const float t = lattice_advance(t_base, dt, lane);
+        if (n_chunks) (*n_chunks)++;
+        const uint32_t bb = __float_as_uint(t_base);
+        const bool fast = lat_c != 0 && bb + 64u * lat_c < (((bb >> 23) + 1u) << 23);
+        const float t = fast ? __uint_as_float(bb + lane * lat_c) : lattice_advance(t_base, dt, lane);
         const float t_after = t + dt;
         const bool valid = t < far;
         float x = 0, y = 0, z = 0, dtp = 0, tt = 0;
@@ -424,8 +466,23 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
             }
             last_t = readlane_f(t_after, 63u - (uint32_t)__clzll((long long)emit_mask));
         }
+        if (rec && emit_mask) {  // what the write pass needs to re-create this chunk's samples without probing again
+            if (rec->n < kMarchMaxRecords) {
+                if (lane == 0) { rec->chunk[rec->n].mask = emit_mask; rec->chunk[rec->n].t_base = t_base; }
+                rec->n++;
+            } else {
+                rec->overflow = true;
+            }
+        }
         if (done) break;
         t_base = readlane_f(t_after, 63);
+        if (!fast) {
+            // the last three lattice points in one binade: the one before last is at least the first step after
+            // entering it, so the last difference is the binade's steady increment
+            const uint32_t b61 = __float_as_uint(readlane_f(t_after, 61)), b62 = __float_as_uint(readlane_f(t_after, 62));
+            const uint32_t b63 = __float_as_uint(t_base);
+            lat_c = ((b61 >> 23) == (b63 >> 23) && (b62 >> 23) == (b63 >> 23)) ? b63 - b62 : 0u;
+        }
     }
     return emitted;
 }
@@ -435,17 +492,29 @@ constexpr uint32_t kRaysPerBlock = kBlock / kWave;
 __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                              const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
                                                              uint32_t N, uint32_t C, uint32_t H, const float *__restrict__ nears,
-                                                             const float *__restrict__ fars, int32_t *__restrict__ rays, uint32_t perturb) {
+                                                             const float *__restrict__ fars, int32_t *__restrict__ rays, uint32_t perturb,
+                                                             MarchRayRecords *__restrict__ records, const int32_t *__restrict__ counter) {
+    if (records && blockIdx.x == 0 && threadIdx.x == 0) records[N].n = (uint32_t)counter[0];  // the caller's running sample offset
     const uint32_t n = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
+#ifdef PVD_MARCH_PROFILE
+    const long long prof_t0 = __builtin_readcyclecounter();
+    uint32_t prof_chunks = 0;
+#endif
     Dda r;
     r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
     const float far = fars[n];
     uint32_t num;
     if (t0 >= 0.0f && t0 < far) {
-        num = march_ray_wave<false>(r, t0, far, max_steps, lane, nullptr, nullptr, nullptr);
+        MarchRecord rec = {records ? records[n].chunk : nullptr, 0u, false};
+#ifdef PVD_MARCH_PROFILE
+        num = march_ray_wave<false>(r, t0, far, max_steps, lane, nullptr, nullptr, nullptr, &prof_chunks, records ? &rec : nullptr);
+#else
+        num = march_ray_wave<false>(r, t0, far, max_steps, lane, nullptr, nullptr, nullptr, nullptr, records ? &rec : nullptr);
+#endif
+        if (records && lane == 0) { records[n].n = rec.n; records[n].overflow = rec.overflow ? 1u : 0u; }
     } else {  // empty ray, or a start the lattice walk does not cover (t0 < 0, NaN): serial walk, every lane the same
         float t = t0;
         num = 0;
@@ -454,8 +523,12 @@ __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__rest
             if (r.probe(t, x, y, z, dt, tn)) { num++; t += dt; }
             else t = tn;
         }
+        if (records && lane == 0) { records[n].n = 0; records[n].overflow = num ? 1u : 0u; }  // write pass walks it serially again
     }
     if (lane == 0) rays[3 * (size_t)n + 2] = (int32_t)num;
+#ifdef PVD_MARCH_PROFILE
+    if (lane == 0) { rays[3 * (size_t)n] = (int32_t)(__builtin_readcyclecounter() - prof_t0); rays[3 * (size_t)n + 1] = (int32_t)prof_chunks; }
+#endif
 }
 
 __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
@@ -493,6 +566,99 @@ __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__rest
                 t = tn;
             }
         }
+    }
+}
+
+
+// Write pass from the chunk records, with the exclusive scan of the counts folded in (N small: every workgroup sums the
+// counts of the rays before its own -- a few KB from L2 -- instead of a separate single-workgroup scan launch).
+__global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                               const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
+                                                               uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                               const float *__restrict__ nears, const float *__restrict__ fars,
+                                                               float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                               int32_t *__restrict__ rays, uint32_t perturb,
+                                                               const MarchRayRecords *__restrict__ records, int32_t *__restrict__ counter) {
+    __shared__ uint32_t part[kBlock / kWave];
+    const uint32_t n0 = blockIdx.x * kRaysPerBlock;
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // ---- exclusive prefix of the counts of rays [0, n0)
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < n0; i += kBlock) acc += (uint32_t)rays[3 * (size_t)i + 2];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) part[wid] = acc;
+    __syncthreads();
+    uint32_t prefix = records[N].n;  // running offset the caller passed in counter[0]
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / kWave; w++) prefix += part[w];
+    const uint32_t n = n0 + wid;
+    uint32_t cnt[kRaysPerBlock];
+#pragma unroll
+    for (uint32_t w = 0; w < kRaysPerBlock; w++) cnt[w] = (n0 + w < N) ? (uint32_t)rays[3 * (size_t)(n0 + w) + 2] : 0u;
+    uint32_t off = prefix;
+#pragma unroll
+    for (uint32_t w = 0; w < kRaysPerBlock; w++) off += (w < wid) ? cnt[w] : 0u;
+    if (n0 + kRaysPerBlock >= N && threadIdx.x == 0) {  // the last workgroup publishes the totals (reference: the two atomics, :408-409)
+        uint32_t total = prefix;
+#pragma unroll
+        for (uint32_t w = 0; w < kRaysPerBlock; w++) total += cnt[w];
+        counter[0] = (int32_t)total;
+        counter[1] += (int32_t)N;
+    }
+    if (n >= N) return;
+    const uint32_t num = cnt[wid];
+    if (lane == 0) { rays[3 * (size_t)n] = (int32_t)n; rays[3 * (size_t)n + 1] = (int32_t)off; }
+    if (num == 0) return;
+    if (off + num >= M) return;  // strict (:419)
+    Dda r;
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
+    const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
+    float *px = xyzs + 3 * (size_t)off, *pd = dirs + 3 * (size_t)off, *pl = deltas + 2 * (size_t)off;
+    const MarchRayRecords &rr = records[n];
+    if (rr.overflow) {  // more chunks than the record holds, or a start the lattice walk does not cover: march again
+        const float far = fars[n];
+        if (t0 >= 0.0f) {
+            march_ray_wave<true>(r, t0, far, num, lane, px, pd, pl);
+        } else if (lane == 0) {
+            float t = t0, last_t = t0;
+            uint32_t step = 0;
+            while (t < far && step < num) {
+                float x, y, z, dt, tn;
+                if (r.probe(t, x, y, z, dt, tn)) {
+                    px[0] = x; px[1] = y; px[2] = z;
+                    pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+                    t += dt;
+                    pl[0] = dt; pl[1] = t - last_t; last_t = t;
+                    px += 3; pd += 3; pl += 2; step++;
+                } else {
+                    t = tn;
+                }
+            }
+        }
+        return;
+    }
+    const float dt = r.dt_min;
+    float last_t = t0;
+    uint32_t emitted = 0;
+    for (uint32_t c = 0; c < rr.n; c++) {
+        const uint64_t emit_mask = rr.chunk[c].mask;
+        const float t = lattice_advance(rr.chunk[c].t_base, dt, lane);
+        const float t_after = t + dt;
+        const uint64_t below = emit_mask & ((1ull << lane) - 1ull);
+        const int prev_lane = below ? 63 - __clzll((long long)below) : 0;
+        const float prev_after = __shfl(t_after, prev_lane, 64);
+        if ((emit_mask >> lane) & 1ull) {
+            const size_t k = emitted + (uint32_t)__popcll(below);
+            xyzs[3 * (size_t)off + 3 * k] = clampf(fmaf(t, r.dx, r.ox), -bound, bound);
+            xyzs[3 * (size_t)off + 3 * k + 1] = clampf(fmaf(t, r.dy, r.oy), -bound, bound);
+            xyzs[3 * (size_t)off + 3 * k + 2] = clampf(fmaf(t, r.dz, r.oz), -bound, bound);
+            pd[3 * k] = r.dx; pd[3 * k + 1] = r.dy; pd[3 * k + 2] = r.dz;
+            pl[2 * k] = clampf(t * r.dt_gamma, r.dt_min, r.dt_max);
+            pl[2 * k + 1] = t_after - (below ? prev_after : last_t);
+        }
+        emitted += (uint32_t)__popcll(emit_mask);
+        last_t = readlane_f(t_after, 63u - (uint32_t)__clzll((long long)emit_mask));
     }
 }
 
@@ -860,17 +1026,40 @@ int pvd_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     return check_launch();
 }
 
+constexpr uint32_t kMarchFusedScanMaxRays = 16384;  // beyond this the per-workgroup prefix (O(N) reads each) stops paying
+
+size_t pvd_march_workspace_bytes(uint32_t N) { return ((size_t)N + 1) * sizeof(MarchRayRecords); }
+
 int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                          const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                          uint32_t perturb, pvd_stream_t stream) {
+    return pvd_march_rays_train_ws(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                   counter, perturb, nullptr, 0, stream);
+}
+
+int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                            const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, pvd_stream_t stream) {
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter);
     PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
     hipStream_t s = (hipStream_t)stream;
     if (dt_gamma == 0.0f) {  // constant step: one wavefront per ray (all BASELINE configs)
         const dim3 g(div_up(N, kRaysPerBlock)), b(kBlock);
-        hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb);
+        MarchRayRecords *records = (workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
+                                       ? (MarchRayRecords *)workspace : nullptr;
+        hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb,
+                           records, counter);
+        if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
+            hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs,
+                               dirs, deltas, rays, perturb, records, counter);
+            return check_launch();
+        }
+#ifdef PVD_MARCH_PROFILE
+        return check_launch();
+#endif
         hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
         hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
                            deltas, rays, perturb);

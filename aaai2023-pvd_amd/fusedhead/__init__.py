@@ -23,12 +23,12 @@ def _w(lin):
 
 
 def _cache_key(tensors):
-    return (pvd_hip.weight_epoch,) + tuple((t._version, t.data_ptr()) for t in tensors if t is not None)
+    return pvd_hip.weights_key(tensors)
 
 
-def _cached_image(model, kind, weights):
+def _cached_image(model, kind, weights, params):
     """Packed f16 weight image of a model that is not being trained right now (frozen teacher / inference)."""
-    key = _cache_key(weights)
+    key = _cache_key(params)
     cache = getattr(model, "_head_image_cache", None)
     if cache is None or cache[0] != key:
         w = [None if t is None else t.detach() for t in weights]
@@ -60,8 +60,9 @@ def hash_head_infer(model, x, d):
     sigma, rgb, feat = _outputs(M, dev)
     a = model.args
     ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight]
     pvd_hip.head_forward(KIND_HASH, out, None, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_min, a.sigma_clip_max,
-                         sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws))
+                         sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws, ps))
     return sigma, rgb, feat
 
 
@@ -74,7 +75,8 @@ def vm_head_infer(model, sigma_raw, prod, d):
     ws = [_w(model.basis_mat), None, _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
     pvd_hip.head_forward(KIND_VM, prod.contiguous(), sigma_raw.float().contiguous(), d.float().contiguous(), M, *ws,
                          smin, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
-                         image=_cached_image(model, KIND_VM, ws))
+                         image=_cached_image(model, KIND_VM, ws, [model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
+                                                                  model.color_net[2].weight]))
     return sigma, rgb, feat
 
 

@@ -89,7 +89,7 @@ class FlatAdamW(torch.optim.Optimizer):
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                            schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None))
-        pvd_hip.note_weights_changed()  # the kernel rewrites the parameters without bumping their autograd versions
+        pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
 
 

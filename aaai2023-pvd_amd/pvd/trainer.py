@@ -225,7 +225,7 @@ class _TrainerBase:
     def replay(self):
         if self.flat_opt:
             import pvd_hip
-            pvd_hip.note_weights_changed()  # the captured optimizer kernel rewrites the parameters
+            pvd_hip.note_weights_changed(self.optimizer.params)  # the captured optimizer kernel rewrites the parameters
         self._g_fwd.replay()
         if self._g_opt is not None:
             self._exchange()

@@ -42,7 +42,7 @@ PVD_F32, PVD_F16 = 0, 1
 ENTRY_POINTS = (
     "pvd_abi_version", "pvd_status_string", "pvd_last_hip_error",
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
-    "pvd_march_rays_train", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
+    "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
@@ -55,6 +55,7 @@ ENTRY_POINTS = (
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
         getattr(_lib, _name).restype = ctypes.c_int
+_lib.pvd_march_workspace_bytes.restype = ctypes.c_size_t
 
 
 class PvdHipError(RuntimeError):
@@ -198,13 +199,30 @@ def packbits(grid, N, density_thresh, bitfield):
 
 
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
-                     xyzs, dirs, deltas, rays, counter, perturb):
+                     xyzs, dirs, deltas, rays, counter, perturb, use_workspace=True):
     dev = _dev(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter)
     _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
     _want(grid, torch.uint8, "grid"), _want(rays, torch.int32, "rays"), _want(counter, torch.int32, "counter")
-    _call("pvd_march_rays_train", dev, _p(rays_o), _p(rays_d), _p(grid), _f32(bound), _f32(dt_gamma), _u32(max_steps),
+    ws = _march_workspace(dev, N) if (dt_gamma == 0 and use_workspace) else None
+    _call("pvd_march_rays_train_ws", dev, _p(rays_o), _p(rays_d), _p(grid), _f32(bound), _f32(dt_gamma), _u32(max_steps),
           _u32(N), _u32(C), _u32(H), _u32(M), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter),
-          _u32(int(perturb)))
+          _u32(int(perturb)), _p(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0))
+
+
+_march_ws = {}
+
+
+def _march_workspace(dev, N):
+    """Scratch of pvd_march_rays_train_ws (chunk records between its two passes), one per (device, stream, ray count);
+    kept alive here so that a captured HIP graph can keep using it."""
+    if N > 16384:
+        return None
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, N)
+    ws = _march_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(_lib.pvd_march_workspace_bytes(_u32(N))), dtype=torch.uint8, device=dev)
+        _march_ws[key] = ws
+    return ws
 
 
 def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image):
@@ -410,14 +428,16 @@ def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sig
           _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
 
 
-# bumped whenever something rewrites parameters behind autograd's back (the flat optimizer kernel, a graph replay):
-# caches of derived weight data (fusedhead's packed teacher image, f16 embedding shadow) key on it
-weight_epoch = 0
+# Kernels that rewrite parameters behind autograd's back (the flat optimizer, a graph replay) do not bump the tensors'
+# autograd versions; they tag the tensors instead, and caches of derived weight data (fusedhead's packed teacher
+# image, the f16 embedding shadow) key on (version, data_ptr, tag).
+def note_weights_changed(params):
+    for p in params:
+        p._pvd_epoch = getattr(p, "_pvd_epoch", 0) + 1
 
 
-def note_weights_changed():
-    global weight_epoch
-    weight_epoch += 1
+def weights_key(tensors):
+    return tuple((t._version, t.data_ptr(), getattr(t, "_pvd_epoch", 0)) for t in tensors if t is not None)
 
 
 def head_image_halfs(kind):

@@ -29,6 +29,7 @@
 #ifndef PVD_HIP_H
 #define PVD_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -92,6 +93,16 @@ int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          const float *nears, const float *fars,
                          float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, uint32_t perturb, pvd_stream_t stream);
+
+/* Same, with a scratch buffer: pvd_march_workspace_bytes(N) bytes of device memory (256 B per ray).  The count pass
+ * then records, per ray, the emit masks of the lattice chunks that produced samples, and the write pass rebuilds the
+ * samples from them and folds the scan in (2 launches, no second walk of the occupancy grid).  Results are identical
+ * to pvd_march_rays_train; workspace == NULL (or too small, or dt_gamma != 0, or N > 16384) takes that path. */
+size_t pvd_march_workspace_bytes(uint32_t N);
+int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                            const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, pvd_stream_t stream);
 
 /* composite_rays_train_forward -- raymarching.cu:585-593 (kernel :504-582). */
 int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,

@@ -256,6 +256,6 @@ def test_teacher_image_cache_follows_weight_updates():
     torch.ops.aten.mul_(m.color_net[2].weight.data, 0.5)  # .data: no version bump on the Parameter, like a raw kernel write
     m.encoder.embeddings.data.mul_(0.5)
     assert m.color_net[2].weight.data_ptr() == ptr
-    pvd_hip.note_weights_changed()
+    pvd_hip.note_weights_changed([m.color_net[2].weight, m.encoder.embeddings])
     s2, c2, _ = fusedhead.hash_head_infer(m, x, d)
     assert not torch.equal(c0, c2) and not torch.equal(s0, s2)

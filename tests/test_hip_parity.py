@@ -95,6 +95,37 @@ def test_march_rays_train_bit_exact(hip, dev, perturb, bound, dt_gamma):
     assert np.array_equal(ref[2], deltas.cpu().numpy())
 
 
+@pytest.mark.parametrize("N,counter0", [(4096, 0), (4099, 17), (1, 0), (3, 5)])
+def test_march_record_pass_equals_three_kernel_path(hip, dev, N, counter0):
+    """pvd_march_rays_train_ws (count with chunk records -> write from records, scan folded in) against the
+    count / scan / re-march path and the oracle: every output bit for bit, including a non-zero running counter, a
+    ray count that is not a multiple of the workgroup's 4 rays, and rays whose chunk records overflow (a dense
+    volume: more than 15 sample-bearing chunks per ray)."""
+    for dense in (False, True):
+        o, d, bits, C = _scene_rays(N, 7)
+        if dense:
+            bits = np.full_like(bits, 255)
+        aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+        n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+        M = N * (1024 if dense else 64) + 128
+        ref = oracle.march_rays_train(o, d, bits, 1.0, C, 128, n_ref, f_ref, M, perturb=1, counter=np.array([counter0, 3], np.int32))
+        outs = []
+        for use_ws in (True, False):
+            xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+            rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+            counter = torch.tensor([counter0, 3], dtype=torch.int32, device=dev)
+            hip.march_rays_train(t(o, dev), t(d, dev), t(bits, dev), 1.0, 0.0, 1024, N, C, 128, M, t(n_ref, dev), t(f_ref, dev),
+                                 xyzs, dirs, deltas, rays, counter, 1, use_workspace=use_ws)
+            outs.append([x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)])
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        assert outs[0][4][1] == 3 + N
+        for a, b in zip(ref, outs[0]):
+            assert np.array_equal(a, b)
+        if dense and N >= 3:
+            assert outs[0][3][:, 2].max() > 15 * 64 // 2  # long rays: the record overflow path ran
+
+
 def test_march_overflow_drops_trailing_rays(hip, dev):
     N = 2048
     o, d, bits, C = _scene_rays(N, 5)
