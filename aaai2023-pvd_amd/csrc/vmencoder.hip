@@ -19,6 +19,8 @@
 // consecutive samples that hit the same texel are merged in registers before touching memory.
 #include "pvd_device.h"
 
+#include <stdlib.h>
+
 namespace pvd {
 
 constexpr uint32_t kVmBlock = 256;
@@ -66,6 +68,279 @@ __device__ __forceinline__ void normalise(const float *__restrict__ xyz, size_t 
 
 constexpr int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
 
+// Register windows.  Consecutive samples of a ray move by about half a texel, so the 2x2 plane footprint (and the
+// 2-tap line footprint) of sample k+1 usually equals or overlaps that of sample k.  Each wave keeps the current
+// footprint in registers -- the texel VALUES (both passes: 18 coalesced 256-byte gathers per sample otherwise, which
+// made the forward L2-bandwidth-bound at 415 MB per launch) and, in the backward, the pending gradient SUMS.  When the
+// footprint slides by one texel along one axis only the row/column that ENTERS is loaded and the one that LEAVES is
+// flushed (one contiguous 64-lane atomic per texel, lane = channel), the overlap is shifted in registers; any other
+// move reloads / flushes everything.  Every texel a ray crosses is thus read about once and receives about one
+// atomic per contiguous visit instead of one per sample and tap.  Control flow is wave-uniform: every lane shares
+// the sample's texel coordinates.
+__device__ __forceinline__ void atom(float *__restrict__ p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool GRAD>
+struct PlaneWin {
+    int x0, y0;
+    bool open;
+    float v[4];  // texel values, index = dy * 2 + dx
+    float a[4];  // pending gradient sums (GRAD only)
+
+    __device__ __forceinline__ void fetch(int k, const float *__restrict__ mat, int W, int H, uint32_t R) {
+        const int x = x0 + (k & 1), y = y0 + (k >> 1);
+        v[k] = (x >= 0 && x < W && y >= 0 && y < H) ? mat[((long)y * W + x) * (long)R] : 0.f;
+    }
+    __device__ __forceinline__ void flush(int k, float *__restrict__ gm, int W, int H, uint32_t R) {
+        if (GRAD) {
+            const int x = x0 + (k & 1), y = y0 + (k >> 1);
+            if (x >= 0 && x < W && y >= 0 && y < H) atom(gm + ((long)y * W + x) * (long)R, a[k]);
+            a[k] = 0.f;
+        }
+    }
+    // move the window to (nx, ny); mat / gm are the lane's channel pointers into the table / its gradient
+    __device__ __forceinline__ void move(int nx, int ny, const float *__restrict__ mat, float *__restrict__ gm, int W, int H, uint32_t R) {
+        if (!open) {
+            open = true; x0 = nx; y0 = ny;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { fetch(k, mat, W, H, R); a[k] = 0.f; }
+            return;
+        }
+        const int dx = nx - x0, dy = ny - y0;
+        if (dx == 0 && dy == 0) return;
+        // static register indices in every branch (a runtime index would send the arrays to scratch)
+        if (dy == 0 && dx == 1) slide<0, 1, 2, 3>(nx, ny, mat, gm, W, H, R);         // column 0 leaves, column 1 -> 0
+        else if (dy == 0 && dx == -1) slide<1, 0, 3, 2>(nx, ny, mat, gm, W, H, R);   // column 1 leaves, column 0 -> 1
+        else if (dx == 0 && dy == 1) slide<0, 2, 1, 3>(nx, ny, mat, gm, W, H, R);    // row 0 leaves, row 1 -> 0
+        else if (dx == 0 && dy == -1) slide<2, 0, 3, 1>(nx, ny, mat, gm, W, H, R);   // row 1 leaves, row 0 -> 1
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) flush(k, gm, W, H, R);
+            x0 = nx; y0 = ny;
+#pragma unroll
+            for (int k = 0; k < 4; k++) fetch(k, mat, W, H, R);
+        }
+    }
+    // texels LA, LB leave (flushed at the old position); SA, SB stay and move into LA, LB; SA, SB are re-fetched
+    template <int LA, int SA, int LB, int SB>
+    __device__ __forceinline__ void slide(int nx, int ny, const float *__restrict__ mat, float *__restrict__ gm, int W, int H, uint32_t R) {
+        flush(LA, gm, W, H, R); flush(LB, gm, W, H, R);
+        v[LA] = v[SA]; v[LB] = v[SB];
+        if (GRAD) { a[LA] = a[SA]; a[LB] = a[SB]; a[SA] = 0.f; a[SB] = 0.f; }
+        x0 = nx; y0 = ny;
+        fetch(SA, mat, W, H, R); fetch(SB, mat, W, H, R);
+    }
+    __device__ __forceinline__ void close(float *__restrict__ gm, int W, int H, uint32_t R) {
+        if (!open) return;
+#pragma unroll
+        for (int k = 0; k < 4; k++) flush(k, gm, W, H, R);
+        open = false;
+    }
+
+    // ---- interior fast path: the move code comes precomputed with the sample (see WalkCtl), old and new footprints
+    // are known to lie inside the table, so there are no comparisons and no bounds checks; `t` is a texel index.
+    template <int K>
+    __device__ __forceinline__ void fetch_at(int t, const float *__restrict__ mat, uint32_t R) { v[K] = mat[(long)t * (long)R]; }
+    template <int K>
+    __device__ __forceinline__ void flush_at(int t, float *__restrict__ gm, uint32_t R) {
+        if (GRAD) { atom(gm + (long)t * (long)R, a[K]); a[K] = 0.f; }
+    }
+    __device__ __forceinline__ void move_fast(uint32_t code, int nx, int ny, const float *__restrict__ mat, float *__restrict__ gm, int W, uint32_t R) {
+        const int nb = ny * W + nx;  // new origin texel
+        if (code == 1) {         // +x: column 0 leaves
+            flush_at<0>(nb - 1, gm, R); flush_at<2>(nb - 1 + W, gm, R);
+            v[0] = v[1]; v[2] = v[3];
+            if (GRAD) { a[0] = a[1]; a[2] = a[3]; a[1] = 0.f; a[3] = 0.f; }
+            fetch_at<1>(nb + 1, mat, R); fetch_at<3>(nb + W + 1, mat, R);
+        } else if (code == 2) {  // -x: column 1 leaves
+            flush_at<1>(nb + 2, gm, R); flush_at<3>(nb + 2 + W, gm, R);
+            v[1] = v[0]; v[3] = v[2];
+            if (GRAD) { a[1] = a[0]; a[3] = a[2]; a[0] = 0.f; a[2] = 0.f; }
+            fetch_at<0>(nb, mat, R); fetch_at<2>(nb + W, mat, R);
+        } else if (code == 3) {  // +y: row 0 leaves
+            flush_at<0>(nb - W, gm, R); flush_at<1>(nb - W + 1, gm, R);
+            v[0] = v[2]; v[1] = v[3];
+            if (GRAD) { a[0] = a[2]; a[1] = a[3]; a[2] = 0.f; a[3] = 0.f; }
+            fetch_at<2>(nb + W, mat, R); fetch_at<3>(nb + W + 1, mat, R);
+        } else if (code == 4) {  // -y: row 1 leaves
+            flush_at<2>(nb + 2 * W, gm, R); flush_at<3>(nb + 2 * W + 1, gm, R);
+            v[2] = v[0]; v[3] = v[1];
+            if (GRAD) { a[2] = a[0]; a[3] = a[1]; a[0] = 0.f; a[1] = 0.f; }
+            fetch_at<0>(nb, mat, R); fetch_at<1>(nb + 1, mat, R);
+        } else {                 // jump: everything leaves (the old footprint is interior, too)
+            const int ob = y0 * W + x0;
+            flush_at<0>(ob, gm, R); flush_at<1>(ob + 1, gm, R); flush_at<2>(ob + W, gm, R); flush_at<3>(ob + W + 1, gm, R);
+            fetch_at<0>(nb, mat, R); fetch_at<1>(nb + 1, mat, R); fetch_at<2>(nb + W, mat, R); fetch_at<3>(nb + W + 1, mat, R);
+        }
+        x0 = nx; y0 = ny;
+    }
+};
+
+template <bool GRAD>
+struct LineWin {
+    int l0;
+    bool open;
+    float v[2], a[2];
+    __device__ __forceinline__ void fetch(int k, const float *__restrict__ vec, int L, uint32_t R) {
+        const int l = l0 + k;
+        v[k] = (l >= 0 && l < L) ? vec[(long)l * R] : 0.f;
+    }
+    __device__ __forceinline__ void flush(int k, float *__restrict__ gv, int L, uint32_t R) {
+        if (GRAD) {
+            const int l = l0 + k;
+            if (l >= 0 && l < L) atom(gv + (long)l * R, a[k]);
+            a[k] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void move(int nl, const float *__restrict__ vec, float *__restrict__ gv, int L, uint32_t R) {
+        if (!open) {
+            open = true; l0 = nl;
+            fetch(0, vec, L, R); fetch(1, vec, L, R);
+            a[0] = a[1] = 0.f;
+            return;
+        }
+        const int d = nl - l0;
+        if (d == 0) return;
+        if (d == 1) {
+            flush(0, gv, L, R);
+            v[0] = v[1]; a[0] = a[1]; a[1] = 0.f;
+            l0 = nl;
+            fetch(1, vec, L, R);
+        } else if (d == -1) {
+            flush(1, gv, L, R);
+            v[1] = v[0]; a[1] = a[0]; a[0] = 0.f;
+            l0 = nl;
+            fetch(0, vec, L, R);
+        } else {
+            flush(0, gv, L, R); flush(1, gv, L, R);
+            l0 = nl;
+            fetch(0, vec, L, R); fetch(1, vec, L, R);
+        }
+    }
+    __device__ __forceinline__ void close(float *__restrict__ gv, int L, uint32_t R) {
+        if (!open) return;
+        flush(0, gv, L, R); flush(1, gv, L, R);
+        open = false;
+    }
+    // interior fast path (see PlaneWin::move_fast): code 1 = +1, 2 = -1, 3 = jump
+    __device__ __forceinline__ void move_fast(uint32_t code, int nl, const float *__restrict__ vec, float *__restrict__ gv, uint32_t R) {
+        if (code == 1) {
+            if (GRAD) { atom(gv + (long)(nl - 1) * (long)R, a[0]); a[0] = a[1]; a[1] = 0.f; }
+            v[0] = v[1];
+            v[1] = vec[(long)(nl + 1) * (long)R];
+        } else if (code == 2) {
+            if (GRAD) { atom(gv + (long)(nl + 2) * (long)R, a[1]); a[1] = a[0]; a[0] = 0.f; }
+            v[1] = v[0];
+            v[0] = vec[(long)nl * (long)R];
+        } else {
+            if (GRAD) {
+                atom(gv + (long)l0 * (long)R, a[0]); atom(gv + (long)(l0 + 1) * (long)R, a[1]);
+                a[0] = 0.f; a[1] = 0.f;
+            }
+            v[0] = vec[(long)nl * (long)R];
+            v[1] = vec[(long)(nl + 1) * (long)R];
+        }
+        l0 = nl;
+    }
+};
+
+// plane value and line value of one sample from the windows, accumulated in grid_sample's tap order
+template <bool GRAD>
+__device__ __forceinline__ float plane_value(const PlaneWin<GRAD> &w, const Tap1 &tx, const Tap1 &ty) {
+    float pv = w.v[0] * (tx.w0 * ty.w0);  // nw
+    pv += w.v[1] * (tx.w1 * ty.w0);       // ne
+    pv += w.v[2] * (tx.w0 * ty.w1);       // sw
+    pv += w.v[3] * (tx.w1 * ty.w1);       // se
+    return pv;
+}
+template <bool GRAD>
+__device__ __forceinline__ float line_value(const LineWin<GRAD> &w, const Tap1 &tl) {
+    // the line is a [L,1] image sampled at x = 0: weights (1 * w0, 0 * w0, 1 * w1, 0 * w1)
+    float lv = w.v[0] * tl.w0;
+    lv += w.v[1] * tl.w1;
+    return lv;
+}
+
+// The sampling state of a sample (3 axes x {texel, two weights}) is the same in all 64 lanes; computing it per lane
+// made both kernels instruction-issue-bound on 64-fold redundant coordinate math and window logic (rocprofv3 PMC: 389
+// wave-instructions per sample forward, 0.23 IPC per SIMD = the one-instruction-per-4-cycles ceiling).  Instead lane j
+// evaluates sample s0 + j once -- including, by comparing with lane j-1, HOW each window moves (same / slide +-x / +-y
+// / jump) and whether old and new footprints are interior -- and the walk broadcasts sample m's ten values from
+// lane m - s0 into SGPRs (v_readlane).  The common case per window is then: extract 3 bits, branch, 2 loads.
+struct WalkCtl {
+    int i0[3];
+    float w0[3], w1[3];
+    uint32_t code;  // bits 3i..3i+2: plane i move (0 same, 1 +x, 2 -x, 3 +y, 4 -y, 5 jump); bits 9+2i..: line i move
+                    // (0 same, 1 +1, 2 -1, 3 jump); bit 15+i: plane i takes the interior fast path; bit 18+i: line i
+};
+__device__ __forceinline__ WalkCtl precompute_ctl(const float *__restrict__ xyz, uint32_t s0, uint32_t s1, uint32_t lane, const VmTables &tb) {
+    WalkCtl p;
+    float xn[3] = {0.f, 0.f, 0.f};
+    if (s0 + lane < s1) normalise(xyz, s0 + lane, tb, xn);
+    // axis a is always sampled at resolution res[a]: planes use (W_i, H_i) = (res[m0], res[m1]), lines res[vec_id]
+    const int size[3] = {(int)tb.W[0], (int)tb.H[0], (int)tb.L[0]};  // res[0], res[1], res[2]  (mat_0 = (x, y), vec_0 = z)
+    bool inside[3];
+    int prev[3];
+    bool prev_inside[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const Tap1 t = tap1(xn[a], (uint32_t)size[a]);
+        p.i0[a] = t.i0; p.w0[a] = t.w0; p.w1[a] = t.w1;
+        inside[a] = t.i0 >= 0 && t.i0 + 1 < size[a];  // both taps of this axis in range
+        prev[a] = __shfl_up(t.i0, 1, 64);
+        prev_inside[a] = __shfl_up((int)inside[a], 1, 64) != 0;
+    }
+    uint32_t code = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int dx = p.i0[kM0[i]] - prev[kM0[i]], dy = p.i0[kM1[i]] - prev[kM1[i]];
+        uint32_t c = (dx == 0 && dy == 0) ? 0u : (dy == 0 && dx == 1) ? 1u : (dy == 0 && dx == -1) ? 2u : (dx == 0 && dy == 1) ? 3u
+                                                                                                   : (dx == 0 && dy == -1) ? 4u : 5u;
+        const int dl = p.i0[kV[i]] - prev[kV[i]];
+        uint32_t cl = dl == 0 ? 0u : dl == 1 ? 1u : dl == -1 ? 2u : 3u;
+        bool fast = inside[kM0[i]] && inside[kM1[i]] && prev_inside[kM0[i]] && prev_inside[kM1[i]];
+        bool fast_l = inside[kV[i]] && prev_inside[kV[i]];
+        if (lane == 0) { c = 5u; cl = 3u; fast = false; fast_l = false; }  // first sample of the run: open the windows (generic path)
+        code |= c << (3 * i) | cl << (9 + 2 * i) | (fast ? 1u : 0u) << (15 + i) | (fast_l ? 1u : 0u) << (18 + i);
+    }
+    p.code = code;
+    return p;
+}
+__device__ __forceinline__ float bcast_f(float v, uint32_t lane) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)lane));
+}
+struct SampleTaps {
+    Tap1 ax[3];
+    uint32_t code;
+};
+__device__ __forceinline__ SampleTaps bcast_sample(const WalkCtl &p, uint32_t lane) {
+    SampleTaps t;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        t.ax[a].i0 = __builtin_amdgcn_readlane(p.i0[a], (int)lane);
+        t.ax[a].w0 = bcast_f(p.w0[a], lane);
+        t.ax[a].w1 = bcast_f(p.w1[a], lane);
+        t.ax[a].in0 = t.ax[a].in1 = true;  // bounds are checked where texels are touched
+    }
+    t.code = (uint32_t)__builtin_amdgcn_readlane((int)p.code, (int)lane);
+    return t;
+}
+// move window set i to the sample's footprint
+template <bool GRAD>
+__device__ __forceinline__ void walk_move(PlaneWin<GRAD> &pw, LineWin<GRAD> &lw, const SampleTaps &t, int i, const float *__restrict__ mat,
+                                          float *__restrict__ gm, const float *__restrict__ vec, float *__restrict__ gv, int W, int H, int L,
+                                          uint32_t R) {
+    const Tap1 &tx = t.ax[kM0[i]], &ty = t.ax[kM1[i]], &tl = t.ax[kV[i]];
+    const uint32_t c = (t.code >> (3 * i)) & 7u, cl = (t.code >> (9 + 2 * i)) & 3u;
+    if (c) {
+        if ((t.code >> (15 + i)) & 1u) pw.move_fast(c, tx.i0, ty.i0, mat, gm, W, R);
+        else pw.move(tx.i0, ty.i0, mat, gm, W, H, R);
+    }
+    if (cl) {
+        if ((t.code >> (18 + i)) & 1u) lw.move_fast(cl, tl.i0, vec, gv, R);
+        else lw.move(tl.i0, vec, gv, L, R);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
                                                      float *__restrict__ sigma_feat, T *__restrict__ color_prod) {
@@ -78,32 +353,21 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     const uint32_t R = kind ? kRc : kRs;
     const uint32_t ch = kind ? lane - kRs : lane;
 
+    PlaneWin<false> pw[3];
+    LineWin<false> lw[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pw[i].open = false; lw[i].open = false; }
+
+    const WalkCtl pre = precompute_ctl(xyz, s0, s1, lane, tb);  // chunk <= 64
     for (uint32_t m = s0; m < s1; m++) {
-        float xn[3];
-        normalise(xyz, m, tb, xn);
+        const SampleTaps st = bcast_sample(pre, m - s0);
         float sig = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const Tap1 tx = tap1(xn[kM0[i]], tb.W[i]), ty = tap1(xn[kM1[i]], tb.H[i]), tl = tap1(xn[kV[i]], tb.L[i]);
-            const float *__restrict__ mat = tb.mat[kind][i] + ch;
-            const float *__restrict__ vec = tb.vec[kind][i] + ch;
-            const size_t W = tb.W[i];
-            // 4 plane taps + 2 line taps, all independent loads
-            const float nw = (tx.in0 && ty.in0) ? mat[((size_t)ty.i0 * W + tx.i0) * R] : 0.f;
-            const float ne = (tx.in1 && ty.in0) ? mat[((size_t)ty.i0 * W + tx.i0 + 1) * R] : 0.f;
-            const float sw = (tx.in0 && ty.in1) ? mat[((size_t)(ty.i0 + 1) * W + tx.i0) * R] : 0.f;
-            const float se = (tx.in1 && ty.in1) ? mat[((size_t)(ty.i0 + 1) * W + tx.i0 + 1) * R] : 0.f;
-            const float l0 = tl.in0 ? vec[(size_t)tl.i0 * R] : 0.f;
-            const float l1 = tl.in1 ? vec[(size_t)(tl.i0 + 1) * R] : 0.f;
-            // accumulate in grid_sample's tap order nw, ne, sw, se
-            float pv = nw * (tx.w0 * ty.w0);
-            pv += ne * (tx.w1 * ty.w0);
-            pv += sw * (tx.w0 * ty.w1);
-            pv += se * (tx.w1 * ty.w1);
-            // the line is a [L,1] image sampled at x = 0: weights (1 * w0, 0 * w0, 1 * w1, 0 * w1)
-            float lv = l0 * tl.w0;
-            lv += l1 * tl.w1;
-            const float prod = pv * lv;
+            const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
+            walk_move<false>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, nullptr, tb.vec[kind][i] + ch, nullptr, (int)tb.W[i], (int)tb.H[i],
+                             (int)tb.L[i], R);
+            const float prod = plane_value(pw[i], tx, ty) * line_value(lw[i], tl);
             if (kind) color_prod[(size_t)m * (3 * kRc) + i * kRc + ch] = (T)prod;
             else sig += prod;
         }
@@ -112,76 +376,6 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
         for (int off = 8; off >= 1; off >>= 1) sig += __shfl_xor(sig, off, 64);
         if (lane == 0) sigma_feat[m] = sig;
     }
-}
-
-// Gradient accumulation windows.  Consecutive samples of a ray move by a fraction of a texel, so the 2x2
-// plane footprint (and the 2-tap line footprint) of sample k+1 usually overlaps that of sample k.  Each
-// wave keeps the current footprint's partial sums in registers; when the footprint slides by one texel
-// along one axis only the row/column that LEAVES is flushed (one contiguous 64-lane atomic per texel, lane =
-// channel), the overlapping one is shifted in registers; any other move flushes everything.  Every texel a
-// ray crosses thus receives about one atomic per contiguous visit instead of one per sample and tap --
-// the memory-side atomic rate, not bandwidth, is what bounds this kernel (rocprofv3: WRITE_SIZE 153 MB/launch).
-struct PlaneWin { int x0, y0; float a00, a01, a10, a11; bool open; };  // a[dy][dx]
-struct LineWin { int l0; float a0, a1; bool open; };
-
-__device__ __forceinline__ void atom(float *__restrict__ p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ void flush_texel(float *__restrict__ gm, int x, int y, int W, int H, uint32_t R, float v) {
-    if (x >= 0 && x < W && y >= 0 && y < H) atom(gm + ((long)y * W + x) * (long)R, v);
-}
-
-__device__ __forceinline__ void plane_move(PlaneWin &w, int nx, int ny, float *__restrict__ gm, int W, int H, uint32_t R) {
-    if (!w.open) {
-        w.open = true; w.x0 = nx; w.y0 = ny; w.a00 = w.a01 = w.a10 = w.a11 = 0.f;
-        return;
-    }
-    const int dx = nx - w.x0, dy = ny - w.y0;
-    if (dx == 0 && dy == 0) return;
-    if (dy == 0 && dx == 1) {          // column x0 leaves
-        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10);
-        w.a00 = w.a01; w.a10 = w.a11; w.a01 = 0.f; w.a11 = 0.f;
-    } else if (dy == 0 && dx == -1) {  // column x0+1 leaves
-        flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
-        w.a01 = w.a00; w.a11 = w.a10; w.a00 = 0.f; w.a10 = 0.f;
-    } else if (dx == 0 && dy == 1) {   // row y0 leaves
-        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
-        w.a00 = w.a10; w.a01 = w.a11; w.a10 = 0.f; w.a11 = 0.f;
-    } else if (dx == 0 && dy == -1) {  // row y0+1 leaves
-        flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
-        w.a10 = w.a00; w.a11 = w.a01; w.a00 = 0.f; w.a01 = 0.f;
-    } else {
-        flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
-        flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
-        w.a00 = w.a01 = w.a10 = w.a11 = 0.f;
-    }
-    w.x0 = nx; w.y0 = ny;
-}
-__device__ __forceinline__ void plane_close(PlaneWin &w, float *__restrict__ gm, int W, int H, uint32_t R) {
-    if (!w.open) return;
-    flush_texel(gm, w.x0, w.y0, W, H, R, w.a00); flush_texel(gm, w.x0 + 1, w.y0, W, H, R, w.a01);
-    flush_texel(gm, w.x0, w.y0 + 1, W, H, R, w.a10); flush_texel(gm, w.x0 + 1, w.y0 + 1, W, H, R, w.a11);
-    w.open = false;
-}
-
-__device__ __forceinline__ void flush_line_texel(float *__restrict__ gv, int l, int L, uint32_t R, float v) {
-    if (l >= 0 && l < L) atom(gv + (long)l * R, v);
-}
-__device__ __forceinline__ void line_move(LineWin &w, int nl, float *__restrict__ gv, int L, uint32_t R) {
-    if (!w.open) {
-        w.open = true; w.l0 = nl; w.a0 = w.a1 = 0.f;
-        return;
-    }
-    const int d = nl - w.l0;
-    if (d == 0) return;
-    if (d == 1) { flush_line_texel(gv, w.l0, L, R, w.a0); w.a0 = w.a1; w.a1 = 0.f; }
-    else if (d == -1) { flush_line_texel(gv, w.l0 + 1, L, R, w.a1); w.a1 = w.a0; w.a0 = 0.f; }
-    else { flush_line_texel(gv, w.l0, L, R, w.a0); flush_line_texel(gv, w.l0 + 1, L, R, w.a1); w.a0 = w.a1 = 0.f; }
-    w.l0 = nl;
-}
-__device__ __forceinline__ void line_close(LineWin &w, float *__restrict__ gv, int L, uint32_t R) {
-    if (!w.open) return;
-    flush_line_texel(gv, w.l0, L, R, w.a0); flush_line_texel(gv, w.l0 + 1, L, R, w.a1);
-    w.open = false;
 }
 
 template <typename T>
@@ -196,58 +390,52 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     const uint32_t R = kind ? kRc : kRs;
     const uint32_t ch = kind ? lane - kRs : lane;
 
-    PlaneWin pw[3];
-    LineWin lw[3];
+    PlaneWin<true> pw[3];
+    LineWin<true> lw[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) { pw[i].open = false; lw[i].open = false; }
 
+    const WalkCtl pre = precompute_ctl(xyz, s0, s1, lane, tb);  // chunk <= 64
+    const float gs_lane = (s0 + lane < s1) ? g_sigma[s0 + lane] : 0.f;
     for (uint32_t m = s0; m < s1; m++) {
-        float xn[3];
-        normalise(xyz, m, tb, xn);
-        const float gs = g_sigma[m];
+        const SampleTaps st = bcast_sample(pre, m - s0);
+        const float gs = bcast_f(gs_lane, m - s0);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const Tap1 tx = tap1(xn[kM0[i]], tb.W[i]), ty = tap1(xn[kM1[i]], tb.H[i]), tl = tap1(xn[kV[i]], tb.L[i]);
+            const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
             const float g = kind ? (float)g_prod[(size_t)m * (3 * kRc) + i * kRc + ch] : gs;
-            const float *__restrict__ mat = tb.mat[kind][i] + ch;
-            const float *__restrict__ vec = tb.vec[kind][i] + ch;
-            const size_t W = tb.W[i];
-            const float nw = (tx.in0 && ty.in0) ? mat[((size_t)ty.i0 * W + tx.i0) * R] : 0.f;
-            const float ne = (tx.in1 && ty.in0) ? mat[((size_t)ty.i0 * W + tx.i0 + 1) * R] : 0.f;
-            const float sw = (tx.in0 && ty.in1) ? mat[((size_t)(ty.i0 + 1) * W + tx.i0) * R] : 0.f;
-            const float se = (tx.in1 && ty.in1) ? mat[((size_t)(ty.i0 + 1) * W + tx.i0 + 1) * R] : 0.f;
-            const float l0 = tl.in0 ? vec[(size_t)tl.i0 * R] : 0.f;
-            const float l1 = tl.in1 ? vec[(size_t)(tl.i0 + 1) * R] : 0.f;
-            float pv = nw * (tx.w0 * ty.w0);
-            pv += ne * (tx.w1 * ty.w0);
-            pv += sw * (tx.w0 * ty.w1);
-            pv += se * (tx.w1 * ty.w1);
-            float lv = l0 * tl.w0;
-            lv += l1 * tl.w1;
-            const float gp = g * lv;  // d loss / d plane value
-            const float gl = g * pv;  // d loss / d line value
-
-            // wave-uniform control flow: every lane shares the sample's texel coordinates
-            plane_move(pw[i], tx.i0, ty.i0, gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
-            pw[i].a00 += gp * (tx.w0 * ty.w0);
-            pw[i].a01 += gp * (tx.w1 * ty.w0);
-            pw[i].a10 += gp * (tx.w0 * ty.w1);
-            pw[i].a11 += gp * (tx.w1 * ty.w1);
-            line_move(lw[i], tl.i0, gr.vec[kind][i] + ch, (int)tb.L[i], R);
-            lw[i].a0 += gl * tl.w0;
-            lw[i].a1 += gl * tl.w1;
+            walk_move<true>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, gr.mat[kind][i] + ch, tb.vec[kind][i] + ch, gr.vec[kind][i] + ch,
+                            (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R);
+            const float gp = g * line_value(lw[i], tl);       // d loss / d plane value
+            const float gl = g * plane_value(pw[i], tx, ty);  // d loss / d line value
+            pw[i].a[0] += gp * (tx.w0 * ty.w0);
+            pw[i].a[1] += gp * (tx.w1 * ty.w0);
+            pw[i].a[2] += gp * (tx.w0 * ty.w1);
+            pw[i].a[3] += gp * (tx.w1 * ty.w1);
+            lw[i].a[0] += gl * tl.w0;
+            lw[i].a[1] += gl * tl.w1;
         }
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        plane_close(pw[i], gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
-        line_close(lw[i], gr.vec[kind][i] + ch, (int)tb.L[i], R);
+        pw[i].close(gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
+        lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], R);
     }
 }
 
 static uint32_t pick_chunk(uint32_t M, bool backward) {
-    // forward: short runs, many waves (pure latency hiding).  backward: longer runs so the accumulation
-    // windows see more consecutive samples of a ray, while still filling 256 CUs x 16 waves.
+    // A wave walks its run of samples serially, and every step that moves a window waits for a memory round trip
+    // (load of the entering texels / the atomics' addresses): the launch lasts as long as ONE wave's chain, so runs
+    // are kept short as long as the chip is not oversubscribed several times; longer runs only buy window reuse.
+    // PVD_VM_CHUNK_FWD / PVD_VM_CHUNK_BWD override (measurement).
+    static int env_f = -1, env_b = -1;
+    if (env_f < 0) {
+        const char *f = getenv("PVD_VM_CHUNK_FWD"), *b = getenv("PVD_VM_CHUNK_BWD");
+        env_f = f ? atoi(f) : 0;
+        env_b = b ? atoi(b) : 0;
+    }
+    const int forced = backward ? env_b : env_f;
+    if (forced >= 1 && forced <= 64) return (uint32_t)forced;
     uint32_t chunk = 16;
     const uint32_t target_waves = backward ? 256u * 16u : 256u * 32u;
     while (chunk < 64 && (uint64_t)M / chunk > target_waves) chunk <<= 1;
