@@ -78,9 +78,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self._l1_scratch = torch.empty(1024, dtype=torch.float32, device=self.flat_p.device)
 
     @torch.no_grad()
-    def l1_value(self):
+    def l1_value(self, scale=1.0):
         out = torch.empty(1, dtype=torch.float32, device=self.flat_p.device)
-        pvd_hip.l1_ranges(self.flat_p, self._l1, self._l1_scratch, out)
+        ranges = self._l1 if scale == 1.0 else [(b, e, c * scale) for b, e, c in self._l1]
+        pvd_hip.l1_ranges(self.flat_p, ranges, self._l1_scratch, out)
         return out[0]
 
     @torch.no_grad()

@@ -70,7 +70,11 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[0]
         device = rays_o.device
 
-        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        nears_fars = kwargs.get("nears_fars")  # the model that marched first hands its near/far along with the samples
+        if nears_fars is not None:
+            nears, fars = nears_fars
+        else:
+            nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
 
         if self.bg_radius > 0:
             polar = rm.polar_from_ray(rays_o, rays_d, self.bg_radius)
@@ -79,16 +83,16 @@ class NeRFRenderer(nn.Module):
             bg_color = 1
 
         if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-
             # whoever renders first marches; the other model inherits the very same samples
             # (renderer.py:365-411): student first when args.render_stu_first, else teacher first.
             stu_first = bool(getattr(self.args, "render_stu_first", True))
             i_march = (not self.is_teacher) if stu_first else self.is_teacher
             if self.teacher_variant:
                 i_march = True
+            counter = self.step_counter[self.local_step % 16]
+            if i_march:
+                counter.zero_()
+            self.local_step += 1
             if i_march:
                 xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
@@ -113,7 +117,8 @@ class NeRFRenderer(nn.Module):
             weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
-            return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays}
+            return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays,
+                    "nears_fars": (nears, fars)}
 
         # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
         dtype = torch.float32

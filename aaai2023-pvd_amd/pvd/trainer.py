@@ -165,11 +165,19 @@ class _TrainerBase:
             if not self._l1_folded:
                 self.optimizer.set_l1([*m.sigma_mat, *m.sigma_vec], o.l1_reg_weight)
                 self._l1_folded = True
-            return self.optimizer.l1_value() / self.dp.world_size
+            return self.optimizer.l1_value(1.0 / self.dp.world_size)
         return m.density_loss() * (o.l1_reg_weight / self.dp.world_size)
 
     def _backward(self, loss):
-        self.scaler.scale(loss).backward()
+        sc = self.scaler
+        if sc.is_enabled() and loss.is_cuda:
+            if sc._scale is None:
+                sc.scale(loss.detach())  # lazily creates the device-side scale (and nothing else)
+            # d(scale * loss) = scale: seed the backward with the scale instead of launching a multiply, a ones-fill
+            # and MulBackward around it
+            loss.backward(gradient=sc._scale.reshape(loss.shape).to(loss.dtype))
+        else:
+            sc.scale(loss).backward()
 
     def _exchange(self):
         if self.dp.enabled:
@@ -265,7 +273,7 @@ class DistillTrainer(_TrainerBase):
         out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw)
         with torch.no_grad():
             out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                 inherited_params=out_stu["inherited_params"], **kw)
+                                 inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
         self.loss_rate_fea_sc *= 0.995  # decays every step (utils.py:1044)
         self.fea_rate.mul_(0.995)
         have_fea = stu.feature_sigma_color is not None and tea.feature_sigma_color is not None
@@ -294,7 +302,7 @@ class DistillTrainer(_TrainerBase):
             # all four norm terms (utils.py:1109-1176) in one fused objective
             l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
                                         tea.color_l.float(), self.rates, self.dp)
-            loss = loss + l4
+            loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
                 loss = loss + self._l1_term()
             info["rgb"] = norms[0]

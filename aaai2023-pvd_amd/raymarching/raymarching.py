@@ -108,9 +108,8 @@ def make_ops(backend, device_type="cuda"):
                     mean_count += align - mean_count % align
                 M = mean_count
             dev, dt = rays_o.device, rays_o.dtype
-            xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-            dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-            deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+            buf = torch.zeros(M * 8, dtype=dt, device=dev)  # one zero-fill for the three outputs (:240-242)
+            xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:].view(M, 2)
             rays = torch.empty(N, 3, dtype=torch.int32, device=dev)  # id, offset, num_steps
             if step_counter is None:
                 step_counter = torch.zeros(2, dtype=torch.int32, device=dev)  # point counter, ray counter
@@ -150,8 +149,8 @@ def make_ops(backend, device_type="cuda"):
             grad_image = grad_image.contiguous()
             sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
             M, N = ctx.dims
-            grad_sigmas = torch.zeros_like(sigmas)
-            grad_rgbs = torch.zeros_like(rgbs)
+            gbuf = torch.zeros(sigmas.shape[0] * 4, dtype=sigmas.dtype, device=sigmas.device)  # one zero-fill (:339-340)
+            grad_sigmas, grad_rgbs = gbuf[:sigmas.shape[0]], gbuf[sigmas.shape[0]:].view(-1, 3)
             backend.composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
                                                   M, N, grad_sigmas, grad_rgbs)
             return grad_sigmas, grad_rgbs, None, None
@@ -184,8 +183,8 @@ def make_ops(backend, device_type="cuda"):
         def backward(ctx, grad_weights_sum, grad_depth, grad_image):
             sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
             M, N = ctx.dims
-            grad_sigmas = torch.zeros_like(sigmas)
-            grad_rgbs = torch.zeros_like(rgbs)
+            gbuf = torch.zeros(sigmas.shape[0] * 4, dtype=sigmas.dtype, device=sigmas.device)  # one zero-fill (:339-340)
+            grad_sigmas, grad_rgbs = gbuf[:sigmas.shape[0]], gbuf[sigmas.shape[0]:].view(-1, 3)
             gws = grad_weights_sum.contiguous() if grad_weights_sum is not None else None
             backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                      ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
