@@ -89,10 +89,14 @@ class NeRFRenderer(nn.Module):
             i_march = (not self.is_teacher) if stu_first else self.is_teacher
             if self.teacher_variant:
                 i_march = True
-            counter = self.step_counter[self.local_step % 16]
-            if i_march:
-                counter.zero_()
-            self.local_step += 1
+            premarched = kwargs.get("premarched", False)  # march() already ran for this step (see DistillTrainer)
+            if premarched:
+                i_march = False
+            else:
+                counter = self.step_counter[self.local_step % 16]
+                if i_march:
+                    counter.zero_()
+                self.local_step += 1
             if i_march:
                 xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
@@ -154,6 +158,22 @@ class NeRFRenderer(nn.Module):
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
 
     # ------------------------------------------------------------------ occupancy grid upkeep
+    def march(self, rays_o, rays_d, dt_gamma=0, perturb=False, force_all_rays=False, max_steps=1024):
+        """The sampling half of the training branch of run_cuda on its own: near/far + march_rays_train.  Returns
+        (inherited_params, (nears, fars)) for run_cuda(..., inherited_params=, nears_fars=, premarched=True), so that
+        the two models' forwards can be issued on different streams."""
+        rm = self.rm
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                       nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
+                                                       max_steps)
+        return [xyzs, dirs, deltas, rays], (nears, fars)
+
     def _cell_centres(self, coords, cas, jitter):
         """Grid coords [n,3] in [0,H) -> world positions of cascade `cas` (renderer.py:680-693)."""
         H = self.grid_size
