@@ -17,19 +17,15 @@ constexpr float kRPi = 0.3183098861837907f;
 // ------------------------------------------------------------------ utils
 
 // reference: kernel_near_far_from_aabb, raymarching.cu:93-147
-__global__ void __launch_bounds__(kBlock) k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                     const float *__restrict__ aabb, uint32_t N, float min_near,
-                                                     float *__restrict__ nears, float *__restrict__ fars) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
+__device__ __forceinline__ void near_far_of(const float o[3], const float d[3], const float *__restrict__ aabb, float min_near, float &near,
+                                            float &far) {
     float tn = 0.f, tf = 0.f;
     bool miss = false;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float o = rays_o[3 * (size_t)n + a];
-        const float rd = 1.0f / rays_d[3 * (size_t)n + a];
-        float lo = (aabb[a] - o) * rd;
-        float hi = (aabb[a + 3] - o) * rd;
+        const float rd = 1.0f / d[a];
+        float lo = (aabb[a] - o[a]) * rd;
+        float hi = (aabb[a + 3] - o[a]) * rd;
         if (lo > hi) { const float s = lo; lo = hi; hi = s; }
         if (a == 0) {
             tn = lo; tf = hi;
@@ -42,11 +38,21 @@ __global__ void __launch_bounds__(kBlock) k_near_far(const float *__restrict__ r
         }
     }
     if (miss) {
-        nears[n] = FLT_MAX; fars[n] = FLT_MAX;
+        near = FLT_MAX; far = FLT_MAX;
     } else {
-        nears[n] = tn < min_near ? min_near : tn;
-        fars[n] = tf;
+        near = tn < min_near ? min_near : tn;
+        far = tf;
     }
+}
+
+__global__ void __launch_bounds__(kBlock) k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     const float *__restrict__ aabb, uint32_t N, float min_near,
+                                                     float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float o[3] = {rays_o[3 * (size_t)n], rays_o[3 * (size_t)n + 1], rays_o[3 * (size_t)n + 2]};
+    const float d[3] = {rays_d[3 * (size_t)n], rays_d[3 * (size_t)n + 1], rays_d[3 * (size_t)n + 2]};
+    near_far_of(o, d, aabb, min_near, nears[n], fars[n]);
 }
 
 // reference: kernel_polar_from_ray, raymarching.cu:164-200
@@ -70,20 +76,67 @@ __global__ void __launch_bounds__(kBlock) k_polar(const float *__restrict__ rays
 
 // reference: get_rays, distill_mutual/utils.py:324-404 (pixel-centre directions through K^-1, normalise,
 // rotate by the camera-to-world pose).  One thread per ray instead of ~20 elementwise launches.
-__global__ void __launch_bounds__(kBlock) k_get_rays(const float *__restrict__ pose, float fx, float fy, float cx, float cy,
-                                                     const int64_t *__restrict__ inds, uint32_t W, uint32_t N,
-                                                     float *__restrict__ rays_o, float *__restrict__ rays_d) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    const int64_t k = inds ? inds[n] : (int64_t)n;
+__device__ __forceinline__ void ray_of_pixel(const float *__restrict__ pose, float fx, float fy, float cx, float cy, int64_t k, uint32_t W,
+                                             float o[3], float d[3]) {
     const float i = (float)(k % W) + 0.5f, j = (float)(k / W) + 0.5f;
     const float x = (i - cx) / fx, y = (j - cy) / fy, z = 1.0f;
     const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
     const float dx = x * inv, dy = y * inv, dz = z * inv;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        rays_d[3 * (size_t)n + r] = dx * pose[4 * r] + dy * pose[4 * r + 1] + dz * pose[4 * r + 2];
-        rays_o[3 * (size_t)n + r] = pose[4 * r + 3];
+        d[r] = dx * pose[4 * r] + dy * pose[4 * r + 1] + dz * pose[4 * r + 2];
+        o[r] = pose[4 * r + 3];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_get_rays(const float *__restrict__ pose, float fx, float fy, float cx, float cy,
+                                                     const int64_t *__restrict__ inds, uint32_t W, uint32_t N,
+                                                     float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    float o[3], d[3];
+    ray_of_pixel(pose, fx, fy, cx, cy, inds ? inds[n] : (int64_t)n, W, o, d);
+#pragma unroll
+    for (int r = 0; r < 3; r++) { rays_o[3 * (size_t)n + r] = o[r]; rays_d[3 * (size_t)n + r] = d[r]; }
+}
+
+// One training batch in one launch (the reference's data side: Trainer.train_one_epoch -> get_rays with
+// N random pixels of one pose and a random background colour per ray, utils.py:354, 987-995; then run_cuda's
+// near_far_from_aabb): pose = poses[state[0]], pixel ids and background from a PCG32 stream keyed by (seed, batch
+// counter, ray), rays, near/far.  The last workgroup to finish advances state = {pose index, batch counter, done}.
+__global__ void __launch_bounds__(kBlock) k_make_ray_batch(const float *__restrict__ poses, uint32_t P, long long *__restrict__ state,
+                                                           uint64_t seed, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                                                           uint32_t N, const float *__restrict__ aabb, float min_near,
+                                                           int64_t *__restrict__ inds, float *__restrict__ rays_o,
+                                                           float *__restrict__ rays_d, float *__restrict__ bg, float *__restrict__ nears,
+                                                           float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    const long long pose_idx = state[0], batch = state[1];
+    if (n < N) {
+        Pcg32 g;
+        g.seed(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(batch + 1));
+        g.advance(4ull * n);
+        const int64_t k = (int64_t)(((uint64_t)g.next() * (uint64_t)(H * W)) >> 32);  // uniform in [0, H*W)
+        float o[3], d[3];
+        ray_of_pixel(poses + 16 * (size_t)pose_idx, fx, fy, cx, cy, k, W, o, d);
+        if (inds) inds[n] = k;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { rays_o[3 * (size_t)n + r] = o[r]; rays_d[3 * (size_t)n + r] = d[r]; }
+        if (bg) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) bg[3 * (size_t)n + r] = g.next_float();
+        }
+        near_far_of(o, d, aabb, min_near, nears[n], fars[n]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(state + 2), 1ull);
+        if (done == gridDim.x - 1) {  // every workgroup has read the state
+            state[0] = (pose_idx + 1) % (long long)P;
+            state[1] = batch + 1;
+            state[2] = 0;
+        }
     }
 }
 
@@ -994,6 +1047,17 @@ int pvd_get_rays(const float *pose, float fx, float fy, float cx, float cy, cons
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(pose && rays_o && rays_d && W > 0);
     hipLaunchKernelGGL(k_get_rays, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pose, fx, fy, cx, cy, inds, W, N, rays_o, rays_d);
+    return check_launch();
+}
+
+int pvd_make_ray_batch(const float *poses, uint32_t P, int64_t *state, uint64_t seed, float fx, float fy, float cx, float cy, uint32_t H,
+                       uint32_t W, uint32_t N, const float *aabb, float min_near, int64_t *inds, float *rays_o, float *rays_d, float *bg,
+                       float *nears, float *fars, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    PVD_REQUIRE(poses && P > 0 && state && aabb && rays_o && rays_d && nears && fars && H > 0 && W > 0);
+    PVD_REQUIRE((uint64_t)H * W < (1ull << 32));
+    hipLaunchKernelGGL(k_make_ray_batch, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, poses, P, (long long *)state, seed, fx,
+                       fy, cx, cy, H, W, N, aabb, min_near, inds, rays_o, rays_d, bg, nears, fars);
     return check_launch();
 }
 

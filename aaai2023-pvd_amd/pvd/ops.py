@@ -35,5 +35,15 @@ def hip_ops():
         pvd_hip.get_rays(pose.reshape(4, 4).contiguous(), fx, fy, cx, cy, inds, W, N, rays_o, rays_d)
         return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
 
-    return types.SimpleNamespace(raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
+    def make_batch(poses, state, seed, intrinsics, H, W, N, aabb, min_near):
+        """One training batch in one launch (pvd_make_ray_batch): rays of N random pixels of poses[state[0]], a random
+        background per ray and near/far; returns (rays_o [1,N,3], rays_d [1,N,3], bg [1,N,3], (nears, fars))."""
+        dev = poses.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        rays_o, rays_d, bg, nears, fars = f(1, N, 3), f(1, N, 3), f(1, N, 3), f(N), f(N)
+        fx, fy, cx, cy = intrinsics
+        pvd_hip.make_ray_batch(poses, state, seed, fx, fy, cx, cy, H, W, N, aabb, min_near, None, rays_o, rays_d, bg, nears, fars)
+        return rays_o, rays_d, bg, (nears, fars)
+
+    return types.SimpleNamespace(make_batch=make_batch, raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
                                  vm_encode=vmencoder.vm_encode, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

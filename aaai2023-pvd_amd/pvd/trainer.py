@@ -271,10 +271,11 @@ class DistillTrainer(_TrainerBase):
         o = self.opt
         return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps)
 
-    def compute_loss(self, rays_o, rays_d, bg_color):
+    def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None):
         o, stu, tea = self.opt, self.model_stu, self.model_tea
         o.global_step = self.global_step
         kw = self.render_kwargs()
+        kw_stu = dict(kw, nears_fars=nears_fars) if nears_fars is not None else kw  # the batch kernel already intersected the box
         if self.overlap_teacher and rays_o.is_cuda and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
             # march once, then the frozen teacher's forward runs on a side stream next to the student's forward
             # (they share only the samples); in a captured step this becomes two parallel branches of the graph
@@ -288,7 +289,7 @@ class DistillTrainer(_TrainerBase):
                                  inherited_params=inh, nears_fars=nf, premarched=True, **kw)
             main.wait_stream(self._side)
         else:
-            out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw)
+            out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
             with torch.no_grad():
                 out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                                      inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
@@ -343,10 +344,10 @@ class DistillTrainer(_TrainerBase):
         info["rgb"] = l_rgb.detach()
         return loss, info, pred_stu, pred_tea
 
-    def train_step(self, rays_o, rays_d, bg_color):
+    def train_step(self, rays_o, rays_d, bg_color, nears_fars=None):
         self.flat.zero_()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
-            loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color)
+            loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color, nears_fars)
         self._backward_and_step(loss)
         return loss.detach(), info, pred_stu, pred_tea
 
@@ -354,9 +355,9 @@ class DistillTrainer(_TrainerBase):
         """Capture `batch_fn() -> (rays_o, rays_d, bg)` + the whole step into HIP graph(s); the stage
         (which loss terms exist) is frozen at capture time, so re-capture when the stage changes."""
         def body():
-            rays_o, rays_d, bg = batch_fn()
+            rays_o, rays_d, bg, *rest = batch_fn()
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                return self.compute_loss(rays_o, rays_d, bg)
+                return self.compute_loss(rays_o, rays_d, bg, *rest)
         self._captured_stage = self._stage_of(self.global_step)
         return self.capture(body)
 

@@ -139,6 +139,14 @@ class DistillWorkload:
         """next_batch() with nothing on the host: pose index and RNG state live on the device, so the batch
         generation can sit inside a captured HIP graph (default CUDA generator, graph-safe)."""
         opt = self.opt
+        mk = getattr(self.ops, "make_batch", None)
+        if mk is not None:  # pose selection, pixel ids, rays, background and near/far in one kernel
+            if not hasattr(self, "_batch_state"):
+                self._batch_state = torch.zeros(3, dtype=torch.int64, device=self.device)
+                self._poses_c = self.poses.float().contiguous()
+                self._batch_seed = 0x5eed + 1000003 * int(torch.cuda.initial_seed() % (2 ** 31))
+            return mk(self._poses_c, self._batch_state, self._batch_seed, BLENDER_INTRINSICS, 800, 800, opt.num_rays,
+                      self.stu.aabb_train, self.stu.min_near)
         if not hasattr(self, "_pose_idx"):
             self._pose_idx = torch.zeros(1, dtype=torch.long, device=self.device)
         pose = self.poses.index_select(0, self._pose_idx)

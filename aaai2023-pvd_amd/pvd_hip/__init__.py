@@ -46,7 +46,8 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
     "pvd_grid_encode_forward", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_head_forward",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
+    "pvd_head_forward",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
@@ -172,6 +173,22 @@ def get_rays(pose, fx, fy, cx, cy, inds, W, N, rays_o, rays_d):
     if inds is not None:
         _want(inds, torch.int64, "inds")
     _call("pvd_get_rays", dev, _p(pose), _f32(fx), _f32(fy), _f32(cx), _f32(cy), _p(inds), _u32(W), _u32(N), _p(rays_o), _p(rays_d))
+
+
+def make_ray_batch(poses, state, seed, fx, fy, cx, cy, H, W, N, aabb, min_near, inds, rays_o, rays_d, bg, nears, fars):
+    """poses [P,4,4] f32; state int64[3] device = {pose index, batch counter, 0} (advanced by the kernel); aabb [6] device."""
+    dev = _dev(poses, state, aabb, inds, rays_o, rays_d, bg, nears, fars)
+    _f32_all(poses=poses, aabb=aabb, rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars)
+    _want(state, torch.int64, "state")
+    if inds is not None:
+        _want(inds, torch.int64, "inds")
+    if bg is not None:
+        _want(bg, torch.float32, "bg")
+    if state.numel() < 3:
+        raise PvdHipError("state must hold 3 int64 values")
+    _call("pvd_make_ray_batch", dev, _p(poses), _u32(poses.shape[0]), _p(state), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _f32(fx),
+          _f32(fy), _f32(cx), _f32(cy), _u32(H), _u32(W), _u32(N), _p(aabb), _f32(min_near), _p(inds), _p(rays_o), _p(rays_d), _p(bg),
+          _p(nears), _p(fars))
 
 
 def polar_from_ray(rays_o, rays_d, radius, N, coords):

@@ -154,7 +154,7 @@ def main():
     name = "pvd_grid_encode_forward"
     roof = None
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-        rays_o, rays_d, bg = w.device_batch()
+        rays_o, rays_d, bg, *_ = w.device_batch()
         out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
                                max_steps=opt.max_steps)
         xyzs, dirs = out_stu["inherited_params"][0], out_stu["inherited_params"][1]

@@ -69,6 +69,14 @@ int pvd_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
 int pvd_get_rays(const float *pose, float fx, float fy, float cx, float cy, const int64_t *inds, uint32_t W, uint32_t N,
                  float *rays_o, float *rays_d, pvd_stream_t stream);
 
+/* One training batch in one launch: what Trainer.train_one_epoch + get_rays + run_cuda's near_far_from_aabb do with
+ * ~10 torch ops (utils.py:354, 987-995; renderer.py:339): N random pixels of pose poses[state[0]] (PCG32 keyed by seed,
+ * batch counter and ray), their rays, a random background colour per ray (bg may be NULL), near/far against aabb.
+ * state: DEVICE int64[3] = {pose index, batch counter, 0}; advanced by the kernel (pose index cycles through P poses). */
+int pvd_make_ray_batch(const float *poses, uint32_t P, int64_t *state, uint64_t seed, float fx, float fy, float cx,
+                       float cy, uint32_t H, uint32_t W, uint32_t N, const float *aabb, float min_near, int64_t *inds,
+                       float *rays_o, float *rays_d, float *bg, float *nears, float *fars, pvd_stream_t stream);
+
 /* polar_from_ray -- raymarching.cu:203-211 (kernel :164-200).  coords [N,2]. */
 int pvd_polar_from_ray(const float *rays_o, const float *rays_d, float radius,
                        uint32_t N, float *coords, pvd_stream_t stream);

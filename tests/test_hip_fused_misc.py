@@ -197,3 +197,35 @@ def test_flat_adamw_device_schedule_l1_and_finite_check():
         changed = not torch.equal(before, ps[0].detach())
         assert changed == (gval == 1.0)
     assert float(scaler.get_scale()) == 512.0 and float(opt.step_count) == 2.0
+
+
+def test_make_ray_batch_matches_get_rays_and_near_far():
+    """pvd_make_ray_batch == get_rays on the pixel ids it drew + near_far_from_aabb, cycles through the poses, draws
+    different pixels every call and uniform backgrounds."""
+    import pvd_hip
+    import raymarching
+    from pvd.scene import BLENDER_INTRINSICS, synthetic_poses
+    dev = torch.device("cuda:0")
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev).float().contiguous()
+    P, N, H, W = poses.shape[0], 4096, 800, 800
+    state = torch.zeros(3, dtype=torch.int64, device=dev)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev)
+    fx, fy, cx, cy = BLENDER_INTRINSICS
+    seen = []
+    for it in range(P + 2):
+        f = lambda *s: torch.empty(*s, device=dev)
+        inds = torch.empty(N, dtype=torch.int64, device=dev)
+        ro, rd, bg, nears, fars = f(N, 3), f(N, 3), f(N, 3), f(N), f(N)
+        pvd_hip.make_ray_batch(poses, state, 1234, fx, fy, cx, cy, H, W, N, aabb, 0.2, inds, ro, rd, bg, nears, fars)
+        assert state.tolist() == [(it + 1) % P, it + 1, 0]
+        assert int(inds.min()) >= 0 and int(inds.max()) < H * W
+        ro2, rd2 = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+        pvd_hip.get_rays(poses[it % P].contiguous(), fx, fy, cx, cy, inds, W, N, ro2, rd2)
+        assert torch.equal(ro, ro2) and torch.equal(rd, rd2)
+        n2, f2 = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+        assert torch.equal(nears, n2) and torch.equal(fars, f2)
+        assert 0.0 <= float(bg.min()) and float(bg.max()) < 1.0 and abs(float(bg.mean()) - 0.5) < 0.02
+        seen.append(inds.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[0], seen[P])  # new pixels every batch
+    cover = torch.bincount(torch.cat(seen) // (H * W // 16), minlength=16).float()
+    assert (cover / cover.sum() - 1 / 16).abs().max() < 0.01  # uniform over the image

@@ -24,7 +24,7 @@ def test_graph_replay_trains_and_advances_device_state():
     for _ in range(40):
         loss, info, ps, pt = w.step()
         losses.append(float(info["rgb"]))
-        idx.append(int(w._pose_idx))
+        idx.append(int(w._batch_state[0]))
     assert all(np.isfinite(losses))
     assert idx[1] == idx[0] + 1  # the pose index lives on the device and advances inside the graph
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
