@@ -179,9 +179,39 @@ class _TrainerBase:
         else:
             sc.scale(loss).backward()
 
+    compact_exchange = False  # DistillTrainer: the occupancy grid is frozen, the touched table rows are known up front
+
+    def _grad_compactor(self):
+        """pvd/dp_compact.py: exchange only the table rows that occupied cells can touch (exact: the rest is zero on every
+        rank).  Needs the dense L1 gradient out of the flat buffer (folded into the optimizer kernel, or off)."""
+        import os
+        o, m = self.opt, self.model
+        if not self.compact_exchange or os.environ.get("PVD_DP_COMPACT", "1") == "0" or m.model_type not in ("vm", "tensors"):
+            return None
+        if m.model_type == "vm" and o.l1_reg_weight > 0.0 and not self.flat_opt:
+            return None  # autograd writes w/n * sign(p) into every sigma-plane entry
+        c = getattr(self, "_compactor", None)
+        if c is None:
+            from .dp_compact import GradCompactor
+            offs = self.optimizer.offsets if self.flat_opt else None
+            if offs is None:
+                offs, acc = [], 0
+                for p in self.flat.params:
+                    offs.append(acc)
+                    acc += p.numel()
+            c = GradCompactor(m, self.flat.params, offs, self.device)
+            self._compactor = c
+        return c if c.fraction < 0.7 else None
+
     def _exchange(self):
         if self.dp.enabled:
-            self.dp.all_reduce_sum_(self.flat.flat)  # one bucket, SUM (losses are already global objectives)
+            c = self._grad_compactor()
+            if c is None:
+                self.dp.all_reduce_sum_(self.flat.flat)  # one bucket, SUM (losses are already global objectives)
+            else:
+                buf = c.gather(self.flat.flat)
+                self.dp.all_reduce_sum_(buf)
+                c.scatter(self.flat.flat, buf)
 
     def _optimize(self):
         self.scaler.step(self.optimizer)
@@ -246,6 +276,8 @@ class _TrainerBase:
 class DistillTrainer(_TrainerBase):
     """One distillation step = student render (marches, grads on) -> teacher render on the inherited
     samples (no grad) -> staged loss -> backward -> AdamW (reference: utils.py:804-824, 954-1189)."""
+
+    compact_exchange = True  # the occupancy grid is never updated while distilling
 
     def __init__(self, opt, model_tea, model_stu, device, fp16=True, dp=None):
         for p in model_tea.parameters():

@@ -48,7 +48,8 @@ OPT = dict(num_rays=256, resolution0=24, iters=50, fp16=False, model_type="vm",
            loss_rate_fea_sc=0.0, loss_rate_color=0.0, loss_rate_sigma=0.0)  # rgb norm + L1 reg: independent of row padding
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False):
+    OPT = opt_kw or globals()["OPT"]
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -77,6 +78,10 @@ def _worker(rank, world, port, out_path):
     p0 = [p.detach().clone() for p in w.stu.parameters()]
     loss, info, _, _ = w.trainer.train_step(rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous())
     flat = w.trainer.flat.flat.clone()
+    c = w.trainer._grad_compactor()
+    assert (c is not None) == expect_compact
+    if expect_compact:
+        assert 0.0 < c.fraction < 0.7
     # replicas identical after the step
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -129,3 +134,47 @@ def test_ray_dp_two_ranks_equals_single_process(tmp_path):
     scale = flat.abs().max().item()
     assert scale > 0
     assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
+
+
+OPT_COMPACT = dict(OPT, l1_reg_weight=0.0)  # no dense L1 gradient -> only table rows under occupied cells are exchanged
+
+
+@pytest.mark.timeout(600)
+def test_ray_dp_compact_exchange_is_exact(tmp_path):
+    """pvd/dp_compact.py: all-reducing only the rows of the VM planes that occupied cells can touch gives the same
+    full gradient as one process on both shards -- i.e. everything outside the footprint mask is exactly zero."""
+    _setup_paths()
+    port = _free_port()
+    out = str(tmp_path / "dpc.pt")
+    mp.spawn(_worker, args=(2, port, out, OPT_COMPACT, True), nprocs=2, join=True)
+    dp_res = torch.load(out)
+    w = _make(OPT_COMPACT)
+    base = _make(OPT_COMPACT)
+    rays_o, rays_d, bg = base.next_batch()
+    tr, stu, tea = w.trainer, w.stu, w.tea
+    tr.opt.global_step = tr.global_step
+    tr.flat.zero_()
+    diffs = []
+    half = OPT_COMPACT["num_rays"] // 2
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        o, d, b = rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous()
+        out_s = stu.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024)
+        with torch.no_grad():
+            out_t = tea.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False,
+                               inherited_params=out_s["inherited_params"], dt_gamma=0, max_steps=1024)
+        diffs.append(out_t["image"] - out_s["image"])
+    (torch.norm(torch.cat(diffs, dim=1)) * tr.opt.loss_rate_rgb).backward()
+    flat = tr.flat.flat
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale
+    # and the mask really leaves something out
+    from pvd.dp_compact import GradCompactor
+    offs, acc = [], 0
+    for p in tr.flat.params:
+        offs.append(acc); acc += p.numel()
+    c = GradCompactor(stu, tr.flat.params, offs, torch.device("cpu"))
+    outside = torch.ones_like(flat, dtype=torch.bool)
+    outside[c.idx] = False
+    assert outside.any() and flat[outside].abs().max().item() == 0.0

@@ -229,3 +229,30 @@ def test_make_ray_batch_matches_get_rays_and_near_far():
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[0], seen[P])  # new pixels every batch
     cover = torch.bincount(torch.cat(seen) // (H * W // 16), minlength=16).float()
     assert (cover / cover.sum() - 1 / 16).abs().max() < 0.01  # uniform over the image
+
+
+@pytest.mark.parametrize("kind", ["vm", "tensors"])
+def test_gradient_outside_the_footprint_mask_is_zero(kind):
+    """The compact ray-DP exchange (pvd/dp_compact.py) leaves out every table row no occupied cell can touch: after real
+    HIP training steps those gradient entries must be exactly zero, and the rest must not be."""
+    from pvd.config import PVDConfig
+    from pvd.dp_compact import GradCompactor
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    opt = PVDConfig(num_rays=4096, model_type=kind, resolution0=128, plenoxel_res="[64,64,64]", iters=100)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0)
+    tr = w.trainer
+    c = GradCompactor(w.stu, tr.flat.params, tr.optimizer.offsets, dev)
+    assert 0.02 < c.fraction < 0.6, c.fraction
+    touched = torch.zeros(tr.flat.flat.numel(), dtype=torch.bool, device=dev)
+    for _ in range(6):  # different poses
+        tr.flat.zero_()
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, *_ = tr.compute_loss(*w.next_batch())
+        tr._backward(loss)
+        touched |= tr.flat.flat != 0
+    outside = torch.ones_like(touched)
+    outside[c.idx] = False
+    assert outside.any() and not (touched & outside).any(), int((touched & outside).sum())
+    assert int(touched.sum()) > 0.2 * c.idx.numel()  # the mask is not vacuously large
