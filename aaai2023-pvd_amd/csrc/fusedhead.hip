@@ -134,10 +134,8 @@ struct HeadArgs {
 constexpr int KIND_HASH = 0, KIND_VM = 1;
 
 // the 4 SH values k = 4*hi + j of a degree-4 basis for direction d (all 16 computed, 4 kept)
-__device__ __forceinline__ h4 sh_frag(const float *__restrict__ dirs, size_t b, bool valid, uint32_t hi) {
+__device__ __forceinline__ h4 sh_frag(float x, float y, float z, uint32_t hi) {
     float o[16];
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (valid) { x = dirs[3 * b]; y = dirs[3 * b + 1]; z = dirs[3 * b + 2]; }
     pvd_sh_basis<4, false>(x, y, z, [&](int i, float v) { o[i] = v; }, [&](int, float, float, float) {});
     h4 r;
     r.x = (half_t)(hi == 0 ? o[0] : hi == 1 ? o[4] : hi == 2 ? o[8] : o[12]);
@@ -239,25 +237,49 @@ __global__ void __launch_bounds__(256) k_head_pack(HeadArgs a, half_t *__restric
     T.load(a, tid, n);
 }
 
+// the global-memory inputs of one tile.  Loaded one tile AHEAD of their use: at one wave per SIMD (the backward) nothing
+// else hides the ~2k-cycle round trip, which was a quarter of the 17.5k cycles per tile.
 template <int KIND>
-__device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, size_t b, bool valid, uint32_t lane, TileFwd &t) {
+struct TileIn {
+    h4 x[KIND == KIND_VM ? 9 : 2];  // VM: the 144 products; hash: the 28 encoder features
+    float sraw, dx, dy, dz;
+};
+template <int KIND>
+__device__ __forceinline__ TileIn<KIND> load_tile_in(const HeadArgs &a, size_t b, bool valid, uint32_t lane) {
     const uint32_t hi = lane >> 4;
-    const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    // ---- stage A: features -> 16-row feature tile
+    TileIn<KIND> in;
+    const h4 hz = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
     if (KIND == KIND_HASH) {
-        h4 X[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            X[s] = (h4){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+            in.x[s] = hz;
             const int k0 = 16 * s + 4 * hi;  // features k0..k0+3 = levels k0/2, k0/2+1 (2 channels each)
             if (valid && k0 < 28) {
                 const uint32_t lv = k0 >> 1;
                 const uint32_t u0 = *reinterpret_cast<const uint32_t *>(a.x0 + ((size_t)lv * a.M + b) * 2);
                 const uint32_t u1 = *reinterpret_cast<const uint32_t *>(a.x0 + ((size_t)(lv + 1) * a.M + b) * 2);
                 uint32_t w[2] = {u0, u1};
-                __builtin_memcpy(&X[s], w, 8);
+                __builtin_memcpy(&in.x[s], w, 8);
             }
         }
+        in.sraw = 0.f;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 9; s++) in.x[s] = valid ? *reinterpret_cast<const h4 *>(a.x0 + b * 144 + 16 * s + 4 * hi) : hz;
+        in.sraw = (valid && hi == 0) ? a.sigma_raw[b] : 0.f;
+    }
+    in.dx = in.dy = in.dz = 0.f;
+    if (valid) { in.dx = a.dirs[3 * b]; in.dy = a.dirs[3 * b + 1]; in.dz = a.dirs[3 * b + 2]; }
+    return in;
+}
+
+template <int KIND>
+__device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, const TileIn<KIND> &in, uint32_t lane, TileFwd &t) {
+    const uint32_t hi = lane >> 4;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    // ---- stage A: features -> 16-row feature tile
+    if (KIND == KIND_HASH) {
+        const h4 X[2] = {in.x[0], in.x[1]};
         h4 Ha[4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
@@ -285,11 +307,7 @@ __device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadL
     } else {
         f4 acc = zero;
 #pragma unroll
-        for (int s = 0; s < 9; s++) {
-            h4 x = (h4){(half_t)0, (half_t)0, (half_t)0, (half_t)0};
-            if (valid) x = *reinterpret_cast<const h4 *>(a.x0 + b * 144 + 16 * s + 4 * hi);
-            acc = mfma(W.Wa1.afrag(0, s, lane), x, acc);
-        }
+        for (int s = 0; s < 9; s++) acc = mfma(W.Wa1.afrag(0, s, lane), in.x[s], acc);
         const h4 rawh = to_h4(acc);  // basis_mat output, f16
         t.raw = (f4){(float)rawh.x, (float)rawh.y, (float)rawh.z, (float)rawh.w};
         f4 F;
@@ -299,14 +317,14 @@ __device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadL
         F.w = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.w));
         t.sig_raw = 0.f;
         if (hi == 0) {
-            t.sig_raw = valid ? a.sigma_raw[b] : 0.f;
+            t.sig_raw = in.sraw;
             F.x = fminf(a.clip_max, fmaxf(a.clip_sigma_min, t.sig_raw));  // row 0 := clamped sigma feature (fp32)
         }
         t.F = F;
         t.Fh = to_h4(F);
     }
     // ---- stage B: colour head
-    t.sh = sh_frag(a.dirs, b, valid, hi);
+    t.sh = sh_frag(in.dx, in.dy, in.dz, hi);
 #pragma unroll
     for (int n = 0; n < 4; n++) {
         f4 acc = zero;
@@ -345,11 +363,17 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_fwd(HeadArgs a) {
     const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
     const uint32_t nwaves = gridDim.x * (kHeadBlock / 64);
     const uint32_t ntiles = div_up(a.M, 16u);
+    TileIn<KIND> nxt = load_tile_in<KIND>(a, (size_t)wave * 16 + (lane & 15), (size_t)wave * 16 + (lane & 15) < a.M, lane);
     for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
         const size_t b = (size_t)tile * 16 + (lane & 15);
         const bool valid = b < a.M;
+        const TileIn<KIND> in = nxt;
+        if (tile + nwaves < ntiles) {
+            const size_t bn = (size_t)(tile + nwaves) * 16 + (lane & 15);
+            nxt = load_tile_in<KIND>(a, bn, bn < a.M, lane);
+        }
         TileFwd t;
-        head_forward_tile<KIND>(a, W, b, valid, lane, t);
+        head_forward_tile<KIND>(a, W, in, lane, t);
         if (valid) {
             *reinterpret_cast<f4 *>(a.feat16 + b * 16 + 4 * hi) = t.F;
             if (hi == 0) {
@@ -460,21 +484,40 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) dW3[i] = zero;
 
+    struct TileGrad { float r, g, bl, sig; f4 feat; };
+    auto load_grad = [&](size_t b, bool valid) {
+        TileGrad q = {0.f, 0.f, 0.f, 0.f, zero};
+        if (valid) {
+            q.feat = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
+            if (hi == 0) { q.r = a.g_rgb[3 * b]; q.g = a.g_rgb[3 * b + 1]; q.bl = a.g_rgb[3 * b + 2]; q.sig = a.g_sigma[b]; }
+        }
+        return q;
+    };
+    const size_t b_first = (size_t)wave * 16 + (lane & 15);
+    TileIn<KIND> nxt = load_tile_in<KIND>(a.f, b_first, b_first < a.f.M, lane);
+    TileGrad nxt_g = load_grad(b_first, b_first < a.f.M);
     for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
         const size_t b = (size_t)tile * 16 + (lane & 15);
         const bool valid = b < a.f.M;
+        const TileIn<KIND> in = nxt;
+        const TileGrad gin = nxt_g;
+        if (tile + nwaves < ntiles) {  // next tile's inputs: in flight while this tile computes
+            const size_t bn = (size_t)(tile + nwaves) * 16 + (lane & 15);
+            nxt = load_tile_in<KIND>(a.f, bn, bn < a.f.M, lane);
+            nxt_g = load_grad(bn, bn < a.f.M);
+        }
         TileFwd t;
         PVD_STAMP();
-        head_forward_tile<KIND>(a.f, W, b, valid, lane, t);
+        head_forward_tile<KIND>(a.f, W, in, lane, t);
         PVD_STAMP();
 
         // ---- d loss / d (colour layer 3 pre-activation): rows 0..2 live in the hi == 0 lanes
         h4 D3 = hzero;
         if (valid && hi == 0) {
             const float s0 = sigmoid_h(t.out.x), s1 = sigmoid_h(t.out.y), s2 = sigmoid_h(t.out.z);
-            D3.x = (half_t)(a.g_rgb[3 * b] * s0 * (1.0f - s0));
-            D3.y = (half_t)(a.g_rgb[3 * b + 1] * s1 * (1.0f - s1));
-            D3.z = (half_t)(a.g_rgb[3 * b + 2] * s2 * (1.0f - s2));
+            D3.x = (half_t)(gin.r * s0 * (1.0f - s0));
+            D3.y = (half_t)(gin.g * s1 * (1.0f - s1));
+            D3.z = (half_t)(gin.bl * s2 * (1.0f - s2));
         }
         h4 D2[4], D1[4];
 #pragma unroll
@@ -489,15 +532,12 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
         f4 dF = zero;  // rows 16..31 of the colour layer's input = the feature tile (row 16 has zero weights)
 #pragma unroll
         for (int s = 0; s < 4; s++) dF = mfma(Wc1T.afrag(1, s, lane), D1[s], dF);
-        if (valid) {
-            const f4 gf = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
-            dF.x += gf.x; dF.y += gf.y; dF.z += gf.z; dF.w += gf.w;
-        }
+        if (valid) { dF.x += gin.feat.x; dF.y += gin.feat.y; dF.z += gin.feat.z; dF.w += gin.feat.w; }
         // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
         // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
         float g0 = 0.f;
         if (hi == 0 && valid) {
-            g0 = dF.x + a.g_sigma[b] * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
+            g0 = dF.x + gin.sig * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
             g0 = (t.sig_raw >= a.f.clip_sigma_min && t.sig_raw <= a.f.clip_max) ? g0 : 0.f;
         }
         h4 Da;  // gradient of stage A's output tile
@@ -577,11 +617,7 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
         if (KIND == KIND_VM) {
             const h4 TD = transpose_tile(Da, scratch, lane);
 #pragma unroll
-            for (int tk = 0; tk < 9; tk++) {
-                h4 x = hzero;
-                if (valid) x = *reinterpret_cast<const h4 *>(a.f.x0 + b * 144 + 16 * tk + 4 * hi);
-                dWa[tk] = mfma(TD, transpose_tile(x, scratch, lane), dWa[tk]);
-            }
+            for (int tk = 0; tk < 9; tk++) dWa[tk] = mfma(TD, transpose_tile(in.x[tk < (KIND == KIND_VM ? 9 : 2) ? tk : 0], scratch, lane), dWa[tk]);
         } else {
             // sigma_net.0 [64][32]: tiles tn*2+tk;  sigma_net.1 [16][64]: tiles 8+tk
             const h4 TX0 = transpose_tile(t.X[0], scratch, lane), TX1 = transpose_tile(t.X[1], scratch, lane);
