@@ -144,32 +144,36 @@ struct PlaneWin {
     __device__ __forceinline__ void flush_at(int t, float *__restrict__ gm, uint32_t R) {
         if (GRAD) { atom(gm + (long)t * (long)R, a[K]); a[K] = 0.f; }
     }
+    // The entering texels are LOADED before the leaving ones are flushed: memory operations complete in issue order
+    // (one vmcnt), so a load issued behind the atomics would make the next use of the values wait for the atomics.
+    __device__ __forceinline__ float ld(int t, const float *__restrict__ mat, uint32_t R) const { return mat[(long)t * (long)R]; }
     __device__ __forceinline__ void move_fast(uint32_t code, int nx, int ny, const float *__restrict__ mat, float *__restrict__ gm, int W, uint32_t R) {
         const int nb = ny * W + nx;  // new origin texel
         if (code == 1) {         // +x: column 0 leaves
+            const float e1 = ld(nb + 1, mat, R), e3 = ld(nb + W + 1, mat, R);
             flush_at<0>(nb - 1, gm, R); flush_at<2>(nb - 1 + W, gm, R);
-            v[0] = v[1]; v[2] = v[3];
+            v[0] = v[1]; v[2] = v[3]; v[1] = e1; v[3] = e3;
             if (GRAD) { a[0] = a[1]; a[2] = a[3]; a[1] = 0.f; a[3] = 0.f; }
-            fetch_at<1>(nb + 1, mat, R); fetch_at<3>(nb + W + 1, mat, R);
         } else if (code == 2) {  // -x: column 1 leaves
+            const float e0 = ld(nb, mat, R), e2 = ld(nb + W, mat, R);
             flush_at<1>(nb + 2, gm, R); flush_at<3>(nb + 2 + W, gm, R);
-            v[1] = v[0]; v[3] = v[2];
+            v[1] = v[0]; v[3] = v[2]; v[0] = e0; v[2] = e2;
             if (GRAD) { a[1] = a[0]; a[3] = a[2]; a[0] = 0.f; a[2] = 0.f; }
-            fetch_at<0>(nb, mat, R); fetch_at<2>(nb + W, mat, R);
         } else if (code == 3) {  // +y: row 0 leaves
+            const float e2 = ld(nb + W, mat, R), e3 = ld(nb + W + 1, mat, R);
             flush_at<0>(nb - W, gm, R); flush_at<1>(nb - W + 1, gm, R);
-            v[0] = v[2]; v[1] = v[3];
+            v[0] = v[2]; v[1] = v[3]; v[2] = e2; v[3] = e3;
             if (GRAD) { a[0] = a[2]; a[1] = a[3]; a[2] = 0.f; a[3] = 0.f; }
-            fetch_at<2>(nb + W, mat, R); fetch_at<3>(nb + W + 1, mat, R);
         } else if (code == 4) {  // -y: row 1 leaves
+            const float e0 = ld(nb, mat, R), e1 = ld(nb + 1, mat, R);
             flush_at<2>(nb + 2 * W, gm, R); flush_at<3>(nb + 2 * W + 1, gm, R);
-            v[2] = v[0]; v[3] = v[1];
+            v[2] = v[0]; v[3] = v[1]; v[0] = e0; v[1] = e1;
             if (GRAD) { a[2] = a[0]; a[3] = a[1]; a[0] = 0.f; a[1] = 0.f; }
-            fetch_at<0>(nb, mat, R); fetch_at<1>(nb + 1, mat, R);
         } else {                 // jump: everything leaves (the old footprint is interior, too)
             const int ob = y0 * W + x0;
+            const float e0 = ld(nb, mat, R), e1 = ld(nb + 1, mat, R), e2 = ld(nb + W, mat, R), e3 = ld(nb + W + 1, mat, R);
             flush_at<0>(ob, gm, R); flush_at<1>(ob + 1, gm, R); flush_at<2>(ob + W, gm, R); flush_at<3>(ob + W + 1, gm, R);
-            fetch_at<0>(nb, mat, R); fetch_at<1>(nb + 1, mat, R); fetch_at<2>(nb + W, mat, R); fetch_at<3>(nb + W + 1, mat, R);
+            v[0] = e0; v[1] = e1; v[2] = e2; v[3] = e3;
         }
         x0 = nx; y0 = ny;
     }
@@ -224,20 +228,20 @@ struct LineWin {
     // interior fast path (see PlaneWin::move_fast): code 1 = +1, 2 = -1, 3 = jump
     __device__ __forceinline__ void move_fast(uint32_t code, int nl, const float *__restrict__ vec, float *__restrict__ gv, uint32_t R) {
         if (code == 1) {
+            const float e = vec[(long)(nl + 1) * (long)R];
             if (GRAD) { atom(gv + (long)(nl - 1) * (long)R, a[0]); a[0] = a[1]; a[1] = 0.f; }
-            v[0] = v[1];
-            v[1] = vec[(long)(nl + 1) * (long)R];
+            v[0] = v[1]; v[1] = e;
         } else if (code == 2) {
+            const float e = vec[(long)nl * (long)R];
             if (GRAD) { atom(gv + (long)(nl + 2) * (long)R, a[1]); a[1] = a[0]; a[0] = 0.f; }
-            v[1] = v[0];
-            v[0] = vec[(long)nl * (long)R];
+            v[1] = v[0]; v[0] = e;
         } else {
+            const float e0 = vec[(long)nl * (long)R], e1 = vec[(long)(nl + 1) * (long)R];
             if (GRAD) {
                 atom(gv + (long)l0 * (long)R, a[0]); atom(gv + (long)(l0 + 1) * (long)R, a[1]);
                 a[0] = 0.f; a[1] = 0.f;
             }
-            v[0] = vec[(long)nl * (long)R];
-            v[1] = vec[(long)(nl + 1) * (long)R];
+            v[0] = e0; v[1] = e1;
         }
         l0 = nl;
     }
@@ -397,13 +401,25 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
 
     const WalkCtl pre = precompute_ctl(xyz, s0, s1, lane, tb);  // chunk <= 64
     const float gs_lane = (s0 + lane < s1) ? g_sigma[s0 + lane] : 0.f;
+    // the colour lanes' incoming gradients, one sample ahead of their use (a wave has few companions on its SIMD:
+    // a load issued where it is needed costs its full latency on every sample)
+    T g_next[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) g_next[i] = kind ? g_prod[(size_t)s0 * (3 * kRc) + i * kRc + ch] : (T)0;
     for (uint32_t m = s0; m < s1; m++) {
         const SampleTaps st = bcast_sample(pre, m - s0);
         const float gs = bcast_f(gs_lane, m - s0);
+        T g_cur[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) g_cur[i] = g_next[i];
+        if (m + 1 < s1) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) g_next[i] = kind ? g_prod[(size_t)(m + 1) * (3 * kRc) + i * kRc + ch] : (T)0;
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
-            const float g = kind ? (float)g_prod[(size_t)m * (3 * kRc) + i * kRc + ch] : gs;
+            const float g = kind ? (float)g_cur[i] : gs;
             walk_move<true>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, gr.mat[kind][i] + ch, tb.vec[kind][i] + ch, gr.vec[kind][i] + ch,
                             (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R);
             const float gp = g * line_value(lw[i], tl);       // d loss / d plane value

@@ -1,5 +1,9 @@
+"""Cycle-counter stamps from an INSTRUMENTED build of the library (not the product):
+  hipcc <Makefile FLAGS> -DPVD_MARCH_PROFILE -c aaai2023-pvd_amd/csrc/raymarching.hip -o /tmp/x.o; link it with the other objects into a
+  scratch libpvd_hip.so and put that in place of aaai2023-pvd_amd/libpvd_hip.so on the GPU box before running this.
+Used for the section timings quoted in DESIGN.md (weight load / forward / dX / dW / epilogue; cycles per lattice chunk)."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "aaai2023-pvd_amd")]
 import numpy as np, torch, pvd_hip, raymarching
 from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
