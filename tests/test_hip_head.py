@@ -237,7 +237,7 @@ def test_packed_weight_image_is_bit_identical(kind):
     for a, b in zip(*res):
         # the weight gradients are summed by atomics over 16 slices: order-dependent in the last bits
         if a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] != M:
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
         else:
             assert torch.equal(a, b)
 
