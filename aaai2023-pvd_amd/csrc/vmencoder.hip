@@ -382,9 +382,10 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
-                                                     const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr) {
+// factor sets [I0, I1) of one run of samples; (0, 3) = everything in one wave, (i, i + 1) = one plane/line pair per wave
+template <typename T, int I0, int I1>
+__device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, const VmTables &tb,
+                                            const float *__restrict__ g_sigma, const T *__restrict__ g_prod, const VmGrads &gr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kVmBlock + threadIdx.x) >> 6;
     const uint32_t s0 = wave * chunk;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     PlaneWin<true> pw[3];
     LineWin<true> lw[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { pw[i].open = false; lw[i].open = false; }
+    for (int i = I0; i < I1; i++) { pw[i].open = false; lw[i].open = false; }
 
     const WalkCtl pre = precompute_ctl(xyz, s0, s1, lane, tb);  // chunk <= 64
     const float gs_lane = (s0 + lane < s1) ? g_sigma[s0 + lane] : 0.f;
@@ -405,19 +406,19 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
     // a load issued where it is needed costs its full latency on every sample)
     T g_next[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) g_next[i] = kind ? g_prod[(size_t)s0 * (3 * kRc) + i * kRc + ch] : (T)0;
+    for (int i = I0; i < I1; i++) g_next[i] = kind ? g_prod[(size_t)s0 * (3 * kRc) + i * kRc + ch] : (T)0;
     for (uint32_t m = s0; m < s1; m++) {
         const SampleTaps st = bcast_sample(pre, m - s0);
         const float gs = bcast_f(gs_lane, m - s0);
         T g_cur[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) g_cur[i] = g_next[i];
+        for (int i = I0; i < I1; i++) g_cur[i] = g_next[i];
         if (m + 1 < s1) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) g_next[i] = kind ? g_prod[(size_t)(m + 1) * (3 * kRc) + i * kRc + ch] : (T)0;
+            for (int i = I0; i < I1; i++) g_next[i] = kind ? g_prod[(size_t)(m + 1) * (3 * kRc) + i * kRc + ch] : (T)0;
         }
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+        for (int i = I0; i < I1; i++) {
             const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
             const float g = kind ? (float)g_cur[i] : gs;
             walk_move<true>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, gr.mat[kind][i] + ch, tb.vec[kind][i] + ch, gr.vec[kind][i] + ch,
@@ -433,10 +434,25 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = I0; i < I1; i++) {
         pw[i].close(gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
         lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], R);
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
+                                                     const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr) {
+    vm_bwd_body<T, 0, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
+}
+
+// blockIdx.y = factor set: three times the waves, a third of the serial work per sample in each
+template <typename T>
+__global__ void __launch_bounds__(kVmBlock) k_vm_bwd_split(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
+                                                           const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr) {
+    if (blockIdx.y == 0) vm_bwd_body<T, 0, 1>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
+    else if (blockIdx.y == 1) vm_bwd_body<T, 1, 2>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
+    else vm_bwd_body<T, 2, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
 }
 
 static uint32_t pick_chunk(uint32_t M, bool backward) {
@@ -452,9 +468,13 @@ static uint32_t pick_chunk(uint32_t M, bool backward) {
     }
     const int forced = backward ? env_b : env_f;
     if (forced >= 1 && forced <= 64) return (uint32_t)forced;
+    if (backward) {  // three factor sets per run (blockIdx.y): long runs merge the most atomics; keep >= 3072 waves
+        uint32_t chunk = 64;
+        while (chunk > 16 && 3ull * M / chunk < 3072ull) chunk >>= 1;
+        return chunk;
+    }
     uint32_t chunk = 16;
-    const uint32_t target_waves = backward ? 256u * 16u : 256u * 32u;
-    while (chunk < 64 && (uint64_t)M / chunk > target_waves) chunk <<= 1;
+    while (chunk < 64 && (uint64_t)M / chunk > 256u * 32u) chunk <<= 1;
     return chunk;
 }
 
@@ -520,12 +540,20 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
     const uint32_t chunk = pick_chunk(M, true);
     const uint32_t waves = div_up(M, chunk);
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
-    if (prod_dtype == PVD_F32)
-        hipLaunchKernelGGL((k_vm_bwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                           (const float *)grad_color_prod, gr);
-    else if (prod_dtype == PVD_F16)
-        hipLaunchKernelGGL((k_vm_bwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                           (const half_t *)grad_color_prod, gr);
+    static int split = -1;  // PVD_VM_BWD_SPLIT=0/1 (measurement); default: split
+    if (split < 0) { const char *e = getenv("PVD_VM_BWD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const dim3 grid3(grid.x, 3);
+    if (prod_dtype == PVD_F32) {
+        if (split) hipLaunchKernelGGL((k_vm_bwd_split<float>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                                      (const float *)grad_color_prod, gr);
+        else hipLaunchKernelGGL((k_vm_bwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                                (const float *)grad_color_prod, gr);
+    } else if (prod_dtype == PVD_F16) {
+        if (split) hipLaunchKernelGGL((k_vm_bwd_split<half_t>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                                      (const half_t *)grad_color_prod, gr);
+        else hipLaunchKernelGGL((k_vm_bwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                                (const half_t *)grad_color_prod, gr);
+    }
     else
         return PVD_ERR_UNSUPPORTED;
     return check_launch();
