@@ -97,3 +97,51 @@ def test_fused_get_rays_matches_torch_formulation():
     assert torch.equal(r["rays_o"], ref["rays_o"].contiguous())
     assert (r["rays_d"] - ref["rays_d"]).abs().max().item() < 3e-7
     assert torch.allclose(r["rays_d"].norm(dim=-1), torch.ones(1, 4096, device=dev), atol=1e-6)
+
+
+def test_vm_non_cubic_tables_and_incoherent_order():
+    """The kernel's per-axis sampling state assumes axis a is always sampled at res[a] (planes and lines agree by
+    construction, network.py:199-212); check it with three different resolutions, points outside the box (zero padding,
+    generic window path) and a shuffled order (window jumps), against the grid_sample formulation."""
+    import torch.nn.functional as F
+    import vmencoder
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    res = [24, 31, 45]  # x, y, z
+    mat_ids, vec_ids = [[0, 1], [0, 2], [1, 2]], [2, 1, 0]
+    tabs = []
+    for R in (16, 48):
+        mats = [torch.randn(1, R, res[m1], res[m0], device=dev, generator=g) for m0, m1 in mat_ids]
+        vecs = [torch.randn(1, R, res[v], 1, device=dev, generator=g) for v in vec_ids]
+        tabs.append(([vmencoder.to_channels_last_param(t).requires_grad_(True) for t in mats],
+                     [vmencoder.to_channels_last_param(t).requires_grad_(True) for t in vecs]))
+    M = 64 * 300 + 11
+    n_rays = M // 64 + 1
+    o = torch.rand(n_rays, 1, 3, device=dev, generator=g) * 2.2 - 1.1
+    d = torch.randn(n_rays, 1, 3, device=dev, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    x = (o + torch.arange(64, device=dev).view(1, 64, 1) * 0.01 * d).reshape(-1, 3)[:M].contiguous()  # some of it outside [-1,1]
+    x = torch.cat([x[: M // 2], x[M // 2:][torch.randperm(M - M // 2, device=dev, generator=g)]]).contiguous()
+    aabb = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
+    (smat, svec), (cmat, cvec) = tabs
+    sig_h, prod_h = vmencoder.vm_encode(x, aabb, *smat, *svec, *cmat, *cvec)
+
+    def ref(mats, vecs):
+        outs = []
+        for i, (m0, m1) in enumerate(mat_ids):
+            pc = torch.stack([x[:, m0], x[:, m1]], -1).view(1, -1, 1, 2)
+            lc = torch.stack([torch.zeros_like(x[:, 0]), x[:, vec_ids[i]]], -1).view(1, -1, 1, 2)
+            pv = F.grid_sample(mats[i], pc, align_corners=True).view(mats[i].shape[1], -1)
+            lv = F.grid_sample(vecs[i], lc, align_corners=True).view(vecs[i].shape[1], -1)
+            outs.append(pv * lv)
+        return outs
+    sig_r = torch.cat(ref(smat, svec), 0).sum(0)
+    prod_r = torch.cat(ref(cmat, cvec), 0).T
+    assert (sig_h - sig_r).abs().max().item() < 5e-5 and (prod_h.float() - prod_r).abs().max().item() < 5e-5
+    gs = torch.randn(M, device=dev, generator=g)
+    gp = torch.randn(M, 144, device=dev, generator=g)
+    params = [*smat, *svec, *cmat, *cvec]
+    gr = torch.autograd.grad((sig_r * gs).sum() + (prod_r * gp).sum(), params)
+    gh = torch.autograd.grad((sig_h * gs).sum() + (prod_h.float() * gp).sum(), params)
+    for a, b in zip(gh, gr):
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item() + 1e-6
