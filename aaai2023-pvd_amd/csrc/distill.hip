@@ -60,16 +60,39 @@ __global__ void __launch_bounds__(kLossBlock) k_sumsq4_reduce(float *__restrict_
     if (threadIdx.x == 0) { S[0] = a; S[1] = b; S[2] = c; S[3] = d; }
 }
 
-__global__ void k_loss_final(const float *__restrict__ S, const float *__restrict__ rates, float *__restrict__ loss,
-                             float *__restrict__ coef, float *__restrict__ norms) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float total = 0.f;
+// One workgroup: (optionally) finish the sums of squares from the per-block partials, decay the feature rate the way
+// train_step does before using it (utils.py:1044), add a parameter-only term given as partial sums (the L1 regulariser,
+// whose gradient lives in the optimizer kernel), write loss / coefficients / norms.
+__global__ void __launch_bounds__(kLossBlock) k_loss_final(float *__restrict__ S, uint32_t reduce_blocks, float *__restrict__ rates,
+                                                          float fea_decay, const float *__restrict__ extra, uint32_t n_extra,
+                                                          float *__restrict__ loss, float *__restrict__ coef, float *__restrict__ norms) {
+    __shared__ float sh[kLossBlock / 64];
+    float s4[4];
+    if (reduce_blocks) {
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+        for (uint32_t i = threadIdx.x; i < reduce_blocks; i += kLossBlock) {
+            const float4 v = reinterpret_cast<const float4 *>(S + 4)[i];
+            a += v.x; b += v.y; c += v.z; d += v.w;
+        }
+        s4[0] = block_sum(a, sh); s4[1] = block_sum(b, sh); s4[2] = block_sum(c, sh); s4[3] = block_sum(d, sh);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) s4[i] = S[i];
+    }
+    float e = 0.f;
+    for (uint32_t i = threadIdx.x; i < n_extra; i += kLossBlock) e += extra[i];
+    e = block_sum(e, sh);
+    if (threadIdx.x != 0) return;
+    float total = e;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float n = sqrtf(S[i]);
+        float r = rates[i];
+        if (i == 1 && fea_decay != 1.0f) { r *= fea_decay; rates[1] = r; }
+        const float n = sqrtf(s4[i]);
+        S[i] = s4[i];
         norms[i] = n;
-        total += rates[i] * n;
-        coef[i] = n > 0.f ? rates[i] / n : 0.f;  // d (r ||x||) / dx = r x / ||x||
+        total += r * n;
+        coef[i] = n > 0.f ? r / n : 0.f;  // d (r ||x||) / dx = r x / ||x||
     }
     loss[0] = total;
 }
@@ -98,21 +121,27 @@ using namespace pvd;
 
 extern "C" {
 
-int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea, uint32_t M,
-                      const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream) {
-    if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
+static uint32_t sumsq_blocks(uint32_t n_img, uint32_t M) {
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
     if (blocks > kSumsqMaxBlocks) blocks = kSumsqMaxBlocks;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
-    hipLaunchKernelGGL(k_sumsq4_reduce, dim3(1), dim3(kLossBlock), 0, s, S4, blocks);
-    return check_launch();
+    return blocks < 1 ? 1 : blocks;
 }
 
-int pvd_distill_loss_final(const float *S4, const float *rates4, float *loss, float *coef4, float *norms4, pvd_stream_t stream) {
-    if (!S4 || !rates4 || !loss || !coef4 || !norms4) return PVD_ERR_INVALID;
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, (hipStream_t)stream, S4, rates4, loss, coef4, norms4);
+int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea, uint32_t M,
+                      const float *col_stu, const float *col_tea, float *S4, int reduce, pvd_stream_t stream) {
+    if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t blocks = sumsq_blocks(n_img, M);
+    hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
+    if (reduce) hipLaunchKernelGGL(k_sumsq4_reduce, dim3(1), dim3(kLossBlock), 0, s, S4, blocks);
+    return blocks > 0 ? check_launch() : PVD_ERR_INVALID;
+}
+
+int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, float *rates4, float fea_decay, const float *extra,
+                           uint32_t n_extra, float *loss, float *coef4, float *norms4, pvd_stream_t stream) {
+    if (!S4 || !rates4 || !loss || !coef4 || !norms4 || (n_extra && !extra)) return PVD_ERR_INVALID;
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kLossBlock), 0, (hipStream_t)stream, S4, reduce ? sumsq_blocks(n_img, M) : 0u, rates4,
+                       fea_decay, extra, n_extra, loss, coef4, norms4);
     return check_launch();
 }
 

@@ -93,6 +93,27 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
     }
 }
 
+// GradScaler.update() on the device (torch's amp_update_scale_cuda_kernel: back off on inf, grow after `interval` clean
+// steps), then clear the inf flag for the next step: one launch after the update instead of four host-issued ones.
+__global__ void k_adamw_amp_tail(float *__restrict__ scale, int32_t *__restrict__ tracker, float *__restrict__ found_inf, double growth,
+                                 double backoff, int32_t interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (found_inf[0] != 0.f) {
+        scale[0] = (float)((double)scale[0] * backoff);
+        tracker[0] = 0;
+    } else {
+        const int32_t ok = tracker[0] + 1;
+        if (ok == interval) {
+            const float ns = (float)((double)scale[0] * growth);
+            if (!isinf(ns)) scale[0] = ns;
+            tracker[0] = 0;
+        } else {
+            tracker[0] = ok;
+        }
+    }
+    found_inf[0] = 0.f;
+}
+
 // found_inf[0] = 1 if any element is inf / nan (never cleared here): the read-only half of
 // torch._amp_foreach_non_finite_check_and_unscale_, which GradScaler.step runs with a scale of 1 for optimizers
 // that unscale inside their own kernel.
@@ -193,6 +214,11 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, lr, beta1, beta2, eps, weight_decay, step,
                        grad_scale, found_inf, ex);
+    if (extras_host && extras_host->amp_scale) {
+        if (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1) return PVD_ERR_INVALID;
+        hipLaunchKernelGGL(k_adamw_amp_tail, dim3(1), dim3(64), 0, s, extras_host->amp_scale, extras_host->amp_growth_tracker,
+                           const_cast<float *>(found_inf), extras_host->amp_growth, extras_host->amp_backoff, extras_host->amp_interval);
+    }
     return check_launch();
 }
 
@@ -215,14 +241,14 @@ int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t 
 
 int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host, uint32_t n_ranges,
                   float *scratch, float *out, pvd_stream_t stream) {
-    if (!p || !scratch || !out) return PVD_ERR_INVALID;
+    if (!p || !scratch) return PVD_ERR_INVALID;
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_l1_partial, dim3(kL1Blocks), dim3(kOptBlock), 0, s, p, ex, scratch);
-    hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(kOptBlock), 0, s, scratch, kL1Blocks, out);
+    if (out) hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(kOptBlock), 0, s, scratch, kL1Blocks, out);
     return check_launch();
 }
 

@@ -85,11 +85,19 @@ class FlatAdamW(torch.optim.Optimizer):
         return out[0]
 
     @torch.no_grad()
+    def l1_partials(self, scale=1.0):
+        """1024 partial sums of the L1 term's value (to be added by the consumer, e.g. the fused distillation objective)."""
+        ranges = self._l1 if scale == 1.0 else [(b, e, c * scale) for b, e, c in self._l1]
+        pvd_hip.l1_ranges(self.flat_p, ranges, self._l1_scratch, None)
+        return self._l1_scratch
+
+    @torch.no_grad()
     def step(self, closure=None):
         d = self.defaults
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
-                           schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None))
+                           schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
+                           amp_update=getattr(self, "amp_update", None))
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
 
@@ -111,6 +119,42 @@ class DeviceSchedule:
 class FlatGradScaler(torch.amp.GradScaler):
     """GradScaler whose inf check for a FlatAdamW is one read-only pass over the flat gradient buffer
     (pvd_check_finite) instead of the multi-tensor check-and-unscale-by-1 (which also rewrites every gradient)."""
+
+    def step(self, optimizer, *args, **kwargs):
+        """For a FlatAdamW the whole scaler protocol of a step is three launches on the device: inf check (read-only),
+        the update kernel (unscales, skips on inf), and a tail that does what update() would do and clears the flag --
+        instead of fill + check-and-rewrite + sum + update_scale issued from the host around the optimizer."""
+        if not self._enabled or not isinstance(optimizer, FlatAdamW) or "closure" in kwargs:
+            return super().step(optimizer, *args, **kwargs)
+        from torch.amp.grad_scaler import OptState
+        self._check_scale_growth_tracker("step")
+        state = self._per_optimizer_states[id(optimizer)]
+        if state["stage"] is OptState.STEPPED:
+            raise RuntimeError("step() has already been called since the last update().")
+        if state["stage"] is OptState.UNSCALED:
+            return super().step(optimizer, *args, **kwargs)  # unscale_() was called explicitly: generic path
+        flag = getattr(optimizer, "_found_inf_flag", None)
+        if flag is None:
+            flag = optimizer._found_inf_flag = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_g.device)
+        pvd_hip.check_finite(optimizer.flat_g, flag)
+        optimizer.grad_scale, optimizer.found_inf = self._scale, flag
+        optimizer.amp_update = (self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval)
+        try:
+            ret = optimizer.step(*args, **kwargs)
+        finally:
+            del optimizer.grad_scale, optimizer.found_inf, optimizer.amp_update
+        state["stage"] = OptState.STEPPED
+        self._update_done_on_device = True
+        return ret
+
+    def update(self, new_scale=None):
+        if getattr(self, "_update_done_on_device", False) and new_scale is None:
+            from collections import defaultdict
+            from torch.amp.grad_scaler import _refresh_per_optimizer_state
+            self._update_done_on_device = False
+            self._per_optimizer_states = defaultdict(_refresh_per_optimizer_state)
+            return
+        super().update(new_scale)
 
     def _check_inf_per_device(self, optimizer):
         if not isinstance(optimizer, FlatAdamW):

@@ -13,17 +13,19 @@ class _DistillNormL2(Function):
     -> (loss scalar, norms[4] detached: rgb, fea, sigma, colour)"""
 
     @staticmethod
-    def forward(ctx, img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp):
+    def forward(ctx, img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp, fea_decay, extra):
         dev = img_s.device
         args = [t.detach().float().contiguous() for t in (img_s, img_t, fea_s, fea_t, col_s, col_t)]
         S = torch.empty(4 + 4 * 1024, dtype=torch.float32, device=dev)  # 4 sums + per-workgroup partials (scratch)
-        pvd_hip.distill_sumsq(*args, S)
-        if dp is not None and dp.enabled:
+        exchange = dp is not None and dp.enabled
+        pvd_hip.distill_sumsq(*args, S, reduce=exchange)
+        if exchange:
             dp.all_reduce_sum_(S[:4])  # global norms: sum of squares over all shards
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         coef = torch.empty(4, dtype=torch.float32, device=dev)
         norms = torch.empty(4, dtype=torch.float32, device=dev)
-        pvd_hip.distill_loss_final(S, rates, loss, coef, norms)
+        pvd_hip.distill_loss_final(S, rates, loss, coef, norms, n_img=args[0].numel(), M=args[2].shape[0], reduce=not exchange,
+                                   fea_decay=fea_decay, extra=extra)
         ctx.save_for_backward(*args, coef)
         ctx.shapes = (img_s.shape, fea_s.shape, col_s.shape)
         ctx.mark_non_differentiable(norms)
@@ -36,8 +38,10 @@ class _DistillNormL2(Function):
         up = g_loss.detach().float().reshape(1).contiguous()
         pvd_hip.distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef, up, g_img, g_fea, g_col)
         s_img, s_fea, s_col = ctx.shapes
-        return g_img.view(s_img), None, g_fea.view(s_fea), None, g_col.view(s_col), None, None, None
+        return g_img.view(s_img), None, g_fea.view(s_fea), None, g_col.view(s_col), None, None, None, None, None
 
 
-def distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp=None):
-    return _DistillNormL2.apply(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp)
+def distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp=None, fea_decay=1.0, extra=None):
+    """fea_decay: multiply rates[1] in place before use (the per-step decay of the feature rate); extra: partial sums of a
+    parameter-only term to add to the loss value (no gradient: e.g. the L1 regulariser applied inside the optimizer)."""
+    return _DistillNormL2.apply(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp, float(fea_decay), extra)

@@ -156,7 +156,7 @@ class _TrainerBase:
             self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
         self.global_step = 0
 
-    def _l1_term(self):
+    def _l1_term(self, partials_only=False):
         """l1_reg_weight * density_loss() for the VM model (utils.py:1101-1104 / just_train_tea/utils.py:573-581).
         A parameter-only term: under ray-DP every rank adds 1/G of it.  With the flat optimizer its gradient is
         applied inside the update kernel (after the all-reduce, full weight) and only the value is computed here."""
@@ -165,6 +165,8 @@ class _TrainerBase:
             if not self._l1_folded:
                 self.optimizer.set_l1([*m.sigma_mat, *m.sigma_vec], o.l1_reg_weight)
                 self._l1_folded = True
+            if partials_only:
+                return None
             return self.optimizer.l1_value(1.0 / self.dp.world_size)
         return m.density_loss() * (o.l1_reg_weight / self.dp.world_size)
 
@@ -326,8 +328,14 @@ class DistillTrainer(_TrainerBase):
                 out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                                      inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
         self.loss_rate_fea_sc *= 0.995  # decays every step (utils.py:1044)
-        self.fea_rate.mul_(0.995)
         have_fea = stu.feature_sigma_color is not None and tea.feature_sigma_color is not None
+        pred_stu, pred_tea = out_stu.get("image"), out_tea.get("image")
+        fused = (self.fused_loss is not None and o.loss_type == "normL2" and have_fea and pred_stu is not None and pred_stu.is_cuda
+                 and "stage1" not in out_stu and "stage2" not in out_stu
+                 and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc, o.loss_rate_rgb) > 0.0
+                 and stu.feature_sigma_color.dtype == torch.float32 and tea.feature_sigma_color.dtype == torch.float32)
+        if not fused:
+            self.fea_rate.mul_(0.995)  # (the fused objective decays the device-side rate inside its own kernel)
         info = {}
         loss = 0.0
         if "stage1" in out_stu and self.loss_rate_fea_sc > 0.0 and have_fea:
@@ -346,15 +354,17 @@ class DistillTrainer(_TrainerBase):
             info.update(color=l_col.detach(), sigma=l_sig.detach())
             return loss, info, None, None
 
-        pred_stu, pred_tea = out_stu["image"], out_tea["image"]
-        if (self.fused_loss is not None and o.loss_type == "normL2" and have_fea and pred_stu.is_cuda
-                and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc, o.loss_rate_rgb) > 0.0
-                and stu.feature_sigma_color.dtype == torch.float32 and tea.feature_sigma_color.dtype == torch.float32):
-            # all four norm terms (utils.py:1109-1176) in one fused objective
-            l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
-                                        tea.color_l.float(), self.rates, self.dp)
-            loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
+        if fused:
+            # all four norm terms (utils.py:1109-1176), the feature-rate decay and the value of the L1 term: one objective
+            extra = None
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+                if self.flat_opt:
+                    self._l1_term(partials_only=True)
+                    extra = self.optimizer.l1_partials(1.0 / self.dp.world_size)
+            l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
+                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra)
+            loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
+            if o.l1_reg_weight > 0.0 and o.model_type == "vm" and extra is None:
                 loss = loss + self._l1_term()
             info["rgb"] = norms[0]
             return loss, info, pred_stu, pred_tea

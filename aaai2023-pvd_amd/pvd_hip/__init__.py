@@ -518,16 +518,20 @@ def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs,
           _p(weights_sum), _p(image), _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs))
 
 
-def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4):
+def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, reduce=True):
     dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4)
     _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4)
-    _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s), _p(col_t), _p(S4))
+    _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s), _p(col_t),
+          _p(S4), _int(int(bool(reduce))))
 
 
-def distill_loss_final(S4, rates4, loss, coef4, norms4):
-    dev = _dev(S4, rates4, loss, coef4, norms4)
+def distill_loss_final(S4, rates4, loss, coef4, norms4, n_img=0, M=0, reduce=False, fea_decay=1.0, extra=None):
+    dev = _dev(S4, rates4, loss, coef4, norms4, extra)
     _f32_all(S4=S4, rates4=rates4, loss=loss, coef4=coef4, norms4=norms4)
-    _call("pvd_distill_loss_final", dev, _p(S4), _p(rates4), _p(loss), _p(coef4), _p(norms4))
+    if extra is not None:
+        _want(extra, torch.float32, "extra")
+    _call("pvd_distill_loss_final", dev, _p(S4), _u32(n_img), _u32(M), _int(int(bool(reduce))), _p(rates4), _f32(fea_decay), _p(extra),
+          _u32(extra.numel() if extra is not None else 0), _p(loss), _p(coef4), _p(norms4))
 
 
 def distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_img, g_fea, g_col):
@@ -542,7 +546,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
     _fields_ = [("sched_kind", ctypes.c_int32), ("sched_T", ctypes.c_float), ("sched_param", ctypes.c_float),
                 ("base_lr", ctypes.c_void_p), ("sched_step", ctypes.c_void_p), ("n_l1", ctypes.c_uint32),
                 ("l1_begin_host", ctypes.POINTER(ctypes.c_uint64)), ("l1_end_host", ctypes.POINTER(ctypes.c_uint64)),
-                ("l1_coef_host", ctypes.POINTER(ctypes.c_float))]
+                ("l1_coef_host", ctypes.POINTER(ctypes.c_float)), ("amp_scale", ctypes.c_void_p), ("amp_growth_tracker", ctypes.c_void_p),
+                ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32)]
 
 
 def _u64_array(vals):
@@ -550,15 +555,21 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None):
+               l1_ranges=None, amp_update=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
     ex = None
-    if schedule is not None or l1_ranges:
+    if schedule is not None or l1_ranges or amp_update is not None:
         ex = _AdamwExtras()
+        if amp_update is not None:  # (scale, growth_tracker, growth_factor, backoff_factor, growth_interval)
+            sc, tr, gf, bf, gi = amp_update
+            _dev(sc, tr)
+            _want(sc, torch.float32, "scale"), _want(tr, torch.int32, "growth_tracker")
+            ex.amp_scale, ex.amp_growth_tracker = sc.data_ptr(), tr.data_ptr()
+            ex.amp_growth, ex.amp_backoff, ex.amp_interval = float(gf), float(bf), int(gi)
         if schedule is not None:
             kind, T, param, base_lr, sched_step = schedule
             _dev(base_lr, sched_step)
@@ -583,10 +594,11 @@ def check_finite(g, found_inf):
     _call("pvd_check_finite", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
 
 
-def l1_ranges(p, ranges, scratch, out):
-    """out[0] = sum_r coef_r * sum |p[begin_r:end_r]|; ranges = [(begin, end, coef)], scratch >= 1024 floats."""
+def l1_ranges(p, ranges, scratch, out=None):
+    """out[0] = sum_r coef_r * sum |p[begin_r:end_r]|; ranges = [(begin, end, coef)], scratch >= 1024 floats.
+    out None: only the 1024 partial sums are left in scratch."""
     dev = _dev(p, scratch, out)
-    _f32_all(p=p, scratch=scratch, out=out)
+    _f32_all(p=p, scratch=scratch)
     if scratch.numel() < 1024:
         raise PvdHipError("scratch too small")
     b, e = _u64_array([r[0] for r in ranges]), _u64_array([r[1] for r in ranges])

@@ -292,13 +292,21 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
 
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
- *   loss = sum_i rates4[i] * sqrt(S4[i]);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
- * img [n_img] f32 (= N*3), fea [M,16] f32 (16-byte aligned), col [M,3] f32.  Under ray data parallelism the host
- * all-reduces S4[0..3] between pvd_distill_sumsq and pvd_distill_loss_final.  rates4 / upstream are DEVICE scalars.
- * S4 must hold 4 + 4*1024 floats: the four sums, followed by scratch for per-workgroup partials. */
-int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
-                      uint32_t M, const float *col_stu, const float *col_tea, float *S4, pvd_stream_t stream);
-int pvd_distill_loss_final(const float *S4, const float *rates4, float *loss, float *coef4, float *norms4, pvd_stream_t stream);
+ *   loss = sum_i rates4[i] * sqrt(S4[i]) + sum(extra);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
+ * img [n_img] f32 (= N*3), fea [M,16] f32 (16-byte aligned), col [M,3] f32.  rates4 / upstream are DEVICE scalars.
+ * S4 must hold 4 + 4*1024 floats: the four sums, followed by scratch for per-workgroup partials.
+ * pvd_distill_sumsq: reduce != 0 finishes S4[0..3] itself (ray data parallelism: the host all-reduces them before
+ *   pvd_distill_loss_final(reduce = 0)); reduce == 0 leaves the partials for pvd_distill_loss_final(reduce = 1, same
+ *   n_img / M), saving a launch.
+ * pvd_distill_loss_final: fea_decay multiplies rates4[1] in place before it is used (the per-step 0.995 decay of the
+ *   feature rate, utils.py:1044; 1.0 = leave it); extra [n_extra] are partial sums of a parameter-only term added
+ *   to the loss value (pvd_l1_ranges partials), or NULL. */
+int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
+                      const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea, float *S4, int reduce,
+                      pvd_stream_t stream);
+int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, float *rates4, float fea_decay,
+                           const float *extra, uint32_t n_extra, float *loss, float *coef4, float *norms4,
+                           pvd_stream_t stream);
 int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
                                const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea,
                                const float *coef4, const float *upstream, float *g_img, float *g_fea, float *g_col,
@@ -321,7 +329,8 @@ int pvd_adamw_step(float *p, const float *g, float *m, float *v, uint64_t n, con
  *      sched_kind 2: LambdaLR(factor ** min(t / T, 1)) (main_just_train_tea.py:293-296; sched_param = factor)
  *    t = sched_step[0] (DEVICE scalar, advanced by one per call, also on skipped steps, like scheduler.step()).
  *  - an L1 regulariser on parameter ranges (NeRFNetwork.density_loss, network.py:549-557): inside range r the
- *    unscaled gradient gets l1_coef[r] * sign(p), i.e. the gradient of l1_coef[r] * sum|p|. */
+ *    unscaled gradient gets l1_coef[r] * sign(p), i.e. the gradient of l1_coef[r] * sum|p|.
+ *  - the GradScaler's scale update (see amp_* below). */
 typedef struct pvd_adamw_extras {
     int32_t sched_kind;
     float sched_T, sched_param;
@@ -330,6 +339,12 @@ typedef struct pvd_adamw_extras {
     uint32_t n_l1;         /* <= 16 ranges, begin/end multiples of 4 elements */
     const uint64_t *l1_begin_host, *l1_end_host;
     const float *l1_coef_host;
+    /* GradScaler.update() folded in (amp_scale != NULL): after the update, scale / growth tracker are advanced the way
+     * torch's amp_update_scale does (x backoff on inf; x growth after amp_interval clean steps) and found_inf is cleared. */
+    float *amp_scale;             /* DEVICE scalar (== grad_scale) */
+    int32_t *amp_growth_tracker;  /* DEVICE scalar */
+    double amp_growth, amp_backoff;
+    int32_t amp_interval;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,
@@ -340,7 +355,8 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
  * for an optimizer that unscales inside its own kernel (n multiple of 4). */
 int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream);
 
-/* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats). */
+/* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats).
+ * out == NULL: only the 1024 partial sums are left in scratch (for pvd_distill_loss_final's `extra`). */
 int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host,
                   uint32_t n_ranges, float *scratch, float *out, pvd_stream_t stream);
 
