@@ -137,13 +137,23 @@ struct LevelIndex {
     }
 };
 
+// optional input mapping x01 = (x + add) / div applied while reading the positions: GridEncoder.forward's
+// (inputs + bound) / (2 * bound) (grid.py:211) without two elementwise launches; same two IEEE operations
+struct InputAffine {
+    bool on;
+    float add, div;
+};
+static thread_local InputAffine g_input_affine = {false, 0.f, 1.f};
+
 template <uint32_t D>
-__device__ __forceinline__ bool locate(const float *__restrict__ in, float scale, bool align_corners, float (&frac)[D], uint32_t (&cell)[D]) {
+__device__ __forceinline__ bool locate(const float *__restrict__ in, float scale, bool align_corners, float (&frac)[D], uint32_t (&cell)[D],
+                                       InputAffine aff = {false, 0.f, 1.f}) {
     float x[D];
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         x[d] = in[d];
+        if (aff.on) x[d] = (x[d] + aff.add) / aff.div;
         oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
     }
     if (oob) return false;
@@ -181,7 +191,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict
                                                          const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                          uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched, uint32_t gridtype,
                                                          bool align_corners, bool calc_grad_inputs, T *__restrict__ dy_dx,
-                                                         uint32_t level_mask) {
+                                                         uint32_t level_mask, InputAffine aff) {
     using Vec = FeatVec<T, C>;
     uint32_t level, pblock;
     if (!sched.locate(blockIdx.x, level, pblock)) return;
@@ -198,7 +208,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict
 
     float frac[D];
     uint32_t cell[D];
-    if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell)) {
+    if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell, aff)) {
         Vec zero;
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) zero.v[c] = (T)0;
@@ -528,7 +538,8 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_fwd(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
     const LevelScales sc = make_scales(L, S, H);
-    const uint32_t P = calc ? 1u : (uint32_t)g_grid_points_per_thread;
+    const InputAffine aff = g_input_affine;
+    const uint32_t P = (calc || aff.on) ? 1u : (uint32_t)g_grid_points_per_thread;
     if (P > 1 && sizeof(T) * C <= 8) {
         const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock * P), sizeof(T) * C);
         if (P == 2)
@@ -541,7 +552,7 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
     }
     const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
     hipLaunchKernelGGL((k_grid_fwd<T, D, C>), dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const T *)emb, offsets, (T *)outputs, B,
-                       L, sc, sched, gridtype, align, calc, (T *)dy_dx, g_grid_level_mask);
+                       L, sc, sched, gridtype, align, calc, (T *)dy_dx, g_grid_level_mask, aff);
     return check_launch();
 }
 
@@ -635,6 +646,17 @@ int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const i
         return fwd_t<half_t>(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, gridtype,
                              align_corners != 0, (hipStream_t)stream);
     return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_grid_encode_forward_affine(const float *inputs, float in_add, float in_div, const void *embeddings, const int32_t *offsets,
+                                   void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                   int align_corners, int dtype, pvd_stream_t stream) {
+    if (!(in_div != 0.f)) return PVD_ERR_INVALID;
+    g_input_affine = {true, in_add, in_div};
+    const int rc = pvd_grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 0, nullptr, gridtype, align_corners, dtype,
+                                           stream);
+    g_input_affine = {false, 0.f, 1.f};
+    return rc;
 }
 
 int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,

@@ -44,7 +44,7 @@ def hash_head_infer(model, x, d):
     M = x.shape[0]
     dev = x.device
     bound = model.bound
-    x01 = ((x.float() + bound) / (2 * bound)).contiguous()  # GridEncoder.forward's mapping (grid.py:211)
+    xin = x.float().contiguous()  # GridEncoder.forward's mapping (x + bound) / (2 bound) (grid.py:211) happens in the kernel
     emb = enc.embeddings
     cache = getattr(model, "_emb_half_cache", None)
     key = _cache_key([emb])
@@ -55,8 +55,8 @@ def hash_head_infer(model, x, d):
     C = emb.shape[1]
     assert L == 14 and C == 2 and enc.input_dim == 3, "fused head expects the 14-level, 2-feature hash grid"
     out = torch.empty(L, M, C, dtype=torch.float16, device=dev)
-    pvd_hip.grid_encode_forward(x01, cache[2], enc.offsets, out, M, 3, C, L, float(np.log2(enc.per_level_scale)), enc.base_resolution,
-                                False, out, enc.gridtype_id, enc.align_corners)
+    pvd_hip.grid_encode_forward_affine(xin, float(bound), float(2 * bound), cache[2], enc.offsets, out, M, 3, C, L,
+                                       float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners)
     sigma, rgb, feat = _outputs(M, dev)
     a = model.args
     ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
@@ -96,6 +96,7 @@ class _VMHeadTrain(torch.autograd.Function):
         ctx.save_for_backward(sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3)
         ctx.clips = (smin, fmin, cmax)
         ctx.leaves = (Wb, Wc1, Wc2, Wc3)
+        ctx.set_materialize_grads(False)
         return sigma, rgb, feat
 
     @staticmethod
@@ -157,6 +158,7 @@ class _HashHeadTrain(torch.autograd.Function):
         ctx.grid = (S, H, gridtype, align)
         ctx.clips = (smin, smin, cmax)
         ctx.leaves = (Ws0, Ws1, Wc1, Wc2, Wc3)
+        ctx.set_materialize_grads(False)
         return sigma, rgb, feat
 
     @staticmethod

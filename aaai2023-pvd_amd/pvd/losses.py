@@ -29,6 +29,7 @@ class _DistillNormL2(Function):
         ctx.save_for_backward(*args, coef)
         ctx.shapes = (img_s.shape, fea_s.shape, col_s.shape)
         ctx.mark_non_differentiable(norms)
+        ctx.set_materialize_grads(False)
         return loss[0], norms
 
     @staticmethod

@@ -44,7 +44,7 @@ ENTRY_POINTS = (
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
-    "pvd_grid_encode_forward", "pvd_grid_encode_backward",
+    "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward",
@@ -308,6 +308,20 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 
     if status == -2:
         raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")  # the reference's message, gridencoder.cu:355
     _check(status, "pvd_grid_encode_forward")
+
+
+def grid_encode_forward_affine(inputs, in_add, in_div, embeddings, offsets, outputs, B, D, C, L, S, H, gridtype, align_corners):
+    """grid_encode_forward on x01 = (inputs + in_add) / in_div, mapped inside the kernel (no dy_dx)."""
+    dev = _dev(inputs, embeddings, offsets, outputs)
+    _want(inputs, torch.float32, "inputs"), _want(offsets, torch.int32, "offsets")
+    dt = _table_dtype(embeddings, "embeddings")
+    _want(outputs, embeddings.dtype, "outputs")
+    status = _invoke("pvd_grid_encode_forward_affine", dev, _p(inputs), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _p(outputs),
+                     _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), _u32(gridtype), _int(int(bool(align_corners))), _int(dt),
+                     meta=(B, D, C, L, dt))
+    if status == -2:
+        raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")
+    _check(status, "pvd_grid_encode_forward_affine")
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx,

@@ -176,6 +176,7 @@ def make_ops(backend, device_type="cuda"):
             ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
             ctx.bg = (bg_t, bg_s)
             ctx.dims = [M, N]
+            ctx.set_materialize_grads(False)  # unused outputs arrive as None instead of freshly zero-filled tensors
             return weights_sum, depth, image
 
         @staticmethod
@@ -186,6 +187,8 @@ def make_ops(backend, device_type="cuda"):
             gbuf = torch.zeros(sigmas.shape[0] * 4, dtype=sigmas.dtype, device=sigmas.device)  # one zero-fill (:339-340)
             grad_sigmas, grad_rgbs = gbuf[:sigmas.shape[0]], gbuf[sigmas.shape[0]:].view(-1, 3)
             gws = grad_weights_sum.contiguous() if grad_weights_sum is not None else None
+            if grad_image is None:  # only weights_sum was used
+                grad_image = torch.zeros_like(image)
             backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                      ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
             return grad_sigmas, grad_rgbs, None, None, None, None, None, None

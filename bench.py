@@ -151,7 +151,7 @@ def main():
     # (teacher forward = pvd_grid_encode_forward + fused head), 40 times back to back with the queue kept full, each
     # launch bracketed by HIP events on the launch stream (torch's current stream).
     import fusedhead
-    name = "pvd_grid_encode_forward"
+    name = "pvd_grid_encode_forward_affine"  # the teacher's lookup: k_grid_fwd with the [-bound, bound] -> [0, 1] mapping folded in
     roof = None
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
         rays_o, rays_d, bg, *_ = w.device_batch()
@@ -178,7 +178,7 @@ def main():
             pmc = json.load(open(pmc_path))
             per_sample = (pmc["k_grid_fwd"]["fetch_kb"] + pmc["k_grid_fwd"]["write_kb"]) * 1024.0 / pmc["samples_per_launch"]
             traffic = per_sample * B
-        roof = {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward)" % ("f16" if T == 2 else "f32"), "bound": "hbm",
+        roof = {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward_affine)" % ("f16" if T == 2 else "f32"), "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json; gather pattern, uncorrected)",
                 "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps, "samples_per_launch": B,

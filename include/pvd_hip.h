@@ -163,6 +163,14 @@ int pvd_grid_set_variant(int variant);
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
  * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
  * when calc_grad_inputs.  `embeddings` is unused by the arithmetic (as in the reference) and may be null. */
+/* pvd_grid_encode_forward (no dy_dx) on positions given in [-bound, bound]: every coordinate is mapped with
+ * x01 = (x + in_add) / in_div while it is read -- GridEncoder.forward's (inputs + bound) / (2 * bound), grid.py:211, as the
+ * same two IEEE operations inside the kernel instead of two elementwise launches. */
+int pvd_grid_encode_forward_affine(const float *inputs, float in_add, float in_div, const void *embeddings,
+                                   const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                   float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                   pvd_stream_t stream);
+
 int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,
                              const int32_t *offsets, void *grad_embeddings,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,

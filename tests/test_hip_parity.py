@@ -240,6 +240,31 @@ def test_grid_encode_backward(hip, dev, dtype, D, C):
     assert np.array_equal(gi.cpu().numpy(), gi_ref)  # input gradient is deterministic -> bit-exact
 
 
+@pytest.mark.parametrize("dtype,bound", [(np.float32, 1.0), (np.float16, 2.0), (np.float16, 1.0)])
+def test_grid_encode_forward_affine_is_the_mapped_forward(hip, dev, dtype, bound):
+    """pvd_grid_encode_forward_affine(x, bound, 2*bound) == pvd_grid_encode_forward((x + bound) / (2*bound)) bit for bit,
+    and == the oracle on the mapped positions (GridEncoder.forward's input mapping, grid.py:211), incl. out-of-range points."""
+    rng = np.random.RandomState(5)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19)
+    emb = _table(offs[-1], C, rng, dtype)
+    B = 20000
+    x = rng.uniform(-1.05 * bound, 1.05 * bound, (B, D)).astype(np.float32)
+    x[:4] = [[-bound] * 3, [bound] * 3, [0, 0, 0], [bound, -bound, 0.5 * bound]]
+    x01 = ((x + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+    td = torch.float32 if dtype == np.float32 else torch.float16
+    out_a = torch.empty(L, B, C, dtype=td, device=dev)
+    out_p = torch.empty(L, B, C, dtype=td, device=dev)
+    hip.grid_encode_forward_affine(t(x, dev), bound, 2 * bound, t(emb, dev), t(offs, dev), out_a, B, D, C, L, S, H, 0, False)
+    hip.grid_encode_forward(t(x01, dev), t(emb, dev), t(offs, dev), out_p, B, D, C, L, S, H, False, out_p, 0, False)
+    assert torch.equal(out_a, out_p)
+    ref, _ = oracle.grid_encode_forward(x01, emb, offs, S, H)
+    assert np.array_equal(out_a.cpu().numpy().view(np.uint16 if dtype == np.float16 else np.uint32),
+                          np.ascontiguousarray(ref).view(np.uint16 if dtype == np.float16 else np.uint32))
+
+
 @pytest.mark.parametrize("degree", list(range(1, 9)))
 def test_sh_encode(hip, dev, degree):
     rng = np.random.RandomState(degree)
