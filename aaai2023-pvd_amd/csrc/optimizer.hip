@@ -31,6 +31,10 @@ struct AdamExtras {
     uint32_t n_l1;
     uint64_t l1_begin[kMaxSegments], l1_end[kMaxSegments];
     float l1_coef[kMaxSegments];
+    // a second, half-precision gradient for one range (the hash table's scatter-add result, which the reference widens and
+    // adds into the fp32 gradient in a separate pass, grid.py:105-136): added while the fp32 gradient is read
+    const _Float16 *g16;
+    uint64_t g16_begin, g16_end;
 };
 
 // one thread: advance the step count (unless the GradScaler found an inf) and evaluate the schedule.
@@ -73,6 +77,11 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         const float step_size = (float)(lrk / bc1);
         float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<const float4 *>(g)[i];
         float4 M = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+        if (ex.g16 && e >= ex.g16_begin && e < ex.g16_end) {  // 4 halfs = one 8-byte load (range start is a multiple of 4)
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            const h4v h = *reinterpret_cast<const h4v *>(ex.g16 + (e - ex.g16_begin));
+            G.x += (float)h.x; G.y += (float)h.y; G.z += (float)h.z; G.w += (float)h.w;
+        }
         float *pp = &P.x, *gg = &G.x, *mm = &M.x, *vv = &V.x;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -117,6 +126,17 @@ __global__ void k_adamw_amp_tail(float *__restrict__ scale, int32_t *__restrict_
 // found_inf[0] = 1 if any element is inf / nan (never cleared here): the read-only half of
 // torch._amp_foreach_non_finite_check_and_unscale_, which GradScaler.step runs with a scale of 1 for optimizers
 // that unscale inside their own kernel.
+__global__ void __launch_bounds__(kOptBlock) k_check_finite_f16(const _Float16 *__restrict__ g, uint64_t n8, float *__restrict__ found_inf) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * kOptBlock) {
+        const uint4 w = reinterpret_cast<const uint4 *>(g)[i];  // 8 halfs; exponent field 0x7c00 all ones = inf / nan
+        const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) bad |= ((q[k] & 0x7c00u) == 0x7c00u) | ((q[k] & 0x7c000000u) == 0x7c000000u);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+}
+
 __global__ void __launch_bounds__(kOptBlock) k_check_finite(const float *__restrict__ g, uint64_t n4, float *__restrict__ found_inf) {
     bool bad = false;
     for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kOptBlock) {
@@ -199,6 +219,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     }
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -207,6 +228,10 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         ex.base_lr = h.base_lr; ex.sched_step = h.sched_step;
         const int rc = fill_l1(ex, h.l1_begin_host, h.l1_end_host, h.l1_coef_host, h.n_l1);
         if (rc != PVD_OK) return rc;
+        if (h.g16) {
+            if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
+            ex.g16 = (const _Float16 *)h.g16; ex.g16_begin = h.g16_begin; ex.g16_end = h.g16_end;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_adamw_count, dim3(1), dim3(64), 0, s, step, found_inf, ex, lr, n_segments);
@@ -239,11 +264,23 @@ int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t 
     return check_launch();
 }
 
+int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream_t stream) {
+    if (n == 0) return PVD_OK;
+    if (!g || !found_inf) return PVD_ERR_INVALID;
+    if (n & 7u) return PVD_ERR_UNSUPPORTED;
+    uint64_t blocks = (n / 8 + kOptBlock - 1) / kOptBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_check_finite_f16, dim3((uint32_t)blocks), dim3(kOptBlock), 0, (hipStream_t)stream, (const _Float16 *)g, n >> 3,
+                       found_inf);
+    return check_launch();
+}
+
 int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host, uint32_t n_ranges,
                   float *scratch, float *out, pvd_stream_t stream) {
     if (!p || !scratch) return PVD_ERR_INVALID;
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

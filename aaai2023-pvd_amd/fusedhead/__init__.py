@@ -183,7 +183,10 @@ class _HashHeadTrain(torch.autograd.Function):
             g16 = torch.zeros(emb.shape, dtype=torch.float16, device=dev)
             dummy = g16[:1]
             pvd_hip.grid_encode_backward(g_enc, x01, g16, offsets, g16, M, 3, 2, 14, S, H, False, dummy, dummy, gridtype, align)
-            if emb.is_leaf and emb.grad is not None and emb.grad.dtype == torch.float32:
+            taker = getattr(emb, "_pvd_half_grad_taker", None)  # FlatAdamW: adds the f16 table inside its update kernel
+            if emb.is_leaf and taker is not None and taker(emb, g16):
+                pass
+            elif emb.is_leaf and emb.grad is not None and emb.grad.dtype == torch.float32:
                 emb.grad.add_(g16)  # widen + accumulate in one pass
             else:
                 g_emb = g16.float()

@@ -50,6 +50,7 @@ class FlatAdamW(torch.optim.Optimizer):
             g["lr"] = self.lr_dev[k:k + 1]  # LRScheduler.step() fills tensor lrs in place
 
     def zero_grad(self, set_to_none=False):
+        self._half_grad = None
         self.flat_g.zero_()
         self.reattach()
 
@@ -84,6 +85,20 @@ class FlatAdamW(torch.optim.Optimizer):
         pvd_hip.l1_ranges(self.flat_p, ranges, self._l1_scratch, out)
         return out[0]
 
+    def accept_half_grad(self, param, g16):
+        """A half-precision gradient of `param` (the hash table's scatter-add result) for the coming step: added inside the
+        update kernel instead of a widen-and-add pass over the fp32 gradient.  Returns False if it cannot be taken (then
+        the caller adds it into .grad itself)."""
+        if not getattr(self, "half_grad_ok", True) or getattr(self, "_half_grad", None) is not None:
+            return False
+        for p, o in zip(self.params, self.offsets):
+            if p is param:
+                if o % 4 or p.numel() % 8 or not p.is_contiguous() or g16.shape != p.shape:
+                    return False
+                self._half_grad = (o, o + p.numel(), g16.reshape(-1))
+                return True
+        return False
+
     @torch.no_grad()
     def l1_partials(self, scale=1.0):
         """1024 partial sums of the L1 term's value (to be added by the consumer, e.g. the fused distillation objective)."""
@@ -97,7 +112,8 @@ class FlatAdamW(torch.optim.Optimizer):
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                            schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
-                           amp_update=getattr(self, "amp_update", None))
+                           amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None))
+        self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
 
@@ -137,6 +153,9 @@ class FlatGradScaler(torch.amp.GradScaler):
         if flag is None:
             flag = optimizer._found_inf_flag = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_g.device)
         pvd_hip.check_finite(optimizer.flat_g, flag)
+        hg = getattr(optimizer, "_half_grad", None)
+        if hg is not None:
+            pvd_hip.check_finite_f16(hg[2], flag)
         optimizer.grad_scale, optimizer.found_inf = self._scale, flag
         optimizer.amp_update = (self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval)
         try:
@@ -162,5 +181,8 @@ class FlatGradScaler(torch.amp.GradScaler):
         _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
         found_inf = torch.full((), 0.0, dtype=torch.float32, device=_scale.device)
         pvd_hip.check_finite(optimizer.flat_g, found_inf.view(1))
+        hg = getattr(optimizer, "_half_grad", None)
+        if hg is not None:
+            pvd_hip.check_finite_f16(hg[2], found_inf.view(1))
         self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = {_scale.device: found_inf}
         return self._per_optimizer_states[id(optimizer)]["found_inf_per_device"]

@@ -150,6 +150,10 @@ class _TrainerBase:
                 self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
             self.scaler = torch.amp.GradScaler(self.device_type, enabled=amp)
         self._l1_folded = False
+        if self.flat_opt and not self.dp.enabled and model.model_type == "hash":
+            # the hash table's f16 scatter-add result goes straight into the update kernel (under ray-DP it is widened into
+            # the fp32 buffer first, so that the exchange sees it)
+            model.encoder.embeddings._pvd_half_grad_taker = self.optimizer.accept_half_grad
         if self.flat_opt:
             self.flat = _FlatOptGrads(self.optimizer)
         else:

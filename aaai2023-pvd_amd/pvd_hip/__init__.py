@@ -51,7 +51,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_l1_ranges",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -561,7 +561,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("base_lr", ctypes.c_void_p), ("sched_step", ctypes.c_void_p), ("n_l1", ctypes.c_uint32),
                 ("l1_begin_host", ctypes.POINTER(ctypes.c_uint64)), ("l1_end_host", ctypes.POINTER(ctypes.c_uint64)),
                 ("l1_coef_host", ctypes.POINTER(ctypes.c_float)), ("amp_scale", ctypes.c_void_p), ("amp_growth_tracker", ctypes.c_void_p),
-                ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32)]
+                ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32),
+                ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64)]
 
 
 def _u64_array(vals):
@@ -569,15 +570,22 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None):
+               l1_ranges=None, amp_update=None, half_grad=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
     ex = None
-    if schedule is not None or l1_ranges or amp_update is not None:
+    if schedule is not None or l1_ranges or amp_update is not None or half_grad is not None:
         ex = _AdamwExtras()
+        if half_grad is not None:  # (begin, end, f16 tensor with end - begin elements)
+            hb, he, h = half_grad
+            _dev(h)
+            _want(h, torch.float16, "half gradient")
+            if h.numel() != he - hb or not h.is_contiguous():
+                raise PvdHipError("half gradient must be a contiguous f16 tensor covering [begin, end)")
+            ex.g16, ex.g16_begin, ex.g16_end = h.data_ptr(), int(hb), int(he)
         if amp_update is not None:  # (scale, growth_tracker, growth_factor, backoff_factor, growth_interval)
             sc, tr, gf, bf, gi = amp_update
             _dev(sc, tr)
@@ -606,6 +614,12 @@ def check_finite(g, found_inf):
     dev = _dev(g, found_inf)
     _f32_all(g=g, found_inf=found_inf)
     _call("pvd_check_finite", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
+
+
+def check_finite_f16(g, found_inf):
+    dev = _dev(g, found_inf)
+    _want(g, torch.float16, "g"), _want(found_inf, torch.float32, "found_inf")
+    _call("pvd_check_finite_f16", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
 
 
 def l1_ranges(p, ranges, scratch, out=None):

@@ -353,6 +353,11 @@ typedef struct pvd_adamw_extras {
     int32_t *amp_growth_tracker;  /* DEVICE scalar */
     double amp_growth, amp_backoff;
     int32_t amp_interval;
+    /* a second gradient in half precision for elements [g16_begin, g16_end) (multiples of 4; g16 8-byte aligned), added to g
+     * while it is read: the hash table's f16 scatter-add result, which the reference widens and adds in a separate pass
+     * (grid.py:105-136).  NULL = none. */
+    const void *g16;
+    uint64_t g16_begin, g16_end;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,
@@ -362,6 +367,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
 /* found_inf[0] = 1 if any of g[0..n) is inf/nan (never cleared): the read-only inf check GradScaler.step needs
  * for an optimizer that unscales inside its own kernel (n multiple of 4). */
 int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream);
+int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream_t stream); /* n multiple of 8 */
 
 /* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats).
  * out == NULL: only the 1024 partial sums are left in scratch (for pvd_distill_loss_final's `extra`). */

@@ -256,3 +256,45 @@ def test_gradient_outside_the_footprint_mask_is_zero(kind):
     outside[c.idx] = False
     assert outside.any() and not (touched & outside).any(), int((touched & outside).sum())
     assert int(touched.sum()) > 0.2 * c.idx.numel()  # the mask is not vacuously large
+
+
+def test_flat_adamw_half_gradient_equals_widen_and_add():
+    """FlatAdamW.accept_half_grad: an f16 gradient added inside the update kernel == adding it into the fp32 gradient
+    first (what autograd does for the hash table under autocast, grid.py:105-136), incl. the inf check of a scaled step."""
+    import pvd_hip
+    from pvd.flat_adamw import FlatAdamW, FlatGradScaler
+    dev = torch.device("cuda:0")
+    def make():
+        gg = torch.Generator(device=dev).manual_seed(5)
+        return [torch.nn.Parameter(torch.randn(64, 32, device=dev, generator=gg)), torch.nn.Parameter(torch.randn(4096, 2, device=dev, generator=gg))]
+    pa, pb = make(), make()
+    oa = FlatAdamW([{"params": pa, "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+    ob = FlatAdamW([{"params": pb, "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+    g = torch.Generator(device=dev).manual_seed(6)
+    for it in range(5):
+        oa.zero_grad(); ob.zero_grad()
+        g32 = [torch.randn(p.shape, device=dev, generator=g) for p in pa]
+        g16 = (torch.randn(4096, 2, device=dev, generator=g) * 4).half()
+        for p, q, gr in zip(pa, pb, g32):
+            p.grad.copy_(gr); q.grad.copy_(gr)
+        pa[1].grad.add_(g16)
+        assert ob.accept_half_grad(pb[1], g16) and not ob.accept_half_grad(pb[1], g16)  # one pending gradient at a time
+        oa.step(); ob.step()
+        assert ob._half_grad is None
+    for p, q in zip(pa, pb):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
+    flag = torch.zeros(1, device=dev)
+    h = torch.randn(4096, device=dev).half()
+    pvd_hip.check_finite_f16(h, flag)
+    assert float(flag) == 0.0
+    h[1001] = float("inf")
+    pvd_hip.check_finite_f16(h, flag)
+    assert float(flag) == 1.0
+    # a scaled step whose only non-finite value sits in the half gradient is skipped
+    scaler = FlatGradScaler("cuda", init_scale=16.0)
+    scaler.scale(torch.zeros((), device=dev))
+    ob.zero_grad()
+    before = pb[1].detach().clone()
+    assert ob.accept_half_grad(pb[1], h[: 4096 * 2 // 2].repeat(2).reshape(4096, 2).contiguous())
+    scaler.step(ob); scaler.update()
+    assert torch.equal(before, pb[1].detach()) and float(scaler.get_scale()) == 8.0
