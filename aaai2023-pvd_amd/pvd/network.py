@@ -315,6 +315,10 @@ class NeRFNetwork(NeRFRenderer):
                 return {"sigma": torch.exp(h0)}
             h = self.compute_plenoxel_fea(self._unit_cube(x))
             return {"sigma": self.trunc_exp(h[..., 0])}  # the reference's second, unclamped assignment wins (:481)
+        if self.model_type == "hash" and not torch.is_grad_enabled() and self._fused_ok(x):
+            # occupancy-grid maintenance queries ~1e6 densities per update: grid lookup + MFMA head, two launches
+            sigma, _, feat = self.ops.fused_head.hash_head_infer(self, x, torch.zeros_like(x))
+            return {"sigma": sigma, "geo_feat": torch.clamp(feat[..., 1:], a.sigma_clip_min, a.sigma_clip_max)}
         h = self.encoder(x, bound=self.bound) if self.model_type == "hash" else self.forward_nerf_mlp(x)
         for l in range(self.num_layers):
             h = self.linear(h, self.sigma_net[l].weight)

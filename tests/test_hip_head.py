@@ -259,3 +259,20 @@ def test_teacher_image_cache_follows_weight_updates():
     pvd_hip.note_weights_changed([m.color_net[2].weight, m.encoder.embeddings])
     s2, c2, _ = fusedhead.hash_head_infer(m, x, d)
     assert not torch.equal(c0, c2) and not torch.equal(s0, s2)
+
+
+def test_hash_density_fused_matches_layerwise():
+    """NeRFNetwork.density (used by update_extra_state, network.py:439-494) through the fused lookup + head vs the
+    layer-by-layer autocast formulation."""
+    m = _model("hash", seed=21).eval()
+    x, _ = _inputs(16 * 500 + 3, seed=22)
+    import fusedhead
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        m.ops.fused_head = fusedhead
+        assert m._fused_ok(x)
+        fused = m.density(x)
+        m.ops.fused_head = None
+        ref = m.density(x)
+    rel = (fused["sigma"] - ref["sigma"].float()).abs() / (ref["sigma"].float().abs() + 1e-6)
+    assert rel.max().item() <= 8e-3 and rel.mean().item() <= 1e-3
+    assert (fused["geo_feat"] - ref["geo_feat"].float()).abs().max().item() <= 4e-3 * (1 + ref["geo_feat"].float().abs().max().item())
