@@ -22,6 +22,61 @@ def psnr(pred, truth):
     return -10.0 * torch.log10(mse)
 
 
+class SegmentedCapture:
+    """A step as a chain of HIP graphs with eager host calls between them.  `break_for(fn)` ends the graph being
+    captured, runs fn() eagerly (and remembers it), and starts the next graph in the same memory pool; `replay()` replays
+    graph 0, calls fn 0, replays graph 1, ...  Used to keep collectives out of the graphs."""
+
+    def __init__(self, device):
+        self.device = device
+        self.graphs, self.between = [], []
+        self.pool = None
+        self.active = False
+        self._stream = torch.cuda.Stream(device)
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: a communication library's watchdog thread may touch the device while we capture
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()  # one private pool for all segments: tensors live across them
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.graphs.append(g)
+        self.active = True
+
+    def _end(self):
+        self.active = False
+        self.graphs[-1].capture_end()
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self._stream)
+        self._ctx.__enter__()
+        self._begin()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if self.active:
+                self._end()
+        finally:
+            self._ctx.__exit__(exc_type, exc, tb)
+        torch.cuda.current_stream().wait_stream(self._stream)
+        return False
+
+    def break_for(self, fn):
+        self._end()
+        fn()
+        self.between.append(fn)
+        self._begin()
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.between):
+                self.between[i]()
+
+
 class RayDP:
     """Ray-level data parallel context.  world_size == 1 -> every collective is a no-op."""
 
@@ -30,10 +85,15 @@ class RayDP:
         self.group = group
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        self.capture = None  # a SegmentedCapture while the trainer records a step
 
     def all_reduce_sum_(self, t):
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            run = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.capture is not None and self.capture.active:
+                self.capture.break_for(run)  # collectives stay out of the graphs: eager, between two replays
+            else:
+                run()
         return t
 
     def global_sum(self, local):
@@ -232,10 +292,11 @@ class _TrainerBase:
 
     # ---- hipGraph capture of the step (launch-bound otherwise: ~330 kernels of a few us each)
     def capture(self, body, warmup=3):
-        """Capture `body()` (forward + loss + backward [+ optimizer]) into HIP graphs.  Single GPU: one graph
-        for the whole step.  Ray-DP: forward/backward graph, eager RCCL all-reduce, optimizer graph.
-        Everything that changes per step lives on the device (lr tensors, loss-rate tensor, pose index,
-        RNG state), so a replay is a faithful step."""
+        """Capture `body()` (forward + loss + backward) and the optimizer into HIP graph(s).  Single GPU: one graph for
+        the whole step.  Ray-DP: the capture is SEGMENTED at every collective (`SegmentedCapture`): the all-reduce of the
+        four loss sums and the gradient exchange run eagerly between graph replays, so nothing depends on the
+        communication library being capturable.  Everything that changes per step lives on the device (lr, loss rates,
+        pose index, RNG state, loss scale), so a replay is a faithful step."""
         assert self.device_type == "cuda"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -251,29 +312,25 @@ class _TrainerBase:
                 del out  # drop the autograd graph of the warm-up pass before capturing
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._g_fwd = torch.cuda.CUDAGraph()
-        self._g_opt = None
-        # thread_local: RCCL's watchdog thread may touch the device while we capture
-        with torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
-            self.flat.zero_()
-            self._static_out = body()
-            self._backward(self._static_out[0])
-            if not self.dp.enabled:
+        cap = SegmentedCapture(self.device)
+        self.dp.capture = cap
+        try:
+            with cap:
+                self.flat.zero_()
+                self._static_out = body()
+                self._backward(self._static_out[0])
+                self._exchange()  # (breaks the capture around its all-reduce under ray-DP; nothing otherwise)
                 self._optimize()
-        if self.dp.enabled:
-            self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, pool=self._g_fwd.pool(), capture_error_mode="thread_local"):
-                self._optimize()
+        finally:
+            self.dp.capture = None
+        self._cap = cap
         return self._static_out  # capturing records, it does not run: no step was consumed
 
     def replay(self):
         if self.flat_opt:
             import pvd_hip
             pvd_hip.note_weights_changed(self.optimizer.params)  # the captured optimizer kernel rewrites the parameters
-        self._g_fwd.replay()
-        if self._g_opt is not None:
-            self._exchange()
-            self._g_opt.replay()
+        self._cap.replay()
         self.scheduler.step()
         self.global_step += 1
         return self._static_out

@@ -164,4 +164,6 @@ class DistillWorkload:
     def step(self):
         if getattr(self, "_graph", False):
             return self.trainer.replay_step()
+        if getattr(self, "_eager_device_batches", False):
+            return self.trainer.train_step(*self.device_batch())
         return self.trainer.train_step(*self.next_batch())

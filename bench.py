@@ -97,11 +97,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PVD_DIST_BACKEND=gloo + fewer GPUs than ranks: the N > 1 code path (two-graph capture, compact exchange) can be
+    # exercised on a single-GPU box; the driver's runs use one GPU per rank over RCCL
+    backend = os.environ.get("PVD_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "--gpus must match WORLD_SIZE"
 
     import pvd_hip
@@ -129,9 +136,16 @@ def main():
             w.enable_graph()  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
             launch_mode = "hipGraph replay"
         except Exception as e:  # never lose the measurement to a capture problem: fall back to eager launches
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             torch.cuda.synchronize()
+            try:  # a failed capture leaves its error in the runtime's last-error slot: consume it with a throw-away launch
+                pvd_hip.check_finite(torch.zeros(4, device=dev), torch.zeros(1, device=dev))
+            except Exception:
+                pass
             w._graph = False
-            launch_mode = "eager (graph capture failed: %s)" % type(e).__name__
+            w._eager_device_batches = True  # keep using the one-kernel batch generator (no torch generator involved)
+            launch_mode = "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:120])
     for _ in range(args.warmup):
         w.step()
 

@@ -1,0 +1,67 @@
+"""The N > 1 path of bench.py on a GPU: two ranks (gloo, sharing cuda:0 -- RCCL needs one GPU per rank) run the captured
+distillation step.  The capture is segmented at every collective (the all-reduce of the four loss sums, the compact
+gradient exchange), which therefore run eagerly between graph replays; replicas must stay bit-identical and train."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.trainer import RayDP
+    from pvd.workload import DistillWorkload
+    dp = RayDP()
+    opt = PVDConfig(num_rays=1024, resolution0=64, iters=300)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0, dp=dp)  # same seed: identical replicas
+    torch.cuda.manual_seed(100 + rank)  # different rays per rank
+    w.enable_graph()
+    cap = w.trainer._cap
+    assert len(cap.graphs) == 3 and len(cap.between) == 2, (len(cap.graphs), len(cap.between))  # loss sums | exchange | optimizer
+    c = w.trainer._grad_compactor()
+    assert c is not None and c.fraction < 0.7  # compact exchange in use
+    losses = []
+    for _ in range(12):
+        loss, info, ps, pt = w.step()
+        losses.append(float(info["rgb"]))
+    params = torch.cat([p.detach().reshape(-1) for p in w.stu.parameters()]).cpu()
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged"
+    assert all(l == l for l in losses)
+    if rank == 0:
+        torch.save({"losses": losses}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_segmented_graph_capture(tmp_path):
+    out = str(tmp_path / "dpg.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert len(res["losses"]) == 12 and res["losses"][-1] < res["losses"][0] * 1.5
