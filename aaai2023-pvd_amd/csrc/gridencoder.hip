@@ -59,6 +59,8 @@ struct LevelSchedule {
 
 static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain level-major order (default: measured faster)
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
+static int g_grid_pair = 0;               // f16, D = 3, C = 2 without dy_dx: paired x / x+1 gathers (k_grid_fwd_pair); off: measured
+                                          // 15 % faster on uniformly random points but 4-10 % slower on ray-coherent samples
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
 static float g_grid_coarse_scale = 1e30f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off);
                                            // measured best on every level (tools/bench_grid_bwd.py: 179 vs 205 vs 850 us, f16, 9e4 samples)
@@ -274,6 +276,89 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd(const float *__restrict
     }
 }
 
+
+// Forward without dy_dx for the tables of this code base (f16, D = 3, C = 2): the x and x+1 corners of a (y, z) pair
+// come from ONE 8-byte access wherever they are adjacent in the table.  PMC (TCP_TOTAL_CACHE_ACCESSES 8.4 M, 0.7 per
+// cycle per CU; TCP->TCC requests 1.7 M = 5 TB/s, L2 64 % hits) shows the lookup is bound by the L1's one-tag-lookup-
+// per-cycle rate -- every 4-byte gather costs a full lookup -- not by L2 or HBM bandwidth.  Dense levels: index(x+1) =
+// index(x) + 1 always (one dwordx2, 4-byte aligned).  Hashed levels (power-of-two size): index(x+1) = index(x) ^ 1 exactly
+// when x is even -- the hash of x is x * 1 -- so the aligned pair holds both corners; for odd x the second corner is a
+// separate, exec-masked load.  112 -> ~74 lookups per sample; same values, same blend order: bit-identical outputs.
+// Measured: 15 % faster on uniformly random points (where every lane is its own line), but no faster -- 4-10 % slower --
+// on ray-coherent samples, whose lanes already share lines; the training path keeps k_grid_fwd (knob: bit 1).
+struct __attribute__((packed, aligned(4))) PairU32 {
+    uint32_t a, b;
+};
+
+__global__ void __launch_bounds__(kGridBlock) k_grid_fwd_pair(const float *__restrict__ inputs, const uint32_t *__restrict__ grid,
+                                                              const int32_t *__restrict__ offsets, uint32_t *__restrict__ outputs,
+                                                              uint32_t B, uint32_t L, LevelScales scales, LevelSchedule sched,
+                                                              uint32_t gridtype, bool align_corners, uint32_t level_mask, InputAffine aff) {
+    constexpr uint32_t D = 3;
+    uint32_t level, pblock;
+    if (!sched.locate(blockIdx.x, level, pblock)) return;
+    if (level_mask && !((level_mask >> level) & 1u)) return;
+    const uint32_t b = pblock * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+    const uint32_t *__restrict__ table = grid + off0;
+    uint32_t *__restrict__ out = outputs + ((size_t)level * B + b);
+
+    float frac[D];
+    uint32_t cell[D];
+    if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell, aff)) {
+        *out = 0u;
+        return;
+    }
+    uint32_t corner[8];
+    const bool dense_plain = !index.hashed && gridtype == 0 && index.stride[1] != 0 && index.stride[2] != 0 &&
+                             (cell[0] + 1) + (cell[1] + 1) * index.stride[1] + (cell[2] + 1) * index.stride[2] < index.size;
+    if (index.hashed && index.pow2) {
+        const uint32_t mask = index.size - 1u;
+#pragma unroll
+        for (uint32_t yz = 0; yz < 4; yz++) {
+            const uint32_t h = ((cell[1] + (yz & 1u)) * 2654435761u) ^ ((cell[2] + (yz >> 1)) * 805459861u);
+            const uint32_t i0 = (cell[0] ^ h) & mask, i1 = ((cell[0] + 1u) ^ h) & mask;
+            const PairU32 pr = *reinterpret_cast<const PairU32 *>(table + (i0 & ~1u));
+            corner[2 * yz] = (i0 & 1u) ? pr.b : pr.a;
+            uint32_t c1 = (i0 & 1u) ? pr.a : pr.b;
+            if ((i0 ^ i1) != 1u) c1 = table[i1];  // x odd: the neighbour hashes elsewhere
+            corner[2 * yz + 1] = c1;
+        }
+    } else if (dense_plain) {
+#pragma unroll
+        for (uint32_t yz = 0; yz < 4; yz++) {
+            const uint32_t i0 = cell[0] + (cell[1] + (yz & 1u)) * index.stride[1] + (cell[2] + (yz >> 1)) * index.stride[2];
+            const PairU32 pr = *reinterpret_cast<const PairU32 *>(table + i0);
+            corner[2 * yz] = pr.a;
+            corner[2 * yz + 1] = pr.b;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            const uint32_t pg[D] = {cell[0] + (idx & 1u), cell[1] + ((idx >> 1) & 1u), cell[2] + (idx >> 2)};
+            corner[idx] = table[index(pg)];
+        }
+    }
+    half_t acc0 = (half_t)0, acc1 = (half_t)0;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float wi = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) wi *= ((idx >> d) & 1u) ? frac[d] : 1 - frac[d];
+        half_t v[2];
+        __builtin_memcpy(v, &corner[idx], 4);
+        axpy<half_t>(acc0, wi, v[0]);
+        axpy<half_t>(acc1, wi, v[1]);
+    }
+    half_t r[2] = {acc0, acc1};
+    uint32_t packed;
+    __builtin_memcpy(&packed, r, 4);
+    *out = packed;
+}
 
 // Forward without dy_dx, P points per thread (strided by the workgroup so every pass stays coalesced): the
 // P x 2^D gathers of a thread are independent, so more of them are in flight per wave and the launch needs
@@ -539,6 +624,12 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
                       uint32_t H, bool calc, void *dy_dx, uint32_t gridtype, bool align, hipStream_t s) {
     const LevelScales sc = make_scales(L, S, H);
     const InputAffine aff = g_input_affine;
+    if (!calc && g_grid_pair && D == 3 && C == 2 && sizeof(T) == 2) {
+        const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock), sizeof(T) * C);
+        hipLaunchKernelGGL(k_grid_fwd_pair, dim3(sched.total_blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets,
+                           (uint32_t *)outputs, B, L, sc, sched, gridtype, align, g_grid_level_mask, aff);
+        return check_launch();
+    }
     const uint32_t P = (calc || aff.on) ? 1u : (uint32_t)g_grid_points_per_thread;
     if (P > 1 && sizeof(T) * C <= 8) {
         const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock * P), sizeof(T) * C);
@@ -623,9 +714,10 @@ using namespace pvd;
 extern "C" {
 
 // tuning knob for A/B measurements (tools/bench_grid.py); not part of the drop-in surface
-int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bits 4..7: points per thread (0 -> 1, else 2 or 4)
+int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bit 1: paired gathers; bits 4..7: points per thread (0 -> 1, else 2 or 4)
     const int old = g_grid_variant | (g_grid_points_per_thread << 4);
     g_grid_variant = v & 1;
+    g_grid_pair = (v & 2) ? 1 : 0;  // bit 1: the paired-gather kernel
     const int ppt = (v >> 4) & 15;
     g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
     g_grid_level_mask = ((uint32_t)v >> 8) & 0x1fffffu;  // bits 8..28: backward level mask (measurement only)

@@ -240,6 +240,31 @@ def test_grid_encode_backward(hip, dev, dtype, D, C):
     assert np.array_equal(gi.cpu().numpy(), gi_ref)  # input gradient is deterministic -> bit-exact
 
 
+@pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
+def test_grid_encode_forward_paired_gathers_bit_exact(hip, dev, gridtype, align):
+    """k_grid_fwd_pair (knob bit 1: x / x+1 corners from one 8-byte access) == the oracle and == the default kernel."""
+    rng = np.random.RandomState(8)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19, align)
+    emb = _table(offs[-1], C, rng, np.float16)
+    B = 30000
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:5] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 1], [0.999999, 0.25, 0.75]]
+    x[5] = [1.5, 0.5, 0.5]  # out of range: zeros
+    ref, _ = oracle.grid_encode_forward(x, emb, offs, S, H, gridtype=gridtype, align_corners=align)
+    outs = []
+    for knob in (2, 0):
+        hip.grid_set_variant(knob)
+        out = torch.empty(L, B, C, dtype=torch.float16, device=dev)
+        hip.grid_encode_forward(t(x, dev), t(emb, dev), t(offs, dev), out, B, D, C, L, S, H, False, out, gridtype, align)
+        outs.append(out)
+    hip.grid_set_variant(0)
+    assert torch.equal(outs[0], outs[1])
+    assert np.array_equal(outs[0].cpu().numpy().view(np.uint16), np.ascontiguousarray(ref).view(np.uint16))
+
+
 @pytest.mark.parametrize("dtype,bound", [(np.float32, 1.0), (np.float16, 2.0), (np.float16, 1.0)])
 def test_grid_encode_forward_affine_is_the_mapped_forward(hip, dev, dtype, bound):
     """pvd_grid_encode_forward_affine(x, bound, 2*bound) == pvd_grid_encode_forward((x + bound) / (2*bound)) bit for bit,

@@ -51,7 +51,7 @@ def time_it(x01, emb, variant, iters=50):
 
 
 coh = {n: ray_samples(n) for n in (4096, 16384, 65536)}
-VARIANTS = [("plain", 0), ("xcd", 1), ("P2", 2 << 4), ("P4", 4 << 4)]
+VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("P2", 2 << 4), ("P4", 4 << 4)]
 print("%-28s %10s %6s " % ("samples", "B", "dtype") + " ".join("%8s" % (n + " us") for n, _ in VARIANTS) + " %9s" % "best GB/s")
 for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("uniform random", torch.rand(1 << 18, 3, device=dev)),
                                                                            ("uniform random", torch.rand(1 << 20, 3, device=dev))]:

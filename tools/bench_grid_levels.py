@@ -47,13 +47,14 @@ def time_mask(x01, mask, iters=100):
     return a.elapsed_time(b) / iters * 1e3
 
 
-x = samples()
-print("samples", x.shape[0])
-print("all levels      %7.1f us" % time_mask(x, 0))
-print("none (mask bit 20 only: every block exits) %7.1f us" % time_mask(x, 1 << 20))
-print("dense 0-4       %7.1f us" % time_mask(x, 0b11111))
-print("hashed 5-13     %7.1f us" % time_mask(x, 0b11111111100000))
-for l in range(14):
-    print("level %2d        %7.1f us" % (l, time_mask(x, 1 << l)))
-xr = torch.rand(x.shape[0], 3, device=dev)
-print("uniform random points, all levels %7.1f us" % time_mask(xr, 0))
+if __name__ == "__main__":
+    x = samples()
+    print("samples", x.shape[0])
+    print("all levels      %7.1f us" % time_mask(x, 0))
+    print("none (mask bit 20 only: every block exits) %7.1f us" % time_mask(x, 1 << 20))
+    print("dense 0-4       %7.1f us" % time_mask(x, 0b11111))
+    print("hashed 5-13     %7.1f us" % time_mask(x, 0b11111111100000))
+    for l in range(14):
+        print("level %2d        %7.1f us" % (l, time_mask(x, 1 << l)))
+    xr = torch.rand(x.shape[0], 3, device=dev)
+    print("uniform random points, all levels %7.1f us" % time_mask(xr, 0))
