@@ -12,6 +12,8 @@ step over RCCL/xGMI; norm-type losses are made global by all-reducing the sum of
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -318,6 +320,8 @@ class _TrainerBase:
             with cap:
                 self.flat.zero_()
                 self._static_out = body()
+                if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
+                    raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
                 self._backward(self._static_out[0])
                 self._exchange()  # (breaks the capture around its all-reduce under ray-DP; nothing otherwise)
                 self._optimize()
