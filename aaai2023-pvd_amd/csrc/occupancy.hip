@@ -1,0 +1,205 @@
+// occupancy.hip -- maintenance of the occupancy grid on the device (gfx950).
+//
+// Replaces the torch code of NeRFRenderer.update_extra_state (distill_mutual/renderer.py:647-775): per cascade
+//   * which cells to query -- every cell while iter_density < 16, afterwards H^3/4 uniformly random cells plus H^3/4
+//     cells drawn (with replacement) from the currently occupied ones (:700-730) -- and where inside them (cell centre
+//     +- half a cell of jitter, :733-741),
+//   * after the caller's density query: scatter into a scratch grid, decayed running maximum where both old and new
+//     values are valid (:747-750),
+//   * mean of the clamped grid, threshold = min(mean, density_thresh), packbits (:752-760),
+// as five small kernels and NO host round trip (the reference -- and the torch formulation -- synchronise for nonzero(),
+// for the mean and per 64^3 block of the full sweep).  Random numbers: PCG32 keyed by (seed, cell slot); the reference uses
+// torch's generator, so only the distribution is reproduced, not the stream.
+#include "pvd_device.h"
+
+namespace pvd {
+
+constexpr uint32_t kOccBlock = 256;
+
+// occupied cells of one cascade, compacted in wave order (order is irrelevant: they are sampled uniformly)
+__global__ void __launch_bounds__(kOccBlock) k_occ_compact(const float *__restrict__ grid, uint32_t H3, int32_t *__restrict__ list,
+                                                          uint32_t *__restrict__ count) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    const bool occ = i < H3 && grid[i] > 0.f;
+    const uint64_t m = __ballot(occ);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (occ) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+// slot i < n_uniform: a uniformly random cell; n_uniform <= i < n_uniform + n_occ: a random occupied cell (index -1 if
+// there is none); full sweep: slot i = Morton index i.  Writes the Morton index and the jittered world position.
+__global__ void __launch_bounds__(kOccBlock) k_occ_positions(uint32_t H, uint32_t n_uniform, uint32_t n_occ, int full, float bound_c,
+                                                            uint64_t seed, const int32_t *__restrict__ list,
+                                                            const uint32_t *__restrict__ count, int32_t *__restrict__ indices,
+                                                            float *__restrict__ xyz) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n_uniform + n_occ) return;
+    Pcg32 g;
+    g.seed(seed);
+    g.advance(8ull * i);
+    uint32_t cx, cy, cz;
+    int32_t idx;
+    if (full) {
+        idx = (int32_t)i;
+        cx = gather3(i); cy = gather3(i >> 1); cz = gather3(i >> 2);
+    } else if (i < n_uniform) {
+        cx = (uint32_t)(((uint64_t)g.next() * H) >> 32);
+        cy = (uint32_t)(((uint64_t)g.next() * H) >> 32);
+        cz = (uint32_t)(((uint64_t)g.next() * H) >> 32);
+        idx = (int32_t)morton3(cx, cy, cz);
+    } else {
+        const uint32_t n = count[0];
+        if (n == 0) {
+            indices[i] = -1;
+            xyz[3 * (size_t)i] = 0.f; xyz[3 * (size_t)i + 1] = 0.f; xyz[3 * (size_t)i + 2] = 0.f;
+            return;
+        }
+        idx = list[(uint32_t)(((uint64_t)g.next() * n) >> 32)];
+        cx = gather3((uint32_t)idx); cy = gather3((uint32_t)idx >> 1); cz = gather3((uint32_t)idx >> 2);
+    }
+    // xyzs = 2 * coords / (H - 1) - 1;  p = xyzs * (bound - half_grid_size) + (rand * 2 - 1) * half_grid_size  (:733-741)
+    const float hgs = bound_c / (float)H;
+    const float c[3] = {(float)cx, (float)cy, (float)cz};
+    indices[i] = idx;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float u = 2.0f * c[a] / (float)(H - 1) - 1.0f;
+        const float r = g.next_float();
+        xyz[3 * (size_t)i + a] = u * (bound_c - hgs) + (r * 2.0f - 1.0f) * hgs;
+    }
+}
+
+__global__ void __launch_bounds__(kOccBlock) k_occ_fill(float *__restrict__ tmp, uint32_t n4, float v) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i < n4) reinterpret_cast<float4 *>(tmp)[i] = make_float4(v, v, v, v);
+}
+
+// tmp_grid[cas, indices] = sigmas (:743-745; duplicate indices: whichever write lands last, as in the reference)
+__global__ void __launch_bounds__(kOccBlock) k_occ_scatter(float *__restrict__ tmp, const int32_t *__restrict__ indices,
+                                                          const float *__restrict__ sigmas, float scale, uint32_t n) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t idx = indices[i];
+    if (idx >= 0) tmp[idx] = sigmas[i] * scale;
+}
+
+// valid = (grid >= 0) & (tmp >= 0);  grid[valid] = max(grid * decay, tmp)   (:747-750)
+__global__ void __launch_bounds__(kOccBlock) k_occ_ema(float *__restrict__ grid, const float *__restrict__ tmp, uint32_t n4, float decay) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n4) return;
+    float4 g = reinterpret_cast<float4 *>(grid)[i];
+    const float4 t = reinterpret_cast<const float4 *>(tmp)[i];
+    float *gg = &g.x;
+    const float *tt = &t.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (gg[k] >= 0.f && tt[k] >= 0.f) gg[k] = fmaxf(gg[k] * decay, tt[k]);
+    reinterpret_cast<float4 *>(grid)[i] = g;
+}
+
+// partial sums of clamp(grid, min = 0) (:752)
+__global__ void __launch_bounds__(kOccBlock) k_occ_mean_partial(const float *__restrict__ grid, uint32_t n4, float *__restrict__ partials) {
+    __shared__ float sh[kOccBlock / 64];
+    float acc = 0.f;
+    for (uint32_t i = blockIdx.x * kOccBlock + threadIdx.x; i < n4; i += gridDim.x * kOccBlock) {
+        const float4 g = reinterpret_cast<const float4 *>(grid)[i];
+        acc += (fmaxf(g.x, 0.f) + fmaxf(g.y, 0.f)) + (fmaxf(g.z, 0.f) + fmaxf(g.w, 0.f));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (uint32_t w = 0; w < kOccBlock / 64; w++) s += sh[w];
+        partials[blockIdx.x] = s;
+    }
+}
+__global__ void __launch_bounds__(kOccBlock) k_occ_mean_final(const float *__restrict__ partials, uint32_t nparts, float inv_n,
+                                                             float density_thresh, float *__restrict__ mean_thresh) {
+    __shared__ float sh[kOccBlock / 64];
+    float acc = 0.f;
+    for (uint32_t i = threadIdx.x; i < nparts; i += kOccBlock) acc += partials[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (uint32_t w = 0; w < kOccBlock / 64; w++) s += sh[w];
+        const float mean = s * inv_n;
+        mean_thresh[0] = mean;
+        mean_thresh[1] = fminf(mean, density_thresh);  // density_thresh = min(mean_density, density_thresh) (:757)
+    }
+}
+
+// packbits with the threshold on the device (reference: kernel_packbits, raymarching.cu:269-291)
+__global__ void __launch_bounds__(kOccBlock) k_occ_packbits(const float *__restrict__ grid, uint32_t N, const float *__restrict__ thresh_dev,
+                                                           uint8_t *__restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * kOccBlock + threadIdx.x;
+    if (n >= N) return;
+    const float thresh = thresh_dev[1];
+    const float4 a = reinterpret_cast<const float4 *>(grid)[2 * (size_t)n];
+    const float4 b = reinterpret_cast<const float4 *>(grid)[2 * (size_t)n + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;   bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;   bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;  bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;  bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+constexpr uint32_t kOccMeanBlocks = 1024;
+
+}  // namespace pvd
+
+using namespace pvd;
+
+extern "C" {
+
+int pvd_occ_sample(const float *density_grid, uint32_t H, uint32_t n_uniform, uint32_t n_occupied, int full, float bound_c, uint64_t seed,
+                   int32_t *occ_list, uint32_t *occ_count, int32_t *indices, float *xyz, pvd_stream_t stream) {
+    if (!density_grid || !indices || !xyz || H < 2 || H > 1024) return PVD_ERR_INVALID;
+    const uint32_t H3 = H * H * H;
+    if (full) { n_uniform = H3; n_occupied = 0; }
+    if (n_uniform + n_occupied == 0) return PVD_OK;
+    if (n_occupied && (!occ_list || !occ_count)) return PVD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_occupied) {
+        (void)hipMemsetAsync(occ_count, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(k_occ_compact, dim3(div_up(H3, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, H3, occ_list, occ_count);
+    }
+    hipLaunchKernelGGL(k_occ_positions, dim3(div_up(n_uniform + n_occupied, kOccBlock)), dim3(kOccBlock), 0, s, H, n_uniform, n_occupied, full,
+                       bound_c, seed, occ_list, occ_count, indices, xyz);
+    return check_launch();
+}
+
+int pvd_occ_update(float *density_grid, float *tmp, const int32_t *indices, const float *sigmas, uint32_t n, uint32_t H, float sigma_scale,
+                   float decay, pvd_stream_t stream) {
+    if (!density_grid || !tmp || (n && (!indices || !sigmas)) || H < 2 || H > 1024) return PVD_ERR_INVALID;
+    const uint32_t H3 = H * H * H;
+    if (H3 & 3u) return PVD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_occ_fill, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, tmp, H3 / 4, -1.0f);
+    if (n) hipLaunchKernelGGL(k_occ_scatter, dim3(div_up(n, kOccBlock)), dim3(kOccBlock), 0, s, tmp, indices, sigmas, sigma_scale, n);
+    hipLaunchKernelGGL(k_occ_ema, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, tmp, H3 / 4, decay);
+    return check_launch();
+}
+
+int pvd_occ_finish(const float *density_grid, uint32_t n_cells, float density_thresh, float *mean_thresh, float *scratch, uint8_t *bitfield,
+                   pvd_stream_t stream) {
+    if (!density_grid || !mean_thresh || !scratch || !bitfield || n_cells == 0) return PVD_ERR_INVALID;
+    if (n_cells & 7u) return PVD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_occ_mean_partial, dim3(kOccMeanBlocks), dim3(kOccBlock), 0, s, density_grid, n_cells / 4, scratch);
+    hipLaunchKernelGGL(k_occ_mean_final, dim3(1), dim3(kOccBlock), 0, s, scratch, kOccMeanBlocks, 1.0f / (float)n_cells, density_thresh,
+                       mean_thresh);
+    hipLaunchKernelGGL(k_occ_packbits, dim3(div_up(n_cells / 8, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, n_cells / 8, mean_thresh,
+                       bitfield);
+    return check_launch();
+}
+
+}  // extern "C"

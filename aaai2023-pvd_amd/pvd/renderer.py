@@ -223,6 +223,9 @@ class NeRFRenderer(nn.Module):
         (reference: renderer.py:647-775)."""
         if not self.cuda_ray:
             return
+        occ = getattr(self.ops, "occupancy", None)
+        if occ is not None and self.density_grid.is_cuda:
+            return self._update_extra_state_device(occ, decay)
         rm = self.rm
         dev = self.density_grid.device
         H = self.grid_size
@@ -264,6 +267,36 @@ class NeRFRenderer(nn.Module):
         thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = rm.packbits(self.density_grid, thresh, self.density_bitfield)
 
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    def _update_extra_state_device(self, occ, decay):
+        """update_extra_state with the cell selection, jitter, running maximum, mean / threshold and packbits on the
+        device (csrc/occupancy.hip): no nonzero(), no .item() except the one that sizes next steps' sample budget."""
+        dev = self.density_grid.device
+        H, C = self.grid_size, self.cascade
+        H3 = H ** 3
+        st = getattr(self, "_occ_state", None)
+        if st is None:
+            st = self._occ_state = dict(list=torch.empty(H3, dtype=torch.int32, device=dev), count=torch.zeros(1, dtype=torch.int32, device=dev),
+                                        tmp=torch.empty(H3, dtype=torch.float32, device=dev), scratch=torch.empty(1024, device=dev),
+                                        mean_thresh=torch.zeros(2, device=dev), calls=0)
+        full = self.iter_density < 16
+        n_u, n_o = (H3, 0) if full else (H3 // 4, H3 // 4)
+        n = n_u + n_o
+        indices = torch.empty(n, dtype=torch.int32, device=dev)
+        xyz = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        for cas in range(C):
+            st["calls"] += 1
+            occ.occ_sample(self.density_grid[cas], H, n_u, n_o, full, float(min(2 ** cas, self.bound)), 0x0cc0 + 7919 * st["calls"], st["list"],
+                           st["count"], indices, xyz)
+            sig = self.density(xyz)["sigma"].reshape(-1).detach().float().contiguous()
+            occ.occ_update(self.density_grid[cas], st["tmp"], indices, sig, H, float(self.density_scale), float(decay))
+        occ.occ_finish(self.density_grid.view(-1), float(self.density_thresh), st["mean_thresh"], st["scratch"], self.density_bitfield)
+        self.mean_density = st["mean_thresh"][0]  # stays on the device (float(...) to read it)
+        self.iter_density += 1
         total_step = min(16, self.local_step)
         if total_step > 0:
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)

@@ -43,7 +43,7 @@ ENTRY_POINTS = (
     "pvd_abi_version", "pvd_status_string", "pvd_last_hip_error",
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
-    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays",
+    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
@@ -399,6 +399,37 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
 
 
 vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_backward)
+
+
+# --------------------------------------------------------------------------- occupancy-grid maintenance
+def occ_sample(density_grid, H, n_uniform, n_occupied, full, bound_c, seed, occ_list, occ_count, indices, xyz):
+    dev = _dev(density_grid, occ_list, occ_count, indices, xyz)
+    _f32_all(density_grid=density_grid, xyz=xyz)
+    _want(indices, torch.int32, "indices")
+    if occ_list is not None:
+        _want(occ_list, torch.int32, "occ_list"), _want(occ_count, torch.int32, "occ_count")
+    _call("pvd_occ_sample", dev, _p(density_grid), _u32(H), _u32(n_uniform), _u32(n_occupied), _int(int(bool(full))), _f32(bound_c),
+          ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _p(occ_list), _p(occ_count), _p(indices), _p(xyz))
+
+
+def occ_update(density_grid, tmp, indices, sigmas, H, sigma_scale, decay):
+    dev = _dev(density_grid, tmp, indices, sigmas)
+    _f32_all(density_grid=density_grid, tmp=tmp, sigmas=sigmas)
+    _want(indices, torch.int32, "indices")
+    _call("pvd_occ_update", dev, _p(density_grid), _p(tmp), _p(indices), _p(sigmas), _u32(indices.numel()), _u32(H), _f32(sigma_scale),
+          _f32(decay))
+
+
+def occ_finish(density_grid, density_thresh, mean_thresh, scratch, bitfield):
+    dev = _dev(density_grid, mean_thresh, scratch, bitfield)
+    _f32_all(density_grid=density_grid, mean_thresh=mean_thresh, scratch=scratch)
+    _want(bitfield, torch.uint8, "bitfield")
+    if scratch.numel() < 1024 or mean_thresh.numel() < 2:
+        raise PvdHipError("scratch needs 1024 floats, mean_thresh 2")
+    _call("pvd_occ_finish", dev, _p(density_grid), _u32(density_grid.numel()), _f32(density_thresh), _p(mean_thresh), _p(scratch), _p(bitfield))
+
+
+occupancy_backend = types.SimpleNamespace(occ_sample=occ_sample, occ_update=occ_update, occ_finish=occ_finish)
 
 
 # --------------------------------------------------------------------------- Plenoxel dense-volume lookup + SH head

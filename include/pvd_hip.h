@@ -260,6 +260,29 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
                       float *workspace, pvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Occupancy-grid maintenance on the device: the torch code of NeRFRenderer.update_extra_state
+ * (distill_mutual/renderer.py:647-775) without its host round trips.  Per cascade c (grid slice [H^3], Morton order):
+ *   pvd_occ_sample : which cells to query and where.  full != 0: every cell (slot i = Morton index i; the first 16
+ *                    updates).  Otherwise n_uniform uniformly random cells followed by n_occupied cells drawn with
+ *                    replacement from the cells with density > 0 (indices -1 if there are none).  Positions = cell
+ *                    centre +- half a cell of jitter in the cascade's box [-bound_c, bound_c], bound_c = min(2^c, bound).
+ *                    occ_list [H^3] int32 and occ_count [1] are scratch; PCG32 keyed by (seed, slot).
+ *   (the caller evaluates the density at xyz)
+ *   pvd_occ_update : tmp = -1; tmp[indices] = sigmas * sigma_scale; grid = max(grid * decay, tmp) where both >= 0.
+ *                    tmp [H^3] is scratch.
+ * After all cascades:
+ *   pvd_occ_finish : mean_thresh[0] = mean(clamp(grid, 0)), mean_thresh[1] = min(mean, density_thresh) (DEVICE floats),
+ *                    bitfield = packbits(grid > mean_thresh[1]) over all n_cells = C * H^3 cells; scratch: 1024 floats.
+ * ---------------------------------------------------------------------- */
+int pvd_occ_sample(const float *density_grid, uint32_t H, uint32_t n_uniform, uint32_t n_occupied, int full, float bound_c,
+                   uint64_t seed, int32_t *occ_list, uint32_t *occ_count, int32_t *indices, float *xyz,
+                   pvd_stream_t stream);
+int pvd_occ_update(float *density_grid, float *tmp, const int32_t *indices, const float *sigmas, uint32_t n, uint32_t H,
+                   float sigma_scale, float decay, pvd_stream_t stream);
+int pvd_occ_finish(const float *density_grid, uint32_t n_cells, float density_thresh, float *mean_thresh, float *scratch,
+                   uint8_t *bitfield, pvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Plenoxel ("tensors") model: dense-volume lookup + SH colour head, forward and backward.
  * Replaces compute_plenoxel_fea (3-D F.grid_sample, trilinear, align_corners=True, zero padding;
  * distill_mutual/network.py:311-322) and the head around it (network.py:383-409):

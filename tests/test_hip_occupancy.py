@@ -1,0 +1,133 @@
+"""Device-side occupancy-grid maintenance (csrc/occupancy.hip, pvd_occ_*) against the torch formulation of
+NeRFRenderer.update_extra_state (distill_mutual/renderer.py:647-775): cell selection and jitter as distributions (the
+reference draws from torch's generator), the running-maximum update, mean / threshold and packbits exactly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+H = 64
+H3 = H ** 3
+
+
+def _grid(seed=0, frac=0.07):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    grid = torch.rand(H3, device=dev, generator=g)
+    grid = torch.where(grid < frac, grid * 10 + 0.5, torch.zeros_like(grid))
+    grid[::97] = -1.0  # "untrained" cells (mark_untrained_grid)
+    return grid
+
+
+def _scratch():
+    return (torch.empty(H3, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+
+
+def test_full_sweep_enumerates_every_cell_with_jitter_inside_the_cell():
+    import pvd_hip
+    grid = _grid()
+    idx = torch.empty(H3, dtype=torch.int32, device=dev)
+    xyz = torch.empty(H3, 3, device=dev)
+    bound_c = 2.0
+    pvd_hip.occ_sample(grid, H, 0, 0, True, bound_c, 1, None, None, idx, xyz)
+    assert torch.equal(idx, torch.arange(H3, dtype=torch.int32, device=dev))
+    hgs = bound_c / H
+    i = idx.long()
+    from pvd.dp_compact import _gather3
+    c = torch.stack([_gather3(i), _gather3(i >> 1), _gather3(i >> 2)], dim=1).float()
+    centre = (2 * c / (H - 1) - 1) * (bound_c - hgs)
+    d = (xyz - centre).abs()
+    assert d.max().item() <= hgs * (1 + 1e-5) and d.mean().item() > 0.4 * hgs  # uniform jitter of +- half a cell
+    assert (xyz.abs() <= bound_c).all()
+
+
+def test_partial_update_draws_uniform_cells_and_occupied_cells():
+    import pvd_hip
+    grid = _grid(1)
+    n = H3 // 4
+    idx = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    xyz = torch.empty(2 * n, 3, device=dev)
+    lst, cnt = _scratch()
+    pvd_hip.occ_sample(grid, H, n, n, False, 1.0, 7, lst, cnt, idx, xyz)
+    occupied = (grid > 0)
+    assert int(cnt) == int(occupied.sum())
+    assert torch.equal(torch.sort(lst[: int(cnt)].long())[0], torch.nonzero(occupied).squeeze(-1))
+    uni, occ = idx[:n].long(), idx[n:].long()
+    assert int(uni.min()) >= 0 and int(uni.max()) < H3
+    hist = torch.bincount(uni // (H3 // 64), minlength=64).float()
+    assert (hist / hist.sum() - 1 / 64).abs().max().item() < 0.004  # uniform over the grid
+    assert occupied[occ].all()  # second half: occupied cells only
+    hits = torch.bincount(occ, minlength=H3)[occupied].float()
+    assert (hits > 0).float().mean().item() > 0.9 and hits.mean().item() == pytest.approx(n / int(cnt), rel=1e-6)
+    # another seed draws other cells; an empty grid yields no occupied queries
+    idx2 = torch.empty_like(idx)
+    pvd_hip.occ_sample(grid, H, n, n, False, 1.0, 8, lst, cnt, idx2, xyz)
+    assert not torch.equal(idx, idx2)
+    pvd_hip.occ_sample(torch.zeros_like(grid), H, n, n, False, 1.0, 9, lst, cnt, idx2, xyz)
+    assert int(cnt) == 0 and (idx2[n:] == -1).all() and (idx2[:n] >= 0).all()
+
+
+def test_update_and_finish_match_the_torch_formulation():
+    import pvd_hip
+    import raymarching
+    grid = _grid(2)
+    g = torch.Generator(device=dev).manual_seed(3)
+    n = 50000
+    idx = torch.randperm(H3, device=dev, generator=g)[:n].to(torch.int32)  # unique: duplicate order is unspecified in the reference too
+    idx[:10] = -1
+    sig = torch.rand(n, device=dev, generator=g) * 3
+    ref = grid.clone()
+    tmp = -torch.ones_like(ref)
+    ok = idx >= 0
+    tmp[idx[ok].long()] = sig[ok] * 0.5
+    valid = (ref >= 0) & (tmp >= 0)
+    ref[valid] = torch.maximum(ref[valid] * 0.95, tmp[valid])
+    got = grid.clone()
+    pvd_hip.occ_update(got, torch.empty(H3, device=dev), idx, sig, H, 0.5, 0.95)
+    assert torch.equal(got, ref)
+    assert (got[::97] == -1).all()  # untrained cells are never touched
+
+    two = torch.cat([got, _grid(4)])  # two cascades
+    mt = torch.zeros(2, device=dev)
+    bits = torch.empty(two.numel() // 8, dtype=torch.uint8, device=dev)
+    pvd_hip.occ_finish(two, 0.3, mt, torch.empty(1024, device=dev), bits)
+    mean = two.clamp(min=0).mean()
+    assert abs(float(mt[0]) - float(mean)) <= 1e-5 * float(mean)
+    assert float(mt[1]) == min(float(mt[0]), np.float32(0.3))
+    ref_bits = raymarching.packbits(two.view(2, -1), float(mt[1]))
+    assert torch.equal(bits, ref_bits)
+
+
+def test_update_extra_state_device_path_tracks_the_torch_path():
+    """The same density field (the analytic chair: 50 inside, 0 outside), 20 occupancy updates through the device path and
+    through the torch path: different random samples, so compare what matters -- the set of occupied cells (they can only
+    disagree in cells the surface cuts) -- and that the device path reproduces the scene's true occupancy."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import ChairScene
+    from pvd.workload import make_model
+    opt = PVDConfig(num_rays=2048)
+    scene = ChairScene(thicken=0.08)
+    sets, means = [], []
+    for device_path in (True, False):
+        ops = hip_ops()
+        if not device_path:
+            ops.occupancy = None
+        m = make_model(ops, opt, "hash", True, dev)
+        m.density = lambda x: {"sigma": scene.sigma(x)}
+        for _ in range(20):
+            with torch.no_grad():
+                m.update_extra_state()
+        thresh = min(float(m.mean_density), m.density_thresh)
+        sets.append(m.density_grid.view(-1) > thresh)
+        means.append(float(m.mean_density))
+        bits = m.density_bitfield.clone()
+        from pvd.scene import packbits_torch
+        assert torch.equal(bits, packbits_torch(m.density_grid, thresh))  # the bitfield is the thresholded grid
+        assert m.iter_density == 20
+    a, b = sets
+    inter, union = (a & b).sum().item(), (a | b).sum().item()
+    assert union > 50000 and inter / union > 0.97, (inter, union)
+    assert abs(means[0] - means[1]) <= 0.03 * means[1], means
+    truth = scene.density_grid(128, 1.0, 1, device=dev).view(-1) > 10.0  # cell-centre occupancy of the analytic scene
+    assert (a & truth).sum().item() / truth.sum().item() > 0.98  # nothing solid is missed
