@@ -712,13 +712,15 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
 
 // waves per SIMD the backward is compiled for: 1 = all accumulators in registers (> 256 VGPRs), 2 = twice the
 // workgroups with ~40-80 spilled registers.  PVD_HEAD_BWD_OCC overrides (measurement).
-static int head_bwd_occupancy() {
-    static int occ = 0;
-    if (occ == 0) {
+static int head_bwd_occupancy(int kind) {
+    static int forced = -1;
+    if (forced < 0) {
         const char *e = getenv("PVD_HEAD_BWD_OCC");
-        occ = (e && e[0] == '2') ? 2 : 1;
+        forced = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
     }
-    return occ;
+    if (forced) return forced;
+    (void)kind;
+    return 1;  // measured after the one-tile-ahead loads: 1 wins for both heads (teacher step 0.59 vs 0.73 ms at 2)
 }
 
 template <int KIND>
@@ -726,7 +728,7 @@ static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, f
     size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 256;
     if (lds_halfs < 2 * (size_t)DwLayout<KIND>::floats) lds_halfs = 2 * (size_t)DwLayout<KIND>::floats;
     const uint32_t nblocks = nwaves / (kHeadBlock / 64);
-    if (head_bwd_occupancy() == 2)
+    if (head_bwd_occupancy(KIND) == 2)
         hipLaunchKernelGGL((k_head_bwd<KIND, 2>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
     else
         hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
@@ -780,16 +782,16 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
     return PVD_ERR_UNSUPPORTED;
 }
 
-static uint32_t head_bwd_waves(uint32_t M) {
+static uint32_t head_bwd_waves(int kind, uint32_t M) {
     const uint32_t ntiles = div_up(M, 16u);
     uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
-    if (blocks > 256u * head_bwd_occupancy()) blocks = 256u * head_bwd_occupancy();  // one workgroup per CU and occupancy slot
+    if (blocks > 256u * head_bwd_occupancy(kind)) blocks = 256u * head_bwd_occupancy(kind);  // one workgroup per CU and occupancy slot
     if (blocks < 1) blocks = 1;
     return blocks * (kHeadBlock / 64);
 }
 
 int pvd_head_backward_workspace_floats(int kind, uint32_t M) {
-    return (int)(head_bwd_waves(M) / (kHeadBlock / 64) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
+    return (int)(head_bwd_waves(kind, M) / (kHeadBlock / 64) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
 }
 
 int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
@@ -808,7 +810,7 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
     a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr; a.f.image = (const half_t *)image;
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
     a.partials = workspace;
-    const uint32_t nwaves = head_bwd_waves(M);
+    const uint32_t nwaves = head_bwd_waves(kind, M);
     if (kind == KIND_VM) {
         if (!sigma_raw || !g_sigma_raw) return PVD_ERR_INVALID;
         return launch_head_bwd<KIND_VM>(a, nwaves, gWa1, nullptr, gWc1, gWc2, gWc3, (hipStream_t)stream);
