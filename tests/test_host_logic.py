@@ -182,3 +182,37 @@ def test_flat_gradient_views_survive_training():
         assert p.grad.data_ptr() == flat.flat[off:off + 1].data_ptr()
         off += p.numel()
     assert flat.flat.abs().sum() > 0
+
+
+@pytest.mark.parametrize("bound,cascade", [(1.0, 1), (2.0, 2)])
+def test_dp_compact_footprint_mask_covers_every_sample_footprint(bound, cascade):
+    """pvd/dp_compact.py: the footprint mask must contain every texel a linear-interpolation footprint of ANY point inside
+    an occupied cell can touch -- brute force with random points in random occupied cells, two cascades, non-cubic table."""
+    from pvd.dp_compact import footprint_mask, occupied_cells
+    from pvd.scene import ChairScene, packbits_torch
+    g = torch.Generator().manual_seed(0)
+    grid = ChairScene(thicken=0.08).density_grid(128, bound, cascade)
+    bits = packbits_torch(grid, 10.0)
+    boxes = occupied_cells(bits, cascade, 128, bound)
+    assert len(boxes) == cascade
+    aabb = [-bound] * 3 + [bound] * 3
+    sizes, axes = [37, 300], [2, 0]  # table W axis samples world z, H axis samples world x
+    mask = footprint_mask(boxes, aabb, sizes, axes)
+    assert mask.shape == (300, 37) and 0.01 < mask.float().mean().item() < 0.9
+    for lo, hi in boxes:
+        pick = torch.randint(0, lo.shape[0], (20000,), generator=g)
+        p = lo[pick] + (hi[pick] - lo[pick]) * torch.rand(20000, 3, generator=g, dtype=torch.float64)
+        p = p.clamp(-bound, bound)
+        idx = []
+        for k in range(2):
+            a, n = axes[k], sizes[k]
+            u = ((2 * (p[:, a] - aabb[a]) / (aabb[a + 3] - aabb[a]) - 1) + 1) / 2 * (n - 1)
+            idx.append(torch.floor(u).long())
+        for dx in (0, 1):
+            for dy in (0, 1):
+                x, y = idx[0] + dx, idx[1] + dy
+                ok = (x >= 0) & (x < sizes[0]) & (y >= 0) & (y < sizes[1])
+                assert mask[y[ok], x[ok]].all()
+    # 3-D (Plenoxel volume)
+    m3 = footprint_mask(boxes, aabb, [16, 20, 24], [0, 1, 2])
+    assert m3.shape == (24, 20, 16) and m3.any() and not m3.all()
