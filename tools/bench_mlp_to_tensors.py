@@ -1,5 +1,7 @@
 import sys, time
-sys.path[:0] = ["/root/repo", "/root/repo/aaai2023-pvd_amd"]
+import os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "aaai2023-pvd_amd")]
 import torch
 from pvd.config import PVDConfig
 from pvd.ops import hip_ops
