@@ -158,14 +158,14 @@ class NeRFRenderer(nn.Module):
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
 
     # ------------------------------------------------------------------ occupancy grid upkeep
-    def march(self, rays_o, rays_d, dt_gamma=0, perturb=False, force_all_rays=False, max_steps=1024):
+    def march(self, rays_o, rays_d, dt_gamma=0, perturb=False, force_all_rays=False, max_steps=1024, nears_fars=None):
         """The sampling half of the training branch of run_cuda on its own: near/far + march_rays_train.  Returns
         (inherited_params, (nears, fars)) for run_cuda(..., inherited_params=, nears_fars=, premarched=True), so that
         the two models' forwards can be issued on different streams."""
         rm = self.rm
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
-        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        nears, fars = nears_fars if nears_fars is not None else rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         counter = self.step_counter[self.local_step % 16]
         counter.zero_()
         self.local_step += 1

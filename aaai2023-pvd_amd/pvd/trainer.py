@@ -66,10 +66,11 @@ class SegmentedCapture:
         torch.cuda.current_stream().wait_stream(self._stream)
         return False
 
-    def break_for(self, fn):
+    def break_for(self, fn, replay_fn=None):
+        """fn runs now (between two captures); replay_fn (default: fn) is what runs at that point of every replay."""
         self._end()
         fn()
-        self.between.append(fn)
+        self.between.append(replay_fn or fn)
         self._begin()
 
     def replay(self):
@@ -89,11 +90,19 @@ class RayDP:
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.capture = None  # a SegmentedCapture while the trainer records a step
 
-    def all_reduce_sum_(self, t):
+    def all_reduce_sum_(self, t, overlap=None):
+        """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
+        next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
         if self.enabled:
             run = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             if self.capture is not None and self.capture.active:
-                self.capture.break_for(run)  # collectives stay out of the graphs: eager, between two replays
+                replay = None
+                if overlap is not None:
+                    def replay():
+                        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        overlap()
+                        work.wait()
+                self.capture.break_for(run, replay)  # collectives stay out of the graphs: eager, between two replays
             else:
                 run()
         return t
@@ -274,11 +283,12 @@ class _TrainerBase:
     def _exchange(self):
         if self.dp.enabled:
             c = self._grad_compactor()
+            ov = getattr(self, "_overlap_with_exchange", None)
             if c is None:
-                self.dp.all_reduce_sum_(self.flat.flat)  # one bucket, SUM (losses are already global objectives)
+                self.dp.all_reduce_sum_(self.flat.flat, overlap=ov)  # one bucket, SUM (losses are already global objectives)
             else:
                 buf = c.gather(self.flat.flat)
-                self.dp.all_reduce_sum_(buf)
+                self.dp.all_reduce_sum_(buf, overlap=ov)
                 c.scatter(self.flat.flat, buf)
 
     def _optimize(self):
@@ -370,12 +380,32 @@ class DistillTrainer(_TrainerBase):
         o = self.opt
         return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps)
 
-    def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None):
+    def prefetch(self, batch_fn):
+        """The parameter-independent prefix of a step: batch, march, the frozen teacher's forward and compositing.  Its
+        results feed compute_loss(pre=...); under ray-DP it is captured as its own graph and replayed for step k+1 while
+        step k's gradient exchange is in flight."""
+        o, stu, tea = self.opt, self.model_stu, self.model_tea
+        rays_o, rays_d, bg, *rest = batch_fn()
+        kw = self.render_kwargs()
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+            inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, nears_fars=rest[0] if rest else None, **kw)
+            with torch.no_grad():
+                out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False,
+                                     inherited_params=inh, nears_fars=nf, premarched=True, **kw)
+        return dict(rays_o=rays_o, rays_d=rays_d, bg=bg, inh=inh, nf=nf, out_tea=out_tea)
+
+    def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None, pre=None):
         o, stu, tea = self.opt, self.model_stu, self.model_tea
         o.global_step = self.global_step
         kw = self.render_kwargs()
         kw_stu = dict(kw, nears_fars=nears_fars) if nears_fars is not None else kw  # the batch kernel already intersected the box
-        if self.overlap_teacher and rays_o.is_cuda and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
+        if pre is not None:
+            out_tea = dict(pre["out_tea"])
+            if out_tea.get("image") is not None:
+                out_tea["image"] = out_tea["image"].clone()  # the prefix graph overwrites its outputs one step ahead
+            out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
+                                 inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, **kw)
+        elif self.overlap_teacher and rays_o.is_cuda and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
             # march once, then the frozen teacher's forward runs on a side stream next to the student's forward
             # (they share only the samples); in a captured step this becomes two parallel branches of the graph
             inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, **kw)
@@ -466,7 +496,43 @@ class DistillTrainer(_TrainerBase):
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 return self.compute_loss(rays_o, rays_d, bg, *rest)
         self._captured_stage = self._stage_of(self.global_step)
+        if self.dp.enabled and self._captured_stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
+            return self._capture_pipelined(batch_fn, body)
         return self.capture(body)
+
+    def _capture_pipelined(self, batch_fn, body):
+        """Ray-DP: the next step's batch / march / teacher forward do not depend on this step's update, so they are a
+        separate graph that is replayed while the gradient exchange is in flight:
+            [student forward, sums] -> all-reduce(16 B) -> [loss, backward, gather] -> (all-reduce || PREFIX of step k+1)
+            -> [scatter, inf check, AdamW]."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up steps (also build the compactor, the communicators, the caches)
+            for _ in range(3):
+                self.flat.zero_()
+                out = body()
+                self._backward(out[0])
+                self._exchange()
+                self._optimize()
+                self.scheduler.step()
+                self.global_step += 1
+                del out
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_prefix = torch.cuda.CUDAGraph()  # own memory pool: it is replayed out of capture order
+        with torch.cuda.graph(self._g_prefix, capture_error_mode="thread_local"):
+            self._pre = self.prefetch(batch_fn)
+
+        def body_pre():
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                return self.compute_loss(None, None, None, pre=self._pre)
+        self._overlap_with_exchange = self._g_prefix.replay
+        try:
+            out = self.capture(body_pre, warmup=0)
+        finally:
+            self._overlap_with_exchange = None
+        self._g_prefix.replay()  # prologue: the first replayed step needs its prefix
+        return out
 
     def _stage_of(self, step):
         st = self.opt.stage_iters

@@ -23,7 +23,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, overlap):
+    os.environ["PVD_DP_OVERLAP"] = "1" if overlap else "0"
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,6 +43,7 @@ def _worker(rank, world, port, out_path):
     w.enable_graph()
     cap = w.trainer._cap
     assert len(cap.graphs) == 3 and len(cap.between) == 2, (len(cap.graphs), len(cap.between))  # loss sums | exchange | optimizer
+    assert (getattr(w.trainer, "_g_prefix", None) is not None) == overlap  # next step's prefix replayed during the exchange
     c = w.trainer._grad_compactor()
     assert c is not None and c.fraction < 0.7  # compact exchange in use
     losses = []
@@ -59,9 +61,15 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(900)
 def test_two_ranks_segmented_graph_capture(tmp_path):
-    out = str(tmp_path / "dpg.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    res = torch.load(out)
-    assert len(res["losses"]) == 12 and res["losses"][-1] < res["losses"][0] * 1.5
+    runs = []
+    for overlap in (False, True):
+        out = str(tmp_path / ("dpg%d.pt" % overlap))
+        mp.spawn(_worker, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
+        res = torch.load(out)
+        assert len(res["losses"]) == 12 and res["losses"][-1] < res["losses"][0] * 1.5
+        runs.append(res["losses"])
+    # same batches, same update rule: pipelining the next step's prefix under the exchange does not change the training
+    # (float atomics in the backward perturb the trajectory in the last digits only)
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
