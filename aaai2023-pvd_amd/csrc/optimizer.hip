@@ -35,6 +35,9 @@ struct AdamExtras {
     // adds into the fp32 gradient in a separate pass, grid.py:105-136): added while the fp32 gradient is read
     const _Float16 *g16;
     uint64_t g16_begin, g16_end;
+    // value of the L1 term AFTER this update (= at the next step's forward), as one partial sum per workgroup
+    float *l1_next;  // DEVICE [>= gridDim.x] or NULL
+    float l1_next_scale;
 };
 
 // one thread: advance the step count (unless the GradScaler found an inf) and evaluate the schedule.
@@ -61,7 +64,9 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
                                                     double beta1, double beta2, double eps, double weight_decay,
                                                     const float *__restrict__ step, const float *__restrict__ grad_scale,
                                                     const float *__restrict__ found_inf, AdamExtras ex) {
-    if (found_inf && found_inf[0] != 0.f) return;  // GradScaler: skip the whole step
+    if (found_inf && found_inf[0] != 0.f) return;  // GradScaler: skip the whole step (l1_next keeps describing the parameters)
+    __shared__ float l1_sh[kOptBlock / 64];
+    float l1_acc = 0.f;
     const double t = (double)step[0];
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, t));
@@ -95,10 +100,22 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             const float denom = (float)((double)sqrtf(es) / bc2_sqrt + (double)eps);
             param -= step_size * ea / denom;
             pp[c] = param; mm[c] = ea; vv[c] = es;
+            l1_acc += l1 * fabsf(param);
         }
         reinterpret_cast<float4 *>(p)[i] = P;
         reinterpret_cast<float4 *>(m)[i] = M;
         reinterpret_cast<float4 *>(v)[i] = V;
+    }
+    if (ex.l1_next) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) l1_acc += __shfl_xor(l1_acc, off, 64);
+        if ((threadIdx.x & 63u) == 0) l1_sh[threadIdx.x >> 6] = l1_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sacc = 0.f;
+            for (uint32_t w = 0; w < kOptBlock / 64; w++) sacc += l1_sh[w];
+            ex.l1_next[blockIdx.x] = sacc * ex.l1_next_scale;
+        }
     }
 }
 
@@ -219,7 +236,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     }
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
-    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -228,6 +245,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         ex.base_lr = h.base_lr; ex.sched_step = h.sched_step;
         const int rc = fill_l1(ex, h.l1_begin_host, h.l1_end_host, h.l1_coef_host, h.n_l1);
         if (rc != PVD_OK) return rc;
+        if (h.l1_next) { ex.l1_next = h.l1_next; ex.l1_next_scale = h.l1_next_scale; }
         if (h.g16) {
             if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
             ex.g16 = (const _Float16 *)h.g16; ex.g16_begin = h.g16_begin; ex.g16_end = h.g16_end;
@@ -280,7 +298,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     if (!p || !scratch) return PVD_ERR_INVALID;
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
-    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -101,18 +101,25 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def l1_partials(self, scale=1.0):
-        """1024 partial sums of the L1 term's value (to be added by the consumer, e.g. the fused distillation objective)."""
-        ranges = self._l1 if scale == 1.0 else [(b, e, c * scale) for b, e, c in self._l1]
-        pvd_hip.l1_ranges(self.flat_p, ranges, self._l1_scratch, None)
-        return self._l1_scratch
+        """Partial sums of the L1 term's value (to be added by the consumer, e.g. the fused distillation objective).  After
+        the first call the update kernel itself keeps them current (it reads every parameter anyway), so a step costs no
+        extra pass over the regularised tables."""
+        st = getattr(self, "_l1_track", None)
+        if st is None or st["scale"] != scale:
+            buf = torch.zeros(4096, dtype=torch.float32, device=self.flat_p.device)
+            buf[0] = self.l1_value(scale)  # once; every update that goes through overwrites one entry per workgroup
+            st = self._l1_track = dict(buf=buf, scale=scale)
+        return st["buf"]
 
     @torch.no_grad()
     def step(self, closure=None):
         d = self.defaults
+        st = getattr(self, "_l1_track", None)
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                            schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
-                           amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None))
+                           amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
+                           l1_next=(st["buf"], st["scale"]) if st is not None else None)
         self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)

@@ -593,7 +593,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("l1_begin_host", ctypes.POINTER(ctypes.c_uint64)), ("l1_end_host", ctypes.POINTER(ctypes.c_uint64)),
                 ("l1_coef_host", ctypes.POINTER(ctypes.c_float)), ("amp_scale", ctypes.c_void_p), ("amp_growth_tracker", ctypes.c_void_p),
                 ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32),
-                ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64)]
+                ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
+                ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float)]
 
 
 def _u64_array(vals):
@@ -601,7 +602,7 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
@@ -610,6 +611,13 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
     ex = None
     if schedule is not None or l1_ranges or amp_update is not None or half_grad is not None:
         ex = _AdamwExtras()
+        if l1_next is not None:  # (buffer [>= 4096] f32, scale)
+            buf, sc = l1_next
+            _dev(buf)
+            _want(buf, torch.float32, "l1_next")
+            if buf.numel() < 4096:
+                raise PvdHipError("l1_next needs 4096 floats")
+            ex.l1_next, ex.l1_next_scale = buf.data_ptr(), float(sc)
         if half_grad is not None:  # (begin, end, f16 tensor with end - begin elements)
             hb, he, h = half_grad
             _dev(h)

@@ -381,6 +381,11 @@ typedef struct pvd_adamw_extras {
      * (grid.py:105-136).  NULL = none. */
     const void *g16;
     uint64_t g16_begin, g16_end;
+    /* l1_next != NULL (DEVICE, >= 4096 floats): one partial sum per workgroup of l1_next_scale * sum_r l1_coef[r] * |p| over
+     * the UPDATED parameters, i.e. the value of the L1 term at the next step's forward (entries beyond the launch's
+     * workgroups are left alone: zero them once).  Not written when the step is skipped. */
+    float *l1_next;
+    float l1_next_scale;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,

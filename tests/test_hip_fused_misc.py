@@ -156,6 +156,8 @@ def test_flat_adamw_device_schedule_l1_and_finite_check():
         for it in range(50):
             l1_ref = w * (pa[1].abs().mean() + pa[2].abs().mean())
             assert abs(float(mine.l1_value()) - float(l1_ref)) <= 1e-5 * abs(float(l1_ref))
+            # the partial sums kept current by the update kernel itself (one entry per workgroup) describe the same value
+            assert abs(float(mine.l1_partials().sum()) - float(l1_ref)) <= 2e-5 * abs(float(l1_ref))
             for a, b in zip(pa, pb):
                 gr = torch.randn(a.shape, device=dev, generator=g)
                 a.grad = gr.clone()
