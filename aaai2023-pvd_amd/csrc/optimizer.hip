@@ -80,8 +80,13 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
         const double lrk = (double)lr[k];
         const float step_size = (float)(lrk / bc1);
+        // the moments are touched exactly once per step: stream them past the caches (nt) so that the Infinity Cache keeps
+        // the parameters and gradients the other kernels of the step come back to
+        typedef float f4v __attribute__((ext_vector_type(4)));
         float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<const float4 *>(g)[i];
-        float4 M = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+        const f4v Mn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(m) + i);
+        const f4v Vn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v) + i);
+        float4 M = make_float4(Mn.x, Mn.y, Mn.z, Mn.w), V = make_float4(Vn.x, Vn.y, Vn.z, Vn.w);
         if (ex.g16 && e >= ex.g16_begin && e < ex.g16_end) {  // 4 halfs = one 8-byte load (range start is a multiple of 4)
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
             const h4v h = *reinterpret_cast<const h4v *>(ex.g16 + (e - ex.g16_begin));
@@ -103,8 +108,8 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             l1_acc += l1 * fabsf(param);
         }
         reinterpret_cast<float4 *>(p)[i] = P;
-        reinterpret_cast<float4 *>(m)[i] = M;
-        reinterpret_cast<float4 *>(v)[i] = V;
+        __builtin_nontemporal_store((f4v){M.x, M.y, M.z, M.w}, reinterpret_cast<f4v *>(m) + i);
+        __builtin_nontemporal_store((f4v){V.x, V.y, V.z, V.w}, reinterpret_cast<f4v *>(v) + i);
     }
     if (ex.l1_next) {
 #pragma unroll
