@@ -128,6 +128,7 @@ def main():
                     d = d.permute(0, 2, 3, 1) if d.dim() == 4 else d.permute(0, 2, 3, 4, 1)
                     assert d.is_contiguous()
                 dist.broadcast(d, src=0)
+            pvd_hip.note_weights_changed(list(m.parameters()))  # .data writes do not bump autograd versions: drop derived caches
 
     torch.cuda.manual_seed(1234 + rank)  # in-graph ray / background sampling: different rays on every rank
     launch_mode = "eager"
