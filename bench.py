@@ -7,7 +7,7 @@ ray generation -> occupancy-grid march -> student (VM) forward -> teacher (hash)
 inherited samples -> compositing x2 -> distillation losses -> backward -> AdamW.  Inputs (poses,
 tables, occupancy bitfield) are resident in HBM when the timed region starts.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 20 --warmup 5
 
@@ -82,8 +82,8 @@ def cpu_baseline(workload, steps, num_rays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--student", type=str, default="vm")
     ap.add_argument("--teacher-pretrain", type=int, default=300)
