@@ -79,6 +79,64 @@ def cpu_baseline(workload, steps, num_rays):
                       "same weights and occupancy grid as the GPU run" % (steps, num_rays)}
 
 
+def teacher_workload(args, dev):
+    """BASELINE.json configs[1]: training step of the hash (INGP) teacher on the synthetic chair, 4096 rays/batch, incl. the
+    occupancy-grid update every 16 steps.  Eager launches (the sample budget changes with every grid update), so the
+    hash-lookup roofline is timed with HIP events INSIDE the timed region."""
+    import pvd_hip
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays
+    from pvd.trainer import TeacherTrainer, psnr
+    from pvd.workload import DistillWorkload, measure_mean_count
+
+    opt = PVDConfig(num_rays=args.rays, fp16=not args.fp32)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0)
+    topt = PVDConfig(**{**opt.__dict__, "model_type": opt.teacher_type, "iters": 30000, "stage_iters": {"stage1": -1, "stage2": -1}})
+    tea = w.tea
+    tea.teacher_variant = True
+    tea.requires_grad_(True).train()
+    tea.args = tea.opt = topt
+    tr = TeacherTrainer(topt, tea, dev, fp16=not args.fp32)
+    tea.mean_count = measure_mean_count(tea, w.poses, opt, generator=w.gen)
+    batches = []
+    for it in range(16):
+        r = get_rays(w.poses[it % len(w.poses)][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
+        bg = torch.rand(1, opt.num_rays, 3, device=dev, generator=w.gen)
+        batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
+    for it in range(args.warmup):
+        tr.train_step(*batches[it % 16])
+    torch.cuda.synchronize()
+    name = "pvd_grid_encode_forward"
+    t0 = time.perf_counter()
+    with pvd_hip.KernelTimer({name}) as kt:
+        for it in range(args.steps):
+            loss, pred = tr.train_step(*batches[it % 16])
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = kt.mean_ms(name)
+    B, D, C, L, dt_code = kt.meta[name][-1]
+    T = 2 if dt_code == 1 else 4
+    bps = grid_fwd_bytes_per_sample(D, C, L, T)
+    achieved = bps * B / (ms * 1e-3) / 1e9
+    out = {
+        "metric": "train rays/s (hash teacher training step)", "value": args.steps * args.rays / elapsed, "unit": "rays/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP) / f32 marcher+compositor",
+        "data": "synthetic (analytic chair-like scene; no dataset offline)",
+        "config": {"workload": "train hash teacher, synthetic chair, %d rays/step, occupancy update every %d steps, eager launches"
+                               % (args.rays, topt.update_extra_interval), "rays_per_gpu": args.rays, "parallelism": "single GPU",
+                   "launch": "eager", "psnr_vs_analytic_gt_db": float(psnr(pred.detach(), batches[(args.steps - 1) % 16][2])),
+                   "loss": float(loss)},
+        "roofline": {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward), HIP events inside the timed region" % ("f16" if T == 2 else "f32"),
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps, "samples_per_launch": B,
+                     "us_per_launch": ms * 1e3, "launches": kt.launches(name)},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +149,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--fp32", action="store_true", help="disable AMP (the reference forces fp16 on)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
+    ap.add_argument("--workload", choices=["distill", "teacher"], default="distill",
+                    help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +170,9 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, "--gpus must match WORLD_SIZE"
+    if args.workload == "teacher":
+        assert world == 1, "the teacher workload is single-GPU"
+        return teacher_workload(args, dev)
 
     import pvd_hip
     from pvd.config import PVDConfig
