@@ -84,7 +84,9 @@ class RayDP:
     """Ray-level data parallel context.  world_size == 1 -> every collective is a no-op."""
 
     def __init__(self, group=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # PVD_DP_FORCE=1 keeps every collective live in a world of one rank (test mode: the communication library's
+        # streams / watchdog next to graph capture, on a single-GPU box)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("PVD_DP_FORCE") == "1")
         self.group = group
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0

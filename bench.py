@@ -163,8 +163,14 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # PVD_DP_FORCE=1: run the ray-DP code path (collectives, segmented capture, compact exchange) in a world of ONE rank,
+    # so that RCCL itself (its streams and watchdog thread next to graph capture) is exercised on a single-GPU box
+    force_dp = os.environ.get("PVD_DP_FORCE") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
@@ -183,7 +189,7 @@ def main():
     opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type="hash", fp16=not args.fp32)
     dp = RayDP()
     w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp)
-    if world > 1:  # replicas must start bit-identical (teacher pre-training uses float atomics)
+    if dp.enabled:  # replicas must start bit-identical (teacher pre-training uses float atomics)
         for m in (w.tea, w.stu):
             for t in list(m.parameters()) + list(m.buffers()):
                 d = t.data
@@ -213,13 +219,13 @@ def main():
     for _ in range(args.warmup):
         w.step()
 
-    if world > 1:
+    if dp.enabled:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, info, pred_stu, pred_tea = w.step()
-    if world > 1:
+    if dp.enabled:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -292,7 +298,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
