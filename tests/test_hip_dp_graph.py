@@ -73,3 +73,40 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
     # same batches, same update rule: pipelining the next step's prefix under the exchange does not change the training
     # (float atomics in the backward perturb the trajectory in the last digits only)
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
+
+
+def _rccl_worker(rank, port, out_path):
+    os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.trainer import RayDP
+    from pvd.workload import DistillWorkload
+    dp = RayDP()
+    assert dp.enabled and dp.world_size == 1
+    opt = PVDConfig(num_rays=1024, resolution0=64, iters=300)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0, dp=dp)
+    torch.cuda.manual_seed(100)
+    w.enable_graph()
+    cap = w.trainer._cap
+    assert len(cap.graphs) == 3 and len(cap.between) == 2
+    assert getattr(w.trainer, "_g_prefix", None) is not None
+    losses = [float(w.step()[1]["rgb"]) for _ in range(40)]
+    torch.cuda.synchronize()
+    torch.save({"losses": losses}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_collectives_between_captured_segments(tmp_path):
+    """The same segmented capture with the REAL backend (nccl == RCCL) in a world of one rank: RCCL's streams and watchdog
+    thread run next to the captures (thread_local capture mode), the all-reduces are eager between replays."""
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    losses = torch.load(out)["losses"]
+    assert len(losses) == 40 and all(l == l for l in losses) and losses[-1] < losses[0]
