@@ -171,6 +171,42 @@ __global__ void __launch_bounds__(kOptBlock) k_check_finite(const float *__restr
     if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
 }
 
+// ---- segment-table operations over the flat gradient buffer.  The rows of a VM plane / Plenoxel volume that can receive a
+// gradient at all are known from the occupancy grid (harness: pvd/dp_compact.py); zeroing, the inf check and the ray-DP
+// gather/scatter then only touch those rows.  segs[s] = {start (flat), dst (compact), len}, one workgroup per segment.
+enum { kSegZero = 0, kSegGather = 1, kSegScatter = 2, kSegCheck = 3 };
+template <int OP>
+__global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat, float *__restrict__ buf, const uint32_t *__restrict__ segs,
+                                                        uint32_t n_segs, float *__restrict__ found_inf) {
+    bool bad = false;
+    for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
+        const uint32_t start = segs[3 * s], dst = segs[3 * s + 1], len = segs[3 * s + 2];
+        if (((start | dst | len) & 3u) == 0) {
+            float4 *f4 = reinterpret_cast<float4 *>(flat + start);
+            float4 *b4 = reinterpret_cast<float4 *>(buf + dst);
+            for (uint32_t i = threadIdx.x; i < (len >> 2); i += kOptBlock) {
+                if (OP == kSegZero) f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (OP == kSegGather) b4[i] = f4[i];
+                if (OP == kSegScatter) f4[i] = b4[i];
+                if (OP == kSegCheck) {
+                    const float4 G = f4[i];
+                    const uint32_t a = __float_as_uint(G.x), b = __float_as_uint(G.y), c = __float_as_uint(G.z), d = __float_as_uint(G.w);
+                    bad |= ((a & 0x7f800000u) == 0x7f800000u) | ((b & 0x7f800000u) == 0x7f800000u) | ((c & 0x7f800000u) == 0x7f800000u) |
+                           ((d & 0x7f800000u) == 0x7f800000u);
+                }
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < len; i += kOptBlock) {
+                if (OP == kSegZero) flat[start + i] = 0.f;
+                if (OP == kSegGather) buf[dst + i] = flat[start + i];
+                if (OP == kSegScatter) flat[start + i] = buf[dst + i];
+                if (OP == kSegCheck) bad |= (__float_as_uint(flat[start + i]) & 0x7f800000u) == 0x7f800000u;
+            }
+        }
+    }
+    if (OP == kSegCheck && __ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+}
+
 // partials[block] = sum over the block's elements of coef[range] * |p|
 __global__ void __launch_bounds__(kOptBlock) k_l1_partial(const float *__restrict__ p, AdamExtras ex, float *__restrict__ partials) {
     __shared__ float red[kOptBlock / 64];
@@ -295,6 +331,23 @@ int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_check_finite_f16, dim3((uint32_t)blocks), dim3(kOptBlock), 0, (hipStream_t)stream, (const _Float16 *)g, n >> 3,
                        found_inf);
+    return check_launch();
+}
+
+int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf, pvd_stream_t stream) {
+    if (op < kSegZero || op > kSegCheck) return PVD_ERR_INVALID;
+    if (n_segs == 0) return PVD_OK;
+    if (!flat || !segs) return PVD_ERR_INVALID;
+    if ((op == kSegGather || op == kSegScatter) && !buf) return PVD_ERR_INVALID;
+    if (op == kSegCheck && !found_inf) return PVD_ERR_INVALID;
+    const dim3 grid(n_segs < 65535u * 16u ? n_segs : 65535u * 16u), block(kOptBlock);
+    hipStream_t s = (hipStream_t)stream;
+    switch (op) {
+        case kSegZero: hipLaunchKernelGGL(k_segments<kSegZero>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+        case kSegGather: hipLaunchKernelGGL(k_segments<kSegGather>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+        case kSegScatter: hipLaunchKernelGGL(k_segments<kSegScatter>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+        default: hipLaunchKernelGGL(k_segments<kSegCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+    }
     return check_launch();
 }
 

@@ -99,9 +99,62 @@ class GradCompactor:
         self.fraction = kept / max(total, 1)
         self.idx = torch.cat(parts).to(torch.int64) if parts else None
         self.bitfield_version = model.density_bitfield._version
+        self.segs = segments_of(self.idx) if self.idx is not None else None  # the same set as a run table, for the HIP kernels
 
+    # On the GPU the set is walked as a run table by pvd_segments_op (one workgroup per run, float4 moves) instead of an
+    # int64 index per element; on the CPU (gloo tests) it is plain torch indexing.
     def gather(self, flat):
+        if flat.is_cuda:
+            import pvd_hip
+            buf = torch.empty(self.idx.numel(), dtype=flat.dtype, device=flat.device)
+            pvd_hip.segments_op(pvd_hip.SEG_GATHER, flat, self.segs, buf=buf)
+            return buf
         return flat.index_select(0, self.idx)
 
     def scatter(self, flat, buf):
-        flat.index_copy_(0, self.idx, buf)
+        if flat.is_cuda:
+            import pvd_hip
+            pvd_hip.segments_op(pvd_hip.SEG_SCATTER, flat, self.segs, buf=buf)
+        else:
+            flat.index_copy_(0, self.idx, buf)
+
+    def zero(self, flat):
+        """flat[idx] = 0: all a zero_grad has to do once the rest of the buffer is known to be zero."""
+        if flat.is_cuda:
+            import pvd_hip
+            pvd_hip.segments_op(pvd_hip.SEG_ZERO, flat, self.segs)
+        else:
+            flat.index_fill_(0, self.idx, 0.0)
+
+    def check_finite(self, flat, found_inf):
+        """found_inf[0] = 1 if flat[idx] holds an inf / nan (everything outside idx is zero)."""
+        if flat.is_cuda:
+            import pvd_hip
+            pvd_hip.segments_op(pvd_hip.SEG_CHECK, flat, self.segs, found_inf=found_inf)
+        else:
+            found_inf.masked_fill_(~torch.isfinite(flat.index_select(0, self.idx)).all(), 1.0)
+
+
+SEG_MAX = 4096  # elements per run-table entry = per workgroup
+
+
+def segments_of(idx, seg_max=SEG_MAX):
+    """Sorted unique element indices -> run table [n, 3] int32 (start, dst, len): maximal runs of consecutive indices, cut
+    into pieces of at most seg_max elements; dst = position of the piece in the compact order."""
+    n = idx.numel()
+    dev = idx.device
+    if n == 0:
+        return torch.zeros(0, 3, dtype=torch.int32, device=dev)
+    assert int(idx[-1]) < 2 ** 31
+    brk = torch.ones(n, dtype=torch.bool, device=dev)
+    brk[1:] = idx[1:] != idx[:-1] + 1
+    run_pos = brk.nonzero().squeeze(-1)  # compact position where each run starts
+    run_len = torch.diff(torch.cat([run_pos, torch.tensor([n], device=dev)]))
+    pieces = (run_len + seg_max - 1) // seg_max
+    run_of = torch.repeat_interleave(torch.arange(run_pos.numel(), device=dev), pieces)
+    first = torch.cumsum(pieces, 0) - pieces  # index of each run's first piece
+    k = torch.arange(run_of.numel(), device=dev) - first[run_of]  # piece number inside its run
+    dst = run_pos[run_of] + k * seg_max
+    length = torch.minimum(run_len[run_of] - k * seg_max, torch.tensor(seg_max, device=dev))
+    start = idx[run_pos][run_of] + k * seg_max
+    return torch.stack([start, dst, length], dim=1).to(torch.int32).contiguous()

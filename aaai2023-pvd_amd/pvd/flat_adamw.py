@@ -49,10 +49,34 @@ class FlatAdamW(torch.optim.Optimizer):
         for k, g in enumerate(self.param_groups):
             g["lr"] = self.lr_dev[k:k + 1]  # LRScheduler.step() fills tensor lrs in place
 
+    touched = None  # set_touched(): the only entries of flat_g anything ever writes (pvd/dp_compact.py), or None = all
+    _outside_is_zero = False
+
+    def set_touched(self, touched):
+        """touched: an object with zero(flat) / check_finite(flat, flag) over a fixed index set, under the caller's
+        guarantee that no gradient is ever written outside that set.  zero_grad and the scaler's inf check then walk
+        only the set (after one full zero)."""
+        self.touched = touched
+        self._outside_is_zero = False
+
     def zero_grad(self, set_to_none=False):
         self._half_grad = None
-        self.flat_g.zero_()
+        if self.touched is not None and self._outside_is_zero:
+            self.touched.zero(self.flat_g)
+        else:
+            self.flat_g.zero_()
+            self._outside_is_zero = self.touched is not None
         self.reattach()
+
+    def check_finite(self, flag):
+        """flag[0] = 1 if a gradient is inf / nan (read-only; never cleared here)."""
+        if self.touched is not None and self._outside_is_zero:
+            self.touched.check_finite(self.flat_g, flag)
+        else:
+            pvd_hip.check_finite(self.flat_g, flag)
+        hg = getattr(self, "_half_grad", None)
+        if hg is not None:
+            pvd_hip.check_finite_f16(hg[2], flag)
 
     def reattach(self):
         for p, o in zip(self.params, self.offsets):
@@ -159,10 +183,7 @@ class FlatGradScaler(torch.amp.GradScaler):
         flag = getattr(optimizer, "_found_inf_flag", None)
         if flag is None:
             flag = optimizer._found_inf_flag = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_g.device)
-        pvd_hip.check_finite(optimizer.flat_g, flag)
-        hg = getattr(optimizer, "_half_grad", None)
-        if hg is not None:
-            pvd_hip.check_finite_f16(hg[2], flag)
+        optimizer.check_finite(flag)
         optimizer.grad_scale, optimizer.found_inf = self._scale, flag
         optimizer.amp_update = (self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval)
         try:
@@ -187,9 +208,6 @@ class FlatGradScaler(torch.amp.GradScaler):
             return super()._check_inf_per_device(optimizer)
         _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
         found_inf = torch.full((), 0.0, dtype=torch.float32, device=_scale.device)
-        pvd_hip.check_finite(optimizer.flat_g, found_inf.view(1))
-        hg = getattr(optimizer, "_half_grad", None)
-        if hg is not None:
-            pvd_hip.check_finite_f16(hg[2], found_inf.view(1))
+        optimizer.check_finite(found_inf.view(1))
         self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = {_scale.device: found_inf}
         return self._per_optimizer_states[id(optimizer)]["found_inf_per_device"]

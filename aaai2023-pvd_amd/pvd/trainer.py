@@ -270,6 +270,8 @@ class _TrainerBase:
         if m.model_type == "vm" and o.l1_reg_weight > 0.0 and not self.flat_opt:
             return None  # autograd writes w/n * sign(p) into every sigma-plane entry
         c = getattr(self, "_compactor", None)
+        if c is not None and c.bitfield_version != m.density_bitfield._version:
+            c = None  # the occupancy grid was rewritten: the touched rows changed
         if c is None:
             from .dp_compact import GradCompactor
             offs = self.optimizer.offsets if self.flat_opt else None
@@ -281,6 +283,17 @@ class _TrainerBase:
             c = GradCompactor(m, self.flat.params, offs, self.device)
             self._compactor = c
         return c if c.fraction < 0.7 else None
+
+    def _zero_grads(self):
+        """zero_grad.  With the flat optimizer and a frozen occupancy grid only the rows a sample can touch are ever
+        written (the same set the compact exchange moves), so after one full clear only those are cleared and
+        inf-checked (FlatAdamW.set_touched); PVD_TOUCHED_SET=0 turns that off."""
+        if self.flat_opt:
+            import os
+            c = self._grad_compactor() if os.environ.get("PVD_TOUCHED_SET", "1") != "0" else None
+            if c is not self.optimizer.touched:
+                self.optimizer.set_touched(c)
+        self.flat.zero_()
 
     def _exchange(self):
         if self.dp.enabled:
@@ -316,7 +329,7 @@ class _TrainerBase:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.flat.zero_()
+                self._zero_grads()
                 out = body()
                 self._backward(out[0])
                 self._exchange()
@@ -330,7 +343,7 @@ class _TrainerBase:
         self.dp.capture = cap
         try:
             with cap:
-                self.flat.zero_()
+                self._zero_grads()
                 self._static_out = body()
                 if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
                     raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
@@ -484,7 +497,7 @@ class DistillTrainer(_TrainerBase):
         return loss, info, pred_stu, pred_tea
 
     def train_step(self, rays_o, rays_d, bg_color, nears_fars=None):
-        self.flat.zero_()
+        self._zero_grads()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color, nears_fars)
         self._backward_and_step(loss)
@@ -511,7 +524,7 @@ class DistillTrainer(_TrainerBase):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # eager warm-up steps (also build the compactor, the communicators, the caches)
             for _ in range(3):
-                self.flat.zero_()
+                self._zero_grads()
                 out = body()
                 self._backward(out[0])
                 self._exchange()
@@ -560,7 +573,7 @@ class TeacherTrainer(_TrainerBase):
         if m.cuda_ray and self.global_step % o.update_extra_interval == 0:
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
                 m.update_extra_state()
-        self.flat.zero_()
+        self._zero_grads()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                            dt_gamma=o.dt_gamma, max_steps=o.max_steps)

@@ -51,7 +51,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -659,6 +659,28 @@ def check_finite_f16(g, found_inf):
     dev = _dev(g, found_inf)
     _want(g, torch.float16, "g"), _want(found_inf, torch.float32, "found_inf")
     _call("pvd_check_finite_f16", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
+
+
+SEG_ZERO, SEG_GATHER, SEG_SCATTER, SEG_CHECK = 0, 1, 2, 3
+
+
+def segments_op(op, flat, segs, buf=None, found_inf=None):
+    """pvd_segments_op: zero / gather / scatter / inf-check the [start, start+len) ranges of `flat` listed in
+    segs [n, 3] int32 = (start, dst, len); `dst` indexes the compact buffer `buf`."""
+    dev = _dev(flat, segs, buf, found_inf)
+    _f32_all(flat=flat)
+    _want(segs, torch.int32, "segs")
+    if segs.dim() != 2 or segs.shape[1] != 3 or not segs.is_contiguous():
+        raise PvdHipError("segs must be a contiguous [n, 3] int32 tensor")
+    if op in (SEG_GATHER, SEG_SCATTER):
+        if buf is None:
+            raise PvdHipError("gather / scatter need the compact buffer")
+        _f32_all(buf=buf)
+    if op == SEG_CHECK:
+        if found_inf is None:
+            raise PvdHipError("the inf check needs found_inf")
+        _f32_all(found_inf=found_inf)
+    _call("pvd_segments_op", dev, ctypes.c_int(op), _p(flat), _p(buf), _p(segs), ctypes.c_uint32(segs.shape[0]), _p(found_inf))
 
 
 def l1_ranges(p, ranges, scratch, out=None):

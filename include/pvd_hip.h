@@ -397,6 +397,16 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
 int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream);
 int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream_t stream); /* n multiple of 8 */
 
+/* Segment-table operations over a flat f32 buffer.  segs = n_segs x {start, dst, len} (uint32, in elements): `start`
+ * indexes `flat`, `dst` indexes the compact buffer `buf`.  Only the table rows the occupancy grid lets a sample touch can
+ * ever hold a gradient, so the per-step zero_grad (utils.py:1012 `optimizer.zero_grad()`), GradScaler's inf check
+ * (utils.py:1016 `scaler.step`) and the ray-DP gradient exchange only need those rows.
+ *   op 0: flat[start+i] = 0            op 1: buf[dst+i] = flat[start+i]   (gather)
+ *   op 2: flat[start+i] = buf[dst+i]   op 3: found_inf[0] = 1 if any flat[start+i] is inf/nan (never cleared)
+ * Segments whose start, dst and len are multiples of 4 move as float4. */
+int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf,
+                    pvd_stream_t stream);
+
 /* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats).
  * out == NULL: only the 1024 partial sums are left in scratch (for pvd_distill_loss_final's `extra`). */
 int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *end_host, const float *coef_host,

@@ -300,3 +300,91 @@ def test_flat_adamw_half_gradient_equals_widen_and_add():
     assert ob.accept_half_grad(pb[1], h[: 4096 * 2 // 2].repeat(2).reshape(4096, 2).contiguous())
     scaler.step(ob); scaler.update()
     assert torch.equal(before, pb[1].detach()) and float(scaler.get_scale()) == 8.0
+
+
+def test_segments_op_matches_index_ops():
+    """pvd_segments_op (zero / gather / scatter / inf check over a run table) against torch indexing with the same set:
+    ragged runs, runs longer than one table entry, unaligned starts and lengths."""
+    import pvd_hip
+    from pvd.dp_compact import segments_of
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n = 300000
+    keep = torch.zeros(n, dtype=torch.bool)
+    for start, length in [(0, 5), (17, 1), (64, 4096 * 2 + 13), (20000, 48 * 300), (90001, 7), (120000, 16 * 1000), (n - 9, 9)]:
+        keep[start:start + length] = True
+    keep |= torch.rand(n, generator=g) < 0.01  # isolated elements and chance merges
+    idx = keep.nonzero().squeeze(-1).to(dev)
+    segs = segments_of(idx)
+    assert int(segs[:, 2].sum()) == idx.numel() and int(segs[:, 2].max()) <= 4096
+    flat = torch.randn(n, generator=g).to(dev)
+    buf = torch.empty(idx.numel(), device=dev)
+    pvd_hip.segments_op(pvd_hip.SEG_GATHER, flat, segs, buf=buf)
+    assert torch.equal(buf, flat[idx])
+    new = torch.randn(idx.numel(), generator=g).to(dev)
+    want = flat.clone()
+    want[idx] = new
+    pvd_hip.segments_op(pvd_hip.SEG_SCATTER, flat, segs, buf=new)
+    assert torch.equal(flat, want)
+    flag = torch.zeros(1, device=dev)
+    pvd_hip.segments_op(pvd_hip.SEG_CHECK, flat, segs, found_inf=flag)
+    assert float(flag) == 0.0
+    outside = (~keep).nonzero().squeeze(-1).to(dev)
+    flat[outside[5]] = float("inf")  # outside the set: not looked at
+    pvd_hip.segments_op(pvd_hip.SEG_CHECK, flat, segs, found_inf=flag)
+    assert float(flag) == 0.0
+    for bad in (float("nan"), float("-inf")):
+        f2 = flat.clone()
+        f2[idx[idx.numel() // 2 + 3]] = bad
+        flag.zero_()
+        pvd_hip.segments_op(pvd_hip.SEG_CHECK, f2, segs, found_inf=flag)
+        assert float(flag) == 1.0
+    want = flat.clone()
+    want[idx] = 0
+    pvd_hip.segments_op(pvd_hip.SEG_ZERO, flat, segs)
+    assert torch.equal(torch.nan_to_num(flat, posinf=7.0), torch.nan_to_num(want, posinf=7.0))
+    empty = torch.zeros(0, 3, dtype=torch.int32, device=dev)
+    pvd_hip.segments_op(pvd_hip.SEG_ZERO, flat, empty)  # no-op
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.segments_op(pvd_hip.SEG_GATHER, flat, segs)  # no compact buffer
+
+
+def test_touched_set_training_equals_dense_zero_and_check(monkeypatch):
+    """zero_grad / inf check restricted to the rows a sample can touch (FlatAdamW.set_touched) is the same training as
+    clearing and checking the whole buffer: identical gradients before the update, step by step."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PVD_TOUCHED_SET", mode)
+        opt = PVDConfig(num_rays=2048, resolution0=96, iters=200)
+        w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0)
+        tr = w.trainer
+        torch.cuda.manual_seed(5)
+        out = []
+        for it in range(5):
+            batch = w.next_batch()
+            tr._zero_grads()
+            assert (tr.optimizer.touched is not None) == (mode == "1")
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, *_ = tr.compute_loss(*batch)
+            tr._backward(loss)
+            out.append(tr.flat.flat.clone())
+            tr._exchange()
+            tr._optimize()
+            tr.scheduler.step()
+            tr.global_step += 1
+        grads[mode] = out
+        if mode == "1":
+            assert tr.optimizer._outside_is_zero
+            # a poisoned gradient inside the set is seen by the restricted check and skips the step
+            p0 = tr.optimizer.flat_p.clone()
+            tr._zero_grads()
+            tr.flat.flat[tr.optimizer.touched.idx[10]] = float("inf")
+            tr._optimize()
+            assert torch.equal(tr.optimizer.flat_p, p0)
+    for a, b in zip(grads["1"], grads["0"]):
+        # float atomics in the backward: same values up to summation order
+        assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-12

@@ -216,3 +216,23 @@ def test_dp_compact_footprint_mask_covers_every_sample_footprint(bound, cascade)
     # 3-D (Plenoxel volume)
     m3 = footprint_mask(boxes, aabb, [16, 20, 24], [0, 1, 2])
     assert m3.shape == (24, 20, 16) and m3.any() and not m3.all()
+
+
+def test_dp_compact_run_table_covers_the_index_set_exactly():
+    """segments_of(): the run table the HIP kernels walk lists exactly the index set, in compact order, in pieces of at most
+    seg_max elements."""
+    from pvd.dp_compact import segments_of
+    g = torch.Generator().manual_seed(0)
+    for n, p, seg_max in [(5000, 0.5, 64), (20000, 0.97, 256), (3000, 0.02, 4096), (10, 1.1, 4)]:
+        keep = torch.rand(n, generator=g) < p
+        idx = keep.nonzero().squeeze(-1)
+        segs = segments_of(idx, seg_max)
+        assert segs.dtype == torch.int32 and segs.shape[1] == 3
+        assert int(segs[:, 2].max()) <= seg_max and int(segs[:, 2].min()) >= 1
+        rebuilt = torch.cat([torch.arange(s, s + l) for s, d, l in segs.tolist()])
+        assert torch.equal(rebuilt, idx)
+        assert segs[:, 1].tolist() == (torch.cumsum(segs[:, 2], 0) - segs[:, 2]).tolist()  # dst = exclusive prefix sum
+        # maximal runs: consecutive pieces either continue a run cut at seg_max or are separated by a gap
+        for (s0, d0, l0), (s1, d1, l1) in zip(segs.tolist()[:-1], segs.tolist()[1:]):
+            assert s1 > s0 + l0 or (s1 == s0 + l0 and l0 == seg_max)
+    assert segments_of(torch.zeros(0, dtype=torch.int64)).shape == (0, 3)
