@@ -564,8 +564,10 @@ __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__rest
                                                              const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
                                                              uint32_t N, uint32_t C, uint32_t H, const float *__restrict__ nears,
                                                              const float *__restrict__ fars, int32_t *__restrict__ rays, uint32_t perturb,
-                                                             MarchRayRecords *__restrict__ records, const int32_t *__restrict__ counter) {
-    if (records && blockIdx.x == 0 && threadIdx.x == 0) records[N].n = (uint32_t)counter[0];  // the caller's running sample offset
+                                                             MarchRayRecords *__restrict__ records, const int32_t *__restrict__ counter,
+                                                             uint32_t fresh) {
+    // the caller's running sample offset (fresh: the counter is scratch, the offset is zero)
+    if (records && blockIdx.x == 0 && threadIdx.x == 0) records[N].n = fresh ? 0u : (uint32_t)counter[0];
     const uint32_t n = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
@@ -649,20 +651,34 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
                                                                const float *__restrict__ nears, const float *__restrict__ fars,
                                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
                                                                int32_t *__restrict__ rays, uint32_t perturb,
-                                                               const MarchRayRecords *__restrict__ records, int32_t *__restrict__ counter) {
-    __shared__ uint32_t part[kBlock / kWave];
+                                                               const MarchRayRecords *__restrict__ records, int32_t *__restrict__ counter,
+                                                               uint32_t fresh) {
+    __shared__ uint32_t part[kBlock / kWave], part_all[kBlock / kWave];
     const uint32_t n0 = blockIdx.x * kRaysPerBlock;
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // ---- exclusive prefix of the counts of rays [0, n0)
-    uint32_t acc = 0;
-    for (uint32_t i = threadIdx.x; i < n0; i += kBlock) acc += (uint32_t)rays[3 * (size_t)i + 2];
+    // ---- exclusive prefix of the counts of rays [0, n0)  (fresh: also the total, for the tail every workgroup helps to clear)
+    uint32_t acc = 0, all = 0;
+    const uint32_t n_sum = fresh ? N : n0;
+    for (uint32_t i = threadIdx.x; i < n_sum; i += kBlock) {
+        const uint32_t c = (uint32_t)rays[3 * (size_t)i + 2];
+        all += c;
+        acc += i < n0 ? c : 0u;
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
-    if (lane == 0) part[wid] = acc;
+    for (int off = 32; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off, kWave); all += __shfl_xor(all, off, kWave); }
+    if (lane == 0) { part[wid] = acc; part_all[wid] = all; }
     __syncthreads();
     uint32_t prefix = records[N].n;  // running offset the caller passed in counter[0]
+    uint32_t grand = prefix;
 #pragma unroll
-    for (uint32_t w = 0; w < kBlock / kWave; w++) prefix += part[w];
+    for (uint32_t w = 0; w < kBlock / kWave; w++) { prefix += part[w]; grand += part_all[w]; }
+    if (fresh && grand < M) {
+        // outputs arrive uninitialised: nobody writes [grand, M) (no ray was dropped, or grand >= M), clear it here, spread
+        // over the launch.  (When a ray IS dropped, grand >= M and the first dropped ray clears [its offset, M) below.)
+        const size_t stride = (size_t)gridDim.x * kBlock, first = (size_t)blockIdx.x * kBlock + threadIdx.x;
+        for (size_t i = 3 * (size_t)grand + first; i < 3 * (size_t)M; i += stride) { xyzs[i] = 0.f; dirs[i] = 0.f; }
+        for (size_t i = 2 * (size_t)grand + first; i < 2 * (size_t)M; i += stride) deltas[i] = 0.f;
+    }
     const uint32_t n = n0 + wid;
     uint32_t cnt[kRaysPerBlock];
 #pragma unroll
@@ -675,13 +691,19 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
 #pragma unroll
         for (uint32_t w = 0; w < kRaysPerBlock; w++) total += cnt[w];
         counter[0] = (int32_t)total;
-        counter[1] += (int32_t)N;
+        counter[1] = fresh ? (int32_t)N : counter[1] + (int32_t)N;
     }
     if (n >= N) return;
     const uint32_t num = cnt[wid];
     if (lane == 0) { rays[3 * (size_t)n] = (int32_t)n; rays[3 * (size_t)n + 1] = (int32_t)off; }
     if (num == 0) return;
-    if (off + num >= M) return;  // strict (:419)
+    if (off + num >= M) {  // strict (:419): dropped
+        if (fresh && off < M) {  // the first dropped ray (every later one starts at or beyond M): the rest of the buffers stays zero
+            for (size_t i = 3 * (size_t)off + lane; i < 3 * (size_t)M; i += kWave) { xyzs[i] = 0.f; dirs[i] = 0.f; }
+            for (size_t i = 2 * (size_t)off + lane; i < 2 * (size_t)M; i += kWave) deltas[i] = 0.f;
+        }
+        return;
+    }
     Dda r;
     r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
@@ -769,6 +791,9 @@ struct CompositeEpilogue {
     float bg_scalar;
     const float *nears, *fars;
     float depth_eps;
+    // backward only: grad buffers arrive uninitialised and `rays` is a table of pvd_march_rays_train (offsets = exclusive
+    // prefix sum of the counts in row order, from 0): the kernel clears every slot no ray owns
+    uint32_t fresh;
 };
 
 // reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
@@ -840,6 +865,18 @@ __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__re
     const uint32_t index = (uint32_t)rays[3 * (size_t)n];
     const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
+    if (EPI && ep.fresh) {
+        // slots nobody owns: [end of the last ray, M) when no ray was dropped (else that end is >= M), spread over the launch
+        const uint32_t end = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
+        for (size_t i = (size_t)end + (size_t)n * kWave + lane; i < M; i += (size_t)N * kWave) {
+            grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
+        }
+        // ... and [offset, M) of the first dropped ray (every later ray starts at or beyond M)
+        if (num != 0 && offset + num >= M)
+            for (size_t i = (size_t)offset + lane; i < M; i += kWave) {
+                grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
+            }
+    }
     if (num == 0 || offset + num >= M) return;
     float gws = grad_ws ? grad_ws[index] : 0.0f;
     const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
@@ -1117,26 +1154,37 @@ int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                          uint32_t perturb, pvd_stream_t stream) {
     return pvd_march_rays_train_ws(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
-                                   counter, perturb, nullptr, 0, stream);
+                                   counter, perturb, nullptr, 0, 0u, stream);
 }
 
 int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                             const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                            uint32_t perturb, void *workspace, size_t workspace_bytes, pvd_stream_t stream) {
-    if (N == 0) return PVD_OK;
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags, pvd_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const bool fresh = (flags & PVD_MARCH_FRESH) != 0;
+    if (N == 0) {
+        if (fresh && M && xyzs && dirs && deltas && counter) {
+            (void)hipMemsetAsync(xyzs, 0, 3 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(dirs, 0, 3 * (size_t)M * sizeof(float), s);
+            (void)hipMemsetAsync(deltas, 0, 2 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), s);
+        }
+        return PVD_OK;
+    }
     PVD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter);
     PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
-    hipStream_t s = (hipStream_t)stream;
+    MarchRayRecords *records = (dt_gamma == 0.0f && workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
+                                   ? (MarchRayRecords *)workspace : nullptr;
+    if (fresh && !records) {  // only the record path initialises what it does not write: do it up front for the others
+        (void)hipMemsetAsync(xyzs, 0, 3 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(dirs, 0, 3 * (size_t)M * sizeof(float), s);
+        (void)hipMemsetAsync(deltas, 0, 2 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), s);
+    }
     if (dt_gamma == 0.0f) {  // constant step: one wavefront per ray (all BASELINE configs)
         const dim3 g(div_up(N, kRaysPerBlock)), b(kBlock);
-        MarchRayRecords *records = (workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
-                                       ? (MarchRayRecords *)workspace : nullptr;
         hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb,
-                           records, counter);
+                           records, counter, records && fresh ? 1u : 0u);
         if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
             hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs,
-                               dirs, deltas, rays, perturb, records, counter);
+                               dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u);
             return check_launch();
         }
 #ifdef PVD_MARCH_PROFILE
@@ -1182,7 +1230,7 @@ int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, 
                                         float depth_eps, float *weights_sum, float *depth, float *image, pvd_stream_t stream) {
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && weights_sum && depth && image);
-    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps};
+    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps, 0u};
     hipLaunchKernelGGL(k_composite_fwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas,
                        rays, M, N, weights_sum, depth, image, ep);
     return check_launch();
@@ -1191,10 +1239,17 @@ int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, 
 int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
                                          const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
                                          uint32_t M, uint32_t N, const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs,
-                                         pvd_stream_t stream) {
-    if (N == 0) return PVD_OK;
+                                         uint32_t flags, pvd_stream_t stream) {
+    const bool fresh = (flags & PVD_MARCH_FRESH) != 0;
+    if (N == 0) {
+        if (fresh && M && grad_sigmas && grad_rgbs) {
+            (void)hipMemsetAsync(grad_sigmas, 0, (size_t)M * sizeof(float), (hipStream_t)stream);
+            (void)hipMemsetAsync(grad_rgbs, 0, 3 * (size_t)M * sizeof(float), (hipStream_t)stream);
+        }
+        return PVD_OK;
+    }
     PVD_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
-    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f};
+    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f, fresh ? 1u : 0u};
     hipLaunchKernelGGL(k_composite_bwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, ep);
     return check_launch();

@@ -93,14 +93,12 @@ class NeRFRenderer(nn.Module):
             if premarched:
                 i_march = False
             else:
-                counter = self.step_counter[self.local_step % 16]
-                if i_march:
-                    counter.zero_()
+                counter = self.step_counter[self.local_step % 16]  # set to zero (renderer.py:374): the scratch_counter flag below
                 self.local_step += 1
             if i_march:
                 xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
-                                                               force_all_rays, dt_gamma, max_steps)
+                                                               force_all_rays, dt_gamma, max_steps, True)
                 inherited_params = [xyzs, dirs, deltas, rays]
             else:
                 xyzs, dirs, deltas, rays = inherited_params
@@ -118,7 +116,7 @@ class NeRFRenderer(nn.Module):
                 sigmas = self.density_scale * sigmas
             eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
             # compositing + `image += (1 - ws) * bg` + depth normalisation (renderer.py:442-446) as one op
-            weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps)
+            weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True)  # rays: straight from the march
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays,
@@ -166,12 +164,11 @@ class NeRFRenderer(nn.Module):
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         nears, fars = nears_fars if nears_fars is not None else rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
-        counter = self.step_counter[self.local_step % 16]
-        counter.zero_()
+        counter = self.step_counter[self.local_step % 16]  # "counter.zero_()" (renderer.py:374) = the scratch_counter flag below
         self.local_step += 1
         xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                        nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
-                                                       max_steps)
+                                                       max_steps, True)
         return [xyzs, dirs, deltas, rays], (nears, fars)
 
     def _cell_centres(self, coords, cas, jitter):

@@ -96,7 +96,7 @@ def make_ops(backend, device_type="cuda"):
         @staticmethod
         @fwd32
         def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                    perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+                    perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, scratch_counter=False):
             rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
             rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
             density_bitfield = _to_dev(density_bitfield).contiguous()
@@ -108,13 +108,23 @@ def make_ops(backend, device_type="cuda"):
                     mean_count += align - mean_count % align
                 M = mean_count
             dev, dt = rays_o.device, rays_o.dtype
-            buf = torch.zeros(M * 8, dtype=dt, device=dev)  # one zero-fill for the three outputs (:240-242)
+            # scratch_counter: the caller does not care what step_counter held (run_cuda zeroes it right before, renderer.py:374).
+            # A backend with MARCH_FRESH then takes uninitialised outputs and counter and writes the zeros itself.
+            fresh = bool(getattr(backend, "MARCH_FRESH", False)) and (scratch_counter or step_counter is None)
+            alloc = torch.empty if fresh else torch.zeros
+            buf = alloc(M * 8, dtype=dt, device=dev)  # one zero-fill for the three outputs (:240-242)
             xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:].view(M, 2)
             rays = torch.empty(N, 3, dtype=torch.int32, device=dev)  # id, offset, num_steps
             if step_counter is None:
-                step_counter = torch.zeros(2, dtype=torch.int32, device=dev)  # point counter, ray counter
-            backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
-                                     xyzs, dirs, deltas, rays, step_counter, perturb)
+                step_counter = alloc(2, dtype=torch.int32, device=dev)  # point counter, ray counter
+            elif scratch_counter and not fresh:
+                step_counter.zero_()
+            if fresh:
+                backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
+                                         xyzs, dirs, deltas, rays, step_counter, perturb, fresh=True)
+            else:
+                backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
+                                         xyzs, dirs, deltas, rays, step_counter, perturb)
             # warm-up only: trim to the real count (D2H sync, :276-284)
             if force_all_rays or mean_count <= 0:
                 m = step_counter[0].item()
@@ -163,7 +173,8 @@ def make_ops(backend, device_type="cuda"):
 
         @staticmethod
         @fwd32
-        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps):
+        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False):
+            ctx.packed_rays = bool(packed_rays) and bool(getattr(backend, "MARCH_FRESH", False))
             sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
             M, N = sigmas.shape[0], rays.shape[0]
             bg_t = bg.reshape(-1, 3).contiguous().float() if torch.is_tensor(bg) else None
@@ -184,18 +195,25 @@ def make_ops(backend, device_type="cuda"):
         def backward(ctx, grad_weights_sum, grad_depth, grad_image):
             sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
             M, N = ctx.dims
-            gbuf = torch.zeros(sigmas.shape[0] * 4, dtype=sigmas.dtype, device=sigmas.device)  # one zero-fill (:339-340)
+            # packed_rays (a table of march_rays_train: slots in ray order, no gaps): the kernel itself zeroes the slots no
+            # ray owns; otherwise one zero-fill (:339-340)
+            gbuf = (torch.empty if ctx.packed_rays else torch.zeros)(sigmas.shape[0] * 4, dtype=sigmas.dtype, device=sigmas.device)
             grad_sigmas, grad_rgbs = gbuf[:sigmas.shape[0]], gbuf[sigmas.shape[0]:].view(-1, 3)
             gws = grad_weights_sum.contiguous() if grad_weights_sum is not None else None
             if grad_image is None:  # only weights_sum was used
                 grad_image = torch.zeros_like(image)
-            backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
-                                                     ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
-            return grad_sigmas, grad_rgbs, None, None, None, None, None, None
+            if ctx.packed_rays:
+                backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, fresh=True)
+            else:
+                backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
+            return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None
 
-    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps):
+    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False):
+        """packed_rays: `rays` comes straight from march_rays_train (offsets in ray order from 0, no gaps)."""
         if fused_bg:
-            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps)
+            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays)
         # reference formulation (used with the CPU oracle backend in the test-suite)
         weights_sum, depth, image = _CompositeTrain.apply(sigmas, rgbs, deltas, rays)
         if torch.is_tensor(bg):

@@ -105,12 +105,16 @@ int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
 /* Same, with a scratch buffer: pvd_march_workspace_bytes(N) bytes of device memory (256 B per ray).  The count pass
  * then records, per ray, the emit masks of the lattice chunks that produced samples, and the write pass rebuilds the
  * samples from them and folds the scan in (2 launches, no second walk of the occupancy grid).  Results are identical
- * to pvd_march_rays_train; workspace == NULL (or too small, or dt_gamma != 0, or N > 16384) takes that path. */
+ * to pvd_march_rays_train; workspace == NULL (or too small, or dt_gamma != 0, or N > 16384) takes that path.
+ * flags & PVD_MARCH_FRESH: xyzs / dirs / deltas and counter arrive UNINITIALISED (the reference's wrapper zero-fills
+ *   them first, raymarching.py:240-242, and run_cuda clears the counter, renderer.py:374): the counter is treated as
+ *   {0, 0} and every output element no ray owns is written as zero by the march itself -- same results, no fill launches. */
+#define PVD_MARCH_FRESH 1u
 size_t pvd_march_workspace_bytes(uint32_t N);
 int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                             const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                            uint32_t perturb, void *workspace, size_t workspace_bytes, pvd_stream_t stream);
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags, pvd_stream_t stream);
 
 /* composite_rays_train_forward -- raymarching.cu:585-593 (kernel :504-582). */
 int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
@@ -315,11 +319,14 @@ int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, 
                                         uint32_t M, uint32_t N, const float *bg, float bg_scalar, const float *nears,
                                         const float *fars, float depth_eps, float *weights_sum, float *depth, float *image,
                                         pvd_stream_t stream);
-/* grad_image is w.r.t. the BLENDED image; `image` is the blended image the forward returned; grad_weights_sum may be NULL. */
+/* grad_image is w.r.t. the BLENDED image; `image` is the blended image the forward returned; grad_weights_sum may be NULL.
+ * flags & PVD_MARCH_FRESH: grad_sigmas / grad_rgbs arrive uninitialised (the reference zero-fills them,
+ *   raymarching.py:339-340) and `rays` is a table written by pvd_march_rays_train (offsets = exclusive prefix sum of the
+ *   counts in row order, from 0): every slot no ray owns is written as zero by the kernel. */
 int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
                                          const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
                                          const float *image, uint32_t M, uint32_t N, const float *bg, float bg_scalar,
-                                         float *grad_sigmas, float *grad_rgbs, pvd_stream_t stream);
+                                         float *grad_sigmas, float *grad_rgbs, uint32_t flags, pvd_stream_t stream);
 
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)

@@ -388,3 +388,53 @@ def test_touched_set_training_equals_dense_zero_and_check(monkeypatch):
     for a, b in zip(grads["1"], grads["0"]):
         # float atomics in the backward: same values up to summation order
         assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-12
+
+
+@pytest.mark.parametrize("budget", ["slack", "half", "trimmed"])
+def test_composite_bg_backward_fresh_gradients(budget):
+    """packed_rays=True: the fused compositing backward takes UNINITIALISED gradient buffers and clears the slots no ray
+    owns itself (tail beyond the last ray, slots of dropped rays) -- same gradients as the zero-filled call."""
+    import pvd_hip
+    import raymarching
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    dev = torch.device("cuda:0")
+    N = 1500
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(2))).to(dev)
+    r = get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, N, generator=torch.Generator(device=dev).manual_seed(2))
+    bits = packbits_torch(ChairScene().density_grid(128, 1.0, 1, device=dev), 10.0)
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, counter, -1, True, 128, True)
+    total = int(counter[0])
+    if budget == "trimmed":
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)
+    else:
+        mc = total // 2 if budget == "half" else total * 5 // 4
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, mc, True, 128, False)
+    M = xyzs.shape[0]
+    rr = rays.cpu()
+    dropped = (rr[:, 2] > 0) & (rr[:, 1] + rr[:, 2] >= M)
+    assert bool(dropped.any()) == (budget == "half")
+    g = torch.Generator(device=dev).manual_seed(1)
+    sig0 = torch.exp(torch.rand(M, device=dev, generator=g) * 6 - 2)
+    rgb0 = torch.rand(M, 3, device=dev, generator=g)
+    bg = torch.rand(1, N, 3, device=dev, generator=g)
+    w_img = torch.randn(N, 3, device=dev, generator=g)
+    # poison the caching allocator's free blocks so that "uninitialised" is not accidentally zero
+    junk = [torch.full((M * 4,), float("nan"), device=dev) for _ in range(4)]
+    del junk
+    res = []
+    for packed in (True, False):
+        sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+        ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6, packed)
+        (img * w_img).sum().backward()
+        res.append((sig.grad.clone(), rgb.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
+    # and straight through the binding with NaN-filled buffers
+    gs, gr = torch.full((M,), float("nan"), device=dev), torch.full((M, 3), float("nan"), device=dev)
+    ws, depth, img = raymarching.composite_rays_train_bg(sig0, rgb0, deltas, rays, bg, nears, fars, 1e-6)
+    pvd_hip.composite_rays_train_bg_backward(None, w_img, sig0, rgb0, deltas, rays, ws, img, M, N, bg.reshape(-1, 3).contiguous(), 0.0, gs, gr,
+                                             fresh=True)
+    assert torch.equal(gs, res[1][0]) and torch.equal(gr, res[1][1])

@@ -394,3 +394,29 @@ def test_full_size_properties(hip, dev):
     hit = torch.from_numpy(r[:, 2] > 0).to(dev)
     assert torch.allclose(ws[hit], torch.ones_like(ws[hit]), atol=1e-6) and torch.allclose(img[hit], torch.full_like(img[hit], 0.25), atol=1e-6)
     assert bool((ws[~hit] == 0).all())
+
+
+@pytest.mark.parametrize("budget", ["half", "slack", "tight", "tiny", "all"])
+def test_march_fresh_outputs_equal_zero_filled_outputs(hip, dev, budget):
+    """PVD_MARCH_FRESH: outputs and counter handed over UNINITIALISED (here: NaN / garbage) come back bit-identical to the
+    zero-filled call and to the oracle -- budgets that drop trailing rays, leave a tail, hold no ray at all, or are the
+    worst case N * max_steps; record path and the fallback (no workspace: the library clears up front)."""
+    N = 1027
+    o, d, bits, C = _scene_rays(N, 11)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    total = int(oracle.march_rays_train(o, d, bits, 1.0, C, 128, n_ref, f_ref, N * 1024)[4][0])
+    M = {"half": total // 2 // 128 * 128, "slack": (total * 5 // 4) // 128 * 128 + 128, "tight": total, "tiny": 4, "all": N * 1024}[budget]
+    ref = oracle.march_rays_train(o, d, bits, 1.0, C, 128, n_ref, f_ref, M, perturb=1)
+    for use_ws in (True, False):
+        xyzs, dirs, deltas = (torch.full((M, k), float("nan"), device=dev) for k in (3, 3, 2))
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        counter = torch.tensor([123456, -7], dtype=torch.int32, device=dev)
+        hip.march_rays_train(t(o, dev), t(d, dev), t(bits, dev), 1.0, 0.0, 1024, N, C, 128, M, t(n_ref, dev), t(f_ref, dev),
+                             xyzs, dirs, deltas, rays, counter, 1, use_workspace=use_ws, fresh=True)
+        got = [x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)]
+        for name, a, b in zip(("xyzs", "dirs", "deltas", "rays", "counter"), ref, got):
+            assert np.array_equal(a, b), (name, use_ws)
+    r = ref[3]
+    dropped = (r[:, 2] > 0) & (r[:, 1] + r[:, 2] >= M)
+    assert dropped.any() == (budget in ("half", "tight", "tiny"))
