@@ -706,7 +706,7 @@ raymarching_backend = types.SimpleNamespace(
     morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
     composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward,
-    march_rays=march_rays, composite_rays=composite_rays, compact_rays=compact_rays,
+    march_rays=march_rays, composite_rays=composite_rays, compact_rays=compact_rays, MARCH_FRESH=MARCH_FRESH,
 )
 gridencoder_backend = types.SimpleNamespace(grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward)
 shencoder_backend = types.SimpleNamespace(sh_encode_forward=sh_encode_forward, sh_encode_backward=sh_encode_backward)

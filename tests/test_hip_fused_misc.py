@@ -425,11 +425,18 @@ def test_composite_bg_backward_fresh_gradients(budget):
     junk = [torch.full((M * 4,), float("nan"), device=dev) for _ in range(4)]
     del junk
     res = []
-    for packed in (True, False):
-        sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
-        ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6, packed)
-        (img * w_img).sum().backward()
-        res.append((sig.grad.clone(), rgb.grad.clone()))
+    calls = []
+    real = pvd_hip.raymarching_backend.composite_rays_train_bg_backward
+    pvd_hip.raymarching_backend.composite_rays_train_bg_backward = lambda *a, **k: (calls.append(k.get("fresh", False)), real(*a, **k))[1]
+    try:
+        for packed in (True, False):
+            sig, rgb = sig0.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+            ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6, packed)
+            (img * w_img).sum().backward()
+            res.append((sig.grad.clone(), rgb.grad.clone()))
+    finally:
+        pvd_hip.raymarching_backend.composite_rays_train_bg_backward = real
+    assert calls == [True, False]  # the wrapper really handed over uninitialised buffers the first time
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
     # and straight through the binding with NaN-filled buffers

@@ -420,3 +420,30 @@ def test_march_fresh_outputs_equal_zero_filled_outputs(hip, dev, budget):
     r = ref[3]
     dropped = (r[:, 2] > 0) & (r[:, 1] + r[:, 2] >= M)
     assert dropped.any() == (budget in ("half", "tight", "tiny"))
+
+
+def test_march_wrapper_scratch_counter_takes_the_fresh_path(hip, dev):
+    """raymarching.march_rays_train(..., scratch_counter=True) == the reference protocol (counter.zero_() + zero-filled
+    outputs), and it really is the no-fill path."""
+    import pvd_hip
+    import raymarching
+    N = 777
+    o, d, bits, C = _scene_rays(N, 4)
+    to, td_, tb = t(o, dev), t(d, dev), t(bits, dev)
+    nears, fars = raymarching.near_far_from_aabb(to, td_, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    calls = []
+    real = pvd_hip.raymarching_backend.march_rays_train
+    pvd_hip.raymarching_backend.march_rays_train = lambda *a, **k: (calls.append(k.get("fresh", False)), real(*a, **k))[1]
+    try:
+        outs = []
+        for scratch in (True, False):
+            junk = [torch.full((40000 * 8,), float("nan"), device=dev) for _ in range(3)]
+            del junk
+            counter = torch.tensor([999, 999], dtype=torch.int32, device=dev) if scratch else torch.zeros(2, dtype=torch.int32, device=dev)
+            res = raymarching.march_rays_train(to, td_, 1.0, tb, C, 128, nears, fars, counter, 40000, True, 128, False, 0, 1024, scratch)
+            outs.append([x.clone() for x in res] + [counter.clone()])
+    finally:
+        pvd_hip.raymarching_backend.march_rays_train = real
+    assert calls == [True, False]
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
