@@ -40,23 +40,46 @@ struct AdamExtras {
     float l1_next_scale;
 };
 
-// one thread: advance the step count (unless the GradScaler found an inf) and evaluate the schedule.
+// The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
 //   cosine: torch.optim.lr_scheduler.CosineAnnealingLR's closed form (main_distill_mutual.py:346-348)
 //   exponential: LambdaLR(0.1 ** min(iter / iters, 1)) (main_just_train_tea.py:293-296)
-__global__ void k_adamw_count(float *__restrict__ step, const float *__restrict__ found_inf, AdamExtras ex, float *__restrict__ lr,
-                              uint32_t n_segments) {
+__device__ __forceinline__ float scheduled_lr(const AdamExtras &ex, const float *__restrict__ lr, uint32_t k) {
+    if (ex.sched_kind == 0) return lr[k];
+    const double t = (double)ex.sched_step[0], base = (double)ex.base_lr[k];
+    double v;
+    if (ex.sched_kind == 1) v = (double)ex.sched_param + (base - (double)ex.sched_param) * (1.0 + cos(M_PI * t / (double)ex.sched_T)) * 0.5;
+    else v = base * pow((double)ex.sched_param, fmin(t / (double)ex.sched_T, 1.0));
+    return (float)v;
+}
+
+// One thread, AFTER the update: advance the step count (unless the GradScaler found an inf) and the scheduler tick, publish
+// the learning rates the update used; then GradScaler.update() on the device (torch's amp_update_scale_cuda_kernel: back
+// off on inf, grow after `interval` clean steps) and clear the inf flag for the next step -- one launch instead of a
+// counting launch before the update plus four host-issued scaler ops after it.
+__global__ void k_adamw_tail(float *__restrict__ step, float *__restrict__ found_inf, AdamExtras ex, float *__restrict__ lr, uint32_t n_segments,
+                             float *__restrict__ scale, int32_t *__restrict__ tracker, double growth, double backoff, int32_t interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!(found_inf && found_inf[0] != 0.f)) step[0] += 1.0f;
-    if (ex.sched_kind == 0) return;
-    const double t = (double)ex.sched_step[0];
-    ex.sched_step[0] += 1.0f;
-    for (uint32_t k = 0; k < n_segments; k++) {
-        const double base = (double)ex.base_lr[k];
-        double v;
-        if (ex.sched_kind == 1) v = (double)ex.sched_param + (base - (double)ex.sched_param) * (1.0 + cos(M_PI * t / (double)ex.sched_T)) * 0.5;
-        else v = base * pow((double)ex.sched_param, fmin(t / (double)ex.sched_T, 1.0));
-        lr[k] = (float)v;
+    const bool inf = found_inf && found_inf[0] != 0.f;
+    if (!inf) step[0] += 1.0f;
+    if (ex.sched_kind != 0) {
+        for (uint32_t k = 0; k < n_segments; k++) lr[k] = scheduled_lr(ex, lr, k);
+        ex.sched_step[0] += 1.0f;
     }
+    if (!scale) return;
+    if (inf) {
+        scale[0] = (float)((double)scale[0] * backoff);
+        tracker[0] = 0;
+    } else {
+        const int32_t ok = tracker[0] + 1;
+        if (ok == interval) {
+            const float ns = (float)((double)scale[0] * growth);
+            if (!isinf(ns)) scale[0] = ns;
+            tracker[0] = 0;
+        } else {
+            tracker[0] = ok;
+        }
+    }
+    found_inf[0] = 0.f;
 }
 
 __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
@@ -66,8 +89,11 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
                                                     const float *__restrict__ found_inf, AdamExtras ex) {
     if (found_inf && found_inf[0] != 0.f) return;  // GradScaler: skip the whole step (l1_next keeps describing the parameters)
     __shared__ float l1_sh[kOptBlock / 64];
+    __shared__ float lr_sh[kMaxSegments];
+    if (threadIdx.x < seg.count) lr_sh[threadIdx.x] = scheduled_lr(ex, lr, threadIdx.x);
+    __syncthreads();
     float l1_acc = 0.f;
-    const double t = (double)step[0];
+    const double t = (double)step[0] + 1.0;  // the tail kernel advances the stored count after the update
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, t));
     const uint64_t n4 = n >> 2;
@@ -78,7 +104,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         float l1 = 0.f;  // ranges are multiples of 4 elements too
         for (uint32_t r = 0; r < ex.n_l1; r++)
             if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
-        const double lrk = (double)lr[k];
+        const double lrk = (double)lr_sh[k];
         const float step_size = (float)(lrk / bc1);
         // the moments are touched exactly once per step: stream them past the caches (nt) so that the Infinity Cache keeps
         // the parameters and gradients the other kernels of the step come back to
@@ -122,27 +148,6 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             ex.l1_next[blockIdx.x] = sacc * ex.l1_next_scale;
         }
     }
-}
-
-// GradScaler.update() on the device (torch's amp_update_scale_cuda_kernel: back off on inf, grow after `interval` clean
-// steps), then clear the inf flag for the next step: one launch after the update instead of four host-issued ones.
-__global__ void k_adamw_amp_tail(float *__restrict__ scale, int32_t *__restrict__ tracker, float *__restrict__ found_inf, double growth,
-                                 double backoff, int32_t interval) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (found_inf[0] != 0.f) {
-        scale[0] = (float)((double)scale[0] * backoff);
-        tracker[0] = 0;
-    } else {
-        const int32_t ok = tracker[0] + 1;
-        if (ok == interval) {
-            const float ns = (float)((double)scale[0] * growth);
-            if (!isinf(ns)) scale[0] = ns;
-            tracker[0] = 0;
-        } else {
-            tracker[0] = ok;
-        }
-    }
-    found_inf[0] = 0.f;
 }
 
 // found_inf[0] = 1 if any element is inf / nan (never cleared here): the read-only half of
@@ -293,16 +298,15 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adamw_count, dim3(1), dim3(64), 0, s, step, found_inf, ex, lr, n_segments);
     uint64_t blocks = (n / 4 + kOptBlock - 1) / kOptBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, lr, beta1, beta2, eps, weight_decay, step,
                        grad_scale, found_inf, ex);
-    if (extras_host && extras_host->amp_scale) {
-        if (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1) return PVD_ERR_INVALID;
-        hipLaunchKernelGGL(k_adamw_amp_tail, dim3(1), dim3(64), 0, s, extras_host->amp_scale, extras_host->amp_growth_tracker,
-                           const_cast<float *>(found_inf), extras_host->amp_growth, extras_host->amp_backoff, extras_host->amp_interval);
-    }
+    const bool amp = extras_host && extras_host->amp_scale;
+    if (amp && (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1)) return PVD_ERR_INVALID;
+    hipLaunchKernelGGL(k_adamw_tail, dim3(1), dim3(64), 0, s, step, const_cast<float *>(found_inf), ex, lr, n_segments,
+                       amp ? extras_host->amp_scale : nullptr, amp ? extras_host->amp_growth_tracker : nullptr,
+                       amp ? extras_host->amp_growth : 0.0, amp ? extras_host->amp_backoff : 0.0, amp ? extras_host->amp_interval : 1);
     return check_launch();
 }
 
