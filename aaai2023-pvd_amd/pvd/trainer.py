@@ -281,8 +281,16 @@ class _TrainerBase:
                     offs.append(acc)
                     acc += p.numel()
             c = GradCompactor(m, self.flat.params, offs, self.device)
+            c.agreed = True
+            if self.dp.enabled and self.dp.capture is None and c.idx is not None:
+                # every rank must move the same rows (same buffer sizes in the collective, nothing left out): compare
+                # size and checksum of the index set once; on any disagreement ALL ranks use the dense exchange
+                sig = torch.tensor([c.idx.numel(), float(c.idx.sum())], dtype=torch.float64, device=self.device)
+                sig = torch.cat([sig, -sig])
+                dist.all_reduce(sig, op=dist.ReduceOp.MAX, group=self.dp.group)
+                c.agreed = bool(sig[0] == -sig[2]) and bool(sig[1] == -sig[3])
             self._compactor = c
-        return c if c.fraction < 0.7 else None
+        return c if (c.fraction < 0.7 and c.agreed) else None
 
     def _zero_grads(self):
         """zero_grad.  With the flat optimizer and a frozen occupancy grid only the rows a sample can touch are ever

@@ -48,7 +48,7 @@ OPT = dict(num_rays=256, resolution0=24, iters=50, fp16=False, model_type="vm",
            loss_rate_fea_sc=0.0, loss_rate_color=0.0, loss_rate_sigma=0.0)  # rgb norm + L1 reg: independent of row padding
 
 
-def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False):
+def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False, skew_rank=None):
     OPT = opt_kw or globals()["OPT"]
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -71,6 +71,12 @@ def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False):
 
     # --- the real trainer: every rank renders its half of the rays
     w = _make(OPT, dp=dp)
+    if skew_rank is not None and rank == skew_rank:
+        # a replica whose occupancy grid differs (must never happen; if it does the ranks must notice instead of hanging in
+        # a collective with different buffer sizes): one more occupied byte -> a different footprint mask on this rank only
+        bf = w.stu.density_bitfield
+        empty = (bf == 0).nonzero().squeeze(-1)
+        bf[empty[len(empty) // 2]] = 0xFF
     base = _make(OPT)  # only for the shared batch (same seed on every rank)
     rays_o, rays_d, bg = base.next_batch()
     half = OPT["num_rays"] // world
@@ -82,6 +88,11 @@ def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False):
     assert (c is not None) == expect_compact
     if expect_compact:
         assert 0.0 < c.fraction < 0.7
+    if skew_rank is not None:
+        assert w.trainer._compactor is not None and not w.trainer._compactor.agreed  # noticed on every rank
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # replicas identical after the step
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -178,3 +189,11 @@ def test_ray_dp_compact_exchange_is_exact(tmp_path):
     outside = torch.ones_like(flat, dtype=torch.bool)
     outside[c.idx] = False
     assert outside.any() and flat[outside].abs().max().item() == 0.0
+
+
+@pytest.mark.timeout(600)
+def test_ray_dp_ranks_with_different_masks_fall_back_to_the_dense_exchange(tmp_path):
+    """The compact exchange needs the same row set on every rank.  If a replica's occupancy grid differs, the one-off
+    agreement check (size + checksum, all-reduced) makes ALL ranks use the dense all-reduce -- no mismatched collective."""
+    _setup_paths()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path / "skew.pt"), OPT_COMPACT, False, 1), nprocs=2, join=True)
