@@ -412,6 +412,7 @@ struct HeadBwdArgs {
     HeadArgs f;
     const float *g_sigma;   // [M]      d loss / d sigma
     const float *g_rgb;     // [M][3]
+    const float *g_rgb2;    // [M][3] or null: a second consumer's gradient of the same rgb output, added while loading
     const float *g_feat16;  // [M][16]
     float *g_sigma_raw;     // VM: [M]
     half_t *g_x0;           // VM: d loss / d products [M][144];  hash: d loss / d encoder output [14][M][2]
@@ -489,7 +490,10 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
         TileGrad q = {0.f, 0.f, 0.f, 0.f, zero};
         if (valid) {
             q.feat = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
-            if (hi == 0) { q.r = a.g_rgb[3 * b]; q.g = a.g_rgb[3 * b + 1]; q.bl = a.g_rgb[3 * b + 2]; q.sig = a.g_sigma[b]; }
+            if (hi == 0) {
+                q.r = a.g_rgb[3 * b]; q.g = a.g_rgb[3 * b + 1]; q.bl = a.g_rgb[3 * b + 2]; q.sig = a.g_sigma[b];
+                if (a.g_rgb2) { q.r += a.g_rgb2[3 * b]; q.g += a.g_rgb2[3 * b + 1]; q.bl += a.g_rgb2[3 * b + 2]; }
+            }
         }
         return q;
     };
@@ -797,8 +801,8 @@ int pvd_head_backward_workspace_floats(int kind, uint32_t M) {
 int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
                       const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
                       float clip_max,
-                      const float *g_sigma, const float *g_rgb, const float *g_feat16, float *g_sigma_raw, void *g_x0, float *gWa1,
-                      float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
+                      const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16, float *g_sigma_raw, void *g_x0,
+                      float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_x0 || !gWa1 || !gWc1 || !gWc2 || !gWc3 ||
         !workspace)
@@ -808,7 +812,7 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
     a.f.Wa1 = Wa1; a.f.Wa2 = Wa2; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
     a.f.clip_sigma_min = clip_sigma_min; a.f.clip_feat_min = clip_feat_min; a.f.clip_max = clip_max;
     a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr; a.f.image = (const half_t *)image;
-    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_rgb2 = g_rgb2; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
     a.partials = workspace;
     const uint32_t nwaves = head_bwd_waves(kind, M);
     if (kind == KIND_VM) {

@@ -97,16 +97,23 @@ class _VMHeadTrain(torch.autograd.Function):
         ctx.clips = (smin, fmin, cmax)
         ctx.leaves = (Wb, Wc1, Wc2, Wc3)
         ctx.set_materialize_grads(False)
-        return sigma, rgb, feat
+        # rgb feeds the compositing AND the colour term of the distillation objective: hand it out twice (same storage, two
+        # autograd outputs) so that the two gradients arrive separately and the backward kernel adds them while loading,
+        # instead of autograd launching an elementwise add in between
+        rgb_l = torch.empty(0, dtype=rgb.dtype, device=rgb.device).set_(rgb.untyped_storage(), rgb.storage_offset(), rgb.shape, rgb.stride())
+        return sigma, rgb, feat, rgb_l
 
     @staticmethod
-    def backward(ctx, g_sigma, g_rgb, g_feat):
+    def backward(ctx, g_sigma, g_rgb, g_feat, g_rgb_l):
         sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3 = ctx.saved_tensors
         M = prod.shape[0]
         dev = prod.device
         zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         g_sigma = g_sigma.float().contiguous() if g_sigma is not None else zeros(M)
+        if g_rgb is None:
+            g_rgb, g_rgb_l = g_rgb_l, None
         g_rgb = g_rgb.float().contiguous() if g_rgb is not None else zeros(M, 3)
+        g_rgb_l = g_rgb_l.float().contiguous() if g_rgb_l is not None else None
         g_feat = g_feat.float().contiguous() if g_feat is not None else zeros(M, 16)
         g_sraw = torch.empty(M, dtype=torch.float32, device=dev)
         g_prod = torch.empty(M, 144, dtype=torch.float16, device=dev)
@@ -115,12 +122,14 @@ class _VMHeadTrain(torch.autograd.Function):
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
         grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
         pvd_hip.head_backward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
-                              g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws, image=ctx.image)
+                              g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws, image=ctx.image,
+                              g_rgb2=g_rgb_l)
         gw = (None, None, None, None) if direct else tuple(grads)
         return (g_sraw, g_prod, None) + gw + (None, None, None)
 
 
 def vm_head_train(model, sigma_raw, prod, d):
+    """-> (sigma, rgb, feature_sigma_color, rgb_l): rgb_l is rgb again, for the colour term of the objective (see above)."""
     a = model.args
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
     return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,

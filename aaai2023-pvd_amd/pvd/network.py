@@ -5,6 +5,7 @@ reference checkpoints line up (``encoder.embeddings``, ``sigma_net.N.weight``,
 ``color_net.N.weight``, ``sigma_mat.N`` ...).
 """
 import ast
+import os
 
 import torch
 import torch.nn as nn
@@ -247,12 +248,13 @@ class NeRFNetwork(NeRFRenderer):
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student
             if out is not None:
-                sigma, color, feat = out
+                sigma, color, feat = out[:3]
                 self.feature_sigma_color = feat
                 if self._in_stage1():
                     return None, None
                 self.sigma_l = feat[..., 0]
-                self.color_l = color
+                # a second handle on the same values: the fused backward adds the two gradients (PVD_HEAD_RGB2=0: autograd does)
+                self.color_l = out[3] if (len(out) > 3 and os.environ.get("PVD_HEAD_RGB2", "1") != "0") else color
                 return sigma, color
         if self.model_type == "vm":
             sigma_raw, color_raw = self.vm_features(x)

@@ -532,7 +532,7 @@ def head_backward_workspace_floats(kind, M):
 
 
 def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
-                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, image=None):
+                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, image=None, g_rgb2=None):
     """kind 1 (vm): x0 = products [M,144], g_x0 same layout.  kind 0 (hash): x0 = encoder output [14,M,2], g_x0 same."""
     dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_x0, workspace)
     _want(x0, torch.float16, "x0"), _want(g_x0, torch.float16, "g_x0")
@@ -547,8 +547,13 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
     if workspace.numel() < head_backward_workspace_floats(kind, M):
         raise PvdHipError("workspace too small")
     _check_image(kind, image)
+    if g_rgb2 is not None:
+        _dev(g_rgb, g_rgb2)
+        _f32_all(g_rgb2=g_rgb2)
+        if g_rgb2.shape != g_rgb.shape:
+            raise PvdHipError("g_rgb2 must have the shape of g_rgb")
     _call("pvd_head_backward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
-          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
+          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_rgb2), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
           _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
 
 

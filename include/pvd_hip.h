@@ -253,13 +253,15 @@ int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const fl
  *                         sigma_raw / g_sigma_raw unused (NULL).
  *   gWc1 [64][31], gWc2 [64][64], gWc3 [3][64]: color_net.
  * g_sigma [M], g_rgb [M][3], g_feat16 [M][16]: incoming gradients (f32) of pvd_head_forward's three outputs.
+ * g_rgb2 [M][3] or NULL: a second gradient of the rgb output (it feeds both the compositing and the colour term of the
+ *   distillation objective, utils.py:1158-1176), added while loading instead of by a separate elementwise launch.
  * workspace: pvd_head_backward_workspace_floats(kind, M) floats of scratch (per-wave dW partials).
  * Replaces autograd through network.py:395-447 (hash) / 353-393 (vm). */
 int pvd_head_backward_workspace_floats(int kind, uint32_t M);
 int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
                       const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
                       const void *image, float clip_sigma_min, float clip_feat_min, float clip_max,
-                      const float *g_sigma, const float *g_rgb, const float *g_feat16,
+                      const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16,
                       float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3,
                       float *workspace, pvd_stream_t stream);
 

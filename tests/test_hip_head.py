@@ -90,25 +90,37 @@ def test_vm_head_backward_matches_layerwise_autograd():
     names = ["basis_mat.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight"]
     params = dict(m.named_parameters())
 
-    def run(fused):
+    w_rgb_b = torch.randn(M, 3, device="cuda", generator=g)
+
+    def run(fused, split="both"):
         sraw = sraw0.clone().requires_grad_(True)
         prod = prod0.clone().requires_grad_(True)
         for n in names:
             params[n].grad = None
         with torch.autocast("cuda", dtype=torch.float16):
             if fused:
-                sig, rgb, feat = fusedhead.vm_head_train(m, sraw, prod, d)
+                sig, rgb, feat, rgb_l = fusedhead.vm_head_train(m, sraw, prod, d)
+                assert rgb_l.data_ptr() == rgb.data_ptr()  # the same values, a second autograd output
             else:
                 a = m.args
                 cf = torch.clamp(m.linear(prod, m.basis_mat.weight), a.sigma_clip_min, a.sigma_clip_max)
                 sf = torch.clamp(sraw, a.sigma_clip_min, a.sigma_clip_max)
                 feat = torch.cat([sf.unsqueeze(-1), cf], dim=-1)
                 sig = m.trunc_exp(sf)
-                rgb = m._color_head(m.encoder_dir(d), cf)
-        loss = (sig.float() * w_sig).sum() + (rgb.float() * w_rgb).sum() + (feat.float() * w_fea).sum()
+                rgb = rgb_l = m._color_head(m.encoder_dir(d), cf)
+        # rgb has two consumers (compositing, colour term): the fused backward adds their gradients while loading
+        loss = (sig.float() * w_sig).sum() + (feat.float() * w_fea).sum()
+        if split in ("both", "first"):
+            loss = loss + (rgb.float() * w_rgb).sum()
+        if split in ("both", "second"):
+            loss = loss + (rgb_l.float() * w_rgb_b).sum()
         loss.backward()
         return sraw.grad.clone(), prod.grad.float().clone(), [params[n].grad.clone() for n in names]
 
+    for split in ("first", "second"):  # one of the two gradients absent (None reaches the backward)
+        _, gp_r1, _ = run(False, split)
+        _, gp_f1, _ = run(True, split)
+        assert (gp_f1 - gp_r1).abs().max().item() <= 2e-2 * gp_r1.abs().max().item()
     gs_r, gp_r, gw_r = run(False)
     gs_f, gp_f, gw_f = run(True)
     assert torch.isfinite(gp_f).all()
@@ -135,7 +147,7 @@ def test_vm_head_backward_accumulates_into_existing_grads():
         for p in ps:
             p.grad = torch.full_like(p, pre)
         with torch.autocast("cuda", dtype=torch.float16):
-            sig, rgb, feat = fusedhead.vm_head_train(m, sraw.clone().requires_grad_(True), prod.clone().requires_grad_(True), d)
+            sig, rgb, feat = fusedhead.vm_head_train(m, sraw.clone().requires_grad_(True), prod.clone().requires_grad_(True), d)[:3]
         (rgb.sum() + feat.sum()).backward()
         outs.append([p.grad.clone() for p in ps])
     for a, b in zip(*outs):
