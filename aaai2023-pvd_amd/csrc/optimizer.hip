@@ -38,6 +38,10 @@ struct AdamExtras {
     // value of the L1 term AFTER this update (= at the next step's forward), as one partial sum per workgroup
     float *l1_next;  // DEVICE [>= gridDim.x] or NULL
     float l1_next_scale;
+    // one bit per group of 4 parameters, set = "cold": gradient and both moments are known to be zero and stay zero (rows
+    // of a table no sample can reach, outside every L1 / g16 range).  The update of such a group is weight decay alone --
+    // the same bits the full expression yields for g = m = v = 0 -- so g, m, v are neither read nor written for it.
+    const uint32_t *cold;  // DEVICE [ceil(n / 128)] or NULL
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -105,6 +109,16 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         for (uint32_t r = 0; r < ex.n_l1; r++)
             if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
         const double lrk = (double)lr_sh[k];
+        if (ex.cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u)) {
+            // g = m = v = 0: ea = es = 0, denom = eps, param -= step_size * 0 / eps leaves param as decayed below
+            float4 P = reinterpret_cast<float4 *>(p)[i];
+            P.x = (float)((double)P.x - lrk * (double)weight_decay * (double)P.x);
+            P.y = (float)((double)P.y - lrk * (double)weight_decay * (double)P.y);
+            P.z = (float)((double)P.z - lrk * (double)weight_decay * (double)P.z);
+            P.w = (float)((double)P.w - lrk * (double)weight_decay * (double)P.w);
+            reinterpret_cast<float4 *>(p)[i] = P;
+            continue;
+        }
         const float step_size = (float)(lrk / bc1);
         // the moments are touched exactly once per step: stream them past the caches (nt) so that the Infinity Cache keeps
         // the parameters and gradients the other kernels of the step come back to
@@ -282,7 +296,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     }
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
-    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -292,6 +306,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         const int rc = fill_l1(ex, h.l1_begin_host, h.l1_end_host, h.l1_coef_host, h.n_l1);
         if (rc != PVD_OK) return rc;
         if (h.l1_next) { ex.l1_next = h.l1_next; ex.l1_next_scale = h.l1_next_scale; }
+        ex.cold = h.cold_bits;
         if (h.g16) {
             if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
             ex.g16 = (const _Float16 *)h.g16; ex.g16_begin = h.g16_begin; ex.g16_end = h.g16_end;
@@ -360,7 +375,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     if (!p || !scratch) return PVD_ERR_INVALID;
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
-    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f;
+    ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -58,6 +58,30 @@ class FlatAdamW(torch.optim.Optimizer):
         only the set (after one full zero)."""
         self.touched = touched
         self._outside_is_zero = False
+        self._cold_bits, self._cold_dirty = None, touched is not None
+
+    def _build_cold_bits(self):
+        """One bit per group of 4 parameters: set where the group lies outside the touched set, outside every L1 range (the
+        regulariser's gradient reaches every entry there) and has zero moments right now (they stay zero: no gradient will
+        ever arrive).  The update kernel then applies the weight decay alone to those groups -- bit-identical to the full
+        expression with g = m = v = 0 -- without reading or writing g, m, v."""
+        n = self.flat_p.numel()
+        n4 = n // 4
+        dev = self.flat_p.device
+        warm = torch.zeros(n4 + 1, dtype=torch.bool, device=dev)
+        warm[self.touched.idx >> 2] = True
+        for b, e, _ in (getattr(self, "_l1", None) or []):
+            warm[b >> 2:(e + 3) >> 2] = True
+        warm = warm[:n4]
+        warm |= (self.flat_m[:n4 * 4].view(n4, 4) != 0).any(1) | (self.flat_v[:n4 * 4].view(n4, 4) != 0).any(1)
+        cold = ~warm
+        words = (n + 127) // 128
+        bits = torch.zeros(words * 32, dtype=torch.int64, device=dev)
+        bits[:n4] = cold.to(torch.int64)
+        packed = (bits.view(words, 32) << torch.arange(32, device=dev)).sum(1)
+        packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+        self.cold_fraction = float(cold.float().mean()) if n4 else 0.0
+        return packed if self.cold_fraction > 0.05 else None
 
     def zero_grad(self, set_to_none=False):
         self._half_grad = None
@@ -91,7 +115,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self.sched_step = torch.zeros(1, dtype=torch.float32, device=self.lr_dev.device)
         self._schedule = ({"cosine": 1, "exp": 2}[kind], float(T), float(param), self.base_lr, self.sched_step)
 
+    _cold_bits, _cold_dirty = None, False
+
     def set_l1(self, tensors, weight):
+        self._cold_dirty = self.touched is not None  # the regularised ranges are never cold
         """Fold weight * sum_t mean|t| (NeRFNetwork.density_loss) into the update: its gradient weight/numel * sign(p)
         is added to the unscaled gradient inside the kernel; l1_value() returns the term's value."""
         off = {id(p): o for p, o in zip(self.params, self.offsets)}
@@ -139,11 +166,17 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         d = self.defaults
         st = getattr(self, "_l1_track", None)
+        if self._cold_dirty and not torch.cuda.is_current_stream_capturing():
+            import os
+            self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
+            self._cold_dirty = False
+        cold = self._cold_bits if (self.touched is not None and self._outside_is_zero and not self._cold_dirty
+                                   and getattr(self, "_half_grad", None) is None) else None
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                            schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                            amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
-                           l1_next=(st["buf"], st["scale"]) if st is not None else None)
+                           l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold)
         self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)

@@ -604,7 +604,7 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("l1_coef_host", ctypes.POINTER(ctypes.c_float)), ("amp_scale", ctypes.c_void_p), ("amp_growth_tracker", ctypes.c_void_p),
                 ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32),
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
-                ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float)]
+                ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p)]
 
 
 def _u64_array(vals):
@@ -612,15 +612,22 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
-    l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer."""
+    l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer.
+    cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
     ex = None
-    if schedule is not None or l1_ranges or amp_update is not None or half_grad is not None:
+    if schedule is not None or l1_ranges or amp_update is not None or half_grad is not None or cold_bits is not None:
         ex = _AdamwExtras()
+        if cold_bits is not None:
+            _dev(cold_bits)
+            _want(cold_bits, torch.int32, "cold_bits")
+            if cold_bits.numel() * 128 < p.numel() or not cold_bits.is_contiguous():
+                raise PvdHipError("cold_bits needs one bit per 4 parameters")
+            ex.cold_bits = cold_bits.data_ptr()
         if l1_next is not None:  # (buffer [>= 4096] f32, scale)
             buf, sc = l1_next
             _dev(buf)

@@ -395,6 +395,11 @@ typedef struct pvd_adamw_extras {
      * workgroups are left alone: zero them once).  Not written when the step is skipped. */
     float *l1_next;
     float l1_next_scale;
+    /* cold_bits != NULL (DEVICE, ceil(n / 128) words): bit i set = parameters [4i, 4i + 4) are "cold" -- the caller
+     * guarantees their gradient and both moments are zero and stay zero (table rows the occupancy grid lets no sample
+     * reach; outside every L1 and g16 range).  Their update is the weight decay alone, bit-identical to what the full
+     * expression gives for g = m = v = 0, and g / m / v are neither read nor written for them (8 instead of 28 B/parameter). */
+    const uint32_t *cold_bits;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,

@@ -445,3 +445,52 @@ def test_composite_bg_backward_fresh_gradients(budget):
     pvd_hip.composite_rays_train_bg_backward(None, w_img, sig0, rgb0, deltas, rays, ws, img, M, N, bg.reshape(-1, 3).contiguous(), 0.0, gs, gr,
                                              fresh=True)
     assert torch.equal(gs, res[1][0]) and torch.equal(gr, res[1][1])
+
+
+def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
+    """pvd_adamw_extras.cold_bits: groups of 4 parameters whose gradient and moments are zero for good get the weight decay
+    alone, without g / m / v being read or written -- the very bits the dense kernel produces (g = m = v = 0 makes the Adam
+    term exactly zero).  Six steps with a schedule, a GradScaler scale, L1 on a warm range and an inf step in between."""
+    import pvd_hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    n = 128 * 1000 + 64
+    n4 = n // 4
+    cold4 = torch.rand(n4, device=dev, generator=g) < 0.7
+    cold4[: 4096 // 4] = False  # the L1 range is warm
+    cold_el = cold4.repeat_interleave(4)
+    words = (n + 127) // 128
+    bits = torch.zeros(words * 32, dtype=torch.int64, device=dev)
+    bits[:n4] = cold4.to(torch.int64)
+    packed = (bits.view(words, 32) << torch.arange(32, device=dev)).sum(1)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+    p0 = torch.randn(n, device=dev, generator=g)
+    p0[cold_el.nonzero()[:50].squeeze(-1)] = 0.0  # zeros and negative zeros keep their sign bit
+    p0[cold_el.nonzero()[50:60].squeeze(-1)] = -0.0
+    grads = []
+    for s in range(6):
+        gr = torch.randn(n, device=dev, generator=g) * 64.0
+        gr[cold_el] = 0.0
+        if s == 3:
+            gr[(~cold_el).nonzero()[7]] = float("inf")
+        grads.append(gr)
+    res = []
+    for use_cold in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        m_probe = m.clone()
+        lr = torch.tensor([1e-2, 3e-3], device=dev)
+        base = lr.clone()
+        step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        for gr in grads:
+            pvd_hip.check_finite(gr, flag)
+            pvd_hip.adamw_step(p, gr, m, v, [n // 2 // 4 * 4, n], lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag,
+                               schedule=(1, 100.0, 5e-5, base, sched), l1_ranges=[(0, 4096, 1e-3)],
+                               amp_update=(scale, tracker, 2.0, 0.5, 2000), cold_bits=packed if use_cold else None)
+        res.append((p, m, v, step.clone(), scale.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    p, m, v = res[1][:3]
+    assert float(res[1][3]) == 5.0  # one of the six steps was skipped
+    assert not torch.equal(p, p0) and (m[cold_el] == 0).all() and (v[cold_el] == 0).all() and (m[~cold_el] != 0).any()
+    assert (p[cold_el] != p0[cold_el]).any()  # the cold groups did get their weight decay
