@@ -303,7 +303,20 @@ class _TrainerBase:
                 self.optimizer.set_touched(c)
         self.flat.zero_()
 
+    def _fork_prefix(self, launch):
+        """Single GPU, pipelined capture: launch the NEXT step's parameter-independent prefix (its own graph) on a side
+        stream, next to this step's inf check / AdamW on the main stream; joined before the next step starts."""
+        side = self._pipe_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch()
+        self._pipe_pending = True
+
     def _exchange(self):
+        ov = getattr(self, "_overlap_with_exchange", None)
+        if not self.dp.enabled and ov is not None and self.dp.capture is not None and self.dp.capture.active:
+            self.dp.capture.break_for(lambda: None, lambda: self._fork_prefix(ov))  # cut the graph here: fork point
+            return
         if self.dp.enabled:
             c = self._grad_compactor()
             ov = getattr(self, "_overlap_with_exchange", None)
@@ -367,6 +380,9 @@ class _TrainerBase:
         if self.flat_opt:
             import pvd_hip
             pvd_hip.note_weights_changed(self.optimizer.params)  # the captured optimizer kernel rewrites the parameters
+        if getattr(self, "_pipe_pending", False):  # the prefix forked during the previous step feeds this one
+            torch.cuda.current_stream().wait_stream(self._pipe_stream)
+            self._pipe_pending = False
         self._cap.replay()
         self.scheduler.step()
         self.global_step += 1
@@ -521,6 +537,9 @@ class DistillTrainer(_TrainerBase):
         self._captured_stage = self._stage_of(self.global_step)
         if self.dp.enabled and self._captured_stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
             return self._capture_pipelined(batch_fn, body)
+        if not self.dp.enabled and self._captured_stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
+            self._pipe_stream = torch.cuda.Stream()
+            return self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
         return self.capture(body)
 
     def _capture_pipelined(self, batch_fn, body):
