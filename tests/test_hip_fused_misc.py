@@ -494,3 +494,33 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
     assert float(res[1][3]) == 5.0  # one of the six steps was skipped
     assert not torch.equal(p, p0) and (m[cold_el] == 0).all() and (v[cold_el] == 0).all() and (m[~cold_el] != 0).any()
     assert (p[cold_el] != p0[cold_el]).any()  # the cold groups did get their weight decay
+
+
+def test_trainer_cold_bitmap_covers_only_unreachable_unregularised_groups():
+    """FlatAdamW._build_cold_bits in the real trainer: cold groups are disjoint from the touched set and from the L1 ranges,
+    stay at g = m = v = 0 over training steps, still receive their weight decay, and make up most of the colour planes."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    opt = PVDConfig(num_rays=2048, resolution0=96, iters=200)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0)
+    tr, o = w.trainer, w.trainer.optimizer
+    p0 = o.flat_p.clone()
+    for _ in range(4):
+        tr.train_step(*w.next_batch())
+    bits = o._cold_bits
+    assert bits is not None and 0.3 < o.cold_fraction < 0.95, o.cold_fraction
+    n4 = o.flat_p.numel() // 4
+    words = bits.to(torch.int64) & 0xFFFFFFFF
+    cold4 = ((words[:, None] >> torch.arange(32, device=dev)) & 1).reshape(-1)[:n4].bool()
+    cold = cold4.repeat_interleave(4)
+    assert not cold[o.touched.idx].any()
+    for b, e, _ in o._l1:
+        assert not cold[b:e].any()
+    n = cold.numel()
+    assert (o.flat_g[:n][cold] == 0).all() and (o.flat_m[:n][cold] == 0).all() and (o.flat_v[:n][cold] == 0).all()
+    live = p0[:n][cold] != 0
+    assert ((o.flat_p[:n][cold] != p0[:n][cold]) == live).all()  # decayed (AdamW's default weight decay), zeros stay zeros
+    ratio = (o.flat_p[:n][cold][live] / p0[:n][cold][live]).double()
+    assert (ratio < 1).all() and (ratio > 0.99).all() and float(ratio.max() - ratio.min()) < 1e-5  # one common decay factor per lr group
