@@ -12,13 +12,18 @@ tables, occupancy bitfield) are resident in HBM when the timed region starts.
         bench.py --gpus 8 --steps 20 --warmup 5
 
 Multi-GPU = ray data parallel, weak scaling (4096 rays per GPU), one RCCL all-reduce of the flat
-student gradient per step.  Rank 0 prints ONE JSON line.
+student gradient per step (only the table rows the occupancy grid lets a sample touch: 13 of 69 MB).  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# multi-process GPU work on this platform needs dmabuf IPC (the host driver does not support the legacy mode); the
+# environment exports it already -- keep it if the launcher dropped it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd")):
