@@ -297,6 +297,17 @@ def main():
                    "loss": float(loss)},
         "roofline": roof,
     }
+    if dp.enabled:  # what one step's gradient exchange moved (informational; never let it cost the line)
+        try:
+            tr = w.trainer
+            c = getattr(tr, "_compactor", None)
+            compact = c is not None and getattr(c, "agreed", True) and c.fraction < 0.7
+            total = tr.flat.flat.numel() * 4 / 1e6
+            out["config"]["exchange"] = "all-reduce of %.1f MB (%s of %.1f MB of fp32 gradients)%s + 16 B of loss sums" % (
+                c.idx.numel() * 4 / 1e6 if compact else total, "touched rows only" if compact else "dense", total,
+                ", next step's prefix replayed underneath" if getattr(tr, "_g_prefix", None) is not None else "")
+        except Exception as e:  # noqa: BLE001
+            out["config"]["exchange"] = "unknown (%s)" % type(e).__name__
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
     else:
