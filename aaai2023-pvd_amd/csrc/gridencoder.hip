@@ -61,6 +61,8 @@ static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain le
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
 static int g_grid_pair = 0;               // f16, D = 3, C = 2 without dy_dx: paired x / x+1 gathers (k_grid_fwd_pair); off: measured
                                           // 15 % faster on uniformly random points but 4-10 % slower on ray-coherent samples
+static int g_grid_lps = 0;                // f16, D = 3, C = 2 without dy_dx: 2 / 4 = lanes per sample (k_grid_fwd_lps), 0 = thread per sample
+static int g_grid_persist = 0;            // k_grid_fwd_lps: workgroups of the persistent launch (0 = one per work item)
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
 static float g_grid_coarse_scale = 1e30f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off);
                                            // measured best on every level (tools/bench_grid_bwd.py: 179 vs 205 vs 850 us, f16, 9e4 samples)
@@ -360,6 +362,101 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd_pair(const float *__res
     *out = packed;
 }
 
+// ---- "lanes per sample" forward (f16, D = 3, C = 2, no dy_dx): the corners of ONE sample are spread over LPS adjacent
+// lanes, so that corners which sit in the same cache line are fetched by the SAME load instruction and the L1 serves the
+// line once.  Why: the lookup is bound by the L1's tag-lookup rate (PMC, see k_grid_fwd_pair above): a 64-lane dword gather
+// costs one lookup per DISTINCT line, and at the fine hashed levels every lane of the thread-per-sample kernel is its own
+// line in all 8 of its loads.  But the hash of the x coordinate is x itself (prime 1): for fixed (y, z) the entries of
+// x = 16a .. 16a+15 are one aligned 64-byte line (xor-permuted inside it), so corners x and x+1 share a line 15 times out of
+// 16.  LPS = 2: lane pair = (x, x+1), 4 loads per lane (the (y, z) combinations) -> ~4.25 lines per sample and level instead
+// of 8.  LPS = 4: lane quad = (x, y) bits, 2 loads per lane (z) -> the same lines in half the instructions.
+// The blend keeps the reference's order: every lane rounds its own products (same f32-then-f16 rounding), the partner
+// lanes' products come over by DPP quad permutes, and the sum runs over corners 0..7 in sequence as packed f16 adds (both
+// channels at once; per channel the same IEEE add).  Bit-identical to k_grid_fwd.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ uint32_t weighted_pair(float w, uint32_t packed) {
+    half_t v[2];
+    __builtin_memcpy(v, &packed, 4);
+    half_t r[2] = {half_of_product(w, (float)v[0]), half_of_product(w, (float)v[1])};
+    uint32_t out;
+    __builtin_memcpy(&out, r, 4);
+    return out;
+}
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    half2_t x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const half2_t s = x + y;  // v_pk_add_f16
+    uint32_t out;
+    __builtin_memcpy(&out, &s, 4);
+    return out;
+}
+
+template <uint32_t LPS>
+__global__ void __launch_bounds__(kGridBlock) k_grid_fwd_lps(const float *__restrict__ inputs, const uint32_t *__restrict__ grid,
+                                                             const int32_t *__restrict__ offsets, uint32_t *__restrict__ outputs,
+                                                             uint32_t B, uint32_t L, LevelScales scales, uint32_t nb, uint32_t total,
+                                                             uint32_t gridtype, bool align_corners, uint32_t level_mask, InputAffine aff) {
+    constexpr uint32_t D = 3;
+    constexpr uint32_t SPB = kGridBlock / LPS;  // samples per workgroup pass
+    constexpr uint32_t NL = 8 / LPS;            // loads per lane
+    const uint32_t q = threadIdx.x & (LPS - 1);
+    const uint32_t xb = q & 1u, yq = (q >> 1) & 1u;
+    // persistent, level-major: work item id = level * nb + point block
+    for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+        const uint32_t level = id / nb, pblock = id - level * nb;
+        if (level_mask && !((level_mask >> level) & 1u)) continue;
+        const uint32_t b = pblock * SPB + threadIdx.x / LPS;
+        if (b >= B) continue;  // (all LPS lanes of a sample leave together)
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const float scale = scales.scale[level];
+        LevelIndex<D> index;
+        index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+        const uint32_t *__restrict__ table = grid + off0;
+        uint32_t *__restrict__ out = outputs + ((size_t)level * B + b);
+        float frac[D];
+        uint32_t cell[D];
+        if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell, aff)) {
+            if (q == 0) *out = 0u;
+            continue;
+        }
+        uint32_t v[NL];
+        float w[NL];
+#pragma unroll
+        for (uint32_t k = 0; k < NL; k++) {
+            const uint32_t yb = LPS == 2 ? (k & 1u) : yq, zb = LPS == 2 ? (k >> 1) : k;
+            const uint32_t pg[D] = {cell[0] + xb, cell[1] + yb, cell[2] + zb};
+            float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
+            wi *= xb ? frac[0] : 1 - frac[0];
+            wi *= yb ? frac[1] : 1 - frac[1];
+            wi *= zb ? frac[2] : 1 - frac[2];
+            w[k] = wi;
+            v[k] = table[index(pg)];
+        }
+        uint32_t acc = 0u;  // two f16 zeros
+#pragma unroll
+        for (uint32_t k = 0; k < NL; k++) {
+            const uint32_t p = weighted_pair(w[k], v[k]);
+            if (LPS == 2) {  // corners 2k (even lane) and 2k+1 (odd lane)
+                const uint32_t other = dpp_quad<0xB1>(p);  // quad_perm [1,0,3,2]
+                acc = pk_add(acc, xb ? other : p);
+                acc = pk_add(acc, xb ? p : other);
+            } else {  // corners 4k + {0,1,2,3} = the quad's lanes in order
+                acc = pk_add(acc, dpp_quad<0x00>(p));
+                acc = pk_add(acc, dpp_quad<0x55>(p));
+                acc = pk_add(acc, dpp_quad<0xAA>(p));
+                acc = pk_add(acc, dpp_quad<0xFF>(p));
+            }
+        }
+        if (q == 0) *out = acc;
+    }
+}
+
 // Forward without dy_dx, P points per thread (strided by the workgroup so every pass stays coalesced): the
 // P x 2^D gathers of a thread are independent, so more of them are in flight per wave and the launch needs
 // P x fewer workgroups (at ~1e5 samples the plain grid is ~2.4 waves of workgroups: tail-bound).
@@ -630,6 +727,18 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
                            (uint32_t *)outputs, B, L, sc, sched, gridtype, align, g_grid_level_mask, aff);
         return check_launch();
     }
+    if (!calc && g_grid_lps && D == 3 && C == 2 && sizeof(T) == 2) {
+        const uint32_t lps = (uint32_t)g_grid_lps;
+        const uint32_t nb = div_up(B, kGridBlock / lps), total = L * nb;
+        const uint32_t blocks = g_grid_persist > 0 ? (total < (uint32_t)g_grid_persist ? total : (uint32_t)g_grid_persist) : total;
+        if (lps == 2)
+            hipLaunchKernelGGL((k_grid_fwd_lps<2>), dim3(blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets, (uint32_t *)outputs,
+                               B, L, sc, nb, total, gridtype, align, g_grid_level_mask, aff);
+        else
+            hipLaunchKernelGGL((k_grid_fwd_lps<4>), dim3(blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets, (uint32_t *)outputs,
+                               B, L, sc, nb, total, gridtype, align, g_grid_level_mask, aff);
+        return check_launch();
+    }
     const uint32_t P = (calc || aff.on) ? 1u : (uint32_t)g_grid_points_per_thread;
     if (P > 1 && sizeof(T) * C <= 8) {
         const LevelSchedule sched = make_schedule<D>(sc, L, div_up(B, kGridBlock * P), sizeof(T) * C);
@@ -722,6 +831,14 @@ int pvd_grid_set_variant(int v) {  // bit 0: XCD-aware schedule; bit 1: paired g
     g_grid_points_per_thread = ppt == 2 ? 2 : (ppt >= 4 ? 4 : 1);
     g_grid_level_mask = ((uint32_t)v >> 8) & 0x1fffffu;  // bits 8..28: backward level mask (measurement only)
     g_grid_coarse_scale = (v & (1 << 30)) ? 0.f : ((v & (1 << 29)) ? 300.f : 1e30f);  // bit 30: no run merging; bit 29: coarse levels only
+    return old;
+}
+
+int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks) {
+    if (lanes_per_sample != 0 && lanes_per_sample != 2 && lanes_per_sample != 4) return PVD_ERR_INVALID;
+    const int old = g_grid_lps | (g_grid_persist << 4);
+    g_grid_lps = lanes_per_sample;
+    g_grid_persist = persistent_blocks > 0 ? persistent_blocks : 0;
     return old;
 }
 

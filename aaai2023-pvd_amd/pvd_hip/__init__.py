@@ -50,7 +50,7 @@ ENTRY_POINTS = (
     "pvd_head_forward",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
@@ -345,6 +345,14 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
 
 def grid_set_variant(v):
     return int(_lib.pvd_grid_set_variant(_int(int(v))))
+
+
+def grid_set_fwd_kernel(lanes_per_sample, persistent_blocks=0):
+    """0 = thread per (sample, level); 2 / 4 = lanes per sample (k_grid_fwd_lps); see include/pvd_hip.h."""
+    rc = int(_lib.pvd_grid_set_fwd_kernel(_int(int(lanes_per_sample)), _int(int(persistent_blocks))))
+    if rc < 0:
+        raise PvdHipError("grid_set_fwd_kernel: lanes_per_sample must be 0, 2 or 4")
+    return rc
 
 
 # --------------------------------------------------------------------------- _shencoder

@@ -164,6 +164,12 @@ int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const i
  * (big levels dealt out one per XCD, default), 0 = plain level-major.  Returns the previous value.  Results are identical. */
 int pvd_grid_set_variant(int variant);
 
+/* Forward kernel of the f16 / D = 3 / C = 2 lookup without dy_dx: lanes_per_sample 0 = one thread per (sample, level),
+ * 2 / 4 = the corners of a sample spread over 2 / 4 adjacent lanes (corners sharing a cache line are fetched by one
+ * load instruction); persistent_blocks > 0 = that many workgroups loop over the (level, point block) work items.
+ * Results are bit-identical.  Returns the previous setting (lanes | blocks << 4) or PVD_ERR_INVALID. */
+int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks);
+
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
  * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
  * when calc_grad_inputs.  `embeddings` is unused by the arithmetic (as in the reference) and may be null. */

@@ -16,6 +16,8 @@ without its CUDA extensions --
     permute, backward reshapes) driven with the CPU oracle standing in for `_gridencoder` /
     `_shencoder`: pins this repo's wrappers against the reference's wrapper logic (the kernel
     arithmetic in those fixtures is the oracle's, not the reference's).
+  * the reference's `composite_rays_train` autograd wrapper (raymarching/raymarching.py:292-357:
+    allocation, saved tensors, which gradients exist) the same way, forward + backward.
 The reference's kernels themselves cannot be built here (no cuda.h, stand-ins are not allowed), so
 kernel arithmetic is NOT pinned by these fixtures ("parity unpinned", see oracle/pvd_oracle.h).
 Only data (inputs + expected outputs) is written; no reference source is copied.
@@ -94,6 +96,35 @@ ys = sh(d)
 gs = torch.randn_like(ys)
 ys.backward(gs)
 out.update(sh_d=d.detach().numpy(), sh_y=ys.detach().numpy(), sh_g=gs.numpy(), sh_gd=d.grad.numpy())
+
+# ---- reference composite_rays_train wrapper (raymarching/raymarching.py:292-357) over the oracle backend
+import raymarching as ref_rm  # noqa: E402  (the reference's package: REF is first on sys.path)
+assert ref_rm.__file__.startswith(REF)
+rs = np.random.RandomState(7)
+counts = rs.randint(0, 40, size=48).astype(np.int32)
+counts[5] = 0      # a ray that produced no samples
+counts[11] = 1
+counts[20] = 97    # longer than one wavefront's 64 lanes
+offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+M_used = int(counts.sum())
+M = M_used + 9     # slack after the last ray (stays untouched)
+rays_t = np.stack([np.arange(48, dtype=np.int32), offs, counts], axis=1)
+rays_t[47, 1] = M - 3  # offset + count >= M: the overflow rule treats it as empty (raymarching.cu:525)
+rays_t[47, 2] = 5
+rays_t = rays_t[rs.permutation(48)]  # row order != ray id order (the reference's atomics give any order)
+sig = torch.from_numpy(np.exp(rs.uniform(-2, 7, size=M)).astype(np.float32)).requires_grad_(True)
+rgb = torch.from_numpy(rs.uniform(0, 1, size=(M, 3)).astype(np.float32)).requires_grad_(True)
+dl = torch.from_numpy(np.stack([np.full(M, 2 * 3 ** 0.5 / 1024, dtype=np.float32),
+                                rs.uniform(0.003, 0.05, size=M).astype(np.float32)], axis=1))
+ws, dep, img = ref_rm.composite_rays_train(sig, rgb, dl, torch.from_numpy(rays_t))
+g_ws = torch.from_numpy(rs.standard_normal(48).astype(np.float32))
+g_dep = torch.from_numpy(rs.standard_normal(48).astype(np.float32))  # ignored by the reference's backward
+g_img = torch.from_numpy(rs.standard_normal((48, 3)).astype(np.float32))
+torch.autograd.backward([ws, dep, img], [g_ws, g_dep, g_img])
+out.update(comp_sigmas=sig.detach().numpy(), comp_rgbs=rgb.detach().numpy(), comp_deltas=dl.numpy(), comp_rays=rays_t,
+           comp_ws=ws.detach().numpy(), comp_depth=dep.detach().numpy(), comp_image=img.detach().numpy(),
+           comp_g_ws=g_ws.numpy(), comp_g_depth=g_dep.numpy(), comp_g_image=g_img.numpy(),
+           comp_g_sigmas=sig.grad.numpy(), comp_g_rgbs=rgb.grad.numpy())
 
 # ---- trunc_exp
 xs = torch.linspace(-20, 20, 401, requires_grad=True)

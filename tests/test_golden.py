@@ -93,3 +93,20 @@ def test_cameras_and_rays():
     torch.manual_seed(3)
     r2 = get_rays(poses[:1], (1111.1, 1111.1, 400.0, 400.0), 800, 800, 64)
     assert np.array_equal(r2["inds"].numpy(), G["rays_n_inds"])
+
+
+def test_composite_wrapper_logic_matches_reference_wrapper():
+    """comp_*: the reference's composite_rays_train autograd wrapper (raymarching/raymarching.py:292-357) run on the
+    oracle backend vs this repo's wrapper on the same backend: allocation, saved tensors, ignored depth gradient."""
+    from oracle_ops import oracle_ops
+    rm = oracle_ops().raymarching
+    sig = torch.from_numpy(G["comp_sigmas"]).requires_grad_(True)
+    rgb = torch.from_numpy(G["comp_rgbs"]).requires_grad_(True)
+    ws, dep, img = rm.composite_rays_train(sig, rgb, torch.from_numpy(G["comp_deltas"]), torch.from_numpy(G["comp_rays"]))
+    assert np.array_equal(ws.detach().numpy(), G["comp_ws"])
+    assert np.array_equal(dep.detach().numpy(), G["comp_depth"])
+    assert np.array_equal(img.detach().numpy(), G["comp_image"])
+    torch.autograd.backward([ws, dep, img], [torch.from_numpy(G["comp_g_ws"]), torch.from_numpy(G["comp_g_depth"]),
+                                             torch.from_numpy(G["comp_g_image"])])
+    assert np.array_equal(sig.grad.numpy(), G["comp_g_sigmas"])
+    assert np.array_equal(rgb.grad.numpy(), G["comp_g_rgbs"])

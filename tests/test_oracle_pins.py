@@ -546,3 +546,31 @@ def test_wave_marcher_model_equals_serial_oracle():
                 assert np.array_equal(p, xyzs[s + k]) and dtk == deltas[s + k, 0] and dl1 == deltas[s + k, 1], (ray, k)
         checked += 1
     assert checked > 10 and counter[0] > 500
+
+
+def test_polar_from_ray_closed_form_sphere_hit():
+    """pvdo_polar_from_ray (raymarching.cu:164-200) against the geometry it encodes, in float64: the larger root of
+    |o + t d| = r is a point ON the sphere in FRONT of the origin, and (theta, phi) decode back to that point with
+    y as the up axis (theta from +y, phi = atan2(z, x)); coordinates are normalised to [-1, 1]."""
+    import oracle
+    rs = np.random.RandomState(11)
+    o = (rs.uniform(-1, 1, size=(2000, 3)) * 0.6).astype(np.float32)
+    d = rs.standard_normal((2000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::7] *= 2.5  # the quadratic's A term: directions need not be unit
+    for r in (2.0, 3.2):
+        c = oracle.polar_from_ray(o, d, r).astype(np.float64)
+        assert c.shape == (2000, 2) and np.abs(c).max() <= 1.0 + 1e-6
+        o64, d64 = o.astype(np.float64), d.astype(np.float64)
+        A, B, C = (d64 * d64).sum(1), (o64 * d64).sum(1), (o64 * o64).sum(1) - r * r
+        t = (-B + np.sqrt(B * B - A * C)) / A
+        assert (t > 0).all()
+        p = o64 + t[:, None] * d64
+        np.testing.assert_allclose(np.linalg.norm(p, axis=1), r, rtol=1e-12)
+        theta, phi = (c[:, 0] + 1) * np.pi / 2, c[:, 1] * np.pi
+        q = r * np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], axis=1)
+        assert np.abs(q - p).max() <= 2e-5 * r
+    # axis cases from the centre: +y is the pole (theta 0), +x is (pi/2, 0), +z is (pi/2, pi/2), -y the other pole
+    z3 = np.zeros((4, 3), np.float32)
+    ax = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1], [0, -1, 0]], np.float32)
+    np.testing.assert_allclose(oracle.polar_from_ray(z3, ax, 2.0), [[-1, 0], [0, 0], [0, 0.5], [1, 0]], atol=1e-7)

@@ -37,7 +37,13 @@ def ray_samples(n_rays):
 def time_it(x01, emb, variant, iters=50):
     B = x01.shape[0]
     out = torch.empty(14, B, 2, dtype=emb.dtype, device=dev)
-    pvd_hip.grid_set_variant(variant)
+    if isinstance(variant, tuple):  # (lanes per sample, persistent workgroups): k_grid_fwd_lps (f16 tables only)
+        pvd_hip.grid_set_variant(0)
+pvd_hip.grid_set_fwd_kernel(0, 0)
+        pvd_hip.grid_set_fwd_kernel(*variant)
+    else:
+        pvd_hip.grid_set_fwd_kernel(0, 0)
+        pvd_hip.grid_set_variant(variant)
     run = lambda: pvd_hip.grid_encode_forward(x01, emb, enc.offsets, out, B, 3, 2, 14, S, 16, False, out, 0, False)
     for _ in range(5):
         run()
@@ -51,7 +57,8 @@ def time_it(x01, emb, variant, iters=50):
 
 
 coh = {n: ray_samples(n) for n in (4096, 16384, 65536)}
-VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("P2", 2 << 4), ("P4", 4 << 4)]
+VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("P2", 2 << 4), ("lps2", (2, 0)), ("lps4", (4, 0)), ("lps2p", (2, 2048)), ("lps4p", (4, 2048)),
+            ("lps2q", (2, 1024)), ("lps4q", (4, 4096))]
 print("%-28s %10s %6s " % ("samples", "B", "dtype") + " ".join("%8s" % (n + " us") for n, _ in VARIANTS) + " %9s" % "best GB/s")
 for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("uniform random", torch.rand(1 << 18, 3, device=dev)),
                                                                            ("uniform random", torch.rand(1 << 20, 3, device=dev))]:
@@ -63,3 +70,4 @@ for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("un
         print("%-28s %10d %6s " % (name, x.shape[0], "f16" if dt == torch.float16 else "f32") + " ".join("%8.1f" % t for t in ts)
               + " %9.0f" % (bps * x.shape[0] / min(ts) / 1e3))
 pvd_hip.grid_set_variant(0)
+pvd_hip.grid_set_fwd_kernel(0, 0)
