@@ -128,8 +128,9 @@ static uint32_t sumsq_blocks(uint32_t n_img, uint32_t M) {
 }
 
 int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea, uint32_t M,
-                      const float *col_stu, const float *col_tea, float *S4, int reduce, pvd_stream_t stream) {
+                      uint32_t fea_width, const float *col_stu, const float *col_tea, float *S4, int reduce, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
+    if (fea_width != 16u) return PVD_ERR_INVALID;  // rows are read as four float4
     hipStream_t s = (hipStream_t)stream;
     const uint32_t blocks = sumsq_blocks(n_img, M);
     hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
@@ -146,10 +147,11 @@ int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, fl
 }
 
 int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
-                               uint32_t M, const float *col_stu, const float *col_tea, const float *coef4, const float *upstream,
-                               float *g_img, float *g_fea, float *g_col, pvd_stream_t stream) {
+                               uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea, const float *coef4,
+                               const float *upstream, float *g_img, float *g_fea, float *g_col, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !coef4 || !upstream || !g_img || !g_fea || !g_col)
         return PVD_ERR_INVALID;
+    if (fea_width != 16u) return PVD_ERR_INVALID;
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

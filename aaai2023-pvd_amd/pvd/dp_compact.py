@@ -70,9 +70,12 @@ def footprint_mask(boxes, aabb, sizes, axes, margin=1):
 class GradCompactor:
     """Index list (into the flat gradient buffer) of everything that has to be exchanged."""
 
-    def __init__(self, model, params, offsets, device):
+    def __init__(self, model, params, offsets, device, marcher=None):
+        """model: owner of the tables; marcher: the model whose occupancy grid the samples come from (the student itself, or
+        the teacher when it renders first -- distill_mutual/renderer.py:365-411)."""
+        marcher = marcher if marcher is not None else model
         aabb = [float(v) for v in model.aabb_train.tolist()]
-        boxes = occupied_cells(model.density_bitfield.to(device), model.cascade, model.grid_size, model.bound)
+        boxes = occupied_cells(marcher.density_bitfield.to(device), marcher.cascade, marcher.grid_size, marcher.bound)
         masked = {}  # id(param) -> (row mask flattened, channels)
         if model.model_type == "vm":
             for mats in (model.sigma_mat, model.color_mat):
@@ -98,7 +101,7 @@ class GradCompactor:
             kept += parts[-1].numel()
         self.fraction = kept / max(total, 1)
         self.idx = torch.cat(parts).to(torch.int64) if parts else None
-        self.bitfield_version = model.density_bitfield._version
+        self.occ_epoch = marcher.occ_epoch  # the set is valid for this state of the marcher's occupancy grid only
         self.segs = segments_of(self.idx) if self.idx is not None else None  # the same set as a run table, for the HIP kernels
 
     # On the GPU the set is walked as a run table by pvd_segments_op (one workgroup per run, float4 moves) instead of an

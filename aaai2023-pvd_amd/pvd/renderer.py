@@ -42,6 +42,23 @@ class NeRFRenderer(nn.Module):
             self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))  # ring of 16 (renderer.py:108-113)
             self.mean_count = 0
             self.local_step = 0
+        if bg_radius > 0:
+            # the reference's background model is dead code (`assert 1 == 2`, distill_mutual/network.py:496): no encoder_bg /
+            # bg_net exists here either, so refuse the configuration up front instead of failing inside the first render
+            raise NotImplementedError("bg_radius > 0 (background model) is not supported: the reference's own branch asserts out "
+                                      "(distill_mutual/network.py:496)")
+        # Bumped by everything that rewrites density_grid / density_bitfield.  Writers go through ctypes on data_ptr(), which
+        # autograd's tensor versions do not see, so consumers of a frozen grid (the trainer's touched-row set, the compact
+        # gradient exchange) key on this counter instead.
+        self.occ_epoch = 0
+
+    def note_occupancy_changed(self):
+        self.occ_epoch += 1
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.note_occupancy_changed()  # density_grid / density_bitfield may have been replaced
+        return out
 
     def forward(self, x, d):
         raise NotImplementedError()
@@ -53,6 +70,7 @@ class NeRFRenderer(nn.Module):
         if not self.cuda_ray:
             return
         self.density_grid.zero_()
+        self.note_occupancy_changed()
         self.mean_density = 0
         self.iter_density = 0
         self.step_counter.zero_()
@@ -213,6 +231,7 @@ class NeRFRenderer(nn.Module):
                                 & (cam[..., 1].abs() < cy / fy * cam[..., 2] + hgs * 2)
                             count[cas, indices] += seen.sum(0).reshape(-1)
         self.density_grid[count == 0] = -1
+        self.note_occupancy_changed()
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
@@ -263,6 +282,7 @@ class NeRFRenderer(nn.Module):
 
         thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = rm.packbits(self.density_grid, thresh, self.density_bitfield)
+        self.note_occupancy_changed()
 
         total_step = min(16, self.local_step)
         if total_step > 0:
@@ -292,6 +312,7 @@ class NeRFRenderer(nn.Module):
             sig = self.density(xyz)["sigma"].reshape(-1).detach().float().contiguous()
             occ.occ_update(self.density_grid[cas], st["tmp"], indices, sig, H, float(self.density_scale), float(decay))
         occ.occ_finish(self.density_grid.view(-1), float(self.density_thresh), st["mean_thresh"], st["scratch"], self.density_bitfield)
+        self.note_occupancy_changed()
         self.mean_density = st["mean_thresh"][0]  # stays on the device (float(...) to read it)
         self.iter_density += 1
         total_step = min(16, self.local_step)

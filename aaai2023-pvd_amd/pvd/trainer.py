@@ -260,6 +260,10 @@ class _TrainerBase:
 
     compact_exchange = False  # DistillTrainer: the occupancy grid is frozen, the touched table rows are known up front
 
+    def _marching_model(self):
+        """The model whose occupancy grid decides where samples can be."""
+        return self.model
+
     def _grad_compactor(self):
         """pvd/dp_compact.py: exchange only the table rows that occupied cells can touch (exact: the rest is zero on every
         rank).  Needs the dense L1 gradient out of the flat buffer (folded into the optimizer kernel, or off)."""
@@ -269,9 +273,10 @@ class _TrainerBase:
             return None
         if m.model_type == "vm" and o.l1_reg_weight > 0.0 and not self.flat_opt:
             return None  # autograd writes w/n * sign(p) into every sigma-plane entry
+        marcher = self._marching_model()
         c = getattr(self, "_compactor", None)
-        if c is not None and c.bitfield_version != m.density_bitfield._version:
-            c = None  # the occupancy grid was rewritten: the touched rows changed
+        if c is not None and c.occ_epoch != marcher.occ_epoch:
+            c = None  # the marcher's occupancy grid was rewritten (renderer.note_occupancy_changed): the touched rows changed
         if c is None:
             from .dp_compact import GradCompactor
             offs = self.optimizer.offsets if self.flat_opt else None
@@ -280,7 +285,7 @@ class _TrainerBase:
                 for p in self.flat.params:
                     offs.append(acc)
                     acc += p.numel()
-            c = GradCompactor(m, self.flat.params, offs, self.device)
+            c = GradCompactor(m, self.flat.params, offs, self.device, marcher=marcher)
             c.agreed = True
             if self.dp.enabled and self.dp.capture is None and c.idx is not None:
                 # every rank must move the same rows (same buffer sizes in the collective, nothing left out): compare
@@ -374,9 +379,12 @@ class _TrainerBase:
         finally:
             self.dp.capture = None
         self._cap = cap
-        return self._static_out  # capturing records, it does not run: no step was consumed
+        self._captured_occ_epoch = self._marching_model().occ_epoch
+        return self._static_out  # the warm-up steps above are real steps; the capture itself records without running
 
     def replay(self):
+        assert getattr(self, "_captured_occ_epoch", None) in (None, self._marching_model().occ_epoch), \
+            "the occupancy grid changed since the step was captured (touched-row set is stale): capture again"
         if self.flat_opt:
             import pvd_hip
             pvd_hip.note_weights_changed(self.optimizer.params)  # the captured optimizer kernel rewrites the parameters
@@ -418,6 +426,10 @@ class DistillTrainer(_TrainerBase):
     def render_kwargs(self):
         o = self.opt
         return dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps)
+
+    def _marching_model(self):
+        # whoever renders first marches (renderer.py:365-411); the other model inherits its samples
+        return self.model_stu if bool(getattr(self.opt, "render_stu_first", True)) else self.model_tea
 
     def prefetch(self, batch_fn):
         """The parameter-independent prefix of a step: batch, march, the frozen teacher's forward and compositing.  Its
@@ -467,7 +479,10 @@ class DistillTrainer(_TrainerBase):
         fused = (self.fused_loss is not None and o.loss_type == "normL2" and have_fea and pred_stu is not None and pred_stu.is_cuda
                  and "stage1" not in out_stu and "stage2" not in out_stu
                  and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc, o.loss_rate_rgb) > 0.0
-                 and stu.feature_sigma_color.dtype == torch.float32 and tea.feature_sigma_color.dtype == torch.float32)
+                 and stu.feature_sigma_color.dtype == torch.float32 and tea.feature_sigma_color.dtype == torch.float32
+                 # the fused objective reads [M,16] rows whose column 0 is sigma_l (geo_feat_dim = 15, the reference's default)
+                 and stu.feature_sigma_color.dim() == 2 and stu.feature_sigma_color.shape[-1] == 16
+                 and tea.feature_sigma_color.shape == stu.feature_sigma_color.shape)
         if not fused:
             self.fea_rate.mul_(0.995)  # (the fused objective decays the device-side rate inside its own kernel)
         info = {}
@@ -521,6 +536,13 @@ class DistillTrainer(_TrainerBase):
         return loss, info, pred_stu, pred_tea
 
     def train_step(self, rays_o, rays_d, bg_color, nears_fars=None):
+        o, stu = self.opt, self.model_stu
+        if getattr(o, "update_stu_extra", False) and stu.cuda_ray and self.global_step % o.update_extra_interval == 0:
+            # the reference's option (utils.py:786-796): the student's own occupancy grid follows its density while
+            # distilling.  update_extra_state bumps stu.occ_epoch, which retires the touched-row set / compact exchange
+            # (rebuilt by _zero_grads below from the new grid).
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+                stu.update_extra_state()
         self._zero_grads()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             loss, info, pred_stu, pred_tea = self.compute_loss(rays_o, rays_d, bg_color, nears_fars)
@@ -529,18 +551,28 @@ class DistillTrainer(_TrainerBase):
 
     def capture_step(self, batch_fn):
         """Capture `batch_fn() -> (rays_o, rays_d, bg)` + the whole step into HIP graph(s); the stage
-        (which loss terms exist) is frozen at capture time, so re-capture when the stage changes."""
+        (which loss terms exist) is frozen at capture time, so re-capture when the stage changes.  Three eager warm-up
+        steps run first (real steps: global_step advances by 3)."""
         def body():
             rays_o, rays_d, bg, *rest = batch_fn()
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 return self.compute_loss(rays_o, rays_d, bg, *rest)
-        self._captured_stage = self._stage_of(self.global_step)
-        if self.dp.enabled and self._captured_stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
-            return self._capture_pipelined(batch_fn, body)
-        if not self.dp.enabled and self._captured_stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
+        # the 3 eager warm-up steps inside capture() / _capture_pipelined() are real steps: they advance global_step, so the
+        # stage that gets captured is the one AFTER them, and they must not straddle a stage boundary (the warm-up and the
+        # captured step would then build different losses)
+        warm = 3
+        stage = self._stage_of(self.global_step)
+        assert self._stage_of(self.global_step + warm) == stage, \
+            "capture_step: the %d warm-up steps cross a stage boundary (global_step %d); step eagerly past it first" % (warm, self.global_step)
+        if self.dp.enabled and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
+            out = self._capture_pipelined(batch_fn, body)
+        elif not self.dp.enabled and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
             self._pipe_stream = torch.cuda.Stream()
-            return self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
-        return self.capture(body)
+            out = self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
+        else:
+            out = self.capture(body)
+        self._captured_stage = self._stage_of(self.global_step)
+        return out
 
     def _capture_pipelined(self, batch_fn, body):
         """Ray-DP: the next step's batch / march / teacher forward do not depend on this step's update, so they are a

@@ -30,6 +30,7 @@ def install_occupancy(model, scene, opt):
     model.density_grid.copy_(grid)
     model.density_bitfield.copy_(packbits_torch(grid, min(float(grid.clamp(min=0).mean()), opt.density_thresh)))
     model.mean_density = float(grid.clamp(min=0).mean())
+    model.note_occupancy_changed()
     return grid
 
 
@@ -77,7 +78,8 @@ class DistillWorkload:
         torch.manual_seed(seed)
         self.rng = np.random.RandomState(seed)
         self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed + 1000 * (dp.rank if dp else 0))  # different rays on every rank
+        self.dp_rank = dp.rank if dp else 0
+        self.gen.manual_seed(seed + 1000 * self.dp_rank)  # different rays on every rank
         self.scene = ChairScene(thicken=thicken)
         self.poses = torch.from_numpy(synthetic_poses(self.rng, opt.scale)).to(self.device)
 
@@ -144,7 +146,9 @@ class DistillWorkload:
             if not hasattr(self, "_batch_state"):
                 self._batch_state = torch.zeros(3, dtype=torch.int64, device=self.device)
                 self._poses_c = self.poses.float().contiguous()
-                self._batch_seed = 0x5eed + 1000003 * int(torch.cuda.initial_seed() % (2 ** 31))
+                # every ray-DP rank must draw its own pixels: the rank is part of the key (the CUDA seed alone is the same
+                # on every rank unless the caller seeds per rank)
+                self._batch_seed = 0x5eed + 1000003 * int(torch.cuda.initial_seed() % (2 ** 31)) + 0x9E3779B1 * self.dp_rank
             return mk(self._poses_c, self._batch_state, self._batch_seed, BLENDER_INTRINSICS, 800, 800, opt.num_rays,
                       self.stu.aabb_train, self.stu.min_near)
         if not hasattr(self, "_pose_idx"):
@@ -158,6 +162,7 @@ class DistillWorkload:
 
     def enable_graph(self):
         """Whole-step hipGraph capture (GPU only)."""
+        assert not self.opt.update_stu_extra, "update_stu_extra rewrites the occupancy grid between steps: run eagerly"
         self.trainer.capture_step(self.device_batch)
         self._graph = True
 

@@ -581,10 +581,25 @@ def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs,
           _p(weights_sum), _p(image), _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32(1 if fresh else 0))
 
 
+def _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t):
+    """img: same element count; fea [M, W] (the library accepts W = 16 only); col [M, 3]."""
+    if fea_s.dim() != 2 or fea_t.shape != fea_s.shape:
+        raise PvdHipError("feature tensors must both be [M, W], got %s and %s" % (tuple(fea_s.shape), tuple(fea_t.shape)))
+    M = fea_s.shape[0]
+    if tuple(col_s.shape) != (M, 3) or tuple(col_t.shape) != (M, 3):
+        raise PvdHipError("colour tensors must be [M, 3] with M = %d, got %s and %s" % (M, tuple(col_s.shape), tuple(col_t.shape)))
+    if img_s.numel() != img_t.numel():
+        raise PvdHipError("student and teacher images differ in size")
+    return M, fea_s.shape[1]
+
+
 def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, reduce=True):
     dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4)
     _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4)
-    _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s), _p(col_t),
+    M, W = _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t)
+    if S4.numel() < 4 + 4 * 1024:
+        raise PvdHipError("S4 needs 4 + 4*1024 floats")
+    _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(M), _u32(W), _p(col_s), _p(col_t),
           _p(S4), _int(int(bool(reduce))))
 
 
@@ -599,8 +614,12 @@ def distill_loss_final(S4, rates4, loss, coef4, norms4, n_img=0, M=0, reduce=Fal
 
 def distill_sumsq_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_img, g_fea, g_col):
     dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_img, g_fea, g_col)
-    _f32_all(coef4=coef4, upstream=upstream, g_img=g_img, g_fea=g_fea, g_col=g_col)
-    _call("pvd_distill_sumsq_backward", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(fea_s.shape[0]), _p(col_s),
+    _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, coef4=coef4, upstream=upstream, g_img=g_img,
+             g_fea=g_fea, g_col=g_col)
+    M, W = _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t)
+    if g_img.numel() != img_s.numel() or g_fea.shape != fea_s.shape or g_col.shape != col_s.shape:
+        raise PvdHipError("gradient buffers must have the shapes of the student tensors")
+    _call("pvd_distill_sumsq_backward", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(M), _u32(W), _p(col_s),
           _p(col_t), _p(coef4), _p(upstream), _p(g_img), _p(g_fea), _p(g_col))
 
 

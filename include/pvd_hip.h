@@ -339,7 +339,9 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
  *   loss = sum_i rates4[i] * sqrt(S4[i]) + sum(extra);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
- * img [n_img] f32 (= N*3), fea [M,16] f32 (16-byte aligned), col [M,3] f32.  rates4 / upstream are DEVICE scalars.
+ * img [n_img] f32 (= N*3), fea [M,fea_width] f32 (16-byte aligned) with column 0 = the log-density feature, col [M,3] f32.
+ * fea_width must be 16 (1 + geo_feat_dim of the reference's default models, network.py:30): anything else returns
+ * PVD_ERR_INVALID -- the kernels read rows as four float4.  rates4 / upstream are DEVICE scalars.
  * S4 must hold 4 + 4*1024 floats: the four sums, followed by scratch for per-workgroup partials.
  * pvd_distill_sumsq: reduce != 0 finishes S4[0..3] itself (ray data parallelism: the host all-reduces them before
  *   pvd_distill_loss_final(reduce = 0)); reduce == 0 leaves the partials for pvd_distill_loss_final(reduce = 1, same
@@ -348,13 +350,13 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  *   feature rate, utils.py:1044; 1.0 = leave it); extra [n_extra] are partial sums of a parameter-only term added
  *   to the loss value (pvd_l1_ranges partials), or NULL. */
 int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
-                      const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea, float *S4, int reduce,
-                      pvd_stream_t stream);
+                      const float *fea_tea, uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea,
+                      float *S4, int reduce, pvd_stream_t stream);
 int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, float *rates4, float fea_decay,
                            const float *extra, uint32_t n_extra, float *loss, float *coef4, float *norms4,
                            pvd_stream_t stream);
 int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
-                               const float *fea_tea, uint32_t M, const float *col_stu, const float *col_tea,
+                               const float *fea_tea, uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea,
                                const float *coef4, const float *upstream, float *g_img, float *g_fea, float *g_col,
                                pvd_stream_t stream);
 

@@ -43,7 +43,7 @@ def test_grid_encoder_half_table_under_autocast_on_the_fixture():
         y = e(_t("gw_x"), bound=1)
     assert y.dtype == torch.float16
     ref = G["gw_y"]
-    assert np.abs(y.float().cpu().numpy() - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    assert np.abs(y.detach().float().cpu().numpy() - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
 
 
 def test_sh_encoder_on_the_reference_wrapper_fixture():

@@ -1,0 +1,174 @@
+"""BASELINE.json's configurations as GPU workloads (the steps the reference runs in main_distill_mutual.py:239-286 /
+utils.py:954-1189 and main_just_train_tea.py), each checked step by step against the same trainer on the CPU oracle
+operators (tests/oracle_ops.py) from identical weights on identical batches:
+
+  configs[1]  train the hash teacher, occupancy grid updated every 16 steps          test_config1_*
+  configs[3]  distill mlp -> tensors (Plenoxels)                                     test_config3_*
+  configs[4]  distill hash -> hash, bound 2 (two cascades), dt_gamma = 1/256         test_config4_*
+(configs[2], hash -> vm, is what bench.py times: tests/test_hip_amp_parity.py, test_hip_graph.py, test_hip_fused_misc.py.)
+
+fp32 for the GPU-vs-CPU comparison (the oracle path has no half arithmetic in its MLPs); the AMP + fused versions of the
+same configurations are compared with the generic AMP formulation in tests/test_hip_amp_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cpu_state(model):
+    return {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def _pair(**opt_kw):
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    opt_kw = dict(dict(num_rays=512, iters=200, fp16=False), **opt_kw)
+    torch.manual_seed(0)
+    gpu = DistillWorkload(hip_ops(), torch.device(DEV), PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0)
+    cpu = DistillWorkload(oracle_ops(), "cpu", PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0)
+    with torch.no_grad():  # weights away from their initialisation (a density field that is not ~constant)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        for n, p in gpu.tea.named_parameters():
+            if "embeddings" in n:
+                p.copy_((torch.rand(p.shape, device=DEV, generator=g) - 0.5) * 0.6)
+            elif n.startswith(("sigma_net", "color_net")):
+                p.mul_(1.5)
+    cpu.tea.load_state_dict(_cpu_state(gpu.tea))
+    cpu.stu.load_state_dict(_cpu_state(gpu.stu))
+    cpu.tea.mean_count = cpu.stu.mean_count = gpu.tea.mean_count = gpu.stu.mean_count
+    return gpu, cpu
+
+
+def _grads(model):
+    return {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+def _distill_steps(gpu, cpu, n_steps, loss_rtol, grad_tol):
+    """n_steps distillation steps on both sides.  Before every step the CPU student takes the GPU student's weights, so
+    every step compares loss and full gradient from IDENTICAL parameters; the optimizer update of that step is compared too."""
+    worst = 0.0
+    for it in range(n_steps):
+        cpu.stu.load_state_dict(_cpu_state(gpu.stu))
+        rays_o, rays_d, bg = gpu.next_batch()
+        before = {n: p.detach().float().cpu().clone() for n, p in gpu.stu.named_parameters() if p.requires_grad}
+        lg, ig, ps_g, pt_g = gpu.trainer.train_step(rays_o, rays_d, bg)
+        lc, ic, ps_c, pt_c = cpu.trainer.train_step(rays_o.cpu(), rays_d.cpu(), bg.cpu())
+        assert np.isfinite(float(lg)) and abs(float(lg) - float(lc)) <= loss_rtol * abs(float(lc)), (it, float(lg), float(lc))
+        assert (ps_g.float().cpu() - ps_c).abs().max().item() <= 1e-4  # north_star: RGB within 1e-4
+        assert (pt_g.float().cpu() - pt_c).abs().max().item() <= 1e-4
+        gg, gc = _grads(gpu.stu), _grads(cpu.stu)
+        assert gg.keys() == gc.keys() and len(gg) > 0
+        for n in gc:
+            scale = gc[n].abs().max().item()
+            assert scale > 0, n
+            err = (gg[n] - gc[n]).abs().max().item() / scale
+            worst = max(worst, err)
+            assert err <= grad_tol, (it, n, err)
+        # the AdamW update from (almost) the same gradient: compare as a whole (entries whose gradient is pure rounding
+        # noise move by +-lr in Adam's first steps, so an element-wise bar would test the noise)
+        num = den = 0.0
+        for n, p in gpu.stu.named_parameters():
+            if not p.requires_grad:
+                continue
+            dg = p.detach().float().cpu() - before[n]
+            dc = dict(cpu.stu.named_parameters())[n].detach() - before[n]
+            num += float((dg - dc).pow(2).sum())
+            den += float(dc.pow(2).sum())
+        assert den > 0 and (num / den) ** 0.5 <= 0.05, (it, (num / den) ** 0.5)
+    return worst
+
+
+def test_config3_mlp_teacher_to_plenoxel_student():
+    """configs[3]: NeRF-MLP teacher -> Plenoxel (`tensors`) student; stage 1 does not exist for this student
+    (main_distill_mutual.py:243-246), so every step is the stage-3 objective: rgb + sigma + colour terms."""
+    gpu, cpu = _pair(teacher_type="mlp", model_type="tensors", plenoxel_res="[48,48,48]", num_rays=384)
+    assert gpu.stu.model_type == "tensors" and gpu.tea.model_type == "mlp"
+    assert gpu.trainer._stage_of(gpu.trainer.global_step) == 3
+    worst = _distill_steps(gpu, cpu, 3, loss_rtol=2e-4, grad_tol=2e-3)
+    print("configs[3] worst gradient error / max|g|: %.2e" % worst)
+    assert int(gpu.stu.step_counter[:, 0].max()) > 0  # samples were marched
+
+
+def test_config4_hash_to_hash_two_cascades_dt_gamma():
+    """configs[4]: hash -> hash with bound 2 (two cascades of the occupancy grid, 4096^3 finest level) and the
+    distance-proportional step dt_gamma = 1/256 -- the marcher's thread-per-ray branch, mip levels from position and from
+    step size (raymarching.cu:44-56, 368-403)."""
+    gpu, cpu = _pair(teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=384)
+    assert gpu.stu.cascade == 2 and gpu.stu.encoder.embeddings.shape == gpu.tea.encoder.embeddings.shape
+    worst = _distill_steps(gpu, cpu, 3, loss_rtol=2e-4, grad_tol=2e-3)
+    print("configs[4] worst gradient error / max|g|: %.2e" % worst)
+    # samples reached the second cascade (|x| > 1) and the step size grew with distance
+    rays_o, rays_d, bg = gpu.next_batch()
+    inh, _ = gpu.stu.march(rays_o, rays_d, dt_gamma=1.0 / 256, perturb=True, force_all_rays=True)
+    xyzs, _, deltas, rays = inh
+    n = int(rays[:, 2].sum())
+    assert n > 0 and xyzs[:n].abs().max().item() > 1.0
+    assert deltas[:n, 0].max().item() > 1.5 * deltas[:n, 0].min().item()
+
+
+def test_config4_stages_one_and_two():
+    """The same pair through the reference's stage gates: stage 1 (feature loss only, no compositing -- forward returns
+    (None, None), network.py:422-423) and stage 2 (sigma + colour + feature terms, renderer.py:421-438)."""
+    for start, key in (("stage1", "fea"), ("stage2", "sigma")):
+        gpu, cpu = _pair(teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=256)
+        for w in (gpu, cpu):
+            w.trainer.global_step = 0 if start == "stage1" else w.opt.stage_iters["stage1"]
+        assert gpu.trainer._stage_of(gpu.trainer.global_step) == (1 if start == "stage1" else 2)
+        rays_o, rays_d, bg = gpu.next_batch()
+        lg, ig, ps, pt = gpu.trainer.train_step(rays_o, rays_d, bg)
+        lc, ic, _, _ = cpu.trainer.train_step(rays_o.cpu(), rays_d.cpu(), bg.cpu())
+        assert ps is None and pt is None and key in ig
+        assert abs(float(lg) - float(lc)) <= 2e-4 * abs(float(lc)), (start, float(lg), float(lc))
+        gg, gc = _grads(gpu.stu), _grads(cpu.stu)
+        for n in gc:
+            scale = gc[n].abs().max().item()
+            if scale == 0:  # stage 1: the colour head receives no gradient (network.py:422)
+                assert gg[n].abs().max().item() == 0, n
+                continue
+            assert (gg[n] - gc[n]).abs().max().item() <= 2e-3 * scale, (start, n)
+
+
+def test_config1_teacher_training_with_grid_updates():
+    """configs[1]: hash teacher trained on ground-truth pixels, 4096 rays / batch, AMP, the occupancy grid re-estimated
+    from the model's own density every 16 steps (just_train_tea/utils.py:841-846, renderer.py:647-775) -- first the 16
+    full sweeps' worth is not waited for here: 3 updates happen in 40 steps."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays
+    from pvd.trainer import TeacherTrainer, psnr
+    from pvd.workload import DistillWorkload, measure_mean_count
+    dev = torch.device(DEV)
+    opt = PVDConfig(num_rays=4096)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0)
+    topt = PVDConfig(**{**opt.__dict__, "model_type": "hash", "iters": 2000, "update_extra_interval": 16,
+                        "stage_iters": {"stage1": -1, "stage2": -1}})
+    tea = w.tea
+    tea.teacher_variant = True
+    tea.requires_grad_(True).train()
+    tea.args = tea.opt = topt
+    tr = TeacherTrainer(topt, tea, dev, fp16=True)
+    tea.mean_count = measure_mean_count(tea, w.poses, opt, generator=w.gen)
+    batches = []  # ground truth rendered through the analytic occupancy grid, before training rewrites the grid
+    for it in range(8):
+        r = get_rays(w.poses[it % len(w.poses)][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
+        bg = torch.rand(1, opt.num_rays, 3, device=dev, generator=w.gen)
+        batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
+    grid0 = tea.density_grid.clone()
+    epoch0 = tea.occ_epoch
+    losses, counts = [], []
+    for it in range(40):
+        loss, pred = tr.train_step(*batches[it % 8])
+        losses.append(float(loss))
+        counts.append(int(tea.mean_count))
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
+    assert tea.occ_epoch == epoch0 + 3 and tea.iter_density == 3  # steps 0, 16, 32
+    assert not torch.equal(grid0, tea.density_grid)  # running maximum of the model's own density (renderer.py:748-752)
+    bits = tea.density_bitfield.cpu().numpy()
+    occupied = int(np.unpackbits(bits).sum())
+    assert 0 < occupied < 128 ** 3
+    assert counts[-1] > 0  # the sample budget follows the marcher's counters (renderer.py:768-773)
+    assert float(psnr(pred.detach(), batches[39 % 8][2])) > 8.0

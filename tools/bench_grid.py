@@ -39,7 +39,6 @@ def time_it(x01, emb, variant, iters=50):
     out = torch.empty(14, B, 2, dtype=emb.dtype, device=dev)
     if isinstance(variant, tuple):  # (lanes per sample, persistent workgroups): k_grid_fwd_lps (f16 tables only)
         pvd_hip.grid_set_variant(0)
-pvd_hip.grid_set_fwd_kernel(0, 0)
         pvd_hip.grid_set_fwd_kernel(*variant)
     else:
         pvd_hip.grid_set_fwd_kernel(0, 0)
@@ -57,8 +56,8 @@ pvd_hip.grid_set_fwd_kernel(0, 0)
 
 
 coh = {n: ray_samples(n) for n in (4096, 16384, 65536)}
-VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("P2", 2 << 4), ("lps2", (2, 0)), ("lps4", (4, 0)), ("lps2p", (2, 2048)), ("lps4p", (4, 2048)),
-            ("lps2q", (2, 1024)), ("lps4q", (4, 4096))]
+VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("lps2", (2, 0)), ("lps4", (4, 0)), ("l2p512", (2, 512)), ("l2p1k", (2, 1024)), ("l2p2k", (2, 2048)),
+            ("l2p4k", (2, 4096)), ("l4p1k", (4, 1024)), ("l4p2k", (4, 2048))]
 print("%-28s %10s %6s " % ("samples", "B", "dtype") + " ".join("%8s" % (n + " us") for n, _ in VARIANTS) + " %9s" % "best GB/s")
 for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("uniform random", torch.rand(1 << 18, 3, device=dev)),
                                                                            ("uniform random", torch.rand(1 << 20, 3, device=dev))]:
