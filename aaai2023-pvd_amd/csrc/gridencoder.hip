@@ -63,6 +63,9 @@ static int g_grid_pair = 0;               // f16, D = 3, C = 2 without dy_dx: pa
                                           // 15 % faster on uniformly random points but 4-10 % slower on ray-coherent samples
 static int g_grid_lps = 0;                // f16, D = 3, C = 2 without dy_dx: 2 / 4 = lanes per sample (k_grid_fwd_lps), 0 = thread per sample
 static int g_grid_persist = 0;            // k_grid_fwd_lps: workgroups of the persistent launch (0 = one per work item)
+static int g_grid_affine = 0;             // k_grid_fwd_lps: XCD-affine item order (LpsSchedule)
+static float g_grid_level_weight[kMaxLevels] = {0};  // affine schedule: relative cost of a level's items (0 = built-in profile)
+static uint32_t g_grid_hash_rows = 1u << 19;  // rows of a hashed level, for the table-size ordering of the affine schedule
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
 static float g_grid_coarse_scale = 1e30f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off);
                                            // measured best on every level (tools/bench_grid_bwd.py: 179 vs 205 vs 850 us, f16, 9e4 samples)
@@ -397,31 +400,77 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return out;
 }
 
+// Work items of the lanes-per-sample kernel: (level, point block).  Two orders:
+//   plain  : item id = level * nb + pblock, workgroup g takes ids g, g + G, ... (level-major sweep by the whole chip);
+//   affine : every XCD owns a contiguous stretch of the level-major item list (levels sorted by table size, so a big
+//            level's table is walked by ONE XCD -- at most two -- and is fetched into one L2 instead of all eight).
+//            Workgroup g belongs to XCD g % 8 (the hardware's round-robin placement; a different placement costs speed
+//            only) and is the (g / 8)-th of its XCD's G / 8 workgroups.
+struct LpsSchedule {
+    uint32_t nb, total;
+    uint32_t affine;               // 0 / 1
+    uint32_t xcd_begin[9];         // affine: item range [xcd_begin[x], xcd_begin[x + 1]) of the ORDERED list
+    uint8_t level_order[kMaxLevels];  // ordered list position -> level
+
+    __device__ __forceinline__ uint32_t first(uint32_t g, uint32_t G, uint32_t &step, uint32_t &end) const {
+        if (!affine) { step = G; end = total; return g; }
+        const uint32_t x = g & 7u;
+        step = G >> 3;
+        end = xcd_begin[x + 1];
+        return xcd_begin[x] + (g >> 3);
+    }
+    __device__ __forceinline__ void decode(uint32_t i, uint32_t &level, uint32_t &pblock) const {
+        const uint32_t k = i / nb;
+        pblock = i - k * nb;
+        level = affine ? level_order[k] : k;
+    }
+};
+
+struct alignas(4) Pos3 {
+    float x, y, z;
+};
+
 template <uint32_t LPS>
 __global__ void __launch_bounds__(kGridBlock) k_grid_fwd_lps(const float *__restrict__ inputs, const uint32_t *__restrict__ grid,
                                                              const int32_t *__restrict__ offsets, uint32_t *__restrict__ outputs,
-                                                             uint32_t B, uint32_t L, LevelScales scales, uint32_t nb, uint32_t total,
+                                                             uint32_t B, uint32_t L, LevelScales scales, LpsSchedule sched,
                                                              uint32_t gridtype, bool align_corners, uint32_t level_mask, InputAffine aff) {
     constexpr uint32_t D = 3;
     constexpr uint32_t SPB = kGridBlock / LPS;  // samples per workgroup pass
     constexpr uint32_t NL = 8 / LPS;            // loads per lane
     const uint32_t q = threadIdx.x & (LPS - 1);
     const uint32_t xb = q & 1u, yq = (q >> 1) & 1u;
-    // persistent, level-major: work item id = level * nb + point block
-    for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
-        const uint32_t level = id / nb, pblock = id - level * nb;
-        if (level_mask && !((level_mask >> level) & 1u)) continue;
-        const uint32_t b = pblock * SPB + threadIdx.x / LPS;
-        if (b >= B) continue;  // (all LPS lanes of a sample leave together)
-        const uint32_t off0 = (uint32_t)offsets[level];
-        const float scale = scales.scale[level];
+    const uint32_t s_in_block = threadIdx.x / LPS;
+    uint32_t step, end;
+    uint32_t i = sched.first(blockIdx.x, gridDim.x, step, end);
+    // the position of the NEXT item's sample is loaded while this item's gathers are in flight (a wave otherwise pays two
+    // dependent memory round trips per item: position, then corners)
+    auto fetch = [&](uint32_t item, uint32_t &level, uint32_t &b, Pos3 &p) {
+        uint32_t pblock;
+        sched.decode(item, level, pblock);
+        b = pblock * SPB + s_in_block;
+        if (b < B) p = *reinterpret_cast<const Pos3 *>(inputs + (size_t)b * D);  // one 12-byte load
+    };
+    uint32_t level = 0, b = 0;
+    Pos3 pos = {0.f, 0.f, 0.f};
+    if (i < end) fetch(i, level, b, pos);
+    while (i < end) {
+        const uint32_t cur_level = level, cur_b = b;
+        const Pos3 cur = pos;
+        i += step;
+        if (i < end) fetch(i, level, b, pos);
+        if (level_mask && !((level_mask >> cur_level) & 1u)) continue;
+        if (cur_b >= B) continue;  // (all LPS lanes of a sample leave together)
+        const uint32_t off0 = (uint32_t)offsets[cur_level];
+        const float scale = scales.scale[cur_level];
         LevelIndex<D> index;
-        index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+        index.init((uint32_t)offsets[cur_level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
         const uint32_t *__restrict__ table = grid + off0;
-        uint32_t *__restrict__ out = outputs + ((size_t)level * B + b);
+        uint32_t *__restrict__ out = outputs + ((size_t)cur_level * B + cur_b);
         float frac[D];
         uint32_t cell[D];
-        if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell, aff)) {
+        const float xin[D] = {cur.x, cur.y, cur.z};
+        if (!locate<D>(xin, scale, align_corners, frac, cell, aff)) {
             if (q == 0) *out = 0u;
             continue;
         }
@@ -455,6 +504,67 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd_lps(const float *__rest
         }
         if (q == 0) *out = acc;
     }
+}
+
+static LpsSchedule make_lps_schedule(const LevelScales &sc, const int32_t *offsets_host_or_null, uint32_t L, uint32_t nb, bool affine,
+                                     uint32_t hash_rows) {
+    LpsSchedule s;
+    s.nb = nb;
+    s.total = L * nb;
+    s.affine = affine ? 1u : 0u;
+    // level order: biggest tables first (rows from the level's resolution, capped by the hash size)
+    double rows[kMaxLevels];
+    for (uint32_t l = 0; l < L; l++) {
+        const double res = ceil((double)sc.scale[l]) + 2.0;
+        rows[l] = res * res * res;
+        if (rows[l] > (double)hash_rows) rows[l] = (double)hash_rows;
+        s.level_order[l] = (uint8_t)l;
+    }
+    for (uint32_t a = 0; a + 1 < L; a++)  // stable selection sort, L <= 32
+        for (uint32_t c = a + 1; c < L; c++)
+            if (rows[s.level_order[c]] > rows[s.level_order[a]]) {
+                const uint8_t t = s.level_order[c];
+                for (uint32_t m = c; m > a; m--) s.level_order[m] = s.level_order[m - 1];
+                s.level_order[a] = t;
+            }
+    (void)offsets_host_or_null;
+    // XCD boundaries by COST, not by item count: a fine hashed level (every corner its own cache line) costs several times a
+    // coarse one (neighbouring samples share cells).  Default profile = the per-level times measured at the bench size
+    // (dense levels ~0.45 each, hashed levels 1.1 rising to 4.1); pvd_grid_set_level_weights overrides it.
+    double w[kMaxLevels], total_w = 0.0;
+    uint32_t n_hashed_seen = 0;
+    for (uint32_t k = 0; k < L; k++) {
+        const uint32_t l = s.level_order[k];
+        if (g_grid_level_weight[l] > 0.f) w[k] = g_grid_level_weight[l];
+        else w[k] = rows[l] >= (double)hash_rows ? 0.f : 0.45;
+        total_w += 0.0;
+    }
+    // hashed levels in ascending resolution get the rising profile
+    for (uint32_t l = 0; l < L; l++)
+        if (rows[l] >= (double)hash_rows && !(g_grid_level_weight[l] > 0.f)) {
+            for (uint32_t k = 0; k < L; k++)
+                if (s.level_order[k] == l) w[k] = 1.1 + 0.375 * (double)n_hashed_seen;
+            n_hashed_seen++;
+        }
+    for (uint32_t k = 0; k < L; k++) total_w += w[k] * (double)nb;
+    s.xcd_begin[0] = 0;
+    {
+        double acc = 0.0;
+        uint32_t x = 1;
+        for (uint32_t k = 0; k < L && x < 8; k++) {
+            // items k*nb .. (k+1)*nb - 1 carry w[k] each
+            while (x < 8 && acc + w[k] * (double)nb >= total_w * (double)x / 8.0) {
+                const double need = total_w * (double)x / 8.0 - acc;
+                uint32_t within = (uint32_t)(need / w[k]);
+                if (within > nb) within = nb;
+                s.xcd_begin[x++] = k * nb + within;
+            }
+            acc += w[k] * (double)nb;
+        }
+        for (; x < 8; x++) s.xcd_begin[x] = s.total;
+    }
+    s.xcd_begin[8] = s.total;
+    return s;
 }
 
 // Forward without dy_dx, P points per thread (strided by the workgroup so every pass stays coalesced): the
@@ -730,13 +840,16 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
     if (!calc && g_grid_lps && D == 3 && C == 2 && sizeof(T) == 2) {
         const uint32_t lps = (uint32_t)g_grid_lps;
         const uint32_t nb = div_up(B, kGridBlock / lps), total = L * nb;
-        const uint32_t blocks = g_grid_persist > 0 ? (total < (uint32_t)g_grid_persist ? total : (uint32_t)g_grid_persist) : total;
+        uint32_t blocks = g_grid_persist > 0 ? (total < (uint32_t)g_grid_persist ? total : (uint32_t)g_grid_persist) : total;
+        const bool affine = g_grid_affine && blocks >= 8;
+        if (affine) blocks &= ~7u;
+        const LpsSchedule sched = make_lps_schedule(sc, nullptr, L, nb, affine, g_grid_hash_rows);
         if (lps == 2)
             hipLaunchKernelGGL((k_grid_fwd_lps<2>), dim3(blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets, (uint32_t *)outputs,
-                               B, L, sc, nb, total, gridtype, align, g_grid_level_mask, aff);
+                               B, L, sc, sched, gridtype, align, g_grid_level_mask, aff);
         else
             hipLaunchKernelGGL((k_grid_fwd_lps<4>), dim3(blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets, (uint32_t *)outputs,
-                               B, L, sc, nb, total, gridtype, align, g_grid_level_mask, aff);
+                               B, L, sc, sched, gridtype, align, g_grid_level_mask, aff);
         return check_launch();
     }
     const uint32_t P = (calc || aff.on) ? 1u : (uint32_t)g_grid_points_per_thread;
@@ -838,8 +951,16 @@ int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks) {
     if (lanes_per_sample != 0 && lanes_per_sample != 2 && lanes_per_sample != 4) return PVD_ERR_INVALID;
     const int old = g_grid_lps | (g_grid_persist << 4);
     g_grid_lps = lanes_per_sample;
+    g_grid_affine = (persistent_blocks & (1 << 30)) ? 1 : 0;  // bit 30: XCD-affine item order
+    persistent_blocks &= ~(1 << 30);
     g_grid_persist = persistent_blocks > 0 ? persistent_blocks : 0;
     return old;
+}
+
+int pvd_grid_set_level_weights(const float *weights_host, uint32_t n) {
+    if (n > kMaxLevels || (n && !weights_host)) return PVD_ERR_INVALID;
+    for (uint32_t l = 0; l < kMaxLevels; l++) g_grid_level_weight[l] = l < n ? weights_host[l] : 0.f;
+    return PVD_OK;
 }
 
 int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B,

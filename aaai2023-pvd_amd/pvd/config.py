@@ -18,6 +18,9 @@ class PVDConfig:
     bg_radius: float = -1.0
     grid_size: int = 128
     max_steps: int = 1024
+    num_steps: int = 512       # fixed steps per ray when NOT cuda_ray (main_just_train_tea.py:45-50)
+    upsample_steps: int = 0    # (main_just_train_tea.py:51-56)
+    max_ray_batch: int = 4096
     num_rays: int = 4096
     # training
     iters: int = 30000

@@ -18,13 +18,14 @@ from .renderer import NeRFRenderer
 
 
 def _channels_last(t):
-    out = torch.empty_strided(t.shape, (t.shape[1] * t.shape[2] * t.shape[3], 1, t.shape[3] * t.shape[1], t.shape[1]), dtype=t.dtype)
+    out = torch.empty_strided(t.shape, (t.shape[1] * t.shape[2] * t.shape[3], 1, t.shape[3] * t.shape[1], t.shape[1]), dtype=t.dtype,
+                              device=t.device)
     return out.copy_(t)
 
 
 def _channels_last_3d(t):
     _, C, D, H, W = t.shape
-    return torch.empty_strided(t.shape, (C * D * H * W, 1, H * W * C, W * C, C), dtype=t.dtype).copy_(t)
+    return torch.empty_strided(t.shape, (C * D * H * W, 1, H * W * C, W * C, C), dtype=t.dtype, device=t.device).copy_(t)
 
 
 class _L1MeanSum(torch.autograd.Function):
@@ -328,6 +329,21 @@ class NeRFNetwork(NeRFRenderer):
                 h = F.relu(h, inplace=True)
         h = torch.clamp(h, a.sigma_clip_min, a.sigma_clip_max)
         return {"sigma": self.trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """Colours for the rows selected by `mask` (zeros elsewhere): the masked query of the fixed-step sampler
+        (reference: color, network.py:513-546, which asserts out before doing this).  Models whose density() hands out
+        geometry features (hash, mlp) run the colour head on them; the others evaluate the whole model on the rows."""
+        out = torch.zeros(x.shape[0], 3, dtype=torch.float32, device=x.device)
+        if mask is not None and not bool(mask.any()):
+            return out
+        sel = mask if mask is not None else torch.ones(x.shape[0], dtype=torch.bool, device=x.device)
+        if geo_feat is not None and self.model_type in ("hash", "mlp"):
+            rgb = self._color_head(self.encoder_dir(d[sel]), geo_feat[sel])
+        else:
+            rgb = self(x[sel], d[sel])[1]
+        # differentiable scatter of the selected rows (the reference's `rgbs[mask] = h` on a fresh tensor)
+        return out.index_put((sel.nonzero(as_tuple=True)[0],), rgb.to(out.dtype))
 
     def get_params(self, lr, lr2=1e-3):
         """optimizer groups (network.py:646-683)."""

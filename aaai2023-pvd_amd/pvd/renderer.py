@@ -1,16 +1,57 @@
 """Occupancy-grid volume renderer: the harness counterpart of the reference's
 ``NeRFRenderer`` (distill_mutual/renderer.py:66-814; teacher variant just_train_tea/renderer.py).
 
-Only the live path is reproduced -- ``run_cuda`` (train and inference branches),
-``update_extra_state``, ``mark_untrained_grid`` and ``render`` -- with the reference's buffer names
-(``density_grid``, ``density_bitfield``, ``step_counter``, ``aabb_train``, ``aabb_infer``) so that
-state-dicts line up (checkpoint row).  The dead pure-torch ``run`` is not.
+The live path -- ``run_cuda`` (train and inference branches), ``update_extra_state``, ``mark_untrained_grid`` and
+``render`` -- with the reference's buffer names (``density_grid``, ``density_bitfield``, ``step_counter``,
+``aabb_train``, ``aabb_infer``) so that state-dicts line up (checkpoint row); plus ``run``, the
+fixed-step pure-torch sampler of the non-``cuda_ray`` configuration (BASELINE.json configs[0], a plumbing check: in the
+reference its colour query asserts out, network.py:515-516; here it is a masked query).
 """
 import math
 
 import numpy as np
 import torch
 import torch.nn as nn
+
+
+def near_far_from_aabb_torch(rays_o, rays_d, aabb, min_near):
+    """The slab test of raymarching.cu:93-147 as torch ops (same IEEE operations per element, so it agrees with the kernels
+    bit for bit): used by the non-cuda_ray sampler, which must run without any native operator."""
+    rd = 1.0 / rays_d
+    lo = (aabb[:3] - rays_o) * rd
+    hi = (aabb[3:] - rays_o) * rd
+    t_lo, t_hi = torch.minimum(lo, hi), torch.maximum(lo, hi)
+    near, far = t_lo[:, 0], t_hi[:, 0]
+    miss = torch.zeros_like(near, dtype=torch.bool)
+    for a in (1, 2):  # the kernel tests an axis against the interval accumulated so far and leaves at the first miss
+        miss = miss | (near > t_hi[:, a]) | (t_lo[:, a] > far)
+        near, far = torch.maximum(near, t_lo[:, a]), torch.minimum(far, t_hi[:, a])
+    big = torch.finfo(near.dtype).max
+    near = torch.where(miss, torch.full_like(near, big), near.clamp_min(min_near))
+    far = torch.where(miss, torch.full_like(far, big), far)
+    return near, far
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-transform sampling of a piecewise-constant pdf (hierarchical NeRF sampling; reference: sample_pdf,
+    renderer.py:17-52).  bins [B, T], weights [B, T-1] -> [B, n_samples]."""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    shape = list(cdf.shape[:-1]) + [n_samples]
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, n_samples, device=cdf.device).expand(shape)
+    else:
+        u = torch.rand(shape, device=cdf.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp_min(0)
+    hi = hi.clamp_max(cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    width = c_hi - c_lo
+    width = torch.where(width < 1e-5, torch.ones_like(width), width)
+    return b_lo + (u - c_lo) / width * (b_hi - b_lo)
 
 
 class NeRFRenderer(nn.Module):
@@ -76,6 +117,67 @@ class NeRFRenderer(nn.Module):
         self.step_counter.zero_()
         self.mean_count = 0
         self.local_step = 0
+
+    # ------------------------------------------------------------------ run (no occupancy grid, no native operator)
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """reference: run, distill_mutual/renderer.py:139-317.  Uniform steps between the box intersections (+ optional
+        importance resampling), densities for every step, colours only where the compositing weight exceeds 1e-4
+        (`color(mask=...)`), alpha compositing by cumprod.  rays_o / rays_d [B, N, 3] with B == 1."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = near_far_from_aabb_torch(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+
+        z_vals = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0)  # [N, T]
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        def positions(z):
+            x = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)  # [N, T, 3]
+            return torch.min(torch.max(x, aabb[:3]), aabb[3:])  # clipped into the box (:186)
+
+        def weights_of(z, sigma):
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+            trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1), dim=-1)[..., :-1]
+            return alphas * trans, deltas
+
+        xyzs = positions(z_vals)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+
+        if upsample_steps > 0:  # NeRF-style resampling along the first pass's weights (:195-246)
+            with torch.no_grad():
+                w0, d0 = weights_of(z_vals, dens["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * d0[..., :-1]
+                new_z = sample_pdf(z_mid, w0[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = positions(new_z)
+            new_dens = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.gather(torch.cat([xyzs, new_xyzs], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 3))
+            for k in dens:
+                both = torch.cat([dens[k], new_dens[k]], dim=1)
+                dens[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+
+        weights, _ = weights_of(z_vals, dens["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        flat = {k: v.reshape(-1, v.shape[-1]) for k, v in dens.items()}
+        mask = weights > 1e-4  # hard-coded in the reference (:283)
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
+
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3)}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        raise NotImplementedError()
 
     # ------------------------------------------------------------------ run_cuda
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
@@ -322,6 +424,18 @@ class NeRFRenderer(nn.Module):
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """reference: render, renderer.py:777-814 (`staged` is ignored on the cuda_ray path)."""
-        if not self.cuda_ray:
-            raise RuntimeError("only the cuda_ray path exists (the reference forces it on, main_distill_mutual.py:251-254)")
-        return self.run_cuda(rays_o, rays_d, **kwargs)
+        if self.cuda_ray:
+            return self.run_cuda(rays_o, rays_d, **kwargs)
+        kwargs = {k: v for k, v in kwargs.items() if k in ("num_steps", "upsample_steps", "bg_color", "perturb")}
+        B, N = rays_o.shape[:2]
+        if not staged:
+            return self.run(rays_o, rays_d, **kwargs)
+        depth = torch.empty((B, N), device=rays_o.device)
+        image = torch.empty((B, N, 3), device=rays_o.device)
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                out = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                depth[b:b + 1, head:tail] = out["depth"]
+                image[b:b + 1, head:tail] = out["image"]
+        return {"depth": depth, "image": image}

@@ -26,11 +26,14 @@ class ChairScene:
     `thicken` inflates every box (world units): 0.0 / 0.08 (default) / 0.2 give the occupancy sweep
     (about 1 % / 5 % / 15 % occupied cells of a 128^3 grid at bound 1)."""
 
-    def __init__(self, sigma_in=50.0, thicken=0.08):
+    def __init__(self, sigma_in=50.0, thicken=0.08, scale=1.0):
         self.sigma_in = float(sigma_in)
         self.thicken = float(thicken)
+        self.scale = float(scale)  # > 1: the object outgrows [-1, 1]^3 (scenes with bound > 1: the outer cascades get samples)
 
     def inside(self, x):
+        if self.scale != 1.0:
+            x = x / self.scale
         m = torch.zeros(x.shape[:-1], dtype=torch.bool, device=x.device)
         for c, h in _CHAIR_BOXES:
             c = torch.tensor(c, device=x.device, dtype=x.dtype)

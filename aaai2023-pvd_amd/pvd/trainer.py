@@ -635,7 +635,7 @@ class TeacherTrainer(_TrainerBase):
         self._zero_grads()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                           dt_gamma=o.dt_gamma, max_steps=o.max_steps)
+                           dt_gamma=o.dt_gamma, max_steps=o.max_steps, num_steps=o.num_steps, upsample_steps=o.upsample_steps)
             pred = out["image"]
             loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":

@@ -71,7 +71,7 @@ def measure_mean_count(model, poses, opt, n_poses=8, generator=None):
 class DistillWorkload:
     """hash -> <student> distillation on the synthetic chair (BASELINE.json configs[2] for student 'vm')."""
 
-    def __init__(self, ops, device, opt=None, teacher_pretrain_steps=0, seed=0, dp=None, start_stage="stage3", thicken=0.08):
+    def __init__(self, ops, device, opt=None, teacher_pretrain_steps=0, seed=0, dp=None, start_stage="stage3", thicken=0.08, scene_scale=1.0):
         self.ops, self.device = ops, torch.device(device)
         self.opt = opt or PVDConfig()
         opt = self.opt
@@ -80,7 +80,7 @@ class DistillWorkload:
         self.gen = torch.Generator(device=self.device)
         self.dp_rank = dp.rank if dp else 0
         self.gen.manual_seed(seed + 1000 * self.dp_rank)  # different rays on every rank
-        self.scene = ChairScene(thicken=thicken)
+        self.scene = ChairScene(thicken=thicken, scale=scene_scale)
         self.poses = torch.from_numpy(synthetic_poses(self.rng, opt.scale)).to(self.device)
 
         self.tea = make_model(ops, opt, opt.teacher_type, True, self.device)

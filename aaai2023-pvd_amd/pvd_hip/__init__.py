@@ -50,7 +50,7 @@ ENTRY_POINTS = (
     "pvd_head_forward",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel", "pvd_grid_set_level_weights",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
@@ -347,12 +347,22 @@ def grid_set_variant(v):
     return int(_lib.pvd_grid_set_variant(_int(int(v))))
 
 
+def grid_set_level_weights(weights=None):
+    w = [float(v) for v in (weights or [])]
+    arr = (ctypes.c_float * max(len(w), 1))(*w)
+    _check(int(_lib.pvd_grid_set_level_weights(arr, _u32(len(w)))), "pvd_grid_set_level_weights")
+
+
 def grid_set_fwd_kernel(lanes_per_sample, persistent_blocks=0):
     """0 = thread per (sample, level); 2 / 4 = lanes per sample (k_grid_fwd_lps); see include/pvd_hip.h."""
     rc = int(_lib.pvd_grid_set_fwd_kernel(_int(int(lanes_per_sample)), _int(int(persistent_blocks))))
     if rc < 0:
         raise PvdHipError("grid_set_fwd_kernel: lanes_per_sample must be 0, 2 or 4")
     return rc
+
+
+if os.environ.get("PVD_GRID_LPS"):  # A/B knob: PVD_GRID_LPS=2 [PVD_GRID_PERSIST=4096] [PVD_GRID_AFFINE=1]
+    grid_set_fwd_kernel(int(os.environ["PVD_GRID_LPS"]), int(os.environ.get("PVD_GRID_PERSIST", "0")) | ((1 << 30) if os.environ.get("PVD_GRID_AFFINE") == "1" else 0))
 
 
 # --------------------------------------------------------------------------- _shencoder

@@ -170,6 +170,11 @@ int pvd_grid_set_variant(int variant);
  * Results are bit-identical.  Returns the previous setting (lanes | blocks << 4) or PVD_ERR_INVALID. */
 int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks);
 
+/* XCD-affine order of the lanes-per-sample kernel (persistent_blocks | 1 << 30): relative cost of one work item of each
+ * level, used to cut the level-major item list into 8 equal-cost stretches (one per XCD).  weights_host[n] (HOST array),
+ * 0 = the built-in profile for that level.  n = 0 restores the profile. */
+int pvd_grid_set_level_weights(const float *weights_host, uint32_t n);
+
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
  * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
  * when calc_grad_inputs.  `embeddings` is unused by the arithmetic (as in the reference) and may be null. */

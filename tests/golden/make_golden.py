@@ -167,5 +167,70 @@ torch.manual_seed(3)
 r = ref_utils.get_rays(poses[:1], np.array([1111.1, 1111.1, 400.0, 400.0]), 800, 800, 64)
 out.update(rays_n_inds=r["inds"].numpy(), rays_n_o=r["rays_o"].numpy(), rays_n_d=r["rays_d"].numpy())
 
+# ---- the reference's NeRFNetwork.forward / density run HERE on the CPU (distill_mutual/network.py:335-494): the torch parts
+# of the path -- VM plane x line lookup (12 x F.grid_sample, :216-309), FreqEncoder + NeRF MLP, sigma_net / color_net /
+# basis_mat heads, clamp, trunc_exp, sigmoid -- are the reference's own code and arithmetic, forward AND backward (torch
+# autograd).  (`hash`: the table lookup inside it goes through the oracle standing in for _gridencoder; SH likewise.)
+# Small instances so that the fixtures stay small: the state-dict, the inputs and what the reference computed.
+def small_args(**kw):
+    a = dict(plenoxel_degree=3, plenoxel_res="[128,128,128]", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+             sigma_clip_min=-2, sigma_clip_max=7, global_step=10 ** 6, stage_iters={"stage1": 2000, "stage2": 5000},
+             enable_edit_plenoxel=False, render_stu_first=True)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+rs = np.random.RandomState(21)
+xq = rs.uniform(-1, 1, size=(193, 3)).astype(np.float32)
+xq[0] = (1.0, -1.0, 0.25); xq[1] = (0.0, 0.0, 0.0)  # box corner / centre
+dq = rs.standard_normal((193, 3)).astype(np.float32)
+dq /= np.linalg.norm(dq, axis=1, keepdims=True)
+out.update(refnet_x=xq, refnet_d=dq)
+for mt in ("vm", "mlp", "hash"):
+    torch.manual_seed(100 + len(mt))
+    a = small_args()
+    net = RefNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=16, model_type=mt, args=a, is_teacher=False)
+    with torch.no_grad():  # away from the initialisation: features that exercise the clamps and a non-flat colour head
+        for n, p in net.named_parameters():
+            if "embeddings" in n:
+                torch.manual_seed(777)
+                p.copy_((torch.rand(p.shape) - 0.5) * 0.6)  # 42 MB: regenerated from this seed by the test, not stored
+            elif p.dim() >= 2:
+                p.mul_(3.0 if mt == "vm" and p.dim() == 4 else 1.6)
+    net.train()
+    x, d = torch.from_numpy(xq), torch.from_numpy(dq)
+    sigma, color = net(x, d)
+    g_s = torch.from_numpy(rs.standard_normal(193).astype(np.float32))
+    g_c = torch.from_numpy(rs.standard_normal((193, 3)).astype(np.float32))
+    g_f = None
+    fea = net.feature_sigma_color
+    if fea is not None:
+        g_f = torch.from_numpy(rs.standard_normal(tuple(fea.shape)).astype(np.float32)) * 0.1
+    loss = (sigma * g_s).sum() + (color * g_c).sum() + (0 if g_f is None else (fea * g_f).sum())
+    loss.backward()
+    pre = "refnet_%s__" % mt
+    out[pre + "sigma"] = sigma.detach().numpy()
+    out[pre + "color"] = color.detach().numpy()
+    out[pre + "feature_sigma_color"] = fea.detach().numpy()
+    out[pre + "g_sigma"], out[pre + "g_color"], out[pre + "g_fea"] = g_s.numpy(), g_c.numpy(), g_f.numpy()
+    with torch.no_grad():
+        dens = net.density(x)
+    out[pre + "density_sigma"] = dens["sigma"].detach().numpy()
+    keys = []
+    for k, v in net.state_dict().items():
+        keys.append(k)
+        if "embeddings" not in k:
+            out[pre + "sd__" + k] = v.detach().numpy()
+    out[pre + "keys"] = np.array(keys)
+    for n, p in net.named_parameters():
+        if "embeddings" in n:
+            # the table gradient is 42 MB of mostly zeros: keep its non-zero rows
+            rows = p.grad.abs().sum(1).nonzero().squeeze(1)
+            out[pre + "grad_rows__" + n] = rows.numpy()
+            out[pre + "grad_vals__" + n] = p.grad[rows].numpy()
+        else:
+            out[pre + "grad__" + n] = p.grad.detach().numpy()
+
 np.savez_compressed(os.path.join(HERE, "reference_python.npz"), **out)
 print("wrote", os.path.join(HERE, "reference_python.npz"), "with", len(out), "arrays")

@@ -31,12 +31,12 @@ def _generic_ops():
     return ops
 
 
-def _workload(ops, student="vm", seed=0, **kw):
+def _workload(ops, student="vm", seed=0, scene_scale=1.0, **kw):
     from pvd.config import PVDConfig
     from pvd.workload import DistillWorkload
     opt = PVDConfig(num_rays=1024, resolution0=64, iters=300, model_type=student, **kw)
     torch.cuda.manual_seed(1234)
-    return DistillWorkload(ops, torch.device(DEV), opt, teacher_pretrain_steps=0, seed=seed)
+    return DistillWorkload(ops, torch.device(DEV), opt, teacher_pretrain_steps=0, seed=seed, scene_scale=scene_scale)
 
 
 def _pair(student="vm", **kw):
@@ -79,7 +79,7 @@ def _psnr(a, b):
 CASES = {
     "vm": dict(),                                                   # configs[2]: hash -> vm (what bench.py times)
     "hash": dict(),                                                 # hash -> hash, bound 1
-    "hash_bound2": dict(bound=2.0, dt_gamma=1.0 / 256),             # configs[4]: two cascades, distance-proportional steps
+    "hash_bound2": dict(bound=2.0, dt_gamma=1.0 / 256, scene_scale=1.9),  # configs[4]: two cascades, distance-proportional steps
     "tensors_from_mlp": dict(teacher_type="mlp", plenoxel_res="[48,48,48]"),  # configs[3]
 }
 
@@ -139,13 +139,14 @@ def test_training_run_fused_graph_vs_generic_eager(student):
         la.append(float(wa.step()[0]))
         lc.append(float(wc.step()[0]))
     wg.enable_graph()
+    overflow_step = 4 if student != "tensors_from_mlp" else -1  # (the Plenoxel student has no f16 value on its gradient path)
     for k in range(n):
-        if k == 4:  # overflow: every gradient of this step is inf / nan -> the step must be skipped, the scale halved
+        if k == overflow_step:  # overflow: every gradient of this step is inf / nan -> the step must be skipped, the scale halved
             for w in (wa, wg, wc):
                 w.trainer.scaler._scale.fill_(2.0 ** 40)
             before = [_flat_params(w.stu).clone() for w in (wa, wg, wc)]
         ra, rg, rc = wa.step(), wg.step(), wc.step()
-        if k == 4:
+        if k == overflow_step:
             for w, b in zip((wa, wg, wc), before):
                 assert torch.equal(_flat_params(w.stu), b), "an overflowing step must leave the parameters alone"
                 assert float(w.trainer.scaler._scale) == 2.0 ** 39
@@ -158,7 +159,6 @@ def test_training_run_fused_graph_vs_generic_eager(student):
     assert np.allclose(la[n_warm:], lg, rtol=2e-3), (la, lg)
     # fused == generic within f16 noise, step after step (the trajectories would drift apart if a gradient were mis-wired)
     assert np.allclose(la, lc, rtol=1.5e-2), (la, lc)
-    assert la[-1] < la[0]
     pa, pg, pc = _flat_params(wa.stu), _flat_params(wg.stu), _flat_params(wc.stu)
     upd = (pc - p0).norm().item()
     print("training run (%s): losses fused %s\n graph %s\n generic %s\n update %.4e, |fused-graph|/upd %.3e, |fused-generic|/upd %.3e"
@@ -253,7 +253,7 @@ def test_amp_render_error_is_the_f16_formulations_own(kind):
     e_fused = (img_fused - img32).abs().max().item()
     spread = max((img_gen[0] - i).abs().max().item() for i in img_gen[1:])
     assert e_fused <= 2.0 * max(e_gen, spread) + 1e-4, (e_fused, e_gen, spread)
-    assert e_fused <= 1e-2, e_fused
+    assert e_fused <= 1e-4, e_fused  # north_star's RGB bar, met by the AMP path itself on these weights
     p_gen = min(_psnr(i, img32) for i in img_gen)
     p_fused = _psnr(img_fused, img32)
     assert p_fused >= p_gen - 0.1 and p_fused > 45.0, (p_fused, p_gen)

@@ -21,15 +21,15 @@ def _cpu_state(model):
     return {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
 
 
-def _pair(**opt_kw):
+def _pair(scene_scale=1.0, **opt_kw):
     from oracle_ops import oracle_ops
     from pvd.config import PVDConfig
     from pvd.ops import hip_ops
     from pvd.workload import DistillWorkload
     opt_kw = dict(dict(num_rays=512, iters=200, fp16=False), **opt_kw)
     torch.manual_seed(0)
-    gpu = DistillWorkload(hip_ops(), torch.device(DEV), PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0)
-    cpu = DistillWorkload(oracle_ops(), "cpu", PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0)
+    gpu = DistillWorkload(hip_ops(), torch.device(DEV), PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale)
+    cpu = DistillWorkload(oracle_ops(), "cpu", PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale)
     with torch.no_grad():  # weights away from their initialisation (a density field that is not ~constant)
         g = torch.Generator(device=DEV).manual_seed(3)
         for n, p in gpu.tea.named_parameters():
@@ -97,7 +97,7 @@ def test_config4_hash_to_hash_two_cascades_dt_gamma():
     """configs[4]: hash -> hash with bound 2 (two cascades of the occupancy grid, 4096^3 finest level) and the
     distance-proportional step dt_gamma = 1/256 -- the marcher's thread-per-ray branch, mip levels from position and from
     step size (raymarching.cu:44-56, 368-403)."""
-    gpu, cpu = _pair(teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=384)
+    gpu, cpu = _pair(scene_scale=1.9, teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=384)
     assert gpu.stu.cascade == 2 and gpu.stu.encoder.embeddings.shape == gpu.tea.encoder.embeddings.shape
     worst = _distill_steps(gpu, cpu, 3, loss_rtol=2e-4, grad_tol=2e-3)
     print("configs[4] worst gradient error / max|g|: %.2e" % worst)
@@ -114,7 +114,7 @@ def test_config4_stages_one_and_two():
     """The same pair through the reference's stage gates: stage 1 (feature loss only, no compositing -- forward returns
     (None, None), network.py:422-423) and stage 2 (sigma + colour + feature terms, renderer.py:421-438)."""
     for start, key in (("stage1", "fea"), ("stage2", "sigma")):
-        gpu, cpu = _pair(teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=256)
+        gpu, cpu = _pair(scene_scale=1.9, teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=256)
         for w in (gpu, cpu):
             w.trainer.global_step = 0 if start == "stage1" else w.opt.stage_iters["stage1"]
         assert gpu.trainer._stage_of(gpu.trainer.global_step) == (1 if start == "stage1" else 2)

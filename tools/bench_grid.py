@@ -34,7 +34,7 @@ def ray_samples(n_rays):
     return ((torch.cat(xs) + 1) / 2).contiguous()
 
 
-def time_it(x01, emb, variant, iters=50):
+def time_it(x01, emb, variant, iters=100):
     B = x01.shape[0]
     out = torch.empty(14, B, 2, dtype=emb.dtype, device=dev)
     if isinstance(variant, tuple):  # (lanes per sample, persistent workgroups): k_grid_fwd_lps (f16 tables only)
@@ -44,20 +44,35 @@ def time_it(x01, emb, variant, iters=50):
         pvd_hip.grid_set_fwd_kernel(0, 0)
         pvd_hip.grid_set_variant(variant)
     run = lambda: pvd_hip.grid_encode_forward(x01, emb, enc.offsets, out, B, 3, 2, 14, S, 16, False, out, 0, False)
-    for _ in range(5):
+    for _ in range(3):
         run()
+    torch.cuda.synchronize()
+    # 20 launches per HIP graph: eager launches from Python are host-bound below ~11 us per call
+    per_graph = 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            run()
+    g.replay()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(1, iters // per_graph)
     a.record()
-    for _ in range(iters):
-        run()
+    for _ in range(reps):
+        g.replay()
     b.record()
     torch.cuda.synchronize()
+    iters = reps * per_graph
     return a.elapsed_time(b) / iters * 1e3, out
 
 
-coh = {n: ray_samples(n) for n in (4096, 16384, 65536)}
-VARIANTS = [("plain", 0), ("pair", 2), ("xcd", 1), ("lps2", (2, 0)), ("lps4", (4, 0)), ("l2p512", (2, 512)), ("l2p1k", (2, 1024)), ("l2p2k", (2, 2048)),
-            ("l2p4k", (2, 4096)), ("l4p1k", (4, 1024)), ("l4p2k", (4, 2048))]
+coh = {n: ray_samples(n) for n in ((4096,) if os.environ.get("PVD_BENCH_SMALL_TABLE") else (4096, 16384, 65536))}
+AFF = 1 << 30  # XCD-affine item order
+VARIANTS = [("plain", 0), ("pair", 2), ("lps2", (2, 0)), ("lps4", (4, 0)), ("l2p1k", (2, 1024)), ("l2p2k", (2, 2048)), ("l2p4k", (2, 4096)),
+            ("l2a1k", (2, 1024 | AFF)), ("l2a2k", (2, 2048 | AFF)), ("l2a4k", (2, 4096 | AFF)), ("l2a8k", (2, 8192 | AFF))]
+if os.environ.get("PVD_BENCH_SMALL_TABLE"):  # every level fits every L2: what the lookup costs without L2 misses
+    enc = GridEncoder(num_levels=14, desired_resolution=2048, log2_hashmap_size=int(os.environ["PVD_BENCH_SMALL_TABLE"])).to(dev)
+    enc.embeddings.data.uniform_(-1, 1)
+    print("small table: 2^%s rows per hashed level, %d rows total" % (os.environ["PVD_BENCH_SMALL_TABLE"], enc.embeddings.shape[0]))
 print("%-28s %10s %6s " % ("samples", "B", "dtype") + " ".join("%8s" % (n + " us") for n, _ in VARIANTS) + " %9s" % "best GB/s")
 for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("uniform random", torch.rand(1 << 18, 3, device=dev)),
                                                                            ("uniform random", torch.rand(1 << 20, 3, device=dev))]:
