@@ -28,7 +28,7 @@
 // forms the weight gradients dW = dY . X^T with MFMAs whose operands are 16x16 transposes of the
 // register tiles (through a 512-byte LDS scratch per wave); dW tiles live in accumulators for the whole
 // launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
-#include "pvd_device.h"
+#include "grid_lookup.h"
 
 #include <stdlib.h>
 
@@ -36,7 +36,6 @@ namespace pvd {
 
 #include "sh_basis.inc"
 
-typedef _Float16 half_t;
 typedef half_t h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -393,6 +392,142 @@ static int launch_head_fwd(const HeadArgs &a, hipStream_t s) {
     if (blocks > 1024) blocks = 1024;  // 256 CUs x 4; every workgroup pays one weight load
     const size_t lds_bytes = HeadLds<KIND>::halfs * sizeof(half_t);
     hipLaunchKernelGGL((k_head_fwd<KIND>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a);
+    return check_launch();
+}
+
+// ====================================================================== frozen hash model: lookup + head in ONE launch
+//
+// The teacher of a distillation run (and every inference / occupancy query of a hash model) needs no autograd state, so the
+// [14][M][2] f16 encoder output that pvd_grid_encode_forward writes and pvd_head_forward reads back is pure overhead, and so
+// is the second launch.  Here a workgroup owns 128 samples: phase 1 is the lanes-per-sample lookup (gridencoder.hip,
+// k_grid_fwd_lps<2>: lane pair = corners x / x+1, DPP blend in the reference's corner order -- bit-identical values) looped
+// over the 14 levels with the results going to an LDS feature tile [128][28] f16; phase 2 runs the MFMA head on that tile
+// (16 samples per wave and pass, weights from the packed LDS image).  All workgroups of a launch are co-resident (726 at the
+// bench size, <= 3 per CU) and walk the levels in step, so at any moment the whole chip gathers from one or two levels'
+// tables (2 MiB each) -- the level-major sweep that keeps the lookup's working set inside the L2s -- without a grid of
+// (level, block) workgroups; the position of a sample is read once instead of 14 times.
+constexpr uint32_t kFusedTile = 128;        // samples per workgroup pass (= 256 threads / 2 lanes per sample)
+constexpr int kFeatStride = 36;             // halfs per LDS feature row: 28 features + 4 zeros + 4 pad (8-byte B-fragment reads)
+
+struct FusedLookup {
+    const float *xyz;        // [M][3] positions in [-bound, bound]
+    InputAffine aff;         // x01 = (x + add) / div   (GridEncoder.forward's mapping, grid.py:211)
+    const uint32_t *grid;    // embeddings as packed f16 pairs [rows]
+    const int32_t *offsets;  // [15]
+    LevelScales scales;
+    uint32_t gridtype;
+    bool align_corners;
+};
+
+__global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g) {
+    extern __shared__ __align__(16) half_t lds[];
+    constexpr uint32_t D = 3, L = 14;
+    HeadLds<KIND_HASH> W;
+    W.carve(lds);
+    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
+    if (a.image) copy_image(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x, kHeadBlock);
+    else W.load(a, threadIdx.x, kHeadBlock);
+    for (uint32_t i = threadIdx.x; i < kFusedTile * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
+        *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
+    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
+    const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
+    const uint32_t nchunks = div_up(a.M, kFusedTile);
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // ---------------- phase 1: 14-level lookup of sample b by the lane pair (b, xb)
+        const uint32_t b = chunk * kFusedTile + s_local;
+        float x01[D] = {0.f, 0.f, 0.f};
+        bool inside = b < a.M;
+        if (inside) {
+            const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)b * D);
+            x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if (g.aff.on) x01[d] = (x01[d] + g.aff.add) / g.aff.div;
+                inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
+            }
+        }
+        // The 14 levels in two groups of 7: all 28 gathers of a group are issued before the first blend, so a wave has one
+        // memory round trip per group instead of one per level (the levels are independent; with <= 3 workgroups per CU nothing
+        // else hides that latency).  Branch-free: a sample outside the box gathers row 0 of every level and is zeroed afterwards.
+        constexpr uint32_t G = 7;
+#pragma unroll
+        for (uint32_t l0 = 0; l0 < L; l0 += G) {
+            uint32_t v[G][4];
+            float fr[G][D];
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                const uint32_t level = l0 + j;
+                const uint32_t off0 = (uint32_t)g.offsets[level];
+                const float scale = g.scales.scale[level];
+                LevelIndex<D> index;
+                index.init((uint32_t)g.offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, g.gridtype, g.align_corners);
+                const uint32_t *__restrict__ table = g.grid + off0;
+                uint32_t cell[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    const float p = fmaf(x01[d], scale, g.align_corners ? 0.0f : 0.5f);
+                    const float fl = floorf(p);
+                    cell[d] = inside ? (uint32_t)fl : 0u;
+                    fr[j][d] = p - (float)(uint32_t)fl;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t pg[D] = {cell[0] + xb, cell[1] + (k & 1u), cell[2] + (k >> 1)};
+                    v[j][k] = table[inside ? index(pg) : 0u];
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                uint32_t acc = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t yb = k & 1u, zb = k >> 1;
+                    float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
+                    wi *= xb ? fr[j][0] : 1 - fr[j][0];
+                    wi *= yb ? fr[j][1] : 1 - fr[j][1];
+                    wi *= zb ? fr[j][2] : 1 - fr[j][2];
+                    const uint32_t pr = weighted_pair(wi, v[j][k]);
+                    const uint32_t other = dpp_quad<0xB1>(pr);
+                    acc = pk_add(acc, xb ? other : pr);
+                    acc = pk_add(acc, xb ? pr : other);
+                }
+                if (xb == 0) *reinterpret_cast<uint32_t *>(feat + s_local * kFeatStride + 2 * (l0 + j)) = inside ? acc : 0u;
+            }
+        }
+        __syncthreads();  // (also covers the weights / zero columns on the first pass)
+        // ---------------- phase 2: the head on the tile, 16 samples per wave and pass
+        for (uint32_t t16 = wave; t16 < kFusedTile / 16; t16 += kHeadBlock / 64) {
+            const uint32_t row = t16 * 16 + (lane & 15);
+            const size_t bs = (size_t)chunk * kFusedTile + row;
+            const bool valid = bs < a.M;
+            TileIn<KIND_HASH> in;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + row * kFeatStride + 16 * s2 + 4 * hi);
+            in.sraw = 0.f;
+            in.dx = in.dy = in.dz = 0.f;
+            if (valid) { in.dx = a.dirs[3 * bs]; in.dy = a.dirs[3 * bs + 1]; in.dz = a.dirs[3 * bs + 2]; }
+            TileFwd t;
+            head_forward_tile<KIND_HASH>(a, W, in, lane, t);
+            if (valid) {
+                *reinterpret_cast<f4 *>(a.feat16 + bs * 16 + 4 * hi) = t.F;
+                if (hi == 0) {
+                    a.sigma[bs] = __expf(t.F.x);
+                    a.rgb[3 * bs] = sigmoid_h(t.out.x);
+                    a.rgb[3 * bs + 1] = sigmoid_h(t.out.y);
+                    a.rgb[3 * bs + 2] = sigmoid_h(t.out.z);
+                }
+            }
+        }
+        __syncthreads();  // the next chunk's lookup overwrites the tile
+    }
+}
+
+static int launch_hash_fwd_fused(const HeadArgs &a, const FusedLookup &g, hipStream_t s) {
+    const uint32_t nchunks = div_up(a.M, kFusedTile);
+    uint32_t blocks = nchunks;
+    if (blocks > 256u * 4u) blocks = 256u * 4u;  // persistent beyond 4 workgroups per CU
+    const size_t lds_bytes = (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + kFusedTile * kFeatStride * sizeof(half_t);
+    hipLaunchKernelGGL(k_hash_fwd_fused, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g);
     return check_launch();
 }
 
@@ -784,6 +919,24 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
         return launch_head_fwd<KIND_VM>(a, (hipStream_t)stream);
     }
     return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, const void *embeddings_f16, const int32_t *offsets, float S,
+                                uint32_t H, uint32_t gridtype, int align_corners, const float *dirs, uint32_t M, const float *Wa1,
+                                const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
+                                float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
+    if (M == 0) return PVD_OK;
+    if (!xyz || !embeddings_f16 || !offsets || !dirs || !Wa1 || !Wa2 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
+    if (!(in_div != 0.f)) return PVD_ERR_INVALID;
+    HeadArgs a;
+    a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = dirs; a.M = M;
+    a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_sigma_min; a.clip_max = clip_max;
+    a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16; a.image = (const half_t *)image;
+    FusedLookup g;
+    g.xyz = xyz; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
+    g.scales = make_scales(14, S, H); g.gridtype = gridtype; g.align_corners = align_corners != 0;
+    return launch_hash_fwd_fused(a, g, (hipStream_t)stream);
 }
 
 static uint32_t head_bwd_waves(int kind, uint32_t M) {

@@ -10,19 +10,11 @@
 // XCD-local L2 (2 MiB per hashed level in f16) while neighbouring workgroups sweep it, and
 // the [L,B,C] store is a fully coalesced C*sizeof(T)-per-lane write.  One feature vector
 // (C elements) is one global load / one packed atomic.
-#include "pvd_device.h"
-
-#include <math.h>
+#include "grid_lookup.h"
 
 namespace pvd {
 
 constexpr uint32_t kGridBlock = 256;
-constexpr uint32_t kMaxLevels = 32;
-
-struct LevelScales {
-    float scale[kMaxLevels];
-};
-
 // XCD-aware (level, point-block) schedule.  MI355X has 8 XCDs with private 4 MiB L2s and dispatches
 // workgroup i to XCD i % 8.  With a plain (point-block, level) grid every XCD sweeps every level, so each
 // level's table (2 MiB per hashed level in f16) is pulled into all eight L2s: 8 x 21 MB of fabric traffic per
@@ -61,10 +53,11 @@ static int g_grid_variant = 0;           // 1 = XCD-aware schedule, 0 = plain le
 static int g_grid_points_per_thread = 1;  // forward without dy_dx: 1, 2 or 4
 static int g_grid_pair = 0;               // f16, D = 3, C = 2 without dy_dx: paired x / x+1 gathers (k_grid_fwd_pair); off: measured
                                           // 15 % faster on uniformly random points but 4-10 % slower on ray-coherent samples
-static int g_grid_lps = 0;                // f16, D = 3, C = 2 without dy_dx: 2 / 4 = lanes per sample (k_grid_fwd_lps), 0 = thread per sample
-static int g_grid_persist = 0;            // k_grid_fwd_lps: workgroups of the persistent launch (0 = one per work item)
+static int g_grid_lps = 2;                // f16, D = 3, C = 2 without dy_dx: 2 / 4 = lanes per sample (k_grid_fwd_lps, default 2: measured
+                                          // 15-20 % faster than thread-per-sample at the bench size, more on random points), 0 = thread per sample
+static int g_grid_persist = 4096;         // k_grid_fwd_lps: workgroups of the persistent launch (0 = one per work item)
+static int g_grid_bwd_lps = 1;            // backward, f16 / D = 3 / C = 2: two lanes per sample (k_grid_bwd_lps2); 0 = k_grid_bwd_coarse
 static int g_grid_affine = 0;             // k_grid_fwd_lps: XCD-affine item order (LpsSchedule)
-static float g_grid_level_weight[kMaxLevels] = {0};  // affine schedule: relative cost of a level's items (0 = built-in profile)
 static uint32_t g_grid_hash_rows = 1u << 19;  // rows of a hashed level, for the table-size ordering of the affine schedule
 static uint32_t g_grid_level_mask = 0;    // measurement only: if non-zero, the backward scatters just these levels
 static float g_grid_coarse_scale = 1e30f;  // backward: levels with scale below this merge runs of equal rows per wave (0 = off);
@@ -93,104 +86,7 @@ static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t n
     return s;
 }
 
-// C consecutive table elements moved as one naturally aligned access
-template <typename T, uint32_t C>
-struct alignas(sizeof(T) * C) FeatVec {
-    T v[C];
-};
-
-typedef _Float16 half_t;
-typedef half_t half2_t __attribute__((ext_vector_type(2)));
-
-// level-uniform indexing state (reference: get_grid_index, gridencoder.cu:54-72)
-template <uint32_t D>
-struct LevelIndex {
-    uint32_t size;       // hashmap_size = offsets[l+1] - offsets[l]
-    uint32_t stride[D];  // 0 for dimensions the dense loop never reaches
-    bool hashed;
-    bool pow2;
-
-    __device__ __forceinline__ void init(uint32_t size_, uint32_t resolution, uint32_t gridtype, bool align_corners) {
-        size = size_;
-        uint32_t s = 1;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            if (s <= size) {
-                stride[d] = s;
-                s *= align_corners ? resolution : (resolution + 1);
-            } else {
-                stride[d] = 0;
-            }
-        }
-        hashed = (gridtype == 0) && (s > size);
-        pow2 = (size & (size - 1)) == 0;
-    }
-
-    __device__ __forceinline__ uint32_t operator()(const uint32_t (&pg)[D]) const {
-        uint32_t index;
-        if (hashed) {
-            constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
-            index = 0;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) index ^= pg[d] * primes[d];
-            index = pow2 ? (index & (size - 1)) : (index % size);
-        } else {
-            index = 0;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) index += pg[d] * stride[d];
-            if (index >= size) index %= size;  // only when the table was sized smaller than the kernel's resolution
-        }
-        return index;
-    }
-};
-
-// optional input mapping x01 = (x + add) / div applied while reading the positions: GridEncoder.forward's
-// (inputs + bound) / (2 * bound) (grid.py:211) without two elementwise launches; same two IEEE operations
-struct InputAffine {
-    bool on;
-    float add, div;
-};
 static thread_local InputAffine g_input_affine = {false, 0.f, 1.f};
-
-template <uint32_t D>
-__device__ __forceinline__ bool locate(const float *__restrict__ in, float scale, bool align_corners, float (&frac)[D], uint32_t (&cell)[D],
-                                       InputAffine aff = {false, 0.f, 1.f}) {
-    float x[D];
-    bool oob = false;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        x[d] = in[d];
-        if (aff.on) x[d] = (x[d] + aff.add) / aff.div;
-        oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
-    }
-    if (oob) return false;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        const float p = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);  // canonical fused form
-        const float fl = floorf(p);
-        cell[d] = (uint32_t)fl;
-        frac[d] = p - (float)cell[d];
-    }
-    return true;
-}
-
-// accumulate one weighted feature vector with the reference's scalar_t arithmetic:
-//   f32: acc = fma(w, v, acc);   f16: acc = half(acc + half(w * float(v)))  (gridencoder.cu:166)
-template <typename T>
-__device__ __forceinline__ void axpy(T &acc, float w, T v);
-template <>
-__device__ __forceinline__ void axpy<float>(float &acc, float w, float v) { acc = fmaf(w, v, acc); }
-// (half)(float product): the product must be rounded to f32 FIRST and then to f16, as c10::Half /
-// __half conversions of a float expression do (gridencoder.cu:166,303).  hipcc otherwise selects
-// v_fma_mixlo_f16 (one rounding of the exact product), which differs in the last half-ulp for
-// about 1 value in 10^4; the empty asm pins the f32 intermediate.
-__device__ __forceinline__ half_t half_of_product(float a, float b) {
-    float p = a * b;
-    asm volatile("" : "+v"(p));
-    return (half_t)p;
-}
-template <>
-__device__ __forceinline__ void axpy<half_t>(half_t &acc, float w, half_t v) { acc = acc + half_of_product(w, (float)v); }
 
 // reference: kernel_grid, gridencoder.cu:75-224
 template <typename T, uint32_t D, uint32_t C>
@@ -376,36 +272,14 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_fwd_pair(const float *__res
 // The blend keeps the reference's order: every lane rounds its own products (same f32-then-f16 rounding), the partner
 // lanes' products come over by DPP quad permutes, and the sum runs over corners 0..7 in sequence as packed f16 adds (both
 // channels at once; per channel the same IEEE add).  Bit-identical to k_grid_fwd.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
-}
-
-__device__ __forceinline__ uint32_t weighted_pair(float w, uint32_t packed) {
-    half_t v[2];
-    __builtin_memcpy(v, &packed, 4);
-    half_t r[2] = {half_of_product(w, (float)v[0]), half_of_product(w, (float)v[1])};
-    uint32_t out;
-    __builtin_memcpy(&out, r, 4);
-    return out;
-}
-
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
-    half2_t x, y;
-    __builtin_memcpy(&x, &a, 4);
-    __builtin_memcpy(&y, &b, 4);
-    const half2_t s = x + y;  // v_pk_add_f16
-    uint32_t out;
-    __builtin_memcpy(&out, &s, 4);
-    return out;
-}
-
 // Work items of the lanes-per-sample kernel: (level, point block).  Two orders:
 //   plain  : item id = level * nb + pblock, workgroup g takes ids g, g + G, ... (level-major sweep by the whole chip);
 //   affine : every XCD owns a contiguous stretch of the level-major item list (levels sorted by table size, so a big
 //            level's table is walked by ONE XCD -- at most two -- and is fetched into one L2 instead of all eight).
 //            Workgroup g belongs to XCD g % 8 (the hardware's round-robin placement; a different placement costs speed
-//            only) and is the (g / 8)-th of its XCD's G / 8 workgroups.
+//            only) and is the (g / 8)-th of its XCD's G / 8 workgroups.  MEASURED AND REJECTED (kept as an A/B knob): 25 us
+//            against 18 us -- the lookup is bound by the L2s' REQUEST rate (PMC: ~1.3 M line requests per launch, ~9 G/s per
+//            XCD), and pinning a fine level to one XCD piles a third of all requests onto one L2.
 struct LpsSchedule {
     uint32_t nb, total;
     uint32_t affine;               // 0 / 1
@@ -424,10 +298,6 @@ struct LpsSchedule {
         pblock = i - k * nb;
         level = affine ? level_order[k] : k;
     }
-};
-
-struct alignas(4) Pos3 {
-    float x, y, z;
 };
 
 template <uint32_t LPS>
@@ -528,42 +398,7 @@ static LpsSchedule make_lps_schedule(const LevelScales &sc, const int32_t *offse
                 s.level_order[a] = t;
             }
     (void)offsets_host_or_null;
-    // XCD boundaries by COST, not by item count: a fine hashed level (every corner its own cache line) costs several times a
-    // coarse one (neighbouring samples share cells).  Default profile = the per-level times measured at the bench size
-    // (dense levels ~0.45 each, hashed levels 1.1 rising to 4.1); pvd_grid_set_level_weights overrides it.
-    double w[kMaxLevels], total_w = 0.0;
-    uint32_t n_hashed_seen = 0;
-    for (uint32_t k = 0; k < L; k++) {
-        const uint32_t l = s.level_order[k];
-        if (g_grid_level_weight[l] > 0.f) w[k] = g_grid_level_weight[l];
-        else w[k] = rows[l] >= (double)hash_rows ? 0.f : 0.45;
-        total_w += 0.0;
-    }
-    // hashed levels in ascending resolution get the rising profile
-    for (uint32_t l = 0; l < L; l++)
-        if (rows[l] >= (double)hash_rows && !(g_grid_level_weight[l] > 0.f)) {
-            for (uint32_t k = 0; k < L; k++)
-                if (s.level_order[k] == l) w[k] = 1.1 + 0.375 * (double)n_hashed_seen;
-            n_hashed_seen++;
-        }
-    for (uint32_t k = 0; k < L; k++) total_w += w[k] * (double)nb;
-    s.xcd_begin[0] = 0;
-    {
-        double acc = 0.0;
-        uint32_t x = 1;
-        for (uint32_t k = 0; k < L && x < 8; k++) {
-            // items k*nb .. (k+1)*nb - 1 carry w[k] each
-            while (x < 8 && acc + w[k] * (double)nb >= total_w * (double)x / 8.0) {
-                const double need = total_w * (double)x / 8.0 - acc;
-                uint32_t within = (uint32_t)(need / w[k]);
-                if (within > nb) within = nb;
-                s.xcd_begin[x++] = k * nb + within;
-            }
-            acc += w[k] * (double)nb;
-        }
-        for (; x < 8; x++) s.xcd_begin[x] = s.total;
-    }
-    s.xcd_begin[8] = s.total;
+    for (uint32_t x = 0; x <= 8; x++) s.xcd_begin[x] = (uint32_t)(((uint64_t)s.total * x) / 8u);
     return s;
 }
 
@@ -796,6 +631,74 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_bwd_coarse(const T *__restr
     }
 }
 
+// Scatter-add for the tables of this code base (f16, D = 3, C = 2) with TWO lanes per sample, as in the forward
+// (k_grid_fwd_lps): lane pair = corners x / x+1 of the same (y, z), whose rows sit in one cache line 15 times out of 16 (the
+// hash of x is x).  The memory side sees one request per distinct line of a wave-instruction, and a 4-byte packed-f16 atomic
+// is a whole request of its own otherwise: the fabric's request rate (~35 G/s measured), not bytes, bounds this
+// kernel.  Runs of consecutive samples that hit the same row are still merged first (k_grid_bwd_coarse), now among the lanes
+// of equal parity: segmented scan with strides 2, 4, .., 32, the run's last lane issues the atomic.
+__global__ void __launch_bounds__(kGridBlock) k_grid_bwd_lps2(const uint32_t *__restrict__ grad, const float *__restrict__ inputs,
+                                                              const int32_t *__restrict__ offsets, half_t *__restrict__ grad_grid, uint32_t B,
+                                                              uint32_t L, LevelScales scales, uint32_t gridtype, bool align_corners,
+                                                              uint32_t level_mask) {
+    constexpr uint32_t D = 3;
+    const uint32_t level = blockIdx.y;
+    if (level >= L) return;
+    if (level_mask && !((level_mask >> level) & 1u)) return;
+    const uint32_t t = blockIdx.x * kGridBlock + threadIdx.x;
+    const uint32_t b = t >> 1, xb = t & 1u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const float scale = scales.scale[level];
+    LevelIndex<D> index;
+    index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
+    float frac[D];
+    uint32_t cell[D];
+    const bool live = b < B && locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell);
+    float g0 = 0.f, g1 = 0.f;
+    if (live) {
+        half_t gv[2];
+        const uint32_t packed = grad[(size_t)level * B + b];
+        __builtin_memcpy(gv, &packed, 4);
+        g0 = (float)gv[0];
+        g1 = (float)gv[1];
+    }
+    half_t *__restrict__ table = grad_grid + (size_t)off0 * 2;
+    const unsigned long long parity = xb ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t yb = k & 1u, zb = k >> 1;
+        float wi = 1;
+        wi *= live ? (xb ? frac[0] : 1 - frac[0]) : 0.f;
+        wi *= live ? (yb ? frac[1] : 1 - frac[1]) : 0.f;
+        wi *= live ? (zb ? frac[2] : 1 - frac[2]) : 0.f;
+        uint32_t key = 0xffffffffu;
+        if (live) {
+            const uint32_t pg[D] = {cell[0] + xb, cell[1] + yb, cell[2] + zb};
+            key = index(pg);
+        }
+        float v0 = wi * g0, v1 = wi * g1;
+        const uint32_t prev = __shfl_up(key, 2, 64);
+        const bool head = lane < 2 || prev != key;
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = (uint32_t)__popcll(heads & parity & ((2ull << lane) - 1ull));
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) {
+            const uint32_t r_up = __shfl_up(run, off, 64);
+            const bool same = (int)lane >= off && r_up == run;
+            const float u0 = __shfl_up(v0, off, 64), u1 = __shfl_up(v1, off, 64);
+            if (same) { v0 += u0; v1 += u1; }
+        }
+        const bool tail = lane >= 62 || ((heads >> (lane + 2)) & 1ull);
+        if (live && tail) {
+            FeatVec<half_t, 2> sum;
+            sum.v[0] = (half_t)v0;
+            sum.v[1] = (half_t)v1;
+            scatter_add<half_t, 2>(table + (size_t)key * 2, 1.0f, sum);
+        }
+    }
+}
+
 // reference: kernel_input_backward, gridencoder.cu:317-343
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx,
@@ -815,15 +718,6 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_input_bwd(const T *__restri
         }
     }
     grad_inputs[t] = r;
-}
-
-static LevelScales make_scales(uint32_t L, float S, uint32_t H) {
-    LevelScales s;
-    for (uint32_t l = 0; l < kMaxLevels; l++) s.scale[l] = 0.f;
-    // per-level scale on the HOST with libm exp2f: device exp2 differs from libm/CUDA by an ulp or
-    // two, which would move knife-edge samples across cells (SURVEY.md section 7 "hard parts").
-    for (uint32_t l = 0; l < L; l++) s.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:126
-    return s;
 }
 
 template <typename T, uint32_t D, uint32_t C>
@@ -873,6 +767,11 @@ template <typename T, uint32_t D, uint32_t C>
 static int launch_bwd(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, float S,
                       uint32_t H, bool calc, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool align, hipStream_t s) {
     const LevelScales sc = make_scales(L, S, H);
+    if (g_grid_bwd_lps && !calc && D == 3 && C == 2 && sizeof(T) == 2) {
+        hipLaunchKernelGGL(k_grid_bwd_lps2, dim3(div_up(2u * B, kGridBlock), L), dim3(kGridBlock), 0, s, (const uint32_t *)grad, inputs, offsets,
+                           (half_t *)grad_emb, B, L, sc, gridtype, align, g_grid_level_mask);
+        return check_launch();
+    }
     // levels whose cells are wider than a few marching steps go through the run-merging kernel
     uint32_t n_coarse = 0;
     if (g_grid_coarse_scale > 0.f)
@@ -952,15 +851,11 @@ int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks) {
     const int old = g_grid_lps | (g_grid_persist << 4);
     g_grid_lps = lanes_per_sample;
     g_grid_affine = (persistent_blocks & (1 << 30)) ? 1 : 0;  // bit 30: XCD-affine item order
+    g_grid_bwd_lps = (persistent_blocks & (1 << 29)) ? 0 : 1;  // bit 29: backward through k_grid_bwd_coarse (A/B)
+    persistent_blocks &= ~(1 << 29);
     persistent_blocks &= ~(1 << 30);
     g_grid_persist = persistent_blocks > 0 ? persistent_blocks : 0;
     return old;
-}
-
-int pvd_grid_set_level_weights(const float *weights_host, uint32_t n) {
-    if (n > kMaxLevels || (n && !weights_host)) return PVD_ERR_INVALID;
-    for (uint32_t l = 0; l < kMaxLevels; l++) g_grid_level_weight[l] = l < n ? weights_host[l] : 0.f;
-    return PVD_OK;
 }
 
 int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B,

@@ -4,12 +4,15 @@ Reference formulation: NeRFNetwork.forward under autocast (distill_mutual/networ
 bias-free half Linear layers, clamp, trunc_exp, SH degree 4, sigmoid.  Only valid under fp16 autocast (the
 reference forces fp16 on, main_distill_mutual.py:251-254); callers fall back to the layer-by-layer torch
 formulation otherwise."""
+import os
+
 import numpy as np
 import torch
 
 import pvd_hip
 
 KIND_HASH, KIND_VM = 0, 1
+FUSED_LOOKUP = os.environ.get("PVD_HASH_FUSED", "1") != "0"  # frozen hash model: lookup + head in one launch (A/B knob, tests)
 
 
 def _outputs(M, dev):
@@ -54,15 +57,22 @@ def hash_head_infer(model, x, d):
     L = enc.offsets.shape[0] - 1
     C = emb.shape[1]
     assert L == 14 and C == 2 and enc.input_dim == 3, "fused head expects the 14-level, 2-feature hash grid"
-    out = torch.empty(L, M, C, dtype=torch.float16, device=dev)
-    pvd_hip.grid_encode_forward_affine(xin, float(bound), float(2 * bound), cache[2], enc.offsets, out, M, 3, C, L,
-                                       float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners)
     sigma, rgb, feat = _outputs(M, dev)
     a = model.args
     ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
     ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight]
+    image = _cached_image(model, KIND_HASH, ws, ps)
+    S = float(np.log2(enc.per_level_scale))
+    if FUSED_LOOKUP:  # lookup + head in one launch, no [L,M,C] intermediate (bit-identical outputs)
+        pvd_hip.hash_head_forward_fused(xin, float(bound), float(2 * bound), cache[2], enc.offsets, S, enc.base_resolution, enc.gridtype_id,
+                                        enc.align_corners, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
+                                        image=image)
+        return sigma, rgb, feat
+    out = torch.empty(L, M, C, dtype=torch.float16, device=dev)
+    pvd_hip.grid_encode_forward_affine(xin, float(bound), float(2 * bound), cache[2], enc.offsets, out, M, 3, C, L, S, enc.base_resolution,
+                                       enc.gridtype_id, enc.align_corners)
     pvd_hip.head_forward(KIND_HASH, out, None, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_min, a.sigma_clip_max,
-                         sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws, ps))
+                         sigma, rgb, feat, image=image)
     return sigma, rgb, feat
 
 

@@ -47,10 +47,10 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
-    "pvd_head_forward",
+    "pvd_head_forward", "pvd_hash_head_forward_fused",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel", "pvd_grid_set_level_weights",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
@@ -347,13 +347,7 @@ def grid_set_variant(v):
     return int(_lib.pvd_grid_set_variant(_int(int(v))))
 
 
-def grid_set_level_weights(weights=None):
-    w = [float(v) for v in (weights or [])]
-    arr = (ctypes.c_float * max(len(w), 1))(*w)
-    _check(int(_lib.pvd_grid_set_level_weights(arr, _u32(len(w)))), "pvd_grid_set_level_weights")
-
-
-def grid_set_fwd_kernel(lanes_per_sample, persistent_blocks=0):
+def grid_set_fwd_kernel(lanes_per_sample=2, persistent_blocks=4096):
     """0 = thread per (sample, level); 2 / 4 = lanes per sample (k_grid_fwd_lps); see include/pvd_hip.h."""
     rc = int(_lib.pvd_grid_set_fwd_kernel(_int(int(lanes_per_sample)), _int(int(persistent_blocks))))
     if rc < 0:
@@ -511,6 +505,23 @@ def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sig
     _check_image(kind, image)
     _call("pvd_head_forward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
           _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+
+
+def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, gridtype, align_corners, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3,
+                            clip_sigma_min, clip_max, sigma, rgb, feat16, image=None):
+    """Lookup (f16 table, 14 levels x 2 features) + hash head of a frozen model in one launch; see include/pvd_hip.h."""
+    dev = _dev(xyz, embeddings, offsets, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
+    _want(embeddings, torch.float16, "embeddings"), _want(offsets, torch.int32, "offsets")
+    _f32_all(xyz=xyz, dirs=dirs, Wa1=Wa1, Wa2=Wa2, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
+    if offsets.numel() != 15 or embeddings.dim() != 2 or embeddings.shape[1] != 2:
+        raise PvdHipError("the fused hash forward expects the 14-level, 2-feature table")
+    if xyz.shape[0] < M or dirs.shape[0] < M or sigma.numel() < M or rgb.numel() < 3 * M or feat16.numel() < 16 * M:
+        raise PvdHipError("buffers shorter than M rows")
+    _check_image(0, image)
+    status = _invoke("pvd_hash_head_forward_fused", dev, _p(xyz), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H),
+                     _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
+                     _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), meta=(M, 3, 2, 14, PVD_F16))
+    _check(status, "pvd_hash_head_forward_fused")
 
 
 # Kernels that rewrite parameters behind autograd's back (the flat optimizer, a graph replay) do not bump the tensors'

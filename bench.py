@@ -42,6 +42,15 @@ def grid_fwd_bytes_per_sample(D, C, L, T):
     return 4 * D + L * (2 ** D) * C * T + L * C * T
 
 
+def kernel_source_sha16():
+    """Hash of the sources of the roofline kernel: a PMC traffic record is only quoted for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fusedhead.hip", "grid_lookup.h", "gridencoder.hip"):
+        h.update(open(os.path.join(REPO, "aaai2023-pvd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(workload, steps, num_rays):
     """The same distillation step on the host cores through the CPU oracle (fp32), on a bounded
     sample: `steps` steps of `num_rays` rays with the GPU run's weights and occupancy grid."""
@@ -235,43 +244,65 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # ---- roofline of the hash-grid lookup (the kernel north_star names).  Per-kernel HIP events cannot sit inside a
-    # replayed graph, so right after the timed region the SAME kernel is re-launched on the samples of one more step
-    # (teacher forward = pvd_grid_encode_forward + fused head), 40 times back to back with the queue kept full, each
-    # launch bracketed by HIP events on the launch stream (torch's current stream).
+    # ---- roofline of the hash-grid lookup (the kernel north_star names).  HIP events cannot sit inside the replayed step,
+    # so right after the timed region the SAME kernel is launched on the samples of one more step: the frozen teacher's
+    # forward is ONE launch (pvd_hash_head_forward_fused: 14-level lookup + sigma/colour head).  100 launches, captured 20
+    # to a HIP graph so that the host is out of the picture, between one pair of HIP events on the launch stream; the mean
+    # therefore includes one kernel boundary (~1.5 us) per launch.
     import fusedhead
-    name = "pvd_grid_encode_forward_affine"  # the teacher's lookup: k_grid_fwd with the [-bound, bound] -> [0, 1] mapping folded in
     roof = None
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-        rays_o, rays_d, bg, *_ = w.device_batch()
-        out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
-                               max_steps=opt.max_steps)
-        xyzs, dirs = out_stu["inherited_params"][0], out_stu["inherited_params"][1]
-        for _ in range(5):
-            fusedhead.hash_head_infer(w.tea, xyzs, dirs)
-        torch.cuda.synchronize()
-        with pvd_hip.KernelTimer({name}) as kt:
-            for _ in range(40):
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+            rays_o, rays_d, bg, *_ = w.device_batch()
+            out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
+                                   max_steps=opt.max_steps)
+            xyzs, dirs = out_stu["inherited_params"][0], out_stu["inherited_params"][1]
+            for _ in range(3):
                 fusedhead.hash_head_infer(w.tea, xyzs, dirs)
             torch.cuda.synchronize()
-    n_launch = kt.launches(name)
-    if n_launch:
-        mean_ms = kt.mean_ms(name)
-        B, D, C, L, dt_code = kt.meta[name][-1]
-        T = 2 if dt_code == 1 else 4
-        bps = grid_fwd_bytes_per_sample(D, C, L, T)
-        achieved = bps * B / (mean_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):  # FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes, per sample
+            per_graph, reps = 20, 5
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(per_graph):
+                        fusedhead.hash_head_infer(w.tea, xyzs, dirs)
+                g.replay()
+                ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev_a.record(side)
+                for _ in range(reps):
+                    g.replay()
+                ev_b.record(side)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        n_launch = per_graph * reps
+        us = ev_a.elapsed_time(ev_b) / n_launch * 1e3
+        B = int(xyzs.shape[0])
+        fused = bool(getattr(fusedhead, "FUSED_LOOKUP", False)) and opt.fp16
+        # algorithmic bytes per sample: position 12 + 14 levels x 8 corners x 4 B (f16 pair) = 448; the two-launch
+        # form adds the [14][M][2] f16 write (56: 516 B/sample in total); the fused launch adds instead what the head reads and
+        # writes: dirs 12 + sigma 4 + rgb 12 + feature_sigma_color 64 = 92 (552 B/sample)
+        bps = 552 if fused else 516 + 56 + 92
+        achieved = bps * B / (us * 1e-6) / 1e9
+        traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
+        pmc_path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc_path):  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
             pmc = json.load(open(pmc_path))
-            per_sample = (pmc["k_grid_fwd"]["fetch_kb"] + pmc["k_grid_fwd"]["write_kb"]) * 1024.0 / pmc["samples_per_launch"]
-            traffic = per_sample * B
-        roof = {"kernel": "k_grid_fwd<%s,3,2> (pvd_grid_encode_forward_affine)" % ("f16" if T == 2 else "f32"), "bound": "hbm",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json; gather pattern, uncorrected)",
-                "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps, "samples_per_launch": B,
-                "us_per_launch": mean_ms * 1e3, "launches": n_launch}
+            if pmc.get("source_sha16") == kernel_source_sha16() and fused:
+                traffic = (pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0 / pmc["samples_per_launch"] * B
+                traffic_note = "bytes/launch, rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes, tools/pmc_teacher_fwd.py), scaled by samples; " \
+                               "gather pattern, uncorrected (the guide's x2 FETCH_SIZE correction is for wide coalesced streams)"
+            else:
+                traffic_note = "profiles/r02_pmc_traffic.json was taken on a different build of the kernel (source hash differs)"
+        roof = {"kernel": ("k_hash_fwd_fused (pvd_hash_head_forward_fused: hash-grid lookup f16 3x2x14 + sigma/colour head, one launch)" if fused
+                           else "pvd_grid_encode_forward_affine + pvd_head_forward (two launches)"),
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps,
+                "samples_per_launch": B, "us_per_launch": us, "launches": n_launch,
+                "timing": "HIP events on the launch stream around %d launches (HIP graphs of %d), right after the timed region" % (n_launch, per_graph)}
+    except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
+        roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
     total_rays = args.steps * args.rays * world
@@ -290,7 +321,9 @@ def main():
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
         "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
                                "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps" % (args.student, args.rays, args.teacher_pretrain),
-                   "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode, "samples_per_step_per_gpu": samples,
+                   "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
+                   "capture_fallback": (not args.eager) and launch_mode != "hipGraph replay",  # True = the step fell back to eager launches (~5x the ms)
+                   "samples_per_step_per_gpu": samples,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
                    "teacher_psnr_db": w.teacher_psnr,
                    "psnr_student_vs_teacher_db": float(psnr(pred_stu.detach(), pred_tea.detach())) if pred_stu is not None else None,

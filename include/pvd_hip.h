@@ -164,16 +164,13 @@ int pvd_grid_encode_forward(const float *inputs, const void *embeddings, const i
  * (big levels dealt out one per XCD, default), 0 = plain level-major.  Returns the previous value.  Results are identical. */
 int pvd_grid_set_variant(int variant);
 
-/* Forward kernel of the f16 / D = 3 / C = 2 lookup without dy_dx: lanes_per_sample 0 = one thread per (sample, level),
- * 2 / 4 = the corners of a sample spread over 2 / 4 adjacent lanes (corners sharing a cache line are fetched by one
- * load instruction); persistent_blocks > 0 = that many workgroups loop over the (level, point block) work items.
- * Results are bit-identical.  Returns the previous setting (lanes | blocks << 4) or PVD_ERR_INVALID. */
+/* A/B knob of the f16 / D = 3 / C = 2 kernels (results are bit-identical forward, within summation order backward):
+ * lanes_per_sample 0 = one thread per (sample, level), 2 (default) / 4 = the corners of a sample spread over 2 / 4 adjacent
+ * lanes (corners sharing a cache line are fetched by one load instruction); persistent_blocks > 0 (default 4096) = that
+ * many workgroups loop over the (level, point block) work items; | 1 << 30 = XCD-affine item order (rejected, see
+ * gridencoder.hip); | 1 << 29 = backward through the thread-per-sample run-merging kernel instead of the two-lane one.
+ * Returns the previous setting (lanes | blocks << 4) or PVD_ERR_INVALID. */
 int pvd_grid_set_fwd_kernel(int lanes_per_sample, int persistent_blocks);
-
-/* XCD-affine order of the lanes-per-sample kernel (persistent_blocks | 1 << 30): relative cost of one work item of each
- * level, used to cut the level-major item list into 8 equal-cost stretches (one per XCD).  weights_host[n] (HOST array),
- * 0 = the built-in profile for that level.  n = 0 restores the profile. */
-int pvd_grid_set_level_weights(const float *weights_host, uint32_t n);
 
 /* grid_encode_backward -- gridencoder.cu:444-474 (kernels :227-343).
  * grad [L,B,C] dtype; grad_embeddings like embeddings (zero-filled); grad_inputs [B,D] dtype
@@ -245,6 +242,17 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
                      const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
                      const void *image, float clip_sigma_min, float clip_feat_min, float clip_max,
                      float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
+
+/* The frozen hash model in one launch: pvd_grid_encode_forward_affine (f16 table, D = 3, C = 2, L = 14) + pvd_head_forward
+ * (kind = PVD_HEAD_HASH) without the [14][M][2] intermediate -- the teacher of a distillation run, inference, occupancy-grid
+ * density queries (network.py:413-437 under no_grad).  xyz [M,3] in [-bound, bound] mapped with (x + in_add) / in_div;
+ * embeddings_f16 [offsets[14], 2] f16; the other arguments as in the two calls it replaces.  Outputs are bit-identical to
+ * theirs. */
+int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, const void *embeddings_f16,
+                                const int32_t *offsets, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                const float *dirs, uint32_t M, const float *Wa1, const float *Wa2, const float *Wc1,
+                                const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min,
+                                float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
 
 /* Optional weight image.  Every workgroup of the head kernels stages all weights in LDS; converting and
  * (for the backward) transposing the fp32 masters there is the kernels' fixed cost.  pvd_head_pack_weights does it

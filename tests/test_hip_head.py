@@ -288,3 +288,22 @@ def test_hash_density_fused_matches_layerwise():
     rel = (fused["sigma"] - ref["sigma"].float()).abs() / (ref["sigma"].float().abs() + 1e-6)
     assert rel.max().item() <= 8e-3 and rel.mean().item() <= 1e-3
     assert (fused["geo_feat"] - ref["geo_feat"].float()).abs().max().item() <= 4e-3 * (1 + ref["geo_feat"].float().abs().max().item())
+
+
+@pytest.mark.parametrize("M,bound", [(16 * 1000, 1), (4099, 1), (37, 1), (20000, 2)])
+def test_fused_lookup_and_head_is_bit_identical_to_the_two_launches(M, bound, monkeypatch):
+    """pvd_hash_head_forward_fused (lookup + head in one launch, no [14][M][2] intermediate) vs pvd_grid_encode_forward_affine
+    followed by pvd_head_forward: same table values, same blend order, same MFMA chain -> the same bits.  Ragged sizes (not a
+    multiple of the 128-sample workgroup tile or of the 16-sample MFMA tile), samples outside the box, a second cascade."""
+    import fusedhead
+    m = _model("hash").eval()
+    m.bound = bound
+    x, d = _inputs(M)
+    x = x * bound
+    x[-5:] = bound * 1.5  # outside [-bound, bound]: zero features on every level (gridencoder.cu:113-124)
+    monkeypatch.setattr(fusedhead, "FUSED_LOOKUP", False)
+    s0, c0, f0 = fusedhead.hash_head_infer(m, x, d)
+    monkeypatch.setattr(fusedhead, "FUSED_LOOKUP", True)
+    s1, c1, f1 = fusedhead.hash_head_infer(m, x, d)
+    assert torch.equal(s0, s1) and torch.equal(c0, c1) and torch.equal(f0, f1)
+    assert torch.isfinite(s1).all() and f1.abs().max().item() > 0

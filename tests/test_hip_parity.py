@@ -240,6 +240,41 @@ def test_grid_encode_backward(hip, dev, dtype, D, C):
     assert np.array_equal(gi.cpu().numpy(), gi_ref)  # input gradient is deterministic -> bit-exact
 
 
+@pytest.mark.parametrize("coherent", [False, True])
+def test_grid_encode_backward_two_lane_kernel(hip, dev, coherent):
+    """k_grid_bwd_lps2 (f16, D 3, C 2, no input gradient: the training path) and the thread-per-sample run-merging kernel it
+    replaces, both against the oracle.  `coherent`: samples marching along rays, so that whole runs of lanes hit one row (the
+    segmented merge among lanes of equal parity) -- and a ragged size."""
+    rng = np.random.RandomState(12)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19)
+    emb = _table(offs[-1], C, rng, np.float16)
+    B = 20011
+    if coherent:
+        n_rays = 400
+        o = rng.uniform(0.1, 0.9, (n_rays, 1, 3))
+        d = rng.standard_normal((n_rays, 1, 3))
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        steps = np.arange(B // n_rays + 1)[None, :, None] * 1.7e-3
+        x = (o + d * steps).reshape(-1, 3)[:B].astype(np.float32)  # some leave [0,1]: skipped by the kernel (gridencoder.cu:254-259)
+    else:
+        x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    g = (rng.randn(L, B, C) * 0.01).astype(np.float16)
+    ge_ref, _ = oracle.grid_encode_backward(g, x, emb, offs, S, H)
+    ref = ge_ref.astype(np.float32)
+    for knob in (0, 1 << 29):  # two lanes per sample (default) / thread per sample
+        hip.grid_set_fwd_kernel(2, 4096 | knob)
+        ge = torch.zeros(offs[-1], C, dtype=torch.float16, device=dev)
+        dummy = torch.zeros(1, dtype=torch.float16, device=dev)
+        hip.grid_encode_backward(t(g, dev), t(x, dev), t(emb, dev), t(offs, dev), ge, B, D, C, L, S, H, False, dummy, dummy, 0, False)
+        a = ge.float().cpu().numpy()
+        assert np.abs(a - ref).max() <= 2e-2 * np.abs(ref).max(), (knob, np.abs(a - ref).max(), np.abs(ref).max())
+        np.testing.assert_allclose(a.sum(), ref.sum(), rtol=5e-2, atol=1e-2)
+    hip.grid_set_fwd_kernel()
+
+
 @pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
 def test_grid_encode_forward_paired_gathers_bit_exact(hip, dev, gridtype, align):
     """k_grid_fwd_pair (knob bit 1: x / x+1 corners from one 8-byte access) == the oracle and == the default kernel."""
@@ -263,6 +298,32 @@ def test_grid_encode_forward_paired_gathers_bit_exact(hip, dev, gridtype, align)
     hip.grid_set_variant(0)
     assert torch.equal(outs[0], outs[1])
     assert np.array_equal(outs[0].cpu().numpy().view(np.uint16), np.ascontiguousarray(ref).view(np.uint16))
+
+
+@pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
+def test_grid_encode_forward_lanes_per_sample_kernels_bit_exact(hip, dev, gridtype, align):
+    """k_grid_fwd_lps<2> (the default for f16 / D 3 / C 2), <4>, one workgroup per work item or persistent, level-major or
+    XCD-affine item order, and the thread-per-sample k_grid_fwd: all == the oracle bit for bit (the corners of a sample sit on
+    2 / 4 adjacent lanes, products cross by DPP, the sum keeps the reference's corner order); ragged sizes."""
+    rng = np.random.RandomState(18)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19, align)
+    emb = _table(offs[-1], C, rng, np.float16)
+    for B in (30001, 77, 1):
+        x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+        x[:1] = [[1.5, 0.5, 0.5]]  # out of range: zeros
+        if B > 10:
+            x[1:6] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 1], [0.999999, 0.25, 0.75]]
+        ref, _ = oracle.grid_encode_forward(x, emb, offs, S, H, gridtype=gridtype, align_corners=align)
+        ref_bits = np.ascontiguousarray(ref).view(np.uint16)
+        for lps, persist in ((2, 4096), (2, 0), (2, 96), (4, 0), (4, 1000), (2, 64 | (1 << 30)), (0, 0)):
+            hip.grid_set_fwd_kernel(lps, persist)
+            out = torch.full((L, B, C), 7.0, dtype=torch.float16, device=dev)
+            hip.grid_encode_forward(t(x, dev), t(emb, dev), t(offs, dev), out, B, D, C, L, S, H, False, out, gridtype, align)
+            assert np.array_equal(out.cpu().numpy().view(np.uint16), ref_bits), (B, lps, persist)
+    hip.grid_set_fwd_kernel()
 
 
 @pytest.mark.parametrize("dtype,bound", [(np.float32, 1.0), (np.float16, 2.0), (np.float16, 1.0)])

@@ -84,4 +84,4 @@ for name, x in [("ray-coherent %d rays" % n, v) for n, v in coh.items()] + [("un
         print("%-28s %10d %6s " % (name, x.shape[0], "f16" if dt == torch.float16 else "f32") + " ".join("%8.1f" % t for t in ts)
               + " %9.0f" % (bps * x.shape[0] / min(ts) / 1e3))
 pvd_hip.grid_set_variant(0)
-pvd_hip.grid_set_fwd_kernel(0, 0)
+pvd_hip.grid_set_fwd_kernel()
