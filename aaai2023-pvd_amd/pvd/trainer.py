@@ -91,13 +91,21 @@ class RayDP:
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.capture = None  # a SegmentedCapture while the trainer records a step
+        # RCCL collectives can be recorded INTO the step's HIP graph (probed on MI355X / ROCm 7: tools/probe_rccl_capture.py):
+        # the whole step is then ONE graph launch instead of three graphs with two eager collectives between them (~60 us of
+        # fixed overhead per step).  gloo cannot be captured; PVD_DP_INGRAPH=0 keeps the segmented form; a capture that
+        # fails falls back to it (DistillTrainer.capture_step).
+        self.ingraph = (self.enabled and dist.get_backend(group) == "nccl" and os.environ.get("PVD_DP_INGRAPH", "1") != "0")
+
 
     def all_reduce_sum_(self, t, overlap=None):
         """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
         next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
         if self.enabled:
             run = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            if self.capture is not None and self.capture.active:
+            if self.capture is not None and self.capture.active and self.ingraph:
+                run()  # recorded as a node of the graph being captured
+            elif self.capture is not None and self.capture.active:
                 replay = None
                 if overlap is not None:
                     def replay():
@@ -564,7 +572,20 @@ class DistillTrainer(_TrainerBase):
         stage = self._stage_of(self.global_step)
         assert self._stage_of(self.global_step + warm) == stage, \
             "capture_step: the %d warm-up steps cross a stage boundary (global_step %d); step eagerly past it first" % (warm, self.global_step)
-        if self.dp.enabled and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
+        if self.dp.enabled and self.dp.ingraph:
+            # ONE graph for the whole step, both collectives recorded into it (no graph cuts, no eager calls per step); the
+            # gradient exchange is then not overlapped with the next step's prefix -- a replayed child graph cannot be
+            # recorded into a capture here (tools/probe_rccl_capture.py) -- which costs less than the ~60 us of fixed
+            # overhead the three-graph form pays on every step
+            try:
+                out = self.capture(body)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                torch.cuda.synchronize()
+                self.dp.ingraph, self.dp.capture = False, None  # fall back to graphs cut at the collectives
+                return self.capture_step(batch_fn)
+        elif self.dp.enabled and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
             out = self._capture_pipelined(batch_fn, body)
         elif not self.dp.enabled and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
             self._pipe_stream = torch.cuda.Stream()

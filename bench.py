@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--fp32", action="store_true", help="disable AMP (the reference forces fp16 on)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --rays is the GLOBAL batch, split evenly across the ranks (default: weak, --rays per GPU)")
     ap.add_argument("--workload", choices=["distill", "teacher"], default="distill",
                     help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
@@ -190,6 +192,10 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, "--gpus must match WORLD_SIZE"
+    global_rays = args.rays * (1 if args.strong else world)
+    if args.strong:  # SURVEY section 8e's partition: one global batch of pixels, rank r renders its contiguous slice
+        assert args.rays % world == 0, "--strong needs --rays divisible by the number of GPUs"
+        args.rays //= world
     if args.workload == "teacher":
         assert world == 1, "the teacher workload is single-GPU"
         return teacher_workload(args, dev)
@@ -305,7 +311,7 @@ def main():
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
-    total_rays = args.steps * args.rays * world
+    total_rays = args.steps * global_rays
     out = {
         "metric": "train rays/s (hash->%s chair distillation step)" % opt.model_type,
         "value": total_rays / elapsed,
@@ -315,7 +321,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP, as the reference forces) / f32 marcher+compositor",
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
@@ -339,16 +345,25 @@ def main():
             out["config"]["exchange"] = "all-reduce of %.1f MB (%s of %.1f MB of fp32 gradients)%s + 16 B of loss sums" % (
                 c.idx.numel() * 4 / 1e6 if compact else total, "touched rows only" if compact else "dense", total,
                 ", next step's prefix replayed underneath" if getattr(tr, "_g_prefix", None) is not None else "")
+            out["config"]["exchange"] += ("; collectives recorded into the step's HIP graph (1 graph launch per step)" if dp.ingraph else
+                                          "; collectives eager between %d graphs" % len(getattr(tr, "_cap").graphs))
         except Exception as e:  # noqa: BLE001
             out["config"]["exchange"] = "unknown (%s)" % type(e).__name__
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
     else:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST thing on stdout: the communication library writes its version banner through the C
+        # runtime's buffer, which would otherwise be flushed at exit, after Python's
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

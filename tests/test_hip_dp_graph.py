@@ -75,8 +75,8 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
 
 
-def _rccl_worker(rank, port, out_path):
-    os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _rccl_worker(rank, port, out_path, ingraph):
+    os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", PVD_DP_INGRAPH="1" if ingraph else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -94,19 +94,27 @@ def _rccl_worker(rank, port, out_path):
     torch.cuda.manual_seed(100)
     w.enable_graph()
     cap = w.trainer._cap
-    assert len(cap.graphs) == 3 and len(cap.between) == 2
-    assert getattr(w.trainer, "_g_prefix", None) is not None
+    if ingraph:  # both collectives recorded into the one graph of the step
+        assert dp.ingraph and len(cap.graphs) == 1 and len(cap.between) == 0
+    else:
+        assert len(cap.graphs) == 3 and len(cap.between) == 2
+        assert getattr(w.trainer, "_g_prefix", None) is not None
     losses = [float(w.step()[1]["rgb"]) for _ in range(40)]
     torch.cuda.synchronize()
     torch.save({"losses": losses}, out_path)
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_rccl_collectives_between_captured_segments(tmp_path):
-    """The same segmented capture with the REAL backend (nccl == RCCL) in a world of one rank: RCCL's streams and watchdog
-    thread run next to the captures (thread_local capture mode), the all-reduces are eager between replays."""
-    out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
-    losses = torch.load(out)["losses"]
-    assert len(losses) == 40 and all(l == l for l in losses) and losses[-1] < losses[0]
+@pytest.mark.timeout(900)
+def test_rccl_collectives_with_the_captured_step(tmp_path):
+    """The REAL backend (nccl == RCCL) in a world of one rank, both ways: collectives recorded INTO the step's graph (the
+    default: one graph launch per step) and eager between three graphs cut at the collectives (PVD_DP_INGRAPH=0: RCCL's
+    streams and watchdog thread next to thread_local captures).  Same batches, same update rule: same training."""
+    runs = []
+    for ingraph in (True, False):
+        out = str(tmp_path / ("rccl%d.pt" % ingraph))
+        mp.spawn(_rccl_worker, args=(_free_port(), out, ingraph), nprocs=1, join=True)
+        losses = torch.load(out)["losses"]
+        assert len(losses) == 40 and all(l == l for l in losses) and losses[-1] < losses[0]
+        runs.append(losses)
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
