@@ -124,6 +124,7 @@ struct HeadArgs {
     const float *Wc3;  // color_net.2 [3][64]
     const half_t *image;  // optional: the weights pre-packed by pvd_head_pack_weights (LDS image), else NULL
     float clip_sigma_min, clip_feat_min, clip_max;
+    const int32_t *rows_dev;  // optional DEVICE row count: only the first min(M, *rows_dev) rows are processed (inference rounds)
     // outputs
     float *sigma;   // [M]
     float *rgb;     // [M][3]
@@ -353,6 +354,8 @@ __device__ __forceinline__ float sigmoid_h(float pre) {
 template <int KIND>
 __global__ void __launch_bounds__(kHeadBlock) k_head_fwd(HeadArgs a) {
     extern __shared__ __align__(16) half_t lds[];
+    if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
+    if (blockIdx.x * (kHeadBlock / 64) * 16u >= a.M) return;  // nothing for this workgroup: skip the weight staging too
     HeadLds<KIND> W;
     W.carve(lds);
     if (a.image) copy_image(lds, a.image, HeadLds<KIND>::halfs, threadIdx.x, kHeadBlock);
@@ -422,6 +425,8 @@ struct FusedLookup {
 __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g) {
     extern __shared__ __align__(16) half_t lds[];
     constexpr uint32_t D = 3, L = 14;
+    if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
+    if (blockIdx.x * kFusedTile >= a.M) return;  // nothing for this workgroup: skip the weight staging too
     HeadLds<KIND_HASH> W;
     W.carve(lds);
     half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
@@ -902,7 +907,8 @@ int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const fl
 
 int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1,
                      const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min,
-                     float clip_feat_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
+                     float clip_feat_min, float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
+                     pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
     HeadArgs a;
@@ -910,6 +916,7 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
     a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
     a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_feat_min; a.clip_max = clip_max;
     a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16; a.image = (const half_t *)image;
+    a.rows_dev = rows_dev;
     if (kind == KIND_HASH) {
         if (!Wa2) return PVD_ERR_INVALID;
         return launch_head_fwd<KIND_HASH>(a, (hipStream_t)stream);
@@ -924,7 +931,8 @@ int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const flo
 int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, const void *embeddings_f16, const int32_t *offsets, float S,
                                 uint32_t H, uint32_t gridtype, int align_corners, const float *dirs, uint32_t M, const float *Wa1,
                                 const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
-                                float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
+                                float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
+                                pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !embeddings_f16 || !offsets || !dirs || !Wa1 || !Wa2 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
     if (!(in_div != 0.f)) return PVD_ERR_INVALID;
@@ -933,6 +941,7 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
     a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
     a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_sigma_min; a.clip_max = clip_max;
     a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16; a.image = (const half_t *)image;
+    a.rows_dev = rows_dev;
     FusedLookup g;
     g.xyz = xyz; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
     g.scales = make_scales(14, S, H); g.gridtype = gridtype; g.align_corners = align_corners != 0;
@@ -965,6 +974,7 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
     a.f.Wa1 = Wa1; a.f.Wa2 = Wa2; a.f.Wc1 = Wc1; a.f.Wc2 = Wc2; a.f.Wc3 = Wc3;
     a.f.clip_sigma_min = clip_sigma_min; a.f.clip_feat_min = clip_feat_min; a.f.clip_max = clip_max;
     a.f.sigma = nullptr; a.f.rgb = nullptr; a.f.feat16 = nullptr; a.f.image = (const half_t *)image;
+    a.f.rows_dev = nullptr;
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_rgb2 = g_rgb2; a.g_feat16 = g_feat16; a.g_sigma_raw = g_sigma_raw; a.g_x0 = (half_t *)g_x0;
     a.partials = workspace;
     const uint32_t nwaves = head_bwd_waves(kind, M);

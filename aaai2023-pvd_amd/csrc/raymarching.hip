@@ -1079,6 +1079,142 @@ __global__ void __launch_bounds__(kBlock) k_compact_rays(uint32_t n_alive, int32
     }
 }
 
+// ------------------------------------------------------------------ inference rounds without host round trips
+//
+// The reference's inference loop (renderer.py:450-543) reads the number of surviving rays back to the host after every
+// round (`alive_counter.item()`, :488): n_alive sizes the next launches and picks n_step = max(min(N / n_alive, 8), 1).
+// Here that state lives on the device -- `st` below -- and every kernel of a round takes its extent from it, in
+// persistent grid-stride loops, so a round is a fixed launch sequence the host can issue without looking:
+//     [k_infer_compact]  k_infer_begin  k_infer_march  <model forward on st.rows rows>  k_infer_composite
+// The host checks st only every few rounds (to stop, and to shrink the launch sizes).  Per-ray results are those of the
+// reference loop: same n_step rule, same march / composite arithmetic (k_march_rays / k_composite_rays bodies).
+struct InferState {
+    int32_t cnt[2];      // alive counts: round i uses cnt[i & 1] (written by the compaction of its own start)
+    int32_t n_alive;     // this round
+    int32_t n_step;
+    int32_t rows;        // n_alive * n_step: the rows of xyzs / dirs / deltas / sigmas / rgbs in use
+    int32_t steps_done;  // sum of n_step over the rounds so far (the reference's `step`, :483-541)
+    int32_t rounds;
+    int32_t pad;
+};
+
+constexpr uint32_t kInferBlocks = 1024;  // persistent grids: 4 workgroups per CU
+
+__global__ void k_infer_begin(InferState *__restrict__ st, uint32_t parity, uint32_t N, uint32_t max_steps) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int32_t n = st->cnt[parity];
+    if ((uint32_t)st->steps_done >= max_steps) n = 0;  // `while step < max_steps` (:483)
+    const int32_t n_step = n > 0 ? max(min((int32_t)(N / (uint32_t)n), 8), 1) : 0;  // (:493)
+    st->n_alive = n;
+    st->n_step = n_step;
+    st->rows = n * n_step;
+    st->steps_done += n_step;
+    st->rounds += n > 0 ? 1 : 0;
+    st->cnt[parity ^ 1u] = 0;  // target of the next round's compaction
+}
+
+__global__ void __launch_bounds__(kBlock) k_infer_compact(const InferState *__restrict__ st_in, InferState *__restrict__ st, uint32_t parity,
+                                                          int32_t *__restrict__ rays_alive, const int32_t *__restrict__ rays_alive_old,
+                                                          float *__restrict__ rays_t, const float *__restrict__ rays_t_old) {
+    __shared__ uint32_t wave_cnt[kBlock / kWave];
+    __shared__ uint32_t block_base;
+    const uint32_t n_old = (uint32_t)st_in->n_alive;  // the round that just finished
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * kBlock; base < n_old; base += gridDim.x * kBlock) {  // uniform per workgroup
+        const uint32_t n = base + threadIdx.x;
+        float t = -1.0f;
+        int32_t id = 0;
+        if (n < n_old) { t = rays_t_old[n]; id = rays_alive_old[n]; }
+        const bool keep = (n < n_old) && (t >= 0);
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kBlock / kWave; w++) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            block_base = tot ? (uint32_t)atomicAdd(&st->cnt[parity], (int32_t)tot) : 0u;
+        }
+        __syncthreads();
+        if (keep) {
+            const uint32_t dst = block_base + wave_cnt[wid] + rank;
+            rays_alive[dst] = id;
+            rays_t[dst] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_infer_march(const InferState *__restrict__ st, const int32_t *__restrict__ rays_alive,
+                                                        const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                        const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                                        uint32_t C, uint32_t H, const uint8_t *__restrict__ grid, const float *__restrict__ fars,
+                                                        float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                        uint32_t perturb) {
+    const uint32_t n_alive = (uint32_t)st->n_alive, n_step = (uint32_t)st->n_step;
+    for (uint32_t n = blockIdx.x * kBlock + threadIdx.x; n < n_alive; n += gridDim.x * kBlock) {
+        const int32_t index = rays_alive[n];
+        Dda r;
+        r.init(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, bound, dt_gamma, max_steps, C, H, grid);
+        const float far = fars[index];
+        float t = ray_t0(rays_t[n], r.dt_min, perturb, (uint64_t)perturb, n);
+        float last_t = t;
+        float *px = xyzs + 3 * (size_t)n * n_step, *pd = dirs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;
+        uint32_t step = 0;
+        while (t < far && step < n_step) {
+            float x, y, z, dt, tn;
+            if (r.probe(t, x, y, z, dt, tn)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+                t += dt;
+                pl[0] = dt; pl[1] = t - last_t; last_t = t;
+                px += 3; pd += 3; pl += 2; step++;
+            } else {
+                t = tn;
+            }
+        }
+        // the reference hands over zero-filled buffers (raymarching.py:421-426): dt == 0 marks the end of a ray
+        for (; step < n_step; step++) {
+            px[0] = px[1] = px[2] = 0.f; pd[0] = pd[1] = pd[2] = 0.f; pl[0] = pl[1] = 0.f;
+            px += 3; pd += 3; pl += 2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_infer_composite(const InferState *__restrict__ st, const int32_t *__restrict__ rays_alive,
+                                                            float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                            const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                                            float sigma_scale, float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                            float *__restrict__ image) {
+    const uint32_t n_alive = (uint32_t)st->n_alive, n_step = (uint32_t)st->n_step;
+    for (uint32_t n = blockIdx.x * kBlock + threadIdx.x; n < n_alive; n += gridDim.x * kBlock) {
+        const int32_t index = rays_alive[n];
+        float t = rays_t[n];
+        float ws = weights_sum[index], d = depth[index];
+        float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            const size_t i = (size_t)n * n_step + step;
+            const float dl0 = deltas[2 * i];
+            if (dl0 == 0) break;
+            const float alpha = 1.0f - __expf(-(sigma_scale * sigmas[i]) * dl0);  // density_scale * sigmas (renderer.py:528)
+            const float T = 1 - ws;
+            const float w = alpha * T;
+            ws += w;
+            t += deltas[2 * i + 1];
+            d += w * t;
+            r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
+            if ((double)T < 1e-4) break;
+            step++;
+        }
+        rays_t[n] = (step < n_step) ? -1.0f : t;
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    }
+}
+
 }  // namespace pvd
 
 // ====================================================================== C ABI
@@ -1284,6 +1420,44 @@ int pvd_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_
     PVD_REQUIRE(rays_alive && rays_alive_old && rays_t && rays_t_old && alive_counter);
     hipLaunchKernelGGL(k_compact_rays, dim3(div_up(n_alive, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n_alive, rays_alive,
                        rays_alive_old, rays_t, rays_t_old, alive_counter);
+    return check_launch();
+}
+
+static uint32_t infer_blocks(uint32_t upper) {
+    uint32_t b = div_up(upper ? upper : 1u, kBlock);
+    return b < kInferBlocks ? b : kInferBlocks;
+}
+
+int pvd_infer_round_begin(int32_t *state, uint32_t parity, uint32_t N, uint32_t max_steps, pvd_stream_t stream) {
+    PVD_REQUIRE(state && parity < 2 && N > 0);
+    hipLaunchKernelGGL(k_infer_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, (InferState *)state, parity, N, max_steps);
+    return check_launch();
+}
+
+int pvd_infer_compact(int32_t *state, uint32_t parity, uint32_t n_upper, int32_t *rays_alive, const int32_t *rays_alive_old, float *rays_t,
+                      const float *rays_t_old, pvd_stream_t stream) {
+    PVD_REQUIRE(state && parity < 2 && rays_alive && rays_alive_old && rays_t && rays_t_old);
+    hipLaunchKernelGGL(k_infer_compact, dim3(infer_blocks(n_upper)), dim3(kBlock), 0, (hipStream_t)stream, (const InferState *)state,
+                       (InferState *)state, parity, rays_alive, rays_alive_old, rays_t, rays_t_old);
+    return check_launch();
+}
+
+int pvd_infer_march(const int32_t *state, uint32_t n_upper, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                    const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+                    const float *fars, float *xyzs, float *dirs, float *deltas, uint32_t perturb, pvd_stream_t stream) {
+    PVD_REQUIRE(state && rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas);
+    PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
+    hipLaunchKernelGGL(k_infer_march, dim3(infer_blocks(n_upper)), dim3(kBlock), 0, (hipStream_t)stream, (const InferState *)state, rays_alive,
+                       rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    return check_launch();
+}
+
+int pvd_infer_composite(const int32_t *state, uint32_t n_upper, const int32_t *rays_alive, float *rays_t, const float *sigmas,
+                        const float *rgbs, const float *deltas, float sigma_scale, float *weights_sum, float *depth, float *image,
+                        pvd_stream_t stream) {
+    PVD_REQUIRE(state && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image);
+    hipLaunchKernelGGL(k_infer_composite, dim3(infer_blocks(n_upper)), dim3(kBlock), 0, (hipStream_t)stream, (const InferState *)state,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, sigma_scale, weights_sum, depth, image);
     return check_launch();
 }
 

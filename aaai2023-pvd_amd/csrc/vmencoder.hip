@@ -347,7 +347,9 @@ __device__ __forceinline__ void walk_move(PlaneWin<GRAD> &pw, LineWin<GRAD> &lw,
 
 template <typename T>
 __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
-                                                     float *__restrict__ sigma_feat, T *__restrict__ color_prod) {
+                                                     float *__restrict__ sigma_feat, T *__restrict__ color_prod,
+                                                     const int32_t *__restrict__ rows_dev) {
+    if (rows_dev) M = min(M, (uint32_t)max(*rows_dev, 0));  // inference rounds: the row count lives on the device
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kVmBlock + threadIdx.x) >> 6;
     const uint32_t s0 = wave * chunk;
@@ -504,7 +506,7 @@ using namespace pvd;
 extern "C" {
 
 int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
-                   float *sigma_feat, void *color_prod, int prod_dtype, pvd_stream_t stream) {
+                   float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !aabb_host || !tables_host || !res_host || !sigma_feat || !color_prod) return PVD_ERR_INVALID;
     VmTables tb;
@@ -514,9 +516,9 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
     const uint32_t waves = div_up(M, chunk);
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
     if (prod_dtype == PVD_F32)
-        hipLaunchKernelGGL((k_vm_fwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (float *)color_prod);
+        hipLaunchKernelGGL((k_vm_fwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (float *)color_prod, rows_dev);
     else if (prod_dtype == PVD_F16)
-        hipLaunchKernelGGL((k_vm_fwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (half_t *)color_prod);
+        hipLaunchKernelGGL((k_vm_fwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (half_t *)color_prod, rows_dev);
     else
         return PVD_ERR_UNSUPPORTED;
     return check_launch();

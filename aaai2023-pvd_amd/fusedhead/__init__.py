@@ -41,8 +41,9 @@ def _cached_image(model, kind, weights, params):
 
 
 @torch.no_grad()
-def hash_head_infer(model, x, d):
-    """(sigma, rgb, feature_sigma_color) of a hash model for positions x, directions d -- no autograd."""
+def hash_head_infer(model, x, d, rows_dev=None):
+    """(sigma, rgb, feature_sigma_color) of a hash model for positions x, directions d -- no autograd.
+    rows_dev: optional DEVICE int32 row count (inference rounds): only the first min(M, rows_dev) rows are computed."""
     enc = model.encoder
     M = x.shape[0]
     dev = x.device
@@ -66,8 +67,9 @@ def hash_head_infer(model, x, d):
     if FUSED_LOOKUP:  # lookup + head in one launch, no [L,M,C] intermediate (bit-identical outputs)
         pvd_hip.hash_head_forward_fused(xin, float(bound), float(2 * bound), cache[2], enc.offsets, S, enc.base_resolution, enc.gridtype_id,
                                         enc.align_corners, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
-                                        image=image)
+                                        image=image, rows_dev=rows_dev)
         return sigma, rgb, feat
+    assert rows_dev is None, "a device-side row count needs the fused lookup + head launch"
     out = torch.empty(L, M, C, dtype=torch.float16, device=dev)
     pvd_hip.grid_encode_forward_affine(xin, float(bound), float(2 * bound), cache[2], enc.offsets, out, M, 3, C, L, S, enc.base_resolution,
                                        enc.gridtype_id, enc.align_corners)
@@ -77,7 +79,7 @@ def hash_head_infer(model, x, d):
 
 
 @torch.no_grad()
-def vm_head_infer(model, sigma_raw, prod, d):
+def vm_head_infer(model, sigma_raw, prod, d, rows_dev=None):
     M = prod.shape[0]
     sigma, rgb, feat = _outputs(M, prod.device)
     a = model.args
@@ -86,7 +88,7 @@ def vm_head_infer(model, sigma_raw, prod, d):
     pvd_hip.head_forward(KIND_VM, prod.contiguous(), sigma_raw.float().contiguous(), d.float().contiguous(), M, *ws,
                          smin, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
                          image=_cached_image(model, KIND_VM, ws, [model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
-                                                                  model.color_net[2].weight]))
+                                                                  model.color_net[2].weight]), rows_dev=rows_dev)
     return sigma, rgb, feat
 
 

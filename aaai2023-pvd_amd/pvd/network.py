@@ -304,6 +304,25 @@ class NeRFNetwork(NeRFRenderer):
         self.color_l = color
         return sigma, color
 
+    def supports_device_rows(self):
+        """True if forward_rows() exists for this model here: hash and VM models on the HIP operator set under autocast."""
+        return (self.model_type in ("hash", "vm") and getattr(self.ops, "fused_head", None) is not None and self.bg_net is None
+                and (self.model_type != "vm" or getattr(self.ops, "vm_encode_infer", None) is not None)
+                and not (self.model_type == "hash" and not getattr(self.ops.fused_head, "FUSED_LOOKUP", False)))
+
+    @torch.no_grad()
+    def forward_rows(self, x, d, rows_dev):
+        """forward() of the inference rounds: (sigma, rgb) for the first `rows_dev` (DEVICE int32) rows of x / d; the other
+        rows of the outputs are left unwritten.  No host-side knowledge of the row count is needed (renderer._run_rounds_device)."""
+        fh = self.ops.fused_head
+        if self.model_type == "hash":
+            sigma, rgb, _ = fh.hash_head_infer(self, x, d, rows_dev=rows_dev)
+        else:
+            sraw, prod = self.ops.vm_encode_infer(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec,
+                                                  rows_dev=rows_dev)
+            sigma, rgb, _ = fh.vm_head_infer(self, sraw, prod, d, rows_dev=rows_dev)
+        return sigma, rgb
+
     def density(self, x):
         """reference: network.py:439-494 (used by update_extra_state)."""
         a = self.args

@@ -46,4 +46,4 @@ def hip_ops():
         return rays_o, rays_d, bg, (nears, fars)
 
     return types.SimpleNamespace(make_batch=make_batch, occupancy=pvd_hip.occupancy_backend, raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, vm_encode_infer=vmencoder.vm_encode_infer, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

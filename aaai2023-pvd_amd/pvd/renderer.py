@@ -243,6 +243,8 @@ class NeRFRenderer(nn.Module):
                     "nears_fars": (nears, fars)}
 
         # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
+        if self._rounds_on_device(rays_o, perturb):
+            return self._run_rounds_device(rays_o, rays_d, nears, fars, bg_color, dt_gamma, max_steps, prefix, inherited_params)
         dtype = torch.float32
         weights_sum = torch.zeros(N, dtype=dtype, device=device)
         depth = torch.zeros(N, dtype=dtype, device=device)
@@ -271,6 +273,55 @@ class NeRFRenderer(nn.Module):
             rm.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas, rgbs, deltas, weights_sum, depth, image)
             step += n_step
             i += 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
+
+    # ------------------------------------------------------------------ inference rounds, state on the device
+    def _rounds_on_device(self, rays_o, perturb):
+        import os
+        return (rays_o.is_cuda and not perturb and hasattr(self.rm, "infer_march") and torch.is_autocast_enabled("cuda")
+                and getattr(self, "supports_device_rows", lambda: False)() and os.environ.get("PVD_INFER_DEVICE_ROUNDS", "1") != "0")
+
+    @torch.no_grad()
+    def _run_rounds_device(self, rays_o, rays_d, nears, fars, bg_color, dt_gamma, max_steps, prefix, inherited_params, check_every=8):
+        """The inference loop of run_cuda (reference: renderer.py:450-543) without its per-round `alive_counter.item()`: the
+        round state {alive count, n_step, rows, steps done} lives on the device (pvd_infer_*), every launch of a round takes
+        its extent from there, and the host looks at it once every `check_every` rounds -- to stop, and to shrink the upper
+        bound that sizes the launches and the scratch rows.  Same n_step rule, same march / composite arithmetic: per-ray
+        results are those of the reference loop."""
+        rm = self.rm
+        N, device = rays_o.shape[0], rays_o.device
+        f32 = dict(dtype=torch.float32, device=device)
+        weights_sum, depth, image = torch.zeros(N, **f32), torch.zeros(N, **f32), torch.zeros(N, 3, **f32)
+        state = torch.zeros(rm.INFER_STATE_INTS, dtype=torch.int32, device=device)
+        state[0] = N  # cnt[0]: every ray starts alive
+        rays_alive = torch.empty(2, N, dtype=torch.int32, device=device)
+        rays_t = torch.empty(2, N, **f32)
+        rays_alive[0] = torch.arange(N, dtype=torch.int32, device=device)
+        rays_t[0] = nears
+        rows = N + (128 - N % 128) % 128  # n_alive * n_step <= N by the n_step rule
+        xyzs, dirs, deltas = torch.empty(rows, 3, **f32), torch.empty(rows, 3, **f32), torch.empty(rows, 2, **f32)
+        rows_dev = state[4:5]
+        n_upper, i = N, 0
+        while True:
+            for _ in range(check_every):
+                cur, old = i & 1, (i & 1) ^ 1
+                if i > 0:
+                    rm.infer_compact(state, cur, n_upper, rays_alive[cur], rays_alive[old], rays_t[cur], rays_t[old])
+                rm.infer_round_begin(state, cur, N, max_steps)
+                rm.infer_march(state, n_upper, rays_alive[cur], rays_t[cur], rays_o, rays_d, self.bound, dt_gamma, max_steps, self.cascade,
+                               self.grid_size, self.density_bitfield, fars, xyzs, dirs, deltas, False)
+                m_upper = min(rows, 8 * n_upper + (128 - (8 * n_upper) % 128) % 128)
+                sigmas, rgbs = self.forward_rows(xyzs[:m_upper], dirs[:m_upper], rows_dev)
+                rm.infer_composite(state, n_upper, rays_alive[cur], rays_t[cur], sigmas, rgbs.float(), deltas, float(self.density_scale),
+                                   weights_sum, depth, image)
+                i += 1
+            n_alive, steps_done = state[2:6:3].tolist()  # one read-back per `check_every` rounds
+            if n_alive <= 0 or steps_done >= max_steps:
+                break
+            n_upper = min(n_upper, n_alive)  # survivors only shrink
+        self._last_rounds = int(state[6])
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}

@@ -43,7 +43,7 @@ ENTRY_POINTS = (
     "pvd_abi_version", "pvd_status_string", "pvd_last_hip_error",
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
-    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish",
+    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
@@ -291,6 +291,48 @@ def compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_
     _call("pvd_compact_rays", dev, _u32(n_alive), _p(rays_alive), _p(rays_alive_old), _p(rays_t), _p(rays_t_old), _p(alive_counter))
 
 
+# --------------------------------------------------------------------------- inference rounds, round state on the device
+INFER_STATE_INTS = 8  # {cnt[2], n_alive, n_step, rows, steps_done, rounds, pad}
+
+
+def _infer_state(state):
+    _want(state, torch.int32, "state")
+    if state.numel() < INFER_STATE_INTS:
+        raise PvdHipError("state needs %d int32" % INFER_STATE_INTS)
+
+
+def infer_round_begin(state, parity, N, max_steps):
+    dev = _dev(state)
+    _infer_state(state)
+    _call("pvd_infer_round_begin", dev, _p(state), _u32(parity), _u32(N), _u32(max_steps))
+
+
+def infer_compact(state, parity, n_upper, rays_alive, rays_alive_old, rays_t, rays_t_old):
+    dev = _dev(state, rays_alive, rays_alive_old, rays_t, rays_t_old)
+    _infer_state(state)
+    _want(rays_alive, torch.int32, "rays_alive"), _want(rays_alive_old, torch.int32, "rays_alive_old")
+    _f32_all(rays_t=rays_t, rays_t_old=rays_t_old)
+    _call("pvd_infer_compact", dev, _p(state), _u32(parity), _u32(n_upper), _p(rays_alive), _p(rays_alive_old), _p(rays_t), _p(rays_t_old))
+
+
+def infer_march(state, n_upper, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb):
+    dev = _dev(state, rays_alive, rays_t, rays_o, rays_d, grid, fars, xyzs, dirs, deltas)
+    _infer_state(state)
+    _f32_all(rays_t=rays_t, rays_o=rays_o, rays_d=rays_d, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
+    _want(rays_alive, torch.int32, "rays_alive"), _want(grid, torch.uint8, "grid")
+    _call("pvd_infer_march", dev, _p(state), _u32(n_upper), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d), _f32(bound), _f32(dt_gamma),
+          _u32(max_steps), _u32(C), _u32(H), _p(grid), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _u32(int(perturb)))
+
+
+def infer_composite(state, n_upper, rays_alive, rays_t, sigmas, rgbs, deltas, sigma_scale, weights_sum, depth, image):
+    dev = _dev(state, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+    _infer_state(state)
+    _f32_all(rays_t=rays_t, sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, depth=depth, image=image)
+    _want(rays_alive, torch.int32, "rays_alive")
+    _call("pvd_infer_composite", dev, _p(state), _u32(n_upper), _p(rays_alive), _p(rays_t), _p(sigmas), _p(rgbs), _p(deltas), _f32(sigma_scale),
+          _p(weights_sum), _p(depth), _p(image))
+
+
 # --------------------------------------------------------------------------- _gridencoder
 def _table_dtype(t, name):
     if t.dtype == torch.float32:
@@ -393,14 +435,23 @@ def _vm_common(xyz, aabb_host, tables, res):
     return dev, aabb, resa
 
 
-def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod):
+def _rows_dev(rows_dev, dev):
+    if rows_dev is not None:
+        _dev(rows_dev)
+        _want(rows_dev, torch.int32, "rows_dev")
+        if rows_dev.device != dev or rows_dev.numel() < 1:
+            raise PvdHipError("rows_dev must be an int32 tensor on the same device")
+    return _p(rows_dev)
+
+
+def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=None):
     """tables: 12 channels-last factor tensors (physical [H][W][R] / [L][R]); see include/pvd_hip.h."""
     dev, aabb, resa = _vm_common(xyz, aabb_host, tables, res)
     _dev(sigma_feat, color_prod)
     _want(sigma_feat, torch.float32, "sigma_feat")
     dt = _table_dtype(color_prod, "color_prod")
     _check(_invoke("pvd_vm_forward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat), _p(color_prod),
-                   _int(dt), meta=(xyz.shape[0], dt)), "pvd_vm_forward")
+                   _int(dt), _rows_dev(rows_dev, dev), meta=(xyz.shape[0], dt)), "pvd_vm_forward")
 
 
 def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, grad_tables):
@@ -498,17 +549,17 @@ plenoxel_backend = types.SimpleNamespace(plenoxel_forward=plenoxel_forward, plen
 
 # --------------------------------------------------------------------------- fused sigma / colour head
 def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, sigma, rgb, feat16,
-                 image=None):
+                 image=None, rows_dev=None):
     dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
     _want(x0, torch.float16, "x0")
     _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
     _check_image(kind, image)
     _call("pvd_head_forward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
-          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+          _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev))
 
 
 def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, gridtype, align_corners, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3,
-                            clip_sigma_min, clip_max, sigma, rgb, feat16, image=None):
+                            clip_sigma_min, clip_max, sigma, rgb, feat16, image=None, rows_dev=None):
     """Lookup (f16 table, 14 levels x 2 features) + hash head of a frozen model in one launch; see include/pvd_hip.h."""
     dev = _dev(xyz, embeddings, offsets, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
     _want(embeddings, torch.float16, "embeddings"), _want(offsets, torch.int32, "offsets")
@@ -520,7 +571,7 @@ def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, grid
     _check_image(0, image)
     status = _invoke("pvd_hash_head_forward_fused", dev, _p(xyz), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H),
                      _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
-                     _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), meta=(M, 3, 2, 14, PVD_F16))
+                     _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev), meta=(M, 3, 2, 14, PVD_F16))
     _check(status, "pvd_hash_head_forward_fused")
 
 
@@ -767,6 +818,8 @@ raymarching_backend = types.SimpleNamespace(
     composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward,
     march_rays=march_rays, composite_rays=composite_rays, compact_rays=compact_rays, MARCH_FRESH=MARCH_FRESH,
+    infer_round_begin=infer_round_begin, infer_compact=infer_compact, infer_march=infer_march, infer_composite=infer_composite,
+    INFER_STATE_INTS=INFER_STATE_INTS,
 )
 gridencoder_backend = types.SimpleNamespace(grid_encode_forward=grid_encode_forward, grid_encode_backward=grid_encode_backward)
 shencoder_backend = types.SimpleNamespace(sh_encode_forward=sh_encode_forward, sh_encode_backward=sh_encode_backward)

@@ -16,3 +16,7 @@ composite_rays_train_bg = _ops.composite_rays_train_bg  # extension: + run_cuda'
 march_rays = _ops.march_rays
 composite_rays = _ops.composite_rays
 compact_rays = _ops.compact_rays
+
+# inference rounds whose state stays on the device (pvd_infer_*; the reference reads the alive count back every round)
+infer_round_begin, infer_compact, infer_march, infer_composite = _ops.infer_round_begin, _ops.infer_compact, _ops.infer_march, _ops.infer_composite
+INFER_STATE_INTS = _ops.INFER_STATE_INTS

@@ -257,7 +257,12 @@ def make_ops(backend, device_type="cuda"):
             backend.compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter)
             return tuple()
 
+    extra = {}
+    if hasattr(backend, "infer_march"):  # inference rounds whose state stays on the device (pvd_infer_*; not in the reference)
+        extra = dict(infer_round_begin=backend.infer_round_begin, infer_compact=backend.infer_compact, infer_march=backend.infer_march,
+                     infer_composite=backend.infer_composite, INFER_STATE_INTS=backend.INFER_STATE_INTS)
     return types.SimpleNamespace(
+        **extra,
         near_far_from_aabb=_NearFar.apply,
         polar_from_ray=_Polar.apply,
         morton3D=_Morton.apply,

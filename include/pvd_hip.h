@@ -147,6 +147,27 @@ int pvd_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_al
 int pvd_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_alive_old,
                      float *rays_t, const float *rays_t_old, int32_t *alive_counter, pvd_stream_t stream);
 
+/* Inference rounds with the round state on the device (the reference reads the alive count back every round,
+ * distill_mutual/renderer.py:488): state = int32[8] = {cnt[2], n_alive, n_step, rows, steps_done, rounds, pad}.  Round i:
+ *   (i > 0) pvd_infer_compact(parity = i & 1): survivors (rays_t >= 0) of the previous round's lists -> the new lists,
+ *           counted in cnt[parity];
+ *   pvd_infer_round_begin(parity): n_alive = cnt[parity] (0 once steps_done >= max_steps), n_step = max(min(N / n_alive, 8), 1)
+ *           (renderer.py:493), rows = n_alive * n_step, steps_done += n_step, cnt[parity ^ 1] = 0;
+ *   pvd_infer_march: pvd_march_rays for the first n_alive rays, rows beyond a ray's last sample zero-filled;
+ *   (model forward on `rows` rows: the rows_dev argument of the forward entry points)
+ *   pvd_infer_composite: pvd_composite_rays with sigmas * sigma_scale.
+ * n_upper: a host-side upper bound of n_alive that sizes the (persistent) launches.  Initial state: cnt[0] = N, rest 0. */
+int pvd_infer_round_begin(int32_t *state, uint32_t parity, uint32_t N, uint32_t max_steps, pvd_stream_t stream);
+int pvd_infer_compact(int32_t *state, uint32_t parity, uint32_t n_upper, int32_t *rays_alive, const int32_t *rays_alive_old,
+                      float *rays_t, const float *rays_t_old, pvd_stream_t stream);
+int pvd_infer_march(const int32_t *state, uint32_t n_upper, const int32_t *rays_alive, const float *rays_t,
+                    const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                    uint32_t H, const uint8_t *grid, const float *fars, float *xyzs, float *dirs, float *deltas,
+                    uint32_t perturb, pvd_stream_t stream);
+int pvd_infer_composite(const int32_t *state, uint32_t n_upper, const int32_t *rays_alive, float *rays_t,
+                        const float *sigmas, const float *rgbs, const float *deltas, float sigma_scale, float *weights_sum,
+                        float *depth, float *image, pvd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * _gridencoder  (gridencoder/src/gridencoder.h:12-13, bindings.cpp:5-8)
  * ---------------------------------------------------------------------- */
@@ -217,7 +238,8 @@ int pvd_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, u
  * the products feed basis_mat, an autocast-to-half Linear).
  * ---------------------------------------------------------------------- */
 int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
-                   const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, pvd_stream_t stream);
+                   const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev,
+                   pvd_stream_t stream);
 
 /* grad_tables_host[12]: HOST array of DEVICE pointers laid out like tables_host, f32, accumulated into
  * with atomics (zero-filled by the caller, or a gradient buffer to accumulate into). */
@@ -241,18 +263,21 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
 int pvd_head_forward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M,
                      const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
                      const void *image, float clip_sigma_min, float clip_feat_min, float clip_max,
-                     float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
+                     float *sigma, float *rgb, float *feat16, const int32_t *rows_dev, pvd_stream_t stream);
 
 /* The frozen hash model in one launch: pvd_grid_encode_forward_affine (f16 table, D = 3, C = 2, L = 14) + pvd_head_forward
  * (kind = PVD_HEAD_HASH) without the [14][M][2] intermediate -- the teacher of a distillation run, inference, occupancy-grid
  * density queries (network.py:413-437 under no_grad).  xyz [M,3] in [-bound, bound] mapped with (x + in_add) / in_div;
  * embeddings_f16 [offsets[14], 2] f16; the other arguments as in the two calls it replaces.  Outputs are bit-identical to
- * theirs. */
+ * theirs.  rows_dev (here, in pvd_head_forward and in pvd_vm_forward): NULL, or a DEVICE int32 -- only the first
+ * min(M, *rows_dev) rows are computed (M is then just the upper bound that sizes the launch): the inference rounds keep
+ * their row count on the device (pvd_infer_*). */
 int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, const void *embeddings_f16,
                                 const int32_t *offsets, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                 const float *dirs, uint32_t M, const float *Wa1, const float *Wa2, const float *Wc1,
                                 const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min,
-                                float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream);
+                                float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
+                                pvd_stream_t stream);
 
 /* Optional weight image.  Every workgroup of the head kernels stages all weights in LDS; converting and
  * (for the backward) transposing the fp32 masters there is the kernels' fixed cost.  pvd_head_pack_weights does it

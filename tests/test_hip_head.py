@@ -290,7 +290,7 @@ def test_hash_density_fused_matches_layerwise():
     assert (fused["geo_feat"] - ref["geo_feat"].float()).abs().max().item() <= 4e-3 * (1 + ref["geo_feat"].float().abs().max().item())
 
 
-@pytest.mark.parametrize("M,bound", [(16 * 1000, 1), (4099, 1), (37, 1), (20000, 2)])
+@pytest.mark.parametrize("M,bound", [(16 * 1000, 1), (4099, 1), (37, 1), (20000, 2), (300001, 1)])  # the last: several tiles per workgroup
 def test_fused_lookup_and_head_is_bit_identical_to_the_two_launches(M, bound, monkeypatch):
     """pvd_hash_head_forward_fused (lookup + head in one launch, no [14][M][2] intermediate) vs pvd_grid_encode_forward_affine
     followed by pvd_head_forward: same table values, same blend order, same MFMA chain -> the same bits.  Ragged sizes (not a

@@ -1,0 +1,80 @@
+"""f2 of SURVEY section 8: the inference renderer whose round state (alive count, n_step, rows) stays on the device
+(pvd_infer_*, NeRFRenderer._run_rounds_device) against the reference-shaped loop with one `alive_counter.item()` per round
+(distill_mutual/renderer.py:450-543; raymarching.cu:704-948): same rays, same weights -> the same image per ray."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(kind):
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import ChairScene
+    from pvd.workload import install_occupancy, make_model
+    torch.manual_seed(3)
+    opt = PVDConfig(model_type=kind, resolution0=64)
+    opt.stage_iters = {"stage1": -1, "stage2": -1}
+    m = make_model(hip_ops(), opt, kind, False, torch.device(DEV))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "embeddings" in n:
+                p.uniform_(-0.4, 0.4)
+            elif p.dim() == 2:
+                p.mul_(2.0)
+            elif p.dim() == 4:
+                p.mul_(2.5)
+    install_occupancy(m, ChairScene(), opt)
+    return m.eval()
+
+
+def _rays(n, full_image=False):
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(2))).to(DEV)
+    if full_image:  # every pixel of a 200 x 200 view (same field of view): most rays miss the object, some cross all of it
+        r = get_rays(poses[9][None], (277.775, 277.775, 100.0, 100.0), 200, 200, -1)
+    else:
+        r = get_rays(poses[9][None], BLENDER_INTRINSICS, 800, 800, n, generator=torch.Generator(device=DEV).manual_seed(8))
+    return r["rays_o"], r["rays_d"]
+
+
+@pytest.mark.parametrize("kind", ["hash", "vm"])
+@pytest.mark.parametrize("full_image", [False, True])
+def test_device_rounds_match_the_host_synchronised_loop(kind, full_image, monkeypatch):
+    m = _model(kind)
+    o, d = _rays(3000, full_image)
+    outs = []
+    for on_device in ("0", "1"):
+        monkeypatch.setenv("PVD_INFER_DEVICE_ROUNDS", on_device)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+        outs.append((out["image"].float(), out["depth"].float()))
+    (img0, dep0), (img1, dep1) = outs
+    assert m._last_rounds > 3  # the device loop ran (several rounds, no per-round read-back)
+    assert torch.isfinite(img1).all() and img0.std().item() > 0.02
+    assert (img0 - img1).abs().max().item() <= 1e-5
+    # rays that miss the box have near = far = FLT_MAX and a 0 / 0 depth in the reference's normalisation (renderer.py:541)
+    assert torch.equal(torch.isnan(dep0), torch.isnan(dep1))
+    assert (torch.nan_to_num(dep0) - torch.nan_to_num(dep1)).abs().max().item() <= 1e-5
+
+
+def test_device_rounds_respect_max_steps_and_empty_images():
+    """`while step < max_steps` (renderer.py:483): with a small budget every ray stops after the same number of steps as in
+    the host loop; rays that miss the box never enter a round."""
+    m = _model("hash")
+    o, d = _rays(2048)
+    import os
+    res = []
+    for on_device in ("0", "1"):
+        os.environ["PVD_INFER_DEVICE_ROUNDS"] = on_device
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                a = m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=24)["image"].float()
+                b = m.render(o + 100.0, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float()
+        finally:
+            os.environ.pop("PVD_INFER_DEVICE_ROUNDS", None)
+        res.append((a, b))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-5
+    assert torch.equal(res[1][1], torch.ones_like(res[1][1])) and torch.equal(res[0][1], res[1][1])  # all background
