@@ -352,8 +352,12 @@ class _TrainerBase:
         self.global_step += 1
 
     # ---- hipGraph capture of the step (launch-bound otherwise: ~330 kernels of a few us each)
-    def capture(self, body, warmup=3):
-        """Capture `body()` (forward + loss + backward) and the optimizer into HIP graph(s).  Single GPU: one graph for
+    steps_per_replay = 1
+
+    def capture(self, body, warmup=3, steps_per_graph=1):
+        """Capture `body()` (forward + loss + backward) and the optimizer into HIP graph(s).  steps_per_graph > 1 records
+        that many consecutive steps into the one graph (a replay then costs one graph launch -- ~8 us of launch latency
+        between replays in the step's timeline -- for several steps; `replay()` advances the step count accordingly).  Single GPU: one graph for
         the whole step.  Ray-DP: the capture is SEGMENTED at every collective (`SegmentedCapture`): the all-reduce of the
         four loss sums and the gradient exchange run eagerly between graph replays, so nothing depends on the
         communication library being capturable.  Everything that changes per step lives on the device (lr, loss rates,
@@ -375,18 +379,22 @@ class _TrainerBase:
         torch.cuda.synchronize()
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
+        if self.dp.enabled and not self.dp.ingraph:
+            steps_per_graph = 1  # graphs cut at the collectives: one step per chain
         try:
             with cap:
-                self._zero_grads()
-                self._static_out = body()
-                if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
-                    raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
-                self._backward(self._static_out[0])
-                self._exchange()  # (breaks the capture around its all-reduce under ray-DP; nothing otherwise)
-                self._optimize()
+                for _ in range(max(1, int(steps_per_graph))):
+                    self._zero_grads()
+                    self._static_out = body()
+                    if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
+                        raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
+                    self._backward(self._static_out[0])
+                    self._exchange()  # (breaks the capture around its all-reduce under ray-DP; nothing otherwise)
+                    self._optimize()
         finally:
             self.dp.capture = None
         self._cap = cap
+        self.steps_per_replay = max(1, int(steps_per_graph))
         self._captured_occ_epoch = self._marching_model().occ_epoch
         return self._static_out  # the warm-up steps above are real steps; the capture itself records without running
 
@@ -400,8 +408,9 @@ class _TrainerBase:
             torch.cuda.current_stream().wait_stream(self._pipe_stream)
             self._pipe_pending = False
         self._cap.replay()
-        self.scheduler.step()
-        self.global_step += 1
+        for _ in range(self.steps_per_replay):
+            self.scheduler.step()
+        self.global_step += self.steps_per_replay
         return self._static_out
 
 
@@ -557,7 +566,7 @@ class DistillTrainer(_TrainerBase):
         self._backward_and_step(loss)
         return loss.detach(), info, pred_stu, pred_tea
 
-    def capture_step(self, batch_fn):
+    def capture_step(self, batch_fn, steps_per_graph=1):
         """Capture `batch_fn() -> (rays_o, rays_d, bg)` + the whole step into HIP graph(s); the stage
         (which loss terms exist) is frozen at capture time, so re-capture when the stage changes.  Three eager warm-up
         steps run first (real steps: global_step advances by 3)."""
@@ -578,7 +587,7 @@ class DistillTrainer(_TrainerBase):
             # recorded into a capture here (tools/probe_rccl_capture.py) -- which costs less than the ~60 us of fixed
             # overhead the three-graph form pays on every step
             try:
-                out = self.capture(body)
+                out = self.capture(body, steps_per_graph=steps_per_graph)
             except Exception:
                 import traceback
                 traceback.print_exc()
@@ -591,7 +600,7 @@ class DistillTrainer(_TrainerBase):
             self._pipe_stream = torch.cuda.Stream()
             out = self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
         else:
-            out = self.capture(body)
+            out = self.capture(body, steps_per_graph=steps_per_graph)
         self._captured_stage = self._stage_of(self.global_step)
         return out
 
@@ -635,6 +644,7 @@ class DistillTrainer(_TrainerBase):
 
     def replay_step(self):
         assert self._stage_of(self.global_step) == self._captured_stage, "stage changed: capture_step() again"
+        assert self._stage_of(self.global_step + self.steps_per_replay - 1) == self._captured_stage, "the replay would cross a stage boundary"
         loss, info, pred_stu, pred_tea = self.replay()
         return loss.detach(), info, pred_stu, pred_tea
 

@@ -160,11 +160,16 @@ class DistillWorkload:
         bg = torch.rand(1, opt.num_rays, 3, device=self.device)
         return r["rays_o"], r["rays_d"], bg
 
-    def enable_graph(self):
-        """Whole-step hipGraph capture (GPU only)."""
+    def enable_graph(self, steps_per_graph=1):
+        """Whole-step hipGraph capture (GPU only).  steps_per_graph > 1: every step() call then runs that many training steps
+        (one graph launch); `steps_per_call` says how many."""
         assert not self.opt.update_stu_extra, "update_stu_extra rewrites the occupancy grid between steps: run eagerly"
-        self.trainer.capture_step(self.device_batch)
+        self.trainer.capture_step(self.device_batch, steps_per_graph=steps_per_graph)
         self._graph = True
+
+    @property
+    def steps_per_call(self):
+        return self.trainer.steps_per_replay if getattr(self, "_graph", False) else 1
 
     def step(self):
         if getattr(self, "_graph", False):

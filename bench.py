@@ -221,10 +221,13 @@ def main():
 
     torch.cuda.manual_seed(1234 + rank)  # in-graph ray / background sampling: different rays on every rank
     launch_mode = "eager"
+    # steps per graph launch: the largest of 5, 4, 2 that divides both the timed and the warm-up step count (exactly K timed steps)
+    spg = next((k for k in (5, 4, 2) if args.steps % k == 0 and args.warmup % k == 0), 1) if os.environ.get("PVD_STEPS_PER_GRAPH", "") == "" \
+        else int(os.environ["PVD_STEPS_PER_GRAPH"])
     if not args.eager:
         try:
-            w.enable_graph()  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
-            launch_mode = "hipGraph replay"
+            w.enable_graph(steps_per_graph=spg)  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
+            launch_mode = "hipGraph replay" + (" (%d steps per graph launch)" % w.steps_per_call if w.steps_per_call > 1 else "")
         except Exception as e:  # never lose the measurement to a capture problem: fall back to eager launches
             import traceback
             traceback.print_exc(file=sys.stderr)
@@ -236,14 +239,16 @@ def main():
             w._graph = False
             w._eager_device_batches = True  # keep using the one-kernel batch generator (no torch generator involved)
             launch_mode = "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:120])
-    for _ in range(args.warmup):
+    spc = w.steps_per_call
+    assert args.warmup % spc == 0 and args.steps % spc == 0
+    for _ in range(args.warmup // spc):
         w.step()
 
     if dp.enabled:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // spc):  # exactly args.steps optimisation steps
         loss, info, pred_stu, pred_tea = w.step()
     if dp.enabled:
         dist.barrier()
@@ -328,7 +333,7 @@ def main():
         "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
                                "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps" % (args.student, args.rays, args.teacher_pretrain),
                    "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
-                   "capture_fallback": (not args.eager) and launch_mode != "hipGraph replay",  # True = the step fell back to eager launches (~5x the ms)
+                   "capture_fallback": (not args.eager) and not launch_mode.startswith("hipGraph replay"),  # True = the step fell back to eager launches (~5x the ms)
                    "samples_per_step_per_gpu": samples,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
                    "teacher_psnr_db": w.teacher_psnr,

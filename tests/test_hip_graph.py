@@ -51,3 +51,23 @@ def test_graph_and_eager_agree_on_the_same_batches():
         lb.append(float(wb.trainer.train_step(*wb.device_batch())[0]))
     # the first replay corresponds to eager step index 3 (after the 3 warm-up steps)
     assert np.allclose(la, lb[3:6], rtol=1e-3), (la, lb)
+
+
+def test_several_steps_per_graph_launch_train_like_single_step_replays():
+    """enable_graph(steps_per_graph=3): one graph launch = three consecutive optimisation steps (batch generation, schedule,
+    loss-rate decay and loss scale all live on the device, so the second and third step of a replay see their own state).
+    Same seeds -> the same loss trajectory as single-step replays."""
+    wa, wb = _workload(5), _workload(5)
+    wb.stu.load_state_dict(wa.stu.state_dict()); wb.tea.load_state_dict(wa.tea.state_dict())
+    wb.stu.mean_count = wa.stu.mean_count
+    torch.cuda.manual_seed(21)
+    wa.enable_graph()
+    la = [float(wa.step()[0]) for _ in range(6)]
+    torch.cuda.manual_seed(21)
+    wb.enable_graph(steps_per_graph=3)
+    assert wb.steps_per_call == 3 and wa.steps_per_call == 1
+    g0 = wb.trainer.global_step
+    lb = [float(wb.step()[0]) for _ in range(2)]
+    assert wb.trainer.global_step == g0 + 6 and wb.trainer.scheduler.last_epoch == wa.trainer.scheduler.last_epoch
+    assert np.allclose([la[2], la[5]], lb, rtol=2e-3), (la, lb)
+    assert float(wa.trainer.optimizer.param_groups[0]["lr"]) == pytest.approx(float(wb.trainer.optimizer.param_groups[0]["lr"]), rel=1e-6)

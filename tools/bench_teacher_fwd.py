@@ -20,6 +20,8 @@ dev = torch.device("cuda:0")
 opt = PVDConfig(model_type="hash")
 m = make_model(hip_ops(), opt, "hash", True, dev).eval()
 m.encoder.embeddings.data.uniform_(-0.3, 0.3)
+if os.environ.get("PVD_BENCH_TABLE_SCALE"):  # e.g. 1e-4: the initialisation range, mostly f16 subnormals
+    m.encoder.embeddings.data.mul_(float(os.environ["PVD_BENCH_TABLE_SCALE"]) / 0.3)
 x01 = samples()
 x = (x01 * 2 - 1).contiguous()
 d = torch.randn_like(x)
