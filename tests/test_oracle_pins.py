@@ -1,6 +1,7 @@
 """What pins the CPU oracle (the reference ships no tests or golden vectors and its kernels cannot
 be built here): published known answers, independent third-party arithmetic and closed-form
 identities.  CPU only, seconds."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -574,3 +575,74 @@ def test_polar_from_ray_closed_form_sphere_hit():
     z3 = np.zeros((4, 3), np.float32)
     ax = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1], [0, -1, 0]], np.float32)
     np.testing.assert_allclose(oracle.polar_from_ray(z3, ax, 2.0), [[-1, 0], [0, 0], [0, 0.5], [1, 0]], atol=1e-7)
+
+
+def test_fma_contraction_sensitivity_of_the_marcher_with_a_non_power_of_two_bound(tmp_path):
+    """The canonical arithmetic fuses a product into an add only where the source says fmaf().  A CUDA
+    build of the reference contracts more (nvcc -fmad=true): `x * mip_rbound + 1` and `(..) * mip_bound - x` in the marcher,
+    which is exact for power-of-two bounds only.  How much can that matter?  The same oracle source built with
+    -ffp-contract=fast (every contractible product fused) marches a bound-1.5 scene (mip_bound = 1 and 1.5): the two builds
+    must agree on which cells are occupied for all but a vanishing fraction of knife-edge samples, and on coordinates to
+    float rounding.  (Measured here: no ray of 3000 changes -- sample positions are o + t*d with t advanced in whole dt steps,
+    the contractible products only feed the cell index and the skip distance, where an ulp matters on a knife edge only.)"""
+    import ctypes
+    import shutil
+    import subprocess
+    import oracle
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    here = os.path.dirname(os.path.abspath(oracle.__file__))
+    so = str(tmp_path / "libpvd_oracle_fma.so")
+    cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-ffp-contract=fast", "-mfma", "-fno-fast-math", "-fopenmp", "-shared", "-o", so,
+           os.path.join(here, "pvd_oracle.c"), "-lm"]
+    if subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0:
+        import pytest
+        pytest.skip("this host cannot build the -mfma variant")
+    rs = np.random.RandomState(5)
+    bound, C, H, N, M = 1.5, 2, 64, 3000, 3000 * 400
+    # occupancy: a thick spherical shell in both cascades
+    ax = (np.arange(H) + 0.5) / H * 2 - 1
+    grid = np.zeros((C, H ** 3), np.float32)
+    for c in range(C):
+        b = min(2 ** c, bound)
+        X, Y, Z = np.meshgrid(ax * b, ax * b, ax * b, indexing="ij")
+        r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
+        occ = ((r > 0.45) & (r < 1.3)).astype(np.float32)
+        coords = np.stack(np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+        grid[c, oracle.morton3D(coords)] = occ.reshape(-1)
+    bits = oracle.packbits(grid, 0.5)
+    o = rs.standard_normal((N, 3)).astype(np.float32)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 3.0
+    d = (-o + rs.standard_normal((N, 3)).astype(np.float32) * 0.6)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    results, nf = [], []
+    canonical = oracle.lib()
+    fused = ctypes.CDLL(so)
+    assert ctypes.cast(fused.pvdo_march_rays_train, ctypes.c_void_p).value != ctypes.cast(canonical.pvdo_march_rays_train, ctypes.c_void_p).value
+    for lib in (canonical, fused):
+        oracle._lib = lib
+        try:
+            nf.append(oracle.near_far_from_aabb(o, d, aabb, 0.2))
+            x, _, dl, rays, cnt = oracle.march_rays_train(o, d, bits, bound, C, H, nf[-1][0], nf[-1][1], M, perturb=False, dt_gamma=1.0 / 256)
+        finally:
+            oracle._lib = canonical
+        results.append((x, dl, rays, cnt))
+    # the slab test's (bound - o) * rd products do contract: near/far move by an ulp or two, never more
+    hit = np.isfinite(nf[0][1]) & (nf[0][1] < 1e8)
+    assert np.abs(nf[0][0][hit] - nf[1][0][hit]).max() <= 4e-7 * 4 and np.abs(nf[0][1][hit] - nf[1][1][hit]).max() <= 4e-7 * 8
+    (x0, d0, r0, c0), (x1, d1, r1, c1) = results
+    assert int(c0[0]) > 50 * N // 10  # a real march
+    differing = int((r0[:, 2] != r1[:, 2]).sum())
+    assert differing <= N // 100, "rays whose sample count depends on the contraction mode: %d of %d" % (differing, N)
+    same = r0[:, 2] == r1[:, 2]
+    # rays marched identically (all but the knife-edge ones): coordinates agree to rounding of the fused / unfused products
+    worst = 0.0
+    for n in np.nonzero(same)[0][:500]:
+        a, b, k = r0[n, 1], r1[n, 1], r0[n, 2]
+        if k:
+            worst = max(worst, float(np.abs(x0[a:a + k] - x1[b:b + k]).max()))
+    assert worst <= 5e-6, worst
+    print("contraction sensitivity: %d of %d rays differ in sample count; worst coordinate difference %.3g" % (differing, N, worst))
