@@ -30,6 +30,7 @@ constexpr uint32_t kRc = 48;  // color_rank (network.py:80)
 struct VmTables {
     const float *mat[2][3];  // [0] = sigma, [1] = colour; channels-last [H][W][R]
     const float *vec[2][3];  // channels-last [L][R]
+    uint32_t ms[2], vs[2];   // elements between consecutive texels of a plane / taps of a line (>= R: tables may interleave)
     uint32_t W[3], H[3], L[3];
     float lo[3], inv_extent2[3];  // x_n = 2*(x-lo)/(hi-lo) - 1, kept as (2*(x-lo)) / (hi-lo) - 1
     float extent[3];
@@ -332,7 +333,7 @@ __device__ __forceinline__ SampleTaps bcast_sample(const WalkCtl &p, uint32_t la
 template <bool GRAD>
 __device__ __forceinline__ void walk_move(PlaneWin<GRAD> &pw, LineWin<GRAD> &lw, const SampleTaps &t, int i, const float *__restrict__ mat,
                                           float *__restrict__ gm, const float *__restrict__ vec, float *__restrict__ gv, int W, int H, int L,
-                                          uint32_t R) {
+                                          uint32_t R, uint32_t Rv) {
     const Tap1 &tx = t.ax[kM0[i]], &ty = t.ax[kM1[i]], &tl = t.ax[kV[i]];
     const uint32_t c = (t.code >> (3 * i)) & 7u, cl = (t.code >> (9 + 2 * i)) & 3u;
     if (c) {
@@ -340,8 +341,8 @@ __device__ __forceinline__ void walk_move(PlaneWin<GRAD> &pw, LineWin<GRAD> &lw,
         else pw.move(tx.i0, ty.i0, mat, gm, W, H, R);
     }
     if (cl) {
-        if ((t.code >> (18 + i)) & 1u) lw.move_fast(cl, tl.i0, vec, gv, R);
-        else lw.move(tl.i0, vec, gv, L, R);
+        if ((t.code >> (18 + i)) & 1u) lw.move_fast(cl, tl.i0, vec, gv, Rv);
+        else lw.move(tl.i0, vec, gv, L, Rv);
     }
 }
 
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     if (s0 >= M) return;
     const uint32_t s1 = min(M, s0 + chunk);
     const uint32_t kind = lane < kRs ? 0u : 1u;       // 0 sigma, 1 colour
-    const uint32_t R = kind ? kRc : kRs;
+    const uint32_t R = tb.ms[kind], Rv = tb.vs[kind];
     const uint32_t ch = kind ? lane - kRs : lane;
 
     PlaneWin<false> pw[3];
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
         for (int i = 0; i < 3; i++) {
             const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
             walk_move<false>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, nullptr, tb.vec[kind][i] + ch, nullptr, (int)tb.W[i], (int)tb.H[i],
-                             (int)tb.L[i], R);
+                             (int)tb.L[i], R, Rv);
             const float prod = plane_value(pw[i], tx, ty) * line_value(lw[i], tl);
             if (kind) color_prod[(size_t)m * (3 * kRc) + i * kRc + ch] = (T)prod;
             else sig += prod;
@@ -394,7 +395,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
     if (s0 >= M) return;
     const uint32_t s1 = min(M, s0 + chunk);
     const uint32_t kind = lane < kRs ? 0u : 1u;
-    const uint32_t R = kind ? kRc : kRs;
+    const uint32_t R = tb.ms[kind], Rv = tb.vs[kind];
     const uint32_t ch = kind ? lane - kRs : lane;
 
     PlaneWin<true> pw[3];
@@ -424,7 +425,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
             const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
             const float g = kind ? (float)g_cur[i] : gs;
             walk_move<true>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, gr.mat[kind][i] + ch, tb.vec[kind][i] + ch, gr.vec[kind][i] + ch,
-                            (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R);
+                            (int)tb.W[i], (int)tb.H[i], (int)tb.L[i], R, Rv);
             const float gp = g * line_value(lw[i], tl);       // d loss / d plane value
             const float gl = g * plane_value(pw[i], tx, ty);  // d loss / d line value
             pw[i].a[0] += gp * (tx.w0 * ty.w0);
@@ -438,7 +439,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
 #pragma unroll
     for (int i = I0; i < I1; i++) {
         pw[i].close(gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
-        lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], R);
+        lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], Rv);
     }
 }
 
@@ -480,7 +481,7 @@ static uint32_t pick_chunk(uint32_t M, bool backward) {
     return chunk;
 }
 
-static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *res, const float *aabb) {
+static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *res, const float *aabb, const uint32_t *stride) {
     // reference shapes (network.py:199-212): mat_i [1,R,res[m1],res[m0]], vec_i [1,R,res[vec_id],1]
     for (int i = 0; i < 3; i++) {
         tb.W[i] = res[kM0[i]];
@@ -496,6 +497,14 @@ static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *
         tb.extent[i] = aabb[i + 3] - aabb[i];
         tb.inv_extent2[i] = 0.f;
     }
+    // texel strides: {sigma planes, sigma lines, colour planes, colour lines}; NULL = densely packed channels-last tables
+    const uint32_t dense[4] = {kRs, kRs, kRc, kRc};
+    if (!stride) stride = dense;
+    for (int k = 0; k < 2; k++) {
+        tb.ms[k] = stride[2 * k];
+        tb.vs[k] = stride[2 * k + 1];
+        if (tb.ms[k] < dense[2 * k] || tb.vs[k] < dense[2 * k]) return PVD_ERR_INVALID;
+    }
     return PVD_OK;
 }
 
@@ -506,11 +515,12 @@ using namespace pvd;
 extern "C" {
 
 int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
-                   float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, pvd_stream_t stream) {
+                   float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
+                   pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !aabb_host || !tables_host || !res_host || !sigma_feat || !color_prod) return PVD_ERR_INVALID;
     VmTables tb;
-    const int rc = fill_tables(tb, tables_host, res_host, aabb_host);
+    const int rc = fill_tables(tb, tables_host, res_host, aabb_host, texel_stride_host);
     if (rc != PVD_OK) return rc;
     const uint32_t chunk = pick_chunk(M, false);
     const uint32_t waves = div_up(M, chunk);
@@ -526,11 +536,11 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
 
 int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
                     const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype, void *const *grad_tables_host,
-                    pvd_stream_t stream) {
+                    const uint32_t *texel_stride_host, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !aabb_host || !tables_host || !res_host || !grad_sigma_feat || !grad_color_prod || !grad_tables_host) return PVD_ERR_INVALID;
     VmTables tb;
-    const int rc = fill_tables(tb, tables_host, res_host, aabb_host);
+    const int rc = fill_tables(tb, tables_host, res_host, aabb_host, texel_stride_host);
     if (rc != PVD_OK) return rc;
     VmGrads gr;
     for (int i = 0; i < 3; i++)

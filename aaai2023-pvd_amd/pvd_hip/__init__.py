@@ -435,6 +435,25 @@ def _vm_common(xyz, aabb_host, tables, res):
     return dev, aabb, resa
 
 
+def _vm_texel_strides(tables, what="VM factors"):
+    """{sigma planes, sigma lines, colour planes, colour lines} texel strides of channels-last factors [1,R,H,W]: channel
+    stride 1, texel stride S >= R, row stride W*S (S > R: sigma and colour factors interleaved in one [H][W][64] buffer)."""
+    out = []
+    for k in (0, 6):
+        for fam in (tables[k:k + 3], tables[k + 3:k + 6]):
+            S = None
+            for t in fam:
+                if t.dim() != 4 or t.shape[0] != 1:
+                    raise PvdHipError(what + " must be [1,R,H,W] tensors")
+                s = t.stride(3) if t.shape[3] > 1 else t.stride(2)
+                ok = (t.stride(1) == 1 or t.shape[1] == 1) and s >= t.shape[1] and (t.shape[3] == 1 or t.shape[2] == 1 or t.stride(2) == t.shape[3] * s)
+                if not ok or (S is not None and s != S):
+                    raise PvdHipError(what + " must be stored channels-last with one texel stride per family")
+                S = s
+            out.append(S)
+    return (ctypes.c_uint32 * 4)(*out), tuple(out)
+
+
 def _rows_dev(rows_dev, dev):
     if rows_dev is not None:
         _dev(rows_dev)
@@ -450,8 +469,9 @@ def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=Non
     _dev(sigma_feat, color_prod)
     _want(sigma_feat, torch.float32, "sigma_feat")
     dt = _table_dtype(color_prod, "color_prod")
+    strides, _ = _vm_texel_strides(tables)
     _check(_invoke("pvd_vm_forward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat), _p(color_prod),
-                   _int(dt), _rows_dev(rows_dev, dev), meta=(xyz.shape[0], dt)), "pvd_vm_forward")
+                   _int(dt), _rows_dev(rows_dev, dev), strides, meta=(xyz.shape[0], dt)), "pvd_vm_forward")
 
 
 def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, grad_tables):
@@ -462,8 +482,11 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
     for t in grad_tables:
         if not t.is_cuda or t.dtype != torch.float32:
             raise PvdHipError("VM gradient buffers must be float32 HIP tensors")
+    strides, st = _vm_texel_strides(tables)
+    if _vm_texel_strides(grad_tables, "VM gradient buffers")[1] != st:
+        raise PvdHipError("VM gradient buffers must have the factors' own strides")
     _check(_invoke("pvd_vm_backward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
-                   _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), meta=(xyz.shape[0], dt)), "pvd_vm_backward")
+                   _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), strides, meta=(xyz.shape[0], dt)), "pvd_vm_backward")
 
 
 vmencoder_backend = types.SimpleNamespace(vm_forward=vm_forward, vm_backward=vm_backward)

@@ -5,8 +5,27 @@ from torch.amp import custom_bwd, custom_fwd
 
 
 def is_channels_last(t):
-    """[1,R,H,W] stored as [H][W][R] (for lines [1,R,L,1]: [L][R])."""
-    return t.dim() == 4 and t.shape[0] == 1 and t.permute(0, 2, 3, 1).is_contiguous()
+    """[1,R,H,W] stored as [H][W][S >= R] (for lines [1,R,L,1]: [L][S]): channel stride 1, texel stride S, row stride W*S.
+    S > R is the interleaved layout (`interleave_factors`): sigma and colour factors share one [H][W][64] buffer."""
+    if t.dim() != 4 or t.shape[0] != 1 or (t.shape[1] > 1 and t.stride(1) != 1):
+        return False
+    s = t.stride(3) if t.shape[3] > 1 else t.stride(2)
+    return s >= t.shape[1] and (t.shape[3] == 1 or t.shape[2] == 1 or t.stride(2) == t.shape[3] * s)
+
+
+def interleave_factors(sigma, color):
+    """Two channels-last factors over the same texels ([1,Rs,H,W] and [1,Rc,H,W]) re-stored in ONE [H][W][Rs+Rc] buffer;
+    returns the two strided views (same logical shapes and values).  A tap of the lookup is then one contiguous
+    (Rs+Rc)*4-byte access."""
+    assert sigma.shape[2:] == color.shape[2:] and sigma.shape[0] == color.shape[0] == 1
+    Rs, Rc, H, W = sigma.shape[1], color.shape[1], sigma.shape[2], sigma.shape[3]
+    S = Rs + Rc
+    buf = torch.empty(H * W * S, dtype=sigma.dtype, device=sigma.device)
+    vs = torch.as_strided(buf, (1, Rs, H, W), (H * W * S, 1, W * S, S), 0)
+    vc = torch.as_strided(buf, (1, Rc, H, W), (H * W * S, 1, W * S, S), Rs)
+    vs.copy_(sigma)
+    vc.copy_(color)
+    return vs, vc
 
 
 def to_channels_last_param(t):

@@ -236,16 +236,20 @@ int pvd_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, u
  * mat_ids = {{0,1},{0,2},{1,2}}, vec_ids = {2,1,0}; res_host[3] HOST uint32.
  * sigma_feat [M] f32; color_prod [M,144] prod_dtype (f32, or f16 when the caller runs under AMP:
  * the products feed basis_mat, an autocast-to-half Linear).
+ * texel_stride_host: NULL (densely packed tables), or HOST uint32[4] = elements between consecutive texels of
+ *   {sigma planes, sigma lines, colour planes, colour lines} (>= R).  With stride 64 and colour base = sigma base + 16 the
+ *   sigma and colour factors of a plane interleave in one [H][W][64] buffer: a tap is then ONE aligned 256-byte access
+ *   (two cache lines) instead of 64 B + 192 B (three).
  * ---------------------------------------------------------------------- */
 int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
                    const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev,
-                   pvd_stream_t stream);
+                   const uint32_t *texel_stride_host, pvd_stream_t stream);
 
 /* grad_tables_host[12]: HOST array of DEVICE pointers laid out like tables_host, f32, accumulated into
  * with atomics (zero-filled by the caller, or a gradient buffer to accumulate into). */
 int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
                     const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
-                    void *const *grad_tables_host, pvd_stream_t stream);
+                    void *const *grad_tables_host, const uint32_t *texel_stride_host, pvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused sigma / colour head (MFMA).  Torch code in the reference: NeRFNetwork.forward,

@@ -30,16 +30,37 @@ for R in (16, 48):
 tabs = tabs[0:3] + tabs[3:6] + tabs[6:9] + tabs[9:12]
 grads = [torch.zeros_like(t) for t in tabs]
 aabb = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
+# the same factors with sigma and colour interleaved per texel ([H][W][64] / [L][64])
+from vmencoder.vm import interleave_factors
+itabs, igrads = list(tabs), [None] * 12
+for i in range(6):
+    itabs[i], itabs[6 + i] = interleave_factors(tabs[i], tabs[6 + i])
+    igrads[i], igrads[6 + i] = interleave_factors(torch.zeros_like(tabs[i]), torch.zeros_like(tabs[6 + i]))
+M = xyzs.shape[0]
+outs = []
+for T, G in ((tabs, grads), (itabs, igrads)):
+    sig = torch.empty(M, device=dev); prod = torch.empty(M, 144, dtype=torch.float16, device=dev)
+    pvd_hip.vm_forward(xyzs, aabb, T, [res] * 3, sig, prod)
+    torch.manual_seed(1)
+    gs, gp = torch.randn(M, device=dev), torch.randn(M, 144, device=dev).half()
+    for g in G:
+        g.zero_()
+    pvd_hip.vm_backward(xyzs, aabb, T, [res] * 3, gs, gp, G)
+    outs.append((sig, prod, [g.clone() for g in G]))
+assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "interleaved forward differs"
+worst = max(float((a - b).abs().max() / (a.abs().max() + 1e-20)) for a, b in zip(outs[0][2], outs[1][2]))
+print("interleaved layout: forward bit-identical, gradient difference (atomic order) %.2e of max" % worst)
 for name, x in (("ray order", xyzs), ("shuffled", xyzs[torch.randperm(xyzs.shape[0], device=dev)].contiguous()), ("2x samples", torch.cat([xyzs, xyzs]))):
     M = x.shape[0]
     sig = torch.empty(M, device=dev)
     prod = torch.empty(M, 144, dtype=torch.float16, device=dev)
     gs, gp = torch.randn(M, device=dev), torch.randn(M, 144, device=dev).half()
-    f = lambda: pvd_hip.vm_forward(x, aabb, tabs, [res] * 3, sig, prod)
-    b = lambda: pvd_hip.vm_backward(x, aabb, tabs, [res] * 3, gs, gp, grads)
-    for _ in range(3):
-        f(); b()
-    with pvd_hip.KernelTimer({"pvd_vm_forward", "pvd_vm_backward"}) as kt:
-        for _ in range(30):
+    for lay, T, G in (("separate", tabs, grads), ("interleaved", itabs, igrads)):
+        f = lambda: pvd_hip.vm_forward(x, aabb, T, [res] * 3, sig, prod)
+        b = lambda: pvd_hip.vm_backward(x, aabb, T, [res] * 3, gs, gp, G)
+        for _ in range(3):
             f(); b()
-    print(f"{name:12s} M={M:7d}: forward {kt.mean_ms('pvd_vm_forward') * 1e3:7.1f} us   backward {kt.mean_ms('pvd_vm_backward') * 1e3:7.1f} us", flush=True)
+        with pvd_hip.KernelTimer({"pvd_vm_forward", "pvd_vm_backward"}) as kt:
+            for _ in range(30):
+                f(); b()
+        print(f"{name:12s} {lay:12s} M={M:7d}: forward {kt.mean_ms('pvd_vm_forward') * 1e3:7.1f} us   backward {kt.mean_ms('pvd_vm_backward') * 1e3:7.1f} us", flush=True)
