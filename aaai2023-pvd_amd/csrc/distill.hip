@@ -13,7 +13,10 @@
 namespace pvd {
 
 constexpr uint32_t kLossBlock = 256;
-constexpr uint32_t kSumsqMaxBlocks = 1024;  // S4 is [4 + 4 * kSumsqMaxBlocks] floats: sums, then per-block partials
+constexpr uint32_t kSumsqMaxBlocks = 256;  // per-block partials after the four sums in S4 (callers provide room for 1024): one per
+                                           // thread of whoever finishes them (k_loss_final, or EVERY workgroup of k_loss_final_bwd)
+
+static_assert(kSumsqMaxBlocks <= kLossBlock, "k_loss_final_bwd reads one partial per thread");
 
 __device__ __forceinline__ float block_sum(float v, float *__restrict__ sh) {
 #pragma unroll
@@ -31,9 +34,12 @@ __device__ __forceinline__ float block_sum(float v, float *__restrict__ sh) {
 __global__ void __launch_bounds__(kLossBlock) k_sumsq4(const float *__restrict__ img_s, const float *__restrict__ img_t, uint32_t n_img,
                                                       const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
                                                       const float *__restrict__ col_s, const float *__restrict__ col_t,
-                                                      float *__restrict__ S) {
+                                                      float *__restrict__ S, float *__restrict__ rates_decay, float fea_decay) {
     __shared__ float sh[kLossBlock / 64];
     const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
+    // the per-step decay of the feature rate (utils.py:1044) for callers that finish the objective with k_loss_final_bwd,
+    // whose workgroups all READ the rates: nothing reads them during this launch
+    if (rates_decay && tid == 0) rates_decay[1] *= fea_decay;
     float s_img = 0.f, s_fea = 0.f, s_sig = 0.f, s_col = 0.f;
     for (uint32_t i = tid; i < n_img; i += stride) { const float d = img_t[i] - img_s[i]; s_img += d * d; }
     // feature rows as float4 quarters: quarter q of row m; column 0 (q == 0, .x) is also the sigma term
@@ -115,6 +121,61 @@ __global__ void __launch_bounds__(kLossBlock) k_sumsq4_bwd(const float *__restri
     for (uint32_t i = tid; i < M * 3u; i += stride) g_col[i] = c_col * (col_s[i] - col_t[i]);
 }
 
+// k_loss_final + k_sumsq4_bwd in one launch.  EVERY workgroup finishes the four sums (<= 256 partials: one per thread) and
+// forms the coefficients for itself -- 4 KB of L2 hits and five block reductions against an 8 us single-workgroup launch in
+// the middle of the step -- then writes its share of the gradients; workgroup 0 also publishes loss / norms / coefficients.
+// The rates are only read here (the decay happened in k_sumsq4).
+__global__ void __launch_bounds__(kLossBlock) k_loss_final_bwd(const float *__restrict__ img_s, const float *__restrict__ img_t, uint32_t n_img,
+                                                              const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
+                                                              const float *__restrict__ col_s, const float *__restrict__ col_t,
+                                                              float *__restrict__ S, uint32_t reduce_blocks, const float *__restrict__ rates,
+                                                              const float *__restrict__ extra, uint32_t n_extra,
+                                                              const float *__restrict__ upstream, float *__restrict__ loss,
+                                                              float *__restrict__ coef_out, float *__restrict__ norms,
+                                                              float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col) {
+    __shared__ float sh[kLossBlock / 64];
+    float s4[4];
+    if (reduce_blocks) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < reduce_blocks) v = reinterpret_cast<const float4 *>(S + 4)[threadIdx.x];  // reduce_blocks <= kLossBlock
+        s4[0] = block_sum(v.x, sh); s4[1] = block_sum(v.y, sh); s4[2] = block_sum(v.z, sh); s4[3] = block_sum(v.w, sh);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) s4[i] = S[i];
+    }
+    float coef[4], nrm[4], total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float r = rates[i];
+        nrm[i] = sqrtf(s4[i]);
+        total += r * nrm[i];
+        coef[i] = nrm[i] > 0.f ? r / nrm[i] : 0.f;
+    }
+    if (blockIdx.x == 0) {  // the value of the objective (same summation order as k_loss_final: parameter-only term first)
+        float e = 0.f;
+        for (uint32_t i = threadIdx.x; i < n_extra; i += kLossBlock) e += extra[i];
+        e = block_sum(e, sh);
+        if (threadIdx.x == 0) {
+            float t = e;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { t += rates[i] * nrm[i]; S[i] = s4[i]; norms[i] = nrm[i]; coef_out[i] = coef[i]; }
+            loss[0] = t;
+        }
+    }
+    (void)total;
+    const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
+    const float up = upstream[0];
+    const float c_img = coef[0] * up, c_fea = coef[1] * up, c_sig = coef[2] * up, c_col = coef[3] * up;
+    for (uint32_t i = tid; i < n_img; i += stride) g_img[i] = c_img * (img_s[i] - img_t[i]);
+    for (uint32_t i = tid; i < M * 4u; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+        float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
+        if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
+        reinterpret_cast<float4 *>(g_fea)[i] = g;
+    }
+    for (uint32_t i = tid; i < M * 3u; i += stride) g_col[i] = c_col * (col_s[i] - col_t[i]);
+}
+
 }  // namespace pvd
 
 using namespace pvd;
@@ -128,12 +189,14 @@ static uint32_t sumsq_blocks(uint32_t n_img, uint32_t M) {
 }
 
 int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea, uint32_t M,
-                      uint32_t fea_width, const float *col_stu, const float *col_tea, float *S4, int reduce, pvd_stream_t stream) {
+                      uint32_t fea_width, const float *col_stu, const float *col_tea, float *S4, int reduce, float *rates4_decay,
+                      float fea_decay, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
     if (fea_width != 16u) return PVD_ERR_INVALID;  // rows are read as four float4
     hipStream_t s = (hipStream_t)stream;
     const uint32_t blocks = sumsq_blocks(n_img, M);
-    hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4);
+    hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4,
+                       rates4_decay, fea_decay);
     if (reduce) hipLaunchKernelGGL(k_sumsq4_reduce, dim3(1), dim3(kLossBlock), 0, s, S4, blocks);
     return blocks > 0 ? check_launch() : PVD_ERR_INVALID;
 }
@@ -157,6 +220,23 @@ int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint3
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sumsq4_bwd, dim3(blocks), dim3(kLossBlock), 0, (hipStream_t)stream, img_stu, img_tea, n_img, fea_stu, fea_tea, M,
                        col_stu, col_tea, coef4, upstream, g_img, g_fea, g_col);
+    return check_launch();
+}
+
+int pvd_distill_loss_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu, const float *fea_tea,
+                              uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea, float *S4, int reduce,
+                              const float *rates4, const float *extra, uint32_t n_extra, const float *upstream, float *loss, float *coef4,
+                              float *norms4, float *g_img, float *g_fea, float *g_col, pvd_stream_t stream) {
+    if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4 || !rates4 || !upstream || !loss || !coef4 || !norms4 ||
+        !g_img || !g_fea || !g_col || (n_extra && !extra))
+        return PVD_ERR_INVALID;
+    if (fea_width != 16u) return PVD_ERR_INVALID;
+    uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_loss_final_bwd, dim3(blocks), dim3(kLossBlock), 0, (hipStream_t)stream, img_stu, img_tea, n_img, fea_stu, fea_tea, M,
+                       col_stu, col_tea, S4, reduce ? sumsq_blocks(n_img, M) : 0u, rates4, extra, n_extra, upstream, loss, coef4, norms4, g_img,
+                       g_fea, g_col);
     return check_launch();
 }
 

@@ -97,11 +97,12 @@ class _VMHeadTrain(torch.autograd.Function):
     (sigma [M], rgb [M,3], feature_sigma_color [M,16]), all f32; one MFMA kernel each way."""
 
     @staticmethod
-    def forward(ctx, sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3, smin, fmin, cmax):
+    def forward(ctx, sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3, smin, fmin, cmax, image=None):
         M = prod.shape[0]
         sigma_raw, prod, dirs = sigma_raw.float().contiguous(), prod.contiguous(), dirs.float().contiguous()
         sigma, rgb, feat = _outputs(M, prod.device)
-        image = pvd_hip.head_pack_weights(KIND_VM, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach())  # serves both passes
+        if image is None:  # (else: packed ahead of time by prepack_train_image)
+            image = pvd_hip.head_pack_weights(KIND_VM, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach())  # serves both passes
         pvd_hip.head_forward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(),
                              smin, fmin, cmax, sigma, rgb, feat, image=image)
         ctx.image = image
@@ -137,7 +138,7 @@ class _VMHeadTrain(torch.autograd.Function):
                               g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws, image=ctx.image,
                               g_rgb2=g_rgb_l)
         gw = (None, None, None, None) if direct else tuple(grads)
-        return (g_sraw, g_prod, None) + gw + (None, None, None)
+        return (g_sraw, g_prod, None) + gw + (None, None, None, None)
 
 
 def vm_head_train(model, sigma_raw, prod, d):
@@ -145,7 +146,21 @@ def vm_head_train(model, sigma_raw, prod, d):
     a = model.args
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
     return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
-                              model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max)
+                              model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max, model.__dict__.pop("_train_image_ready", None))
+
+
+def prepack_train_image(model):
+    """Pack NOW, on the caller's stream, the weight image the next vm_head_train forward of `model` will use (the trainer
+    issues this next to the marcher, on a parallel branch of the captured step).  The weights must not change in between."""
+    if getattr(model, "model_type", None) != "vm":
+        return False
+    buf = getattr(model, "_train_image_buf", None)
+    if buf is None:
+        buf = model._train_image_buf = torch.empty(pvd_hip.head_image_halfs(KIND_VM), dtype=torch.float16, device=model.basis_mat.weight.device)
+    pvd_hip.head_pack_weights(KIND_VM, model.basis_mat.weight.detach(), None, model.color_net[0].weight.detach(),
+                              model.color_net[1].weight.detach(), model.color_net[2].weight.detach(), image=buf)
+    model._train_image_ready = buf
+    return True
 
 
 def _grid_dims(enc):

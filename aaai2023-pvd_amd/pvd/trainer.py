@@ -316,6 +316,26 @@ class _TrainerBase:
                 self.optimizer.set_touched(c)
         self.flat.zero_()
 
+    def _step_prologue(self):
+        """zero_grad (+ the student's weight image) at the start of a step.  PVD_PROLOGUE_FORK=1: on a side stream, i.e. as a
+        parallel branch of the captured step that joins after the march (compute_loss) -- these launches are a few us of
+        latency each and depend on nothing the marcher does.  Measured: 0.411 vs 0.394 ms/step -- a fork / join pair inside a
+        hipGraph costs more (~17 us) than the ~11 us of launches it hides; off by default."""
+        fh = getattr(getattr(self, "model_stu", None), "ops", None)
+        fh = getattr(fh, "fused_head", None)
+        if os.environ.get("PVD_PROLOGUE_FORK", "0") != "1" or fh is None or not hasattr(fh, "prepack_train_image") or self.dp.enabled:
+            self._zero_grads()
+            return
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_prologue_stream", None)
+        if side is None:
+            side = self._prologue_stream = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._zero_grads()
+            fh.prepack_train_image(self.model_stu)
+        self._prologue_join = lambda: main.wait_stream(side)
+
     def _fork_prefix(self, launch):
         """Single GPU, pipelined capture: launch the NEXT step's parameter-independent prefix (its own graph) on a side
         stream, next to this step's inf check / AdamW on the main stream; joined before the next step starts."""
@@ -384,7 +404,7 @@ class _TrainerBase:
         try:
             with cap:
                 for _ in range(max(1, int(steps_per_graph))):
-                    self._zero_grads()
+                    self._step_prologue()
                     self._static_out = body()
                     if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
                         raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
@@ -486,7 +506,17 @@ class DistillTrainer(_TrainerBase):
                                  inherited_params=inh, nears_fars=nf, premarched=True, **kw)
             main.wait_stream(self._side)
         else:
-            out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
+            join = self.__dict__.pop("_prologue_join", None)
+            if join is not None and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
+                # the step's prologue (zero_grad, weight image) was forked onto a side stream: march first, join, then the forward
+                inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, **kw_stu)
+                join()
+                out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                                     inherited_params=inh, nears_fars=nf, premarched=True, **kw)
+            else:
+                if join is not None:
+                    join()
+                out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
             with torch.no_grad():
                 out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                                      inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
@@ -527,10 +557,16 @@ class DistillTrainer(_TrainerBase):
                 if self.flat_opt:
                     self._l1_term(partials_only=True)
                     extra = self.optimizer.l1_partials(1.0 / self.dp.world_size)
+            add_l1 = o.l1_reg_weight > 0.0 and o.model_type == "vm" and extra is None
+            # PVD_LOSS_DEFER=1: nothing looks at the value of the objective before loss.backward() in a training step, so it can be
+            # finished inside the backward launch (pvd_distill_loss_backward) instead of by a launch of its own.  Bit-identical
+            # (tests/test_hip_fused_misc.py) and measured: 0.3945 vs 0.3930 ms/step -- the single-workgroup launch it removes
+            # was hidden behind its neighbours in the replayed graph; off by default.
+            defer = not add_l1 and torch.is_grad_enabled() and os.environ.get("PVD_LOSS_DEFER", "0") == "1"
             l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
-                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra)
+                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra, defer=defer)
             loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
-            if o.l1_reg_weight > 0.0 and o.model_type == "vm" and extra is None:
+            if add_l1:
                 loss = loss + self._l1_term()
             info["rgb"] = norms[0]
             return loss, info, pred_stu, pred_tea

@@ -19,7 +19,7 @@ import types
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libpvd_hip.so")
+LIB_PATH = os.environ.get("PVD_HIP_LIB") or os.path.join(_PKG_ROOT, "libpvd_hip.so")  # PVD_HIP_LIB: an A/B build of the same ABI
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -50,7 +50,7 @@ ENTRY_POINTS = (
     "pvd_head_forward", "pvd_hash_head_forward_fused",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
+    "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
@@ -688,14 +688,35 @@ def _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t):
     return M, fea_s.shape[1]
 
 
-def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, reduce=True):
-    dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4)
+def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, reduce=True, rates_decay=None, fea_decay=1.0):
+    """rates_decay: the device rates[4] whose entry 1 is multiplied by fea_decay in this launch (for distill_loss_backward)."""
+    dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, rates_decay)
+    if rates_decay is not None:
+        _want(rates_decay, torch.float32, "rates_decay")
     _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4)
     M, W = _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t)
     if S4.numel() < 4 + 4 * 1024:
         raise PvdHipError("S4 needs 4 + 4*1024 floats")
     _call("pvd_distill_sumsq", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(M), _u32(W), _p(col_s), _p(col_t),
-          _p(S4), _int(int(bool(reduce))))
+          _p(S4), _int(int(bool(reduce))), _p(rates_decay), _f32(fea_decay))
+
+
+def distill_loss_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, rates4, upstream, loss, coef4, norms4, g_img, g_fea, g_col,
+                          reduce=False, extra=None):
+    """pvd_distill_loss_backward: finish the objective (loss, norms, coefficients) and write the three gradients, one launch."""
+    dev = _dev(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, rates4, upstream, loss, coef4, norms4, g_img, g_fea, g_col, extra)
+    _f32_all(img_s=img_s, img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4, rates4=rates4, upstream=upstream, loss=loss,
+             coef4=coef4, norms4=norms4, g_img=g_img, g_fea=g_fea, g_col=g_col)
+    if extra is not None:
+        _want(extra, torch.float32, "extra")
+    M, W = _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t)
+    if g_img.numel() != img_s.numel() or g_fea.shape != fea_s.shape or g_col.shape != col_s.shape:
+        raise PvdHipError("gradient buffers must have the shapes of the student tensors")
+    if S4.numel() < 4 + 4 * 1024:
+        raise PvdHipError("S4 needs 4 + 4*1024 floats")
+    _call("pvd_distill_loss_backward", dev, _p(img_s), _p(img_t), _u32(img_s.numel()), _p(fea_s), _p(fea_t), _u32(M), _u32(W), _p(col_s),
+          _p(col_t), _p(S4), _int(int(bool(reduce))), _p(rates4), _p(extra), _u32(extra.numel() if extra is not None else 0), _p(upstream),
+          _p(loss), _p(coef4), _p(norms4), _p(g_img), _p(g_fea), _p(g_col))
 
 
 def distill_loss_final(S4, rates4, loss, coef4, norms4, n_img=0, M=0, reduce=False, fea_decay=1.0, extra=None):

@@ -390,13 +390,22 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  *   n_img / M), saving a launch.
  * pvd_distill_loss_final: fea_decay multiplies rates4[1] in place before it is used (the per-step 0.995 decay of the
  *   feature rate, utils.py:1044; 1.0 = leave it); extra [n_extra] are partial sums of a parameter-only term added
- *   to the loss value (pvd_l1_ranges partials), or NULL. */
+ *   to the loss value (pvd_l1_ranges partials), or NULL.
+ * pvd_distill_loss_backward = pvd_distill_loss_final + pvd_distill_sumsq_backward in ONE launch (every workgroup finishes
+ *   the sums for itself; workgroup 0 publishes loss / coef4 / norms4 / S4[0..3]) for callers that do not need the loss
+ *   value before the backward pass.  It only READS rates4: the decay of the feature rate is then applied by
+ *   pvd_distill_sumsq (rates4_decay != NULL: rates4_decay[1] *= fea_decay; NULL: leave the rates alone). */
 int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
                       const float *fea_tea, uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea,
-                      float *S4, int reduce, pvd_stream_t stream);
+                      float *S4, int reduce, float *rates4_decay, float fea_decay, pvd_stream_t stream);
 int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, float *rates4, float fea_decay,
                            const float *extra, uint32_t n_extra, float *loss, float *coef4, float *norms4,
                            pvd_stream_t stream);
+int pvd_distill_loss_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
+                              const float *fea_tea, uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea,
+                              float *S4, int reduce, const float *rates4, const float *extra, uint32_t n_extra,
+                              const float *upstream, float *loss, float *coef4, float *norms4, float *g_img, float *g_fea,
+                              float *g_col, pvd_stream_t stream);
 int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint32_t n_img, const float *fea_stu,
                                const float *fea_tea, uint32_t M, uint32_t fea_width, const float *col_stu, const float *col_tea,
                                const float *coef4, const float *upstream, float *g_img, float *g_fea, float *g_col,

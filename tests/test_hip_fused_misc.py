@@ -83,6 +83,43 @@ def test_fused_distill_loss_matches_torch_norms():
     assert float(loss) == 0.0 and torch.count_nonzero(z.grad) == 0
 
 
+def test_objective_finished_inside_the_backward_launch_is_bit_identical():
+    """defer=True (pvd_distill_loss_backward: loss / norms / coefficients finished by every workgroup of the backward launch)
+    vs the three-launch form: loss, norms, the decayed feature rate and all three gradients bit for bit, with a parameter-only
+    extra term and the 0.995 decay, over two consecutive steps (the rate carries over)."""
+    from pvd.losses import distill_loss_normL2
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(12)
+    N, M = 4096, 92928
+    img_t = torch.rand(1, N, 3, device=dev, generator=g)
+    fea_t = torch.randn(M, 16, device=dev, generator=g)
+    col_t = torch.rand(M, 3, device=dev, generator=g)
+    extra = torch.rand(1024, device=dev, generator=g) * 1e-3
+    up = torch.tensor(65536.0, device=dev)
+    res = []
+    for defer in (False, True):
+        rates = torch.tensor([1.0, 0.002, 0.003, 0.004], device=dev)
+        out = []
+        for step in range(2):
+            img_s = (img_t + 0.1 * torch.randn(1, N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + step))).requires_grad_(True)
+            fea_s = (fea_t + 0.2 * torch.randn(M, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(4 + step))).requires_grad_(True)
+            col_s = (col_t + 0.05 * torch.randn(M, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(5 + step))).requires_grad_(True)
+            loss, norms = distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, None, fea_decay=0.995, extra=extra, defer=defer)
+            loss.backward(gradient=up)
+            out.append((loss.detach().clone(), norms.clone(), rates.clone(), img_s.grad, fea_s.grad, col_s.grad))
+        res.append(out)
+    for a, b in zip(*res):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert float(res[1][1][2][1]) == float(torch.tensor(0.002) * 0.995 * 0.995)
+    # without autograd (an evaluation pass) defer is ignored: the value is there when the call returns
+    with torch.no_grad():
+        rates = torch.tensor([1.0, 0.002, 0.003, 0.004], device=dev)
+        loss, _ = distill_loss_normL2(img_t * 0.9, img_t, fea_t * 1.1, fea_t, col_t, col_t, rates, None, defer=True)
+        ref = 1.0 * torch.norm(img_t * 0.1) + 0.002 * torch.norm(fea_t * 0.1) + 0.003 * torch.norm(fea_t[:, 0] * 0.1)
+        assert abs(float(loss) - float(ref)) <= 1e-4 * float(ref)
+
+
 def test_flat_adamw_matches_torch_fused_adamw():
     """Same parameters / gradients through torch.optim.AdamW(fused) and FlatAdamW, with GradScaler-style
     grad_scale, a skipped (found_inf) step and two learning-rate groups, over several steps."""

@@ -131,3 +131,39 @@ def test_update_extra_state_device_path_tracks_the_torch_path():
     assert abs(means[0] - means[1]) <= 0.03 * means[1], means
     truth = scene.density_grid(128, 1.0, 1, device=dev).view(-1) > 10.0  # cell-centre occupancy of the analytic scene
     assert (a & truth).sum().item() / truth.sum().item() > 0.98  # nothing solid is missed
+
+
+def test_mark_untrained_grid_on_the_device_marks_the_cells_the_cpu_run_marks():
+    """mark_untrained_grid (reference: renderer.py:561-645) is torch code on top of pvd_morton3D: the HIP-backed model on the
+    GPU must mark exactly the cells the oracle-backed model marks on the CPU (the frustum test is a handful of fp32 compares:
+    cells whose camera-space margin is below 1e-5 of the cell size may fall either way), two cascades, and the marked cells must
+    survive a device-side update_extra_state untouched."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, synthetic_poses
+    from pvd.workload import make_model
+    opt = PVDConfig(model_type="hash", bound=2.0, fp16=True)
+    poses = synthetic_poses(np.random.RandomState(3))[:5]
+    grids = []
+    for ops, d in ((hip_ops(), dev), (oracle_ops(), torch.device("cpu"))):
+        torch.manual_seed(0)
+        m = make_model(ops, opt, "hash", True, d)
+        assert m.cascade == 2
+        m.density_grid.zero_()
+        e0 = m.occ_epoch
+        m.mark_untrained_grid(poses, BLENDER_INTRINSICS)
+        assert m.occ_epoch > e0
+        grids.append((m, m.density_grid.detach().cpu()))
+    g_hip, g_cpu = grids[0][1], grids[1][1]
+    marked = (g_cpu < 0)
+    assert 0.02 < marked.float().mean().item() < 0.9
+    assert ((g_hip < 0) != marked).float().mean().item() < 1e-5
+    m = grids[0][0]
+    before = m.density_grid.clone()
+    with torch.autocast("cuda", dtype=torch.float16):
+        m.update_extra_state()
+    assert torch.equal(m.density_grid[before < 0], before[before < 0])
+    assert (m.density_grid[before >= 0] >= 0).all()

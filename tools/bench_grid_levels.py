@@ -21,13 +21,24 @@ enc = GridEncoder(num_levels=14, desired_resolution=2048).to(dev)
 enc.embeddings.data.uniform_(-1, 1)
 emb = enc.embeddings.detach().half()
 S = float(np.log2(enc.per_level_scale))
-poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
-bits = packbits_torch(ChairScene(thicken=0.08).density_grid(128, 1.0, 1, device=dev), 10.0)
-r = get_rays(poses[0:1], BLENDER_INTRINSICS, 800, 800, 4096)
-o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
-nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
-x = ((raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)[0] + 1) / 2).contiguous()
-B = x.shape[0]
+
+
+def samples(n_rays=4096, pose=0):
+    """The bench's kind of sample set: one training batch of rays of camera `pose` marched through the chair's occupancy grid;
+    positions mapped to [0,1]."""
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
+    bits = packbits_torch(ChairScene(thicken=0.08).density_grid(128, 1.0, 1, device=dev), 10.0)
+    r = get_rays(poses[pose:pose + 1], BLENDER_INTRINSICS, 800, 800, n_rays)
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    return ((raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)[0] + 1) / 2).contiguous()
+
+
+if __name__ != "__main__":
+    x = None
+else:
+    x = samples()
+B = x.shape[0] if x is not None else 0
 offs = enc.offsets.cpu().numpy()
 
 
@@ -87,16 +98,17 @@ def lines_per_level(level):
     return total, res, size
 
 
-print("samples %d; levels, resolution, rows, dense?, distinct lines per 32-sample wave, cumulative time (two lanes per sample, 4096 persistent workgroups / plain)" % B)
-prev = (0.0, 0.0)
-tot_lines = 0
-for L in range(1, 15):
-    t = (timed(L, (2, 4096)), timed(L, (0, 0)))
-    lines, res, size = lines_per_level(L - 1)
-    tot_lines += lines
-    print("L=%2d res %5d rows %7d %s lines/wave %6.1f | lps2 %6.2f us (+%5.2f)  plain %6.2f us (+%5.2f)" % (
-        L, res, size, "dense " if (res + 1) ** 3 <= size else "hashed", lines / (B / 32), t[0], t[0] - prev[0], t[1], t[1] - prev[1]), flush=True)
-    prev = t
-clk = 2.4e9
-print("distinct lines per launch %.2f M -> %.1f us at one line per clock per CU (256 CUs, %.1f GHz), launch floor ~3 us not included" % (tot_lines / 1e6, tot_lines / 256 / clk * 1e6, clk / 1e9))
-pvd_hip.grid_set_fwd_kernel()
+if __name__ == "__main__":
+    print("samples %d; levels, resolution, rows, dense?, distinct lines per 32-sample wave, cumulative time (two lanes per sample, 4096 persistent workgroups / plain)" % B)
+    prev = (0.0, 0.0)
+    tot_lines = 0
+    for L in range(1, 15):
+        t = (timed(L, (2, 4096)), timed(L, (0, 0)))
+        lines, res, size = lines_per_level(L - 1)
+        tot_lines += lines
+        print("L=%2d res %5d rows %7d %s lines/wave %6.1f | lps2 %6.2f us (+%5.2f)  plain %6.2f us (+%5.2f)" % (
+            L, res, size, "dense " if (res + 1) ** 3 <= size else "hashed", lines / (B / 32), t[0], t[0] - prev[0], t[1], t[1] - prev[1]), flush=True)
+        prev = t
+    clk = 2.4e9
+    print("distinct lines per launch %.2f M -> %.1f us at one line per clock per CU (256 CUs, %.1f GHz), launch floor ~3 us not included" % (tot_lines / 1e6, tot_lines / 256 / clk * 1e6, clk / 1e9))
+    pvd_hip.grid_set_fwd_kernel()

@@ -1,7 +1,9 @@
 #!/bin/bash
-TAG=${TAG:-r02vmi}
+TAG=${TAG:-r02defer}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$GRAFT_REPO_ROOT"
-timeout 300 python tools/bench_vm.py 2>&1 | grep -v amdgpu > $OUT/bench_vm.txt; cat $OUT/bench_vm.txt
-timeout 300 python -m pytest tests/test_hip_vm.py -q -x 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_hip_fused_misc.py tests/test_hip_graph.py tests/test_hip_amp_parity.py tests/test_hip_dp_graph.py tests/test_hip_occupancy.py -q -x 2>&1 | tail -5
+for f in 0 1 0 1; do
+  PVD_LOSS_DEFER=$f timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('defer=$f', d['ms_per_step'], d['config']['launch'], d['config']['capture_fallback'], d['config']['loss'])" | tee -a $OUT/defer.txt
+done
