@@ -225,6 +225,20 @@ __device__ __forceinline__ void copy_image(half_t *__restrict__ lds, const half_
     for (int i = tid; i < halfs / 8; i += n) dst[i] = src[i];
 }
 
+// the same copy as LDS-DMA (gfx950 global_load_lds_dwordx4): wave w moves the 1-KB pieces w, w + 4, ... -- lane l's 16 bytes land
+// at piece base + 16 l, which is the linear order of the image -- without passing through registers; completion is the
+// caller's business (s_waitcnt vmcnt(0), which __syncthreads() carries while such a load is in flight)
+__device__ __forceinline__ void copy_image_dma(half_t *__restrict__ lds, const half_t *__restrict__ image, int halfs, uint32_t tid) {
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const int bytes = halfs * 2;
+    for (int c = (int)wave; c * 1024 < bytes; c += (int)(kHeadBlock / 64)) {
+        const int off = c * 1024 + (int)lane * 16;
+        if (off + 16 <= bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)image + off),
+                                             (__attribute__((address_space(3))) void *)((char *)lds + c * 1024), 16, 0, 0);
+    }
+}
+
 // the packed image: [HeadLds<KIND>][HeadLdsT<KIND>], exactly the backward kernel's LDS contents.  One image element per
 // thread and ONE round of loads: the ten matrices (five weights, plain and transposed) used to be ten loops one after the
 // other, i.e. ten dependent memory round trips for 43 k elements (7.6 us in the step's timeline).
@@ -472,11 +486,14 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
     HeadLds<KIND_HASH> W;
     W.carve(lds);
     half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
-    if (a.image) copy_image(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x, kHeadBlock);
-    else W.load(a, threadIdx.x, kHeadBlock);
+    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
+    // The head's weights: with a packed image, 24 KB of L2 hits go straight into LDS (global_load_lds_dwordx4: no data
+    // registers, nothing to wait for here) while the lookup below runs; register-staged in front of the lookup they were 2.3 us
+    // of a 24 us workgroup (cycle stamps, tools/prof_fused_stamps.py).  The barrier after the lookup drains them.
+    bool dma_pending = a.image != nullptr;  // issued behind the first group of gathers (below)
+    if (!dma_pending) W.load(a, threadIdx.x, kHeadBlock);
     for (uint32_t i = threadIdx.x; i < kFusedTile * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
         *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
-    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
     const uint32_t nchunks = div_up(a.M, kFusedTile);
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -492,6 +509,16 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 if (g.aff.on) x01[d] = (x01[d] + g.aff.add) / g.aff.div;
                 inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
             }
+        }
+        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
+        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
+        float dir_pre[kTilesPerWave][3];
+#pragma unroll
+        for (int ti = 0; ti < kTilesPerWave; ti++) {
+            const size_t bs = (size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15);
+            const bool valid = bs < a.M;
+#pragma unroll
+            for (int c = 0; c < 3; c++) dir_pre[ti][c] = valid ? a.dirs[3 * bs + c] : 0.f;
         }
         // The 14 levels in two groups of 7: all 28 gathers of a group are issued before the first blend, so a wave has one
         // memory round trip per group instead of one per level (the levels are independent; with <= 3 workgroups per CU nothing
@@ -523,6 +550,10 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                     v[j][k] = table[inside ? index(pg) : 0u];
                 }
             }
+            if (l0 == 0 && dma_pending) {
+                dma_pending = false;
+                copy_image_dma(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x);
+            }
 #pragma unroll
             for (uint32_t j = 0; j < G; j++) {
                 uint32_t acc = 0u;
@@ -551,8 +582,8 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + row * kFeatStride + 16 * s2 + 4 * hi);
             in.sraw = 0.f;
-            in.dx = in.dy = in.dz = 0.f;
-            if (valid) { in.dx = a.dirs[3 * bs]; in.dy = a.dirs[3 * bs + 1]; in.dz = a.dirs[3 * bs + 2]; }
+            const int tsel = (int)((t16 - wave) / (kHeadBlock / 64));
+            in.dx = dir_pre[tsel][0]; in.dy = dir_pre[tsel][1]; in.dz = dir_pre[tsel][2];
             TileFwd t;
             head_forward_tile<KIND_HASH>(a, W, in, lane, t);
             if (valid) {

@@ -42,6 +42,13 @@ struct AdamExtras {
     // of a table no sample can reach, outside every L1 / g16 range).  The update of such a group is weight decay alone --
     // the same bits the full expression yields for g = m = v = 0 -- so g, m, v are neither read nor written for it.
     const uint32_t *cold;  // DEVICE [ceil(n / 128)] or NULL
+    // Lazy weight decay of the cold groups.  Nothing reads a cold parameter while it is cold (no sample reaches it), so instead
+    // of p <- p - lr wd p on every step the tail kernel LOGS the rates of the step (lazy_log[count][segment]) and
+    // pvd_adamw_lazy_flush replays the logged decays one after the other, in the same arithmetic, when somebody needs the
+    // values (checkpoint, occupancy change): the same bits, 0 instead of 8 B/parameter per step.
+    float *lazy_log;        // DEVICE [lazy_capacity][segments] or NULL
+    uint32_t *lazy_count;   // DEVICE scalar: logged steps
+    uint32_t lazy_capacity;
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -65,10 +72,18 @@ __global__ void k_adamw_tail(float *__restrict__ step, float *__restrict__ found
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool inf = found_inf && found_inf[0] != 0.f;
     if (!inf) step[0] += 1.0f;
-    if (ex.sched_kind != 0) {
+    if (ex.sched_kind != 0)
         for (uint32_t k = 0; k < n_segments; k++) lr[k] = scheduled_lr(ex, lr, k);
-        ex.sched_step[0] += 1.0f;
+    if (ex.lazy_log && !inf) {  // the rates this (applied) step used, for the cold groups' deferred decay
+        const uint32_t c = ex.lazy_count[0];
+        if (c < ex.lazy_capacity) {
+            for (uint32_t k = 0; k < n_segments; k++) ex.lazy_log[(size_t)c * n_segments + k] = lr[k];
+            ex.lazy_count[0] = c + 1u;
+        } else {
+            ex.lazy_count[0] = 0xFFFFFFFFu;  // overflow: the host flushes long before (FlatAdamW); poisoned so that a flush fails loudly
+        }
     }
+    if (ex.sched_kind != 0) ex.sched_step[0] += 1.0f;
     if (!scale) return;
     if (inf) {
         scale[0] = (float)((double)scale[0] * backoff);
@@ -110,6 +125,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
         const double lrk = (double)lr_sh[k];
         if (ex.cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u)) {
+            if (ex.lazy_log) continue;  // decay deferred: logged by the tail kernel, replayed by pvd_adamw_lazy_flush
             // g = m = v = 0: ea = es = 0, denom = eps, param -= step_size * 0 / eps leaves param as decayed below
             float4 P = reinterpret_cast<float4 *>(p)[i];
             P.x = (float)((double)P.x - lrk * (double)weight_decay * (double)P.x);
@@ -161,6 +177,38 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             for (uint32_t w = 0; w < kOptBlock / 64; w++) sacc += l1_sh[w];
             ex.l1_next[blockIdx.x] = sacc * ex.l1_next_scale;
         }
+    }
+}
+
+// Replay of the deferred weight decay: every cold group takes the logged steps one after the other, p <- (float)(p - lr wd p)
+// in the update kernel's own arithmetic (fp64 expression, one rounding per step), so the result is bit for bit what the
+// per-step decay would have left.  The log is read with wave-uniform (scalar) loads.
+__global__ void __launch_bounds__(kOptBlock) k_adamw_lazy_flush(float *__restrict__ p, uint64_t n, AdamSegments seg, const uint32_t *__restrict__ cold,
+                                                               const float *__restrict__ log, const uint32_t *__restrict__ count,
+                                                               double weight_decay) {
+    const uint32_t steps = count[0];
+    if (steps == 0u || steps == 0xFFFFFFFFu) return;
+    const uint64_t n4 = n >> 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kOptBlock) {
+        if (!((cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u)) continue;
+        const uint64_t e = i << 2;
+        uint32_t k = 0;
+        while (k + 1 < seg.count && e >= seg.end[k]) k++;
+        float4 P = reinterpret_cast<float4 *>(p)[i];
+        for (uint32_t s = 0; s < steps; s++) {
+            const double f = (double)log[(size_t)s * seg.count + k] * weight_decay;
+            P.x = (float)((double)P.x - f * (double)P.x);
+            P.y = (float)((double)P.y - f * (double)P.y);
+            P.z = (float)((double)P.z - f * (double)P.z);
+            P.w = (float)((double)P.w - f * (double)P.w);
+        }
+        reinterpret_cast<float4 *>(p)[i] = P;
+    }
+}
+__global__ void k_adamw_lazy_reset(uint32_t *__restrict__ count, int32_t *__restrict__ status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (status) status[0] = count[0] == 0xFFFFFFFFu ? -1 : (int32_t)count[0];
+        count[0] = 0u;
     }
 }
 
@@ -297,6 +345,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -307,6 +356,10 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         if (rc != PVD_OK) return rc;
         if (h.l1_next) { ex.l1_next = h.l1_next; ex.l1_next_scale = h.l1_next_scale; }
         ex.cold = h.cold_bits;
+        if (h.lazy_log) {
+            if (!h.cold_bits || !h.lazy_count || h.lazy_capacity < 1) return PVD_ERR_INVALID;
+            ex.lazy_log = h.lazy_log; ex.lazy_count = h.lazy_count; ex.lazy_capacity = h.lazy_capacity;
+        }
         if (h.g16) {
             if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
             ex.g16 = (const _Float16 *)h.g16; ex.g16_begin = h.g16_begin; ex.g16_end = h.g16_end;
@@ -322,6 +375,21 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     hipLaunchKernelGGL(k_adamw_tail, dim3(1), dim3(64), 0, s, step, const_cast<float *>(found_inf), ex, lr, n_segments,
                        amp ? extras_host->amp_scale : nullptr, amp ? extras_host->amp_growth_tracker : nullptr,
                        amp ? extras_host->amp_growth : 0.0, amp ? extras_host->amp_backoff : 0.0, amp ? extras_host->amp_interval : 1);
+    return check_launch();
+}
+
+int pvd_adamw_lazy_flush(float *p, uint64_t n, const uint64_t *segment_ends_host, uint32_t n_segments, const uint32_t *cold_bits,
+                         const float *lazy_log, uint32_t *lazy_count, double weight_decay, int32_t *status, pvd_stream_t stream) {
+    if (!p || !segment_ends_host || !cold_bits || !lazy_log || !lazy_count) return PVD_ERR_INVALID;
+    if (n_segments < 1 || n_segments > kMaxSegments || (n & 3u)) return PVD_ERR_UNSUPPORTED;
+    AdamSegments seg;
+    seg.count = n_segments;
+    for (uint32_t k = 0; k < n_segments; k++) seg.end[k] = segment_ends_host[k];
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t blocks = (n / 4 + kOptBlock - 1) / kOptBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (n) hipLaunchKernelGGL(k_adamw_lazy_flush, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, n, seg, cold_bits, lazy_log, lazy_count, weight_decay);
+    hipLaunchKernelGGL(k_adamw_lazy_reset, dim3(1), dim3(64), 0, s, lazy_count, status);
     return check_launch();
 }
 
@@ -376,6 +444,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -50,6 +50,7 @@ def upsample_vm(model, resolution):
     """VM factors resampled to `resolution` (bilinear, align_corners) -- reference: upsample_params / upsample_model,
     network.py:559-587.  Keeps the channels-last storage."""
     from .network import _channels_last
+    getattr(model, "_pvd_flush_params", lambda: None)()  # (a flat optimizer's deferred decays, before whole tables are read)
     res = [int(r) for r in resolution]
     for mats, vecs in ((model.sigma_mat, model.sigma_vec), (model.color_mat, model.color_vec)):
         for i in range(3):

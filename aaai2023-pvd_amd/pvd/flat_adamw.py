@@ -56,9 +56,52 @@ class FlatAdamW(torch.optim.Optimizer):
         """touched: an object with zero(flat) / check_finite(flat, flag) over a fixed index set, under the caller's
         guarantee that no gradient is ever written outside that set.  zero_grad and the scaler's inf check then walk
         only the set (after one full zero)."""
+        self.flush()  # deferred decays belong to the OLD cold set
         self.touched = touched
         self._outside_is_zero = False
         self._cold_bits, self._cold_dirty = None, touched is not None
+
+    # ---- lazy weight decay of the cold groups (pvd_adamw_extras.lazy_log): nothing reads a cold parameter while it is cold, so
+    # its per-step decay is logged on the device and replayed -- same arithmetic, same bits -- when the values are needed
+    LAZY_CAPACITY = 1 << 15
+    _lazy, _lazy_logged = None, 0
+
+    def _lazy_state(self):
+        import os
+        if os.environ.get("PVD_ADAMW_LAZY", "1") == "0":
+            return None
+        if self._lazy is None:
+            dev = self.flat_p.device
+            self._lazy = (torch.zeros(self.LAZY_CAPACITY, len(self.segment_ends), dtype=torch.float32, device=dev),
+                          torch.zeros(1, dtype=torch.int32, device=dev))
+        return self._lazy
+
+    def note_device_steps(self, n):
+        """n update steps ran on the device without step() being called (a graph replay): keep the host's idea of the log's
+        fill level current, and empty the log well before it is full."""
+        if self._lazy is not None and self._cold_bits is not None:
+            self._lazy_logged += int(n)
+            if self._lazy_logged > self.LAZY_CAPACITY - 1024 and not torch.cuda.is_current_stream_capturing():
+                self.flush()
+
+    @torch.no_grad()
+    def flush(self):
+        """Apply the deferred decays: after this every parameter holds what per-step updates would have left.  Called before
+        anything reads whole tables (state_dict, checkpoints, a change of the touched set) -- and by whoever compares
+        parameters."""
+        if self._lazy is None or self._cold_bits is None or self._lazy_logged == 0:
+            return
+        status = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)
+        pvd_hip.adamw_lazy_flush(self.flat_p, self.segment_ends, self._cold_bits, self._lazy[0], self._lazy[1],
+                                 self.defaults["weight_decay"], status)
+        n = int(status[0])
+        assert n >= 0, "the lazy-decay log overflowed: decays were lost"
+        self._lazy_logged = 0
+        pvd_hip.note_weights_changed(self.params)
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
 
     def _build_cold_bits(self):
         """One bit per group of 4 parameters: set where the group lies outside the touched set, outside every L1 range (the
@@ -166,17 +209,26 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         d = self.defaults
         st = getattr(self, "_l1_track", None)
-        if self._cold_dirty and not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._cold_dirty and not capturing:
             import os
+            self.flush()  # with the old bitmap
             self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
             self._cold_dirty = False
         cold = self._cold_bits if (self.touched is not None and self._outside_is_zero and not self._cold_dirty
                                    and getattr(self, "_half_grad", None) is None) else None
+        lazy = self._lazy_state() if cold is not None else None
+        if lazy is None and self._lazy_logged and not capturing:
+            self.flush()  # this step decays the cold groups itself: the logged decays come first
+        if lazy is not None:
+            if self._lazy_logged > self.LAZY_CAPACITY - 1024 and not capturing:
+                self.flush()
+            self._lazy_logged += 1
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                            d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                            schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                            amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
-                           l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold)
+                           l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy)
         self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)

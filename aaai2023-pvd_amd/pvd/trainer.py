@@ -237,6 +237,10 @@ class _TrainerBase:
             model.encoder.embeddings._pvd_half_grad_taker = self.optimizer.accept_half_grad
         if self.flat_opt:
             self.flat = _FlatOptGrads(self.optimizer)
+            # the optimizer may hold deferred weight decay for table rows nothing reads (FlatAdamW.flush): whoever reads whole
+            # tables -- state_dict / checkpoints, resampling -- gets them brought up to date first
+            model._pvd_flush_params = self.optimizer.flush
+            model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.optimizer.flush())
         else:
             self.flat = FlatGrads([p for g in self.optimizer.param_groups for p in g["params"]])
         self.global_step = 0
@@ -428,6 +432,8 @@ class _TrainerBase:
             torch.cuda.current_stream().wait_stream(self._pipe_stream)
             self._pipe_pending = False
         self._cap.replay()
+        if self.flat_opt:
+            self.optimizer.note_device_steps(self.steps_per_replay)
         for _ in range(self.steps_per_replay):
             self.scheduler.step()
         self.global_step += self.steps_per_replay

@@ -51,7 +51,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -747,7 +747,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("l1_coef_host", ctypes.POINTER(ctypes.c_float)), ("amp_scale", ctypes.c_void_p), ("amp_growth_tracker", ctypes.c_void_p),
                 ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32),
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
-                ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p)]
+                ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p),
+                ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32)]
 
 
 def _u64_array(vals):
@@ -755,7 +756,7 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer.
     cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good."""
@@ -771,6 +772,13 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
             if cold_bits.numel() * 128 < p.numel() or not cold_bits.is_contiguous():
                 raise PvdHipError("cold_bits needs one bit per 4 parameters")
             ex.cold_bits = cold_bits.data_ptr()
+            if lazy is not None:  # (log f32 [capacity, segments], count int32 [1]): the cold groups' decay is deferred (pvd_adamw_lazy_flush)
+                log, count = lazy
+                _dev(log, count)
+                _want(log, torch.float32, "lazy log"), _want(count, torch.int32, "lazy count")
+                if log.dim() != 2 or log.shape[1] != len(segment_ends) or not log.is_contiguous():
+                    raise PvdHipError("the lazy-decay log must be a contiguous [capacity, segments] f32 tensor")
+                ex.lazy_log, ex.lazy_count, ex.lazy_capacity = log.data_ptr(), count.data_ptr(), int(log.shape[0])
         if l1_next is not None:  # (buffer [>= 4096] f32, scale)
             buf, sc = l1_next
             _dev(buf)
@@ -806,6 +814,19 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
     _call("pvd_adamw_step_ex", dev, _p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.numel()), ends, _u32(len(segment_ends)), _p(lr),
           ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_double(weight_decay), _p(step), _p(grad_scale),
           _p(found_inf), ctypes.byref(ex) if ex is not None else _vp(0))
+
+
+def adamw_lazy_flush(p, segment_ends, cold_bits, log, count, weight_decay, status=None):
+    """pvd_adamw_lazy_flush: replay the logged decays on the cold groups of p, empty the log; status (int32 [1]) <- steps replayed / -1."""
+    dev = _dev(p, cold_bits, log, count, status)
+    _f32_all(p=p, log=log)
+    _want(cold_bits, torch.int32, "cold_bits"), _want(count, torch.int32, "lazy count")
+    if status is not None:
+        _want(status, torch.int32, "status")
+    if cold_bits.numel() * 128 < p.numel() or log.dim() != 2 or log.shape[1] != len(segment_ends):
+        raise PvdHipError("cold_bits / log do not match the parameter buffer")
+    _call("pvd_adamw_lazy_flush", dev, _p(p), ctypes.c_uint64(p.numel()), _u64_array(segment_ends), _u32(len(segment_ends)), _p(cold_bits),
+          _p(log), _p(count), ctypes.c_double(weight_decay), _p(status))
 
 
 def check_finite(g, found_inf):

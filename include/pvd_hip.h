@@ -459,11 +459,25 @@ typedef struct pvd_adamw_extras {
      * reach; outside every L1 and g16 range).  Their update is the weight decay alone, bit-identical to what the full
      * expression gives for g = m = v = 0, and g / m / v are neither read nor written for them (8 instead of 28 B/parameter). */
     const uint32_t *cold_bits;
+    /* lazy_log != NULL (with cold_bits): the weight decay of the cold groups is DEFERRED -- the update skips them entirely
+     * and logs the learning rates of every applied step in lazy_log[lazy_count++][n_segments] (DEVICE, lazy_capacity steps;
+     * lazy_count DEVICE scalar); pvd_adamw_lazy_flush replays the logged decays in order, in the same arithmetic, leaving
+     * the bits the per-step decay would have left.  Nothing may read a cold parameter before the flush. */
+    float *lazy_log;
+    uint32_t *lazy_count;
+    uint32_t lazy_capacity;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,
                       float *step, const float *grad_scale, const float *found_inf, const pvd_adamw_extras *extras_host,
                       pvd_stream_t stream);
+
+/* Replay the deferred decay of the cold groups (see pvd_adamw_extras.lazy_log) and empty the log.  status (DEVICE int32, may
+ * be NULL) receives the number of replayed steps, or -1 if the log had overflowed (the decays beyond lazy_capacity are lost:
+ * flush before that). */
+int pvd_adamw_lazy_flush(float *p, uint64_t n, const uint64_t *segment_ends_host, uint32_t n_segments,
+                         const uint32_t *cold_bits, const float *lazy_log, uint32_t *lazy_count, double weight_decay,
+                         int32_t *status, pvd_stream_t stream);
 
 /* found_inf[0] = 1 if any of g[0..n) is inf/nan (never cleared): the read-only inf check GradScaler.step needs
  * for an optimizer that unscales inside its own kernel (n multiple of 4). */

@@ -62,6 +62,7 @@ def _pair(student="vm", **kw):
 
 
 def _flat_params(model):
+    getattr(model, "_pvd_flush_params", lambda: None)()  # FlatAdamW: deferred weight decay of rows nothing reads
     return torch.cat([p.detach().float().permute(0, 2, 3, 1).reshape(-1) if p.dim() == 4 else p.detach().float().reshape(-1)
                       for p in model.parameters() if p.requires_grad])
 

@@ -50,6 +50,7 @@ def _worker(rank, world, port, out_path, overlap):
     for _ in range(12):
         loss, info, ps, pt = w.step()
         losses.append(float(info["rgb"]))
+    getattr(w.stu, "_pvd_flush_params", lambda: None)()
     params = torch.cat([p.detach().reshape(-1) for p in w.stu.parameters()]).cpu()
     gathered = [torch.zeros_like(params) for _ in range(world)]
     dist.all_gather(gathered, params)

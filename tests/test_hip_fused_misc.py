@@ -512,21 +512,36 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
             gr[(~cold_el).nonzero()[7]] = float("inf")
         grads.append(gr)
     res = []
-    for use_cold in (False, True):
+    seg_ends = [n // 2 // 4 * 4, n]
+    # dense; cold groups decayed on every step; cold groups' decay DEFERRED (lazy log) and replayed in one go at the end, and
+    # in two goes (a flush after the third step)
+    for use_cold, lazy_flush_at in ((False, None), (True, None), (True, (6,)), (True, (3, 6))):
         p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         m_probe = m.clone()
         lr = torch.tensor([1e-2, 3e-3], device=dev)
         base = lr.clone()
         step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
         scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
-        for gr in grads:
+        lazy = (torch.zeros(16, 2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if lazy_flush_at else None
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        replayed = []
+        for k, gr in enumerate(grads):
             pvd_hip.check_finite(gr, flag)
-            pvd_hip.adamw_step(p, gr, m, v, [n // 2 // 4 * 4, n], lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag,
+            pvd_hip.adamw_step(p, gr, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag,
                                schedule=(1, 100.0, 5e-5, base, sched), l1_ranges=[(0, 4096, 1e-3)],
-                               amp_update=(scale, tracker, 2.0, 0.5, 2000), cold_bits=packed if use_cold else None)
+                               amp_update=(scale, tracker, 2.0, 0.5, 2000), cold_bits=packed if use_cold else None, lazy=lazy)
+            if lazy is not None and k + 1 in lazy_flush_at:
+                if k + 1 == 6 and len(lazy_flush_at) == 1:
+                    assert torch.equal(p[cold_el], p0[cold_el])  # untouched until the flush
+                pvd_hip.adamw_lazy_flush(p, seg_ends, packed, lazy[0], lazy[1], 0.01, status)
+                replayed.append(int(status[0]))
+                assert int(lazy[1][0]) == 0
+        if lazy is not None:
+            assert sum(replayed) == 5  # the skipped (inf) step logs nothing
         res.append((p, m, v, step.clone(), scale.clone()))
-    for a, b in zip(*res):
-        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
     p, m, v = res[1][:3]
     assert float(res[1][3]) == 5.0  # one of the six steps was skipped
     assert not torch.equal(p, p0) and (m[cold_el] == 0).all() and (v[cold_el] == 0).all() and (m[~cold_el] != 0).any()
@@ -548,6 +563,13 @@ def test_trainer_cold_bitmap_covers_only_unreachable_unregularised_groups():
         tr.train_step(*w.next_batch())
     bits = o._cold_bits
     assert bits is not None and 0.3 < o.cold_fraction < 0.95, o.cold_fraction
+    if o._lazy is not None:  # the cold groups' decay is deferred: nothing has touched them yet
+        n0 = o.flat_p.numel() // 4
+        w0 = bits.to(torch.int64) & 0xFFFFFFFF
+        c0 = ((w0[:, None] >> torch.arange(32, device=dev)) & 1).reshape(-1)[:n0].bool().repeat_interleave(4)
+        assert torch.equal(o.flat_p[:c0.numel()][c0], p0[:c0.numel()][c0]) and o._lazy_logged >= 1
+        o.flush()
+        assert o._lazy_logged == 0 and int(o._lazy[1][0]) == 0
     n4 = o.flat_p.numel() // 4
     words = bits.to(torch.int64) & 0xFFFFFFFF
     cold4 = ((words[:, None] >> torch.arange(32, device=dev)) & 1).reshape(-1)[:n4].bool()

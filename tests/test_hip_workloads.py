@@ -71,6 +71,7 @@ def _distill_steps(gpu, cpu, n_steps, loss_rtol, grad_tol):
         # the AdamW update from (almost) the same gradient: compare as a whole (entries whose gradient is pure rounding
         # noise move by +-lr in Adam's first steps, so an element-wise bar would test the noise)
         num = den = 0.0
+        getattr(gpu.stu, "_pvd_flush_params", lambda: None)()  # FlatAdamW: deferred weight decay of rows nothing reads
         for n, p in gpu.stu.named_parameters():
             if not p.requires_grad:
                 continue
