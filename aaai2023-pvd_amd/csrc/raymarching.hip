@@ -342,18 +342,26 @@ __global__ void __launch_bounds__(kScanBlock) k_march_scan(int32_t *__restrict__
     }
 }
 
+// The sample budget of a launch: M rows are allocated and (re)initialised; rays are dropped against the LOGICAL budget, which a
+// caller that replays a captured step may keep in device memory (the running mean of the sample count, refreshed by
+// update_extra_state without re-capturing): min(M, *budget).  NULL: the budget is M, as in the reference.
+__device__ __forceinline__ uint32_t logical_budget(uint32_t M, const int32_t *__restrict__ budget) {
+    return budget ? min(M, (uint32_t)max(*budget, 0)) : M;
+}
+
 __global__ void __launch_bounds__(kBlock) k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                         const uint8_t *__restrict__ grid, float bound, float dt_gamma,
                                                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                         const float *__restrict__ nears, const float *__restrict__ fars,
                                                         float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                                                        const int32_t *__restrict__ rays, uint32_t perturb) {
+                                                        const int32_t *__restrict__ rays, uint32_t perturb,
+                                                        const int32_t *__restrict__ budget) {
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N) return;
     const uint32_t off = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
     if (num == 0) return;
-    if (off + num >= M) return;  // strict (:419)
+    if (off + num >= logical_budget(M, budget)) return;  // strict (:419)
     Dda r;
     r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
     const float far = fars[n];
@@ -609,14 +617,15 @@ __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__rest
                                                              uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                              const float *__restrict__ nears, const float *__restrict__ fars,
                                                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                                                             const int32_t *__restrict__ rays, uint32_t perturb) {
+                                                             const int32_t *__restrict__ rays, uint32_t perturb,
+                                                             const int32_t *__restrict__ budget) {
     const uint32_t n = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
     const uint32_t off = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
     if (num == 0) return;
-    if (off + num >= M) return;  // strict (:419)
+    if (off + num >= logical_budget(M, budget)) return;  // strict (:419)
     Dda r;
     r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
@@ -652,8 +661,9 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
                                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
                                                                int32_t *__restrict__ rays, uint32_t perturb,
                                                                const MarchRayRecords *__restrict__ records, int32_t *__restrict__ counter,
-                                                               uint32_t fresh) {
+                                                               uint32_t fresh, const int32_t *__restrict__ budget) {
     __shared__ uint32_t part[kBlock / kWave], part_all[kBlock / kWave];
+    const uint32_t Mlog = logical_budget(M, budget);  // rays are dropped against this; [.., M) is what gets initialised
     const uint32_t n0 = blockIdx.x * kRaysPerBlock;
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // ---- exclusive prefix of the counts of rays [0, n0)  (fresh: also the total, for the tail every workgroup helps to clear)
@@ -672,9 +682,9 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
     uint32_t grand = prefix;
 #pragma unroll
     for (uint32_t w = 0; w < kBlock / kWave; w++) { prefix += part[w]; grand += part_all[w]; }
-    if (fresh && grand < M) {
-        // outputs arrive uninitialised: nobody writes [grand, M) (no ray was dropped, or grand >= M), clear it here, spread
-        // over the launch.  (When a ray IS dropped, grand >= M and the first dropped ray clears [its offset, M) below.)
+    if (fresh && grand < Mlog) {
+        // outputs arrive uninitialised: nobody writes [grand, M) (no ray was dropped, or grand >= Mlog), clear it here, spread
+        // over the launch.  (When a ray IS dropped, grand >= Mlog and the first dropped ray clears [its offset, M) below.)
         const size_t stride = (size_t)gridDim.x * kBlock, first = (size_t)blockIdx.x * kBlock + threadIdx.x;
         for (size_t i = 3 * (size_t)grand + first; i < 3 * (size_t)M; i += stride) { xyzs[i] = 0.f; dirs[i] = 0.f; }
         for (size_t i = 2 * (size_t)grand + first; i < 2 * (size_t)M; i += stride) deltas[i] = 0.f;
@@ -697,8 +707,8 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
     const uint32_t num = cnt[wid];
     if (lane == 0) { rays[3 * (size_t)n] = (int32_t)n; rays[3 * (size_t)n + 1] = (int32_t)off; }
     if (num == 0) return;
-    if (off + num >= M) {  // strict (:419): dropped
-        if (fresh && off < M) {  // the first dropped ray (every later one starts at or beyond M): the rest of the buffers stays zero
+    if (off + num >= Mlog) {  // strict (:419): dropped
+        if (fresh && off < Mlog) {  // the first dropped ray (every later one starts at or beyond Mlog): the rest of the buffers stays zero
             for (size_t i = 3 * (size_t)off + lane; i < 3 * (size_t)M; i += kWave) { xyzs[i] = 0.f; dirs[i] = 0.f; }
             for (size_t i = 2 * (size_t)off + lane; i < 2 * (size_t)M; i += kWave) deltas[i] = 0.f;
         }
@@ -794,6 +804,7 @@ struct CompositeEpilogue {
     // backward only: grad buffers arrive uninitialised and `rays` is a table of pvd_march_rays_train (offsets = exclusive
     // prefix sum of the counts in row order, from 0): the kernel clears every slot no ray owns
     uint32_t fresh;
+    const int32_t *budget;  // logical sample budget in device memory (see logical_budget), or NULL
 };
 
 // reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
@@ -809,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__re
     const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
     float r = 0, g = 0, b = 0, ws = 0, d = 0;
-    if (!(num == 0 || offset + num >= M)) {
+    if (!(num == 0 || offset + num >= logical_budget(M, EPI ? ep.budget : nullptr))) {
         float T_carry = 1.0f, t_carry = 0.0f;
         for (uint32_t base = 0; base < num; base += 64) {
             const uint32_t s = base + lane;
@@ -871,13 +882,13 @@ __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__re
         for (size_t i = (size_t)end + (size_t)n * kWave + lane; i < M; i += (size_t)N * kWave) {
             grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
         }
-        // ... and [offset, M) of the first dropped ray (every later ray starts at or beyond M)
-        if (num != 0 && offset + num >= M)
+        // ... and [offset, M) of the first dropped ray (every later ray starts at or beyond the budget)
+        if (num != 0 && offset + num >= logical_budget(M, ep.budget))
             for (size_t i = (size_t)offset + lane; i < M; i += kWave) {
                 grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
             }
     }
-    if (num == 0 || offset + num >= M) return;
+    if (num == 0 || offset + num >= logical_budget(M, EPI ? ep.budget : nullptr)) return;
     float gws = grad_ws ? grad_ws[index] : 0.0f;
     const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
     float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
@@ -1290,13 +1301,14 @@ int pvd_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
                          uint32_t perturb, pvd_stream_t stream) {
     return pvd_march_rays_train_ws(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
-                                   counter, perturb, nullptr, 0, 0u, stream);
+                                   counter, perturb, nullptr, 0, 0u, nullptr, stream);
 }
 
 int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                             const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags, pvd_stream_t stream) {
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags, const int32_t *budget_dev,
+                            pvd_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool fresh = (flags & PVD_MARCH_FRESH) != 0;
     if (N == 0) {
@@ -1320,7 +1332,7 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
                            records, counter, records && fresh ? 1u : 0u);
         if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
             hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs,
-                               dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u);
+                               dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u, budget_dev);
             return check_launch();
         }
 #ifdef PVD_MARCH_PROFILE
@@ -1328,7 +1340,7 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
 #endif
         hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
         hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
-                           deltas, rays, perturb);
+                           deltas, rays, perturb, budget_dev);
         return check_launch();
     }
     // dt grows with t: the step sequence is inherently serial per ray
@@ -1336,7 +1348,7 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
                        nears, fars, rays, 0u, perturb);
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
     hipLaunchKernelGGL(k_march_write, dim3(div_up(N, kBlock)), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
-                       nears, fars, xyzs, dirs, deltas, rays, perturb);
+                       nears, fars, xyzs, dirs, deltas, rays, perturb, budget_dev);
     return check_launch();
 }
 
@@ -1363,10 +1375,11 @@ int pvd_composite_rays_train_backward(const float *grad_weights_sum, const float
 
 int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
                                         uint32_t N, const float *bg, float bg_scalar, const float *nears, const float *fars,
-                                        float depth_eps, float *weights_sum, float *depth, float *image, pvd_stream_t stream) {
+                                        float depth_eps, float *weights_sum, float *depth, float *image, const int32_t *budget_dev,
+                                        pvd_stream_t stream) {
     if (N == 0) return PVD_OK;
     PVD_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && weights_sum && depth && image);
-    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps, 0u};
+    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps, 0u, budget_dev};
     hipLaunchKernelGGL(k_composite_fwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas,
                        rays, M, N, weights_sum, depth, image, ep);
     return check_launch();
@@ -1375,7 +1388,7 @@ int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, 
 int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas, const float *rgbs,
                                          const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
                                          uint32_t M, uint32_t N, const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs,
-                                         uint32_t flags, pvd_stream_t stream) {
+                                         uint32_t flags, const int32_t *budget_dev, pvd_stream_t stream) {
     const bool fresh = (flags & PVD_MARCH_FRESH) != 0;
     if (N == 0) {
         if (fresh && M && grad_sigmas && grad_rgbs) {
@@ -1385,7 +1398,7 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
         return PVD_OK;
     }
     PVD_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
-    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f, fresh ? 1u : 0u};
+    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f, fresh ? 1u : 0u, budget_dev};
     hipLaunchKernelGGL(k_composite_bwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, ep);
     return check_launch();

@@ -215,10 +215,16 @@ class NeRFRenderer(nn.Module):
             else:
                 counter = self.step_counter[self.local_step % 16]  # set to zero (renderer.py:374): the scratch_counter flag below
                 self.local_step += 1
+            budget = self._budget() if not force_all_rays else None  # (single-model training: the model composites its own march)
             if i_march:
-                xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                               self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
-                                                               force_all_rays, dt_gamma, max_steps, True)
+                if budget is not None:
+                    xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                   self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                   force_all_rays, dt_gamma, max_steps, True, budget)
+                else:
+                    xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                   self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                   force_all_rays, dt_gamma, max_steps, True)
                 inherited_params = [xyzs, dirs, deltas, rays]
             else:
                 xyzs, dirs, deltas, rays = inherited_params
@@ -236,7 +242,10 @@ class NeRFRenderer(nn.Module):
                 sigmas = self.density_scale * sigmas
             eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
             # compositing + `image += (1 - ws) * bg` + depth normalisation (renderer.py:442-446) as one op
-            weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True)  # rays: straight from the march
+            if budget is not None and i_march:
+                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True, budget[1])
+            else:
+                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True)  # rays: straight from the march
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays,
@@ -471,7 +480,37 @@ class NeRFRenderer(nn.Module):
         total_step = min(16, self.local_step)
         if total_step > 0:
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            self._publish_budget()
         self.local_step = 0
+
+    # ---- sample budget in device memory (captured training steps)
+    sample_alloc = None  # rows the training branch allocates when set (>= the aligned mean_count); see fix_sample_alloc
+
+    def _publish_budget(self):
+        """mean_count as march_rays_train will use it (aligned the reference's way, raymarching.py:234-238) in device memory:
+        a captured step reads its budget there, so update_extra_state can move it without a re-capture."""
+        if self.sample_alloc is None or self.mean_count <= 0:
+            return
+        m = self.mean_count + (128 - self.mean_count % 128)
+        if getattr(self, "_budget_dev", None) is None:
+            self._budget_dev = torch.zeros(1, dtype=torch.int32, device=self.density_grid.device)
+        self._budget_dev.fill_(min(m, self.sample_alloc))
+        self.budget_exceeded = m > self.sample_alloc  # (the caller re-captures with more rows)
+
+    def fix_sample_alloc(self, headroom=1.25, granule=16384):
+        """Allocate a FIXED number of sample rows from now on (mean_count x headroom, rounded up to `granule`) and keep the
+        budget rays are dropped against -- mean_count, as in the reference -- in device memory.  For training steps that
+        are captured once and replayed across occupancy-grid updates.  Returns the row count."""
+        assert self.mean_count > 0, "needs a measured mean_count"
+        m = self.mean_count + (128 - self.mean_count % 128)
+        self.sample_alloc = (int(m * headroom) + granule - 1) // granule * granule
+        self._publish_budget()
+        return self.sample_alloc
+
+    def _budget(self):
+        if self.sample_alloc is None or self.mean_count <= 0:
+            return None
+        return (self.sample_alloc, self._budget_dev)
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """reference: render, renderer.py:777-814 (`staged` is ignored on the cuda_ray path)."""

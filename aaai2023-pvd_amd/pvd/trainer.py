@@ -419,7 +419,8 @@ class _TrainerBase:
             self.dp.capture = None
         self._cap = cap
         self.steps_per_replay = max(1, int(steps_per_graph))
-        self._captured_occ_epoch = self._marching_model().occ_epoch
+        # (only a step that relies on a touched-row set is tied to the occupancy grid it was captured with)
+        self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         return self._static_out  # the warm-up steps above are real steps; the capture itself records without running
 
     def replay(self):
@@ -715,3 +716,49 @@ class TeacherTrainer(_TrainerBase):
                 loss = loss + self._l1_term()
         self._backward_and_step(loss)
         return loss.detach(), pred
+
+    # ---- a whole block of steps between two occupancy-grid updates as ONE captured graph
+    def _block_body(self, batches):
+        o, m = self.opt, self.model
+        it = {"k": 0}
+
+        def body():
+            rays_o, rays_d, gt_rgb, bg_color = batches[it["k"] % len(batches)]
+            it["k"] += 1
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+                out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                               dt_gamma=o.dt_gamma, max_steps=o.max_steps, num_steps=o.num_steps, upsample_steps=o.upsample_steps)
+                pred = out["image"]
+                loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
+                if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+                    loss = loss + self._l1_term()
+            return loss, pred
+        return body
+
+    def capture_block(self, batches):
+        """Capture `update_extra_interval` consecutive training steps (one per entry of `batches`: STATIC device tensors
+        (rays_o, rays_d, gt_rgb, bg) that the caller refills in place) as one HIP graph.  The teacher's sample budget moves
+        with every occupancy-grid update (mean_count, renderer.py:773-775); the captured steps therefore allocate a fixed
+        number of sample rows (`fix_sample_alloc`) and read the budget rays are dropped against from device memory, so the
+        graph survives the updates.  Call after at least one eager block (lazy initialisations, a measured mean_count)."""
+        o, m = self.opt, self.model
+        assert len(batches) == o.update_extra_interval == 16, "one batch per step of a block (the step counter has 16 slots)"
+        assert m.cuda_ray and m.mean_count > 0 and self.global_step % o.update_extra_interval == 0
+        m.fix_sample_alloc()
+        self._block_batches = batches
+        self.capture(self._block_body(batches), warmup=0, steps_per_graph=len(batches))
+        self._block_alloc = m.sample_alloc
+
+    def train_block(self):
+        """The occupancy-grid update (eager: it sizes the next block's budget) followed by one replay = 16 training steps."""
+        o, m = self.opt, self.model
+        assert self.global_step % o.update_extra_interval == 0
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+            m.update_extra_state()
+        aligned = m.mean_count + (128 - m.mean_count % 128)
+        if getattr(m, "budget_exceeded", False) or aligned < 0.6 * m.sample_alloc:
+            # the scene needs more rows than were captured (or far fewer: the padding rows cost time): capture again
+            self.capture_block(self._block_batches)
+        out = self.replay()
+        m.local_step += self.steps_per_replay  # the replayed marches filled that many slots of the step counter
+        return out[0].detach(), out[1]

@@ -216,16 +216,19 @@ def packbits(grid, N, density_thresh, bitfield):
 
 
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
-                     xyzs, dirs, deltas, rays, counter, perturb, use_workspace=True, fresh=False):
+                     xyzs, dirs, deltas, rays, counter, perturb, use_workspace=True, fresh=False, budget_dev=None):
     """fresh: xyzs / dirs / deltas / counter are uninitialised scratch (PVD_MARCH_FRESH): the march itself writes zeros
-    wherever no ray writes and overwrites the counter."""
-    dev = _dev(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter)
+    wherever no ray writes and overwrites the counter.  budget_dev: DEVICE int32 logical sample budget (rays are dropped
+    against min(M, budget); M rows are allocated), see include/pvd_hip.h."""
+    dev = _dev(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, budget_dev)
+    if budget_dev is not None:
+        _want(budget_dev, torch.int32, "budget_dev")
     _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
     _want(grid, torch.uint8, "grid"), _want(rays, torch.int32, "rays"), _want(counter, torch.int32, "counter")
     ws = _march_workspace(dev, N) if (dt_gamma == 0 and use_workspace) else None
     _call("pvd_march_rays_train_ws", dev, _p(rays_o), _p(rays_d), _p(grid), _f32(bound), _f32(dt_gamma), _u32(max_steps),
           _u32(N), _u32(C), _u32(H), _u32(M), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter),
-          _u32(int(perturb)), _p(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _u32(1 if fresh else 0))
+          _u32(int(perturb)), _p(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _u32(1 if fresh else 0), _p(budget_dev))
 
 
 MARCH_FRESH = True  # the raymarching wrapper may hand over uninitialised outputs (see march_rays_train / composite_rays_train_bg_backward)
@@ -661,19 +664,21 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
 
 
 # --------------------------------------------------------------------------- fused epilogue / objective
-def composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar, nears, fars, depth_eps, weights_sum, depth, image):
-    dev = _dev(sigmas, rgbs, deltas, rays, bg, nears, fars, weights_sum, depth, image)
+def composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar, nears, fars, depth_eps, weights_sum, depth, image,
+                                    budget_dev=None):
+    dev = _dev(sigmas, rgbs, deltas, rays, bg, nears, fars, weights_sum, depth, image, budget_dev)
     _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, nears=nears, fars=fars, weights_sum=weights_sum, depth=depth, image=image)
     _call("pvd_composite_rays_train_bg_forward", dev, _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u32(M), _u32(N), _p(bg), _f32(bg_scalar),
-          _p(nears), _p(fars), _f32(depth_eps), _p(weights_sum), _p(depth), _p(image))
+          _p(nears), _p(fars), _f32(depth_eps), _p(weights_sum), _p(depth), _p(image), _p(budget_dev))
 
 
 def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, bg, bg_scalar,
-                                     grad_sigmas, grad_rgbs, fresh=False):
-    dev = _dev(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, bg, grad_sigmas, grad_rgbs)
+                                     grad_sigmas, grad_rgbs, fresh=False, budget_dev=None):
+    dev = _dev(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, bg, grad_sigmas, grad_rgbs, budget_dev)
     _f32_all(grad_image=grad_image, sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, image=image)
     _call("pvd_composite_rays_train_bg_backward", dev, _p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(deltas), _p(rays),
-          _p(weights_sum), _p(image), _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32(1 if fresh else 0))
+          _p(weights_sum), _p(image), _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32(1 if fresh else 0),
+          _p(budget_dev))
 
 
 def _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t):

@@ -96,7 +96,7 @@ def make_ops(backend, device_type="cuda"):
         @staticmethod
         @fwd32
         def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                    perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, scratch_counter=False):
+                    perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, scratch_counter=False, budget=None):
             rays_o = _to_dev(rays_o).contiguous().view(-1, 3)
             rays_d = _to_dev(rays_d).contiguous().view(-1, 3)
             density_bitfield = _to_dev(density_bitfield).contiguous()
@@ -107,6 +107,12 @@ def make_ops(backend, device_type="cuda"):
                 if align > 0:
                     mean_count += align - mean_count % align
                 M = mean_count
+            # budget = (rows to allocate, DEVICE int32 logical budget): an extension for captured training steps -- the rows are
+            # fixed when the step is captured, the budget rays are dropped against (the reference's M, above) is read on the device
+            budget_dev = None
+            if budget is not None and not force_all_rays and mean_count > 0:
+                M, budget_dev = int(budget[0]), budget[1]
+                assert M >= 1 and hasattr(backend, "MARCH_FRESH"), "a device-side budget needs the HIP backend"
             dev, dt = rays_o.device, rays_o.dtype
             # scratch_counter: the caller does not care what step_counter held (run_cuda zeroes it right before, renderer.py:374).
             # A backend with MARCH_FRESH then takes uninitialised outputs and counter and writes the zeros itself.
@@ -119,7 +125,10 @@ def make_ops(backend, device_type="cuda"):
                 step_counter = alloc(2, dtype=torch.int32, device=dev)  # point counter, ray counter
             elif scratch_counter and not fresh:
                 step_counter.zero_()
-            if fresh:
+            if budget_dev is not None:
+                backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
+                                         xyzs, dirs, deltas, rays, step_counter, perturb, fresh=fresh, budget_dev=budget_dev)
+            elif fresh:
                 backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars,
                                          xyzs, dirs, deltas, rays, step_counter, perturb, fresh=True)
             else:
@@ -173,8 +182,10 @@ def make_ops(backend, device_type="cuda"):
 
         @staticmethod
         @fwd32
-        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False):
+        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None):
             ctx.packed_rays = bool(packed_rays) and bool(getattr(backend, "MARCH_FRESH", False))
+            ctx.budget_dev = budget_dev
+            kw = {} if budget_dev is None else {"budget_dev": budget_dev}
             sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
             M, N = sigmas.shape[0], rays.shape[0]
             bg_t = bg.reshape(-1, 3).contiguous().float() if torch.is_tensor(bg) else None
@@ -183,7 +194,7 @@ def make_ops(backend, device_type="cuda"):
             depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
             image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
             backend.composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum,
-                                                    depth, image)
+                                                    depth, image, **kw)
             ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
             ctx.bg = (bg_t, bg_s)
             ctx.dims = [M, N]
@@ -202,18 +213,21 @@ def make_ops(backend, device_type="cuda"):
             gws = grad_weights_sum.contiguous() if grad_weights_sum is not None else None
             if grad_image is None:  # only weights_sum was used
                 grad_image = torch.zeros_like(image)
+            kw = {} if ctx.budget_dev is None else {"budget_dev": ctx.budget_dev}
             if ctx.packed_rays:
                 backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
-                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, fresh=True)
+                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, fresh=True, **kw)
             else:
                 backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
-                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs)
-            return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None
+                                                         ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, **kw)
+            return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
 
-    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False):
-        """packed_rays: `rays` comes straight from march_rays_train (offsets in ray order from 0, no gaps)."""
+    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None):
+        """packed_rays: `rays` comes straight from march_rays_train (offsets in ray order from 0, no gaps).  budget_dev: the
+        device-side logical sample budget the march of these rays was given (march_rays_train(budget=...)), if any."""
         if fused_bg:
-            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays)
+            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays, budget_dev)
+        assert budget_dev is None, "a device-side budget needs the fused compositing of the HIP backend"
         # reference formulation (used with the CPU oracle backend in the test-suite)
         weights_sum, depth, image = _CompositeTrain.apply(sigmas, rgbs, deltas, rays)
         if torch.is_tensor(bg):

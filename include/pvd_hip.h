@@ -114,7 +114,12 @@ size_t pvd_march_workspace_bytes(uint32_t N);
 int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *nears,
                             const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays, int32_t *counter,
-                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags, pvd_stream_t stream);
+                            uint32_t perturb, void *workspace, size_t workspace_bytes, uint32_t flags,
+                            const int32_t *budget_dev, pvd_stream_t stream);
+/* budget_dev (here and in pvd_composite_rays_train_bg_*): NULL, or a DEVICE int32 holding the LOGICAL sample budget: rays
+ * are dropped against min(M, *budget_dev) (the reference's `point_index + num_steps >= M`, raymarching.cu:419, with the
+ * running mean of the sample count as M, renderer.py:773-775), while M rows stay allocated and initialised.  A captured
+ * training step can then follow update_extra_state's new mean_count without being re-captured. */
 
 /* composite_rays_train_forward -- raymarching.cu:585-593 (kernel :504-582). */
 int pvd_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
@@ -368,7 +373,7 @@ int pvd_plenoxel_backward(const float *xyz, const float *dirs, uint32_t M, const
 int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
                                         uint32_t M, uint32_t N, const float *bg, float bg_scalar, const float *nears,
                                         const float *fars, float depth_eps, float *weights_sum, float *depth, float *image,
-                                        pvd_stream_t stream);
+                                        const int32_t *budget_dev, pvd_stream_t stream);
 /* grad_image is w.r.t. the BLENDED image; `image` is the blended image the forward returned; grad_weights_sum may be NULL.
  * flags & PVD_MARCH_FRESH: grad_sigmas / grad_rgbs arrive uninitialised (the reference zero-fills them,
  *   raymarching.py:339-340) and `rays` is a table written by pvd_march_rays_train (offsets = exclusive prefix sum of the
@@ -376,7 +381,8 @@ int pvd_composite_rays_train_bg_forward(const float *sigmas, const float *rgbs, 
 int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
                                          const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
                                          const float *image, uint32_t M, uint32_t N, const float *bg, float bg_scalar,
-                                         float *grad_sigmas, float *grad_rgbs, uint32_t flags, pvd_stream_t stream);
+                                         float *grad_sigmas, float *grad_rgbs, uint32_t flags, const int32_t *budget_dev,
+                                         pvd_stream_t stream);
 
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)

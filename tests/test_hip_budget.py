@@ -1,0 +1,111 @@
+"""The sample budget of the training branch in device memory (pvd_march_rays_train_ws / pvd_composite_rays_train_bg_*
+`budget_dev`): M rows allocated, rays dropped against min(M, *budget) -- what lets a captured teacher-training block survive
+update_extra_state's new mean_count.  Bit-exact against the same calls with M = the budget."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(n_rays=2048, seed=0):
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    import raymarching
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(seed))).to(DEV)
+    bits = packbits_torch(ChairScene(thicken=0.08).density_grid(128, 1.0, 1, device=DEV), 10.0)
+    r = get_rays(poses[0:1], BLENDER_INTRINSICS, 800, 800, n_rays, generator=torch.Generator(device=DEV).manual_seed(seed))
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=DEV), 0.2)
+    return o, d, bits, nears, fars
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("frac", [0.5, 0.97, 1.5])
+def test_march_and_composite_with_a_device_budget_equal_the_calls_with_that_budget(frac, perturb):
+    import raymarching
+    o, d, bits, nears, fars = _scene()
+    N = o.shape[0]
+    full = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, perturb, 128, True)
+    total = full[0].shape[0]
+    budget = int(total * frac) // 128 * 128  # (the wrapper adds 128 to a multiple of 128, as the reference does)
+    M_ref = budget + 128
+    alloc = M_ref + 8192
+    cnt_a, cnt_b = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+    ref = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, cnt_a, budget, perturb, 128, False, 0, 1024, True)
+    bud = torch.tensor([M_ref], dtype=torch.int32, device=DEV)
+    got = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, cnt_b, budget, perturb, 128, False, 0, 1024, True, (alloc, bud))
+    assert ref[0].shape[0] == M_ref and got[0].shape[0] == alloc
+    assert torch.equal(ref[3], got[3]) and torch.equal(cnt_a, cnt_b)  # rays table (id, offset, count) and the totals
+    for a, b in zip(ref[:3], got[:3]):
+        assert torch.equal(a, b[:M_ref]) and not b[M_ref:].any()  # same samples, the extra rows are zero
+    dropped = (ref[3][:, 1] + ref[3][:, 2] >= M_ref) & (ref[3][:, 2] > 0)
+    assert bool(dropped.any()) == (frac < 1.0)
+    # compositing, forward and backward, with random sigma / rgb on the rows
+    g = torch.Generator(device=DEV).manual_seed(1)
+    sig = torch.rand(alloc, device=DEV, generator=g) * 20
+    rgb = torch.rand(alloc, 3, device=DEV, generator=g)
+    bg = torch.rand(1, N, 3, device=DEV, generator=g)
+    gi = torch.randn(N, 3, device=DEV, generator=g)
+    outs = []
+    for rows, deltas, rays, kw in ((M_ref, ref[2], ref[3], {}), (alloc, got[2], got[3], {"budget_dev": bud})):
+        s = sig[:rows].clone().requires_grad_(True)
+        c = rgb[:rows].clone().requires_grad_(True)
+        ws, depth, img = raymarching.composite_rays_train_bg(s, c, deltas, rays, bg, nears, fars, 1e-6, True, **kw)
+        img.backward(gi.view_as(img))
+        outs.append((ws, depth, img.detach(), s.grad, c.grad))
+    (ws_a, d_a, i_a, gs_a, gc_a), (ws_b, d_b, i_b, gs_b, gc_b) = outs
+    assert torch.equal(ws_a, ws_b) and torch.equal(d_a, d_b) and torch.equal(i_a, i_b)
+    assert torch.equal(gs_a, gs_b[:M_ref]) and torch.equal(gc_a, gc_b[:M_ref]) and not gs_b[M_ref:].any() and not gc_b[M_ref:].any()
+
+
+def test_teacher_block_graph_follows_the_eager_run_across_grid_updates():
+    """TeacherTrainer.capture_block / train_block: 16 steps per graph launch, the occupancy-grid update between the launches
+    moving the device-side budget -- against the same training run stepped eagerly (same batches, same seeds)."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays
+    from pvd.trainer import TeacherTrainer
+    from pvd.workload import DistillWorkload, measure_mean_count
+    runs = []
+    for block in (False, True):
+        torch.manual_seed(0)
+        opt = PVDConfig(num_rays=1024, fp16=True)
+        w = DistillWorkload(hip_ops(), torch.device(DEV), opt, teacher_pretrain_steps=0, seed=0)
+        topt = PVDConfig(**{**opt.__dict__, "model_type": opt.teacher_type, "iters": 3000, "stage_iters": {"stage1": -1, "stage2": -1}})
+        tea = w.tea
+        tea.teacher_variant = True
+        tea.requires_grad_(True).train()
+        tea.args = tea.opt = topt
+        tr = TeacherTrainer(topt, tea, torch.device(DEV), fp16=True)
+        tea.mean_count = measure_mean_count(tea, w.poses, opt, generator=w.gen)
+        batches = []
+        for it in range(16):
+            r = get_rays(w.poses[it][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
+            bg = torch.rand(1, opt.num_rays, 3, device=DEV, generator=w.gen)
+            batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
+        torch.cuda.manual_seed(5)  # update_extra_state draws cells with the device generator
+        losses, counts = [], []
+        for it in range(16):
+            losses.append(float(tr.train_step(*batches[it])[0]))
+        if block:
+            tr.capture_block(batches)
+            assert tea.sample_alloc >= tea.mean_count
+            for _ in range(3):
+                loss, pred = tr.train_block()
+                losses.append(float(loss))
+                counts.append(int(tea.mean_count))
+        else:
+            for blk in range(3):
+                for it in range(16):
+                    loss, pred = tr.train_step(*batches[it])
+                losses.append(float(loss))
+                counts.append(int(tea.mean_count))
+        assert tr.global_step == 64 and tr.scheduler.last_epoch == 64
+        runs.append((losses, counts, float(tr.optimizer.lr_dev[0])))
+    (la, ca, lra), (lb, cb, lrb) = runs
+    assert np.allclose(la[:16], lb[:16], rtol=1e-3)  # the eager prefix is the same run (up to the order of the scatter-add atomics)
+    # (atomics and update_extra_state's random cells: same statistics, not the same bits)
+    assert np.allclose(la[16:], lb[16:], rtol=0.08), (la[16:], lb[16:])
+    assert all(abs(a - b) <= 0.05 * a for a, b in zip(ca, cb)), (ca, cb)
+    assert lra == lrb and lb[-1] < lb[0] and lb[-1] < lb[15]
