@@ -79,6 +79,24 @@ def hash_head_infer(model, x, d, rows_dev=None):
 
 
 @torch.no_grad()
+def features_head_infer(model, h, d):
+    """sigma_net / color_net head of a frozen model on features that are already there -- the `mlp` model, whose 28 features
+    come out of the NeRF MLP trunk instead of a hash grid (network.py:413-437): h [M,28] f16 (any row stride) is re-laid
+    level-major [14][M][2], the layout pvd_head_forward reads, then one MFMA launch."""
+    M = h.shape[0]
+    assert h.shape[1] == 28 and model.sigma_net[0].weight.shape[1] == 28
+    enc = torch.empty(14, M, 2, dtype=torch.float16, device=h.device)
+    enc.copy_(h.reshape(M, 14, 2).permute(1, 0, 2))
+    sigma, rgb, feat = _outputs(M, h.device)
+    a = model.args
+    ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight]
+    pvd_hip.head_forward(KIND_HASH, enc, None, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_min, a.sigma_clip_max,
+                         sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws, ps))
+    return sigma, rgb, feat
+
+
+@torch.no_grad()
 def vm_head_infer(model, sigma_raw, prod, d, rows_dev=None):
     M = prod.shape[0]
     sigma, rgb, feat = _outputs(M, prod.device)

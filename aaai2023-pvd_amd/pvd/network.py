@@ -201,7 +201,13 @@ class NeRFNetwork(NeRFRenderer):
         return px if (px is not None and x.is_cuda and not self.args.enable_edit_plenoxel) else None
 
     def forward_nerf_mlp(self, x):
+        fe = getattr(self.ops, "freq_encode", None)
+        if (fe is not None and x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
+                and len(self.encoder_nerf_pe.freq_bands) <= 16 and self.skips + 1 < len(self.nerf_mlp) - 1):
+            return self._forward_nerf_mlp_frozen(x, fe)
         x = self.encoder_nerf_pe(x)
+        if x.is_cuda and self.in_dim_nerf % 8:
+            return self._forward_nerf_mlp_aligned(x)
         pts = x
         last = len(self.nerf_mlp) - 1
         for i, layer in enumerate(self.nerf_mlp):
@@ -210,6 +216,71 @@ class NeRFNetwork(NeRFRenderer):
                 x = F.relu(x, inplace=True)
             if i == self.skips:
                 x = torch.cat([pts, x], -1)
+        return x
+
+    @torch.no_grad()
+    def _forward_nerf_mlp_frozen(self, x, freq_encode):
+        """forward_nerf_mlp of a model that is not being trained, under fp16 autocast: the positional encoding comes out of
+        one kernel as f16 rows padded to a multiple of 8 columns; weights and biases are cast to f16 once (not per call and
+        layer); Linear + ReLU is one library GEMM with a ReLU epilogue (torch._addmm_activation).  Same arithmetic as the
+        autocast formulation -- f16 GEMMs with f32 accumulation, bias added before the rounding to f16, ReLU -- in 1 + 8
+        launches instead of ~75 (rocprofv3, profiles/r02: 185 us of sin / cos launches, 17 us of ReLU and 9 us of casts
+        per layer at 92 k rows)."""
+        import pvd_hip
+        enc = self.encoder_nerf_pe
+        n_in = self.in_dim_nerf
+        n_pad = (n_in + 7) // 8 * 8
+        params = [p for layer in self.nerf_mlp for p in (layer.weight, layer.bias)]
+        key = pvd_hip.weights_key(params)
+        cache = getattr(self, "_nerf16_cache", None)
+        if cache is None or cache[0] != key:
+            ws = []
+            last = len(self.nerf_mlp) - 1
+            for i, layer in enumerate(self.nerf_mlp):
+                w = layer.weight.detach().to(torch.float16)
+                b = layer.bias.detach().to(torch.float16)
+                if i == 0:
+                    w = F.pad(w, (0, n_pad - n_in))
+                elif i == self.skips + 1:
+                    w = torch.cat([F.pad(w[:, :n_in], (0, n_pad - n_in)), w[:, n_in:]], dim=1)
+                if i == last and w.shape[0] % 8:  # output rows of 28 halfs are not 16-byte multiples either
+                    extra = (-w.shape[0]) % 8
+                    w, b = F.pad(w, (0, 0, 0, extra)), F.pad(b, (0, extra))
+                ws.append((w.contiguous(), b.contiguous()))
+            cache = self._nerf16_cache = (key, ws)
+        pts = freq_encode(x.reshape(-1, enc.input_dim).float().contiguous(), enc.freq_bands, enc.include_input, torch.float16, n_pad)
+        h = pts
+        last = len(self.nerf_mlp) - 1
+        for i, (w, b) in enumerate(cache[1]):
+            if i != last:
+                h = torch._addmm_activation(b, h, w.t())  # relu(h W^T + b)
+            else:
+                h = torch.addmm(b, h, w.t())
+            if i == self.skips:
+                h = torch.cat([pts, h], -1)
+        return h[:, :self.nerf_mlp[last].out_features]
+
+    def _forward_nerf_mlp_aligned(self, pts):
+        """forward_nerf_mlp with the 63-wide positional encoding padded to 64 by a zero column (and the matching zero weight
+        column): the same sums, but the contraction lengths of the first layer (63) and of the skip layer (319) become 64 and
+        320 -- the library GEMM takes a 5x slower kernel for rows that are not 16-byte multiples (233 vs 43 us per call at
+        92 k rows on MI355X, rocprofv3 r02)."""
+        n_in = self.in_dim_nerf
+        pad = (-n_in) % 8
+        ptsp = F.pad(pts, (0, pad))
+        x = ptsp
+        last = len(self.nerf_mlp) - 1
+        for i, layer in enumerate(self.nerf_mlp):
+            w = layer.weight
+            if i == 0:
+                w = F.pad(w, (0, pad))
+            elif i == self.skips + 1:
+                w = torch.cat([F.pad(w[:, :n_in], (0, pad)), w[:, n_in:]], dim=1)
+            x = F.linear(x, w, layer.bias)
+            if i != last:
+                x = F.relu(x, inplace=True)
+            if i == self.skips:
+                x = torch.cat([ptsp, x], -1)
         return x
 
     def _unit_cube(self, x):
@@ -248,6 +319,9 @@ class NeRFNetwork(NeRFRenderer):
                 out = fh.vm_head_train(self, sraw, prod, d)
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student
+            elif (self.model_type == "mlp" and not torch.is_grad_enabled() and hasattr(fh, "features_head_infer")
+                  and self.in_dim == 28 and self.sigma_net[0].weight.shape == (64, 28) and getattr(self.ops, "freq_encode", None) is not None):
+                out = fh.features_head_infer(self, self.forward_nerf_mlp(x), d)  # frozen NeRF-MLP teacher: trunk, then the fused head
             if out is not None:
                 sigma, color, feat = out[:3]
                 self.feature_sigma_color = feat

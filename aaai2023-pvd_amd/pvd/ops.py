@@ -45,5 +45,8 @@ def hip_ops():
         pvd_hip.make_ray_batch(poses, state, seed, fx, fy, cx, cy, H, W, N, aabb, min_near, None, rays_o, rays_d, bg, nears, fars)
         return rays_o, rays_d, bg, (nears, fars)
 
-    return types.SimpleNamespace(make_batch=make_batch, occupancy=pvd_hip.occupancy_backend, raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
+    def freq_encode(x, bands, include_input=True, out_dtype=torch.float32, row_stride=None):
+        return pvd_hip.freq_encode(x, bands, include_input, out_dtype, row_stride)
+
+    return types.SimpleNamespace(freq_encode=freq_encode, make_batch=make_batch, occupancy=pvd_hip.occupancy_backend, raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
                                  vm_encode=vmencoder.vm_encode, vm_encode_infer=vmencoder.vm_encode_infer, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

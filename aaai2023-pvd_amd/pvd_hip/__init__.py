@@ -51,7 +51,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -661,6 +661,24 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
     _call("pvd_head_backward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
           _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_rgb2), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
           _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
+
+
+def freq_encode(x, freq_bands, include_input=True, out_dtype=torch.float32, row_stride=None):
+    """pvd_freq_encode: [M,D] f32 -> [M, row_stride] positional encoding (zero-padded beyond D (1 + 2 len(freq_bands)))."""
+    dev = _dev(x)
+    _want(x, torch.float32, "x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise PvdHipError("x must be a contiguous [M, D] tensor")
+    M, D = x.shape
+    width = (D if include_input else 0) + 2 * D * len(freq_bands)
+    stride = width if row_stride is None else int(row_stride)
+    if stride < width or len(freq_bands) > 16:
+        raise PvdHipError("row_stride must cover the encoding; at most 16 frequencies")
+    out = torch.empty(M, stride, dtype=out_dtype, device=x.device)
+    bands = (ctypes.c_float * max(1, len(freq_bands)))(*[float(f) for f in freq_bands])
+    _call("pvd_freq_encode", dev, _p(x), _u32(M), _u32(D), bands, _u32(len(freq_bands)), _int(int(bool(include_input))), _p(out),
+          _int(_table_dtype(out, "out")), _u32(stride))
+    return out
 
 
 # --------------------------------------------------------------------------- fused epilogue / objective

@@ -256,6 +256,13 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
                     const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
                     void *const *grad_tables_host, const uint32_t *texel_stride_host, pvd_stream_t stream);
 
+/* NeRF positional encoding -- torch code in the reference: FreqEncoder.forward, tools/encoding.py:6-49.
+ * x [M,D] f32 -> out [M, row_stride] (out_dtype PVD_F32 / PVD_F16): columns [x (if include_input), sin(f_0 x), cos(f_0 x),
+ * sin(f_1 x), ...], each block D wide, f = freq_bands_host[n_freqs] (<= 16; the reference's 2^linspace(0, max_freq_log2, N));
+ * columns from D (1 + 2 n_freqs) up to row_stride are written as zero (padding to a GEMM-friendly row length). */
+int pvd_freq_encode(const float *x, uint32_t M, uint32_t D, const float *freq_bands_host, uint32_t n_freqs, int include_input,
+                    void *out, int out_dtype, uint32_t row_stride, pvd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Fused sigma / colour head (MFMA).  Torch code in the reference: NeRFNetwork.forward,
  * distill_mutual/network.py:335-437 (sigma_net :103-118, color_net :135-152, basis_mat :88-90, trunc_exp,
