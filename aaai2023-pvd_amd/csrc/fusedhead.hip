@@ -600,6 +600,258 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The frozen `mlp` model (vanilla NeRF trunk, network.py:154-182 / forward_nerf_mlp, then the same sigma / colour head) in one
+// launch: positional encoding [M][64] f16 in (pvd_freq_encode), sigma / rgb / feature_sigma_color out.  The reference runs it
+// as ~10 library GEMMs with their activations round-tripping HBM (94 MB per 256-wide layer at 93 k samples, 38 us each on
+// MI355X); here a wave keeps kMlpTS 16-sample tiles of activations in registers for the whole network -- computing
+// Y^T = W X^T makes a layer's D tiles the next layer's B fragments, as in the head -- and the workgroup streams the weights
+// through LDS in chunks of 64 output rows (<= 41.6 KB), double-buffered by LDS-DMA, so that every A fragment read from LDS
+// feeds kMlpTS MFMAs.  Bias in the accumulator's initial value, ReLU and the rounding to f16 on the accumulator: the
+// autocast formulation's arithmetic (f16 GEMM, f32 accumulation, f16 result per layer).
+constexpr int kMlpTS = 3;             // 16-sample tiles per wave: 48 samples; a workgroup = 192 samples
+constexpr int kMlpW = 256;            // hidden width (the reference's nerf_layer_wide default, main_distill_mutual.py)
+constexpr int kMlpIn = 64;            // positional encoding, padded (63 -> 64)
+constexpr int kMlpChunkRows = 64;     // output rows per weight chunk = 4 MFMA tiles
+constexpr int kMlpPad = 16;           // halfs of row padding: row stride (K + 16) / 2 dwords = 8 mod 16 with an odd multiple of 8 mod 64 for K = 64,
+                                      // 256 and 320 -> the 64 lanes' 8-byte A-fragment reads spread two per bank (the minimum)
+constexpr int kMlpMaxChunkHalfs = kMlpChunkRows * (kMlpIn + kMlpW + kMlpPad) + kMlpChunkRows;  // the skip layer's chunk: 21568 halfs
+
+struct MlpArgs {
+    const half_t *pts;     // [M][64] f16 positional encoding (zero-padded column 63)
+    const half_t *wstream; // weight chunks in execution order (see mlp_chunk_halfs), each = rows x (K + kMlpPad) halfs, then rows bias halfs
+    uint32_t n_before;     // hidden 256 -> 256 layers before the skip connection is concatenated (= args.skip)
+    uint32_t n_after;      // hidden 256 -> 256 layers after the skip layer
+};
+
+__host__ __device__ constexpr int mlp_chunk_halfs(int rows, int K) { return rows * (K + kMlpPad) + rows; }
+
+// DMA of one chunk into an LDS buffer (lane-linear 16-byte pieces, like copy_image_dma)
+__device__ __forceinline__ void mlp_dma(half_t *__restrict__ buf, const half_t *__restrict__ src, int halfs, uint32_t tid) {
+    copy_image_dma(buf, src, halfs, tid);
+}
+
+// One chunk of NT output tiles: acc = bias; acc += W[chunk rows, :] . X^T over KP k-steps of `pts` then KX k-steps of `x`.
+// Two k-steps per MFMA: v_mfma_f32_16x16x32_f16 fed with the two K = 16 fragments of A and of B side by side contracts the
+// same k set (a permutation of the contraction index applied to both operands; checked by tools/probes/mfma32_probe.hip).
+// This kernel, unlike the heads, is MFMA-bound, and the K = 32 form is the one gfx950 issues at full rate.
+typedef half_t h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f4 mfma_k32(h4 a0, h4 a1, h4 b0, h4 b1, f4 c) {
+    const h8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const h8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <int KP, int KX, int NT, bool RELU>
+__device__ __forceinline__ void mlp_chunk(const half_t *__restrict__ buf, const h4 (&pts)[kMlpTS][kMlpIn / 16], const h4 (&x)[kMlpTS][kMlpW / 16],
+                                          h4 (&out)[kMlpTS][NT], uint32_t lane) {
+    constexpr int K = 16 * (KP + KX), stride = K + kMlpPad, KS = KP + KX;
+    static_assert(KS % 2 == 0, "k-steps are taken in pairs");
+    const uint32_t r = lane & 15u, hi = lane >> 4;
+    const half_t *__restrict__ bias = buf + 16 * NT * stride;
+    f4 acc[kMlpTS][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const h4 b = *reinterpret_cast<const h4 *>(bias + 16 * nt + 4 * hi);
+        const f4 bf = {(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+#pragma unroll
+        for (int ts = 0; ts < kMlpTS; ts++) acc[ts][nt] = bf;
+    }
+    const half_t *__restrict__ arow = buf + r * stride + 4 * hi;
+    h4 a0[NT], a1[NT];  // the pair of k-steps in flight; the next pair is requested before this one is consumed
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        a0[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride);
+        a1[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; k += 2) {
+        h4 n0[NT], n1[NT];
+        if (k + 2 < KS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                n0[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16 * (k + 2));
+                n1[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16 * (k + 3));
+            }
+        }
+#pragma unroll
+        for (int ts = 0; ts < kMlpTS; ts++) {
+            const h4 b0 = k < KP ? pts[ts][k < KP ? k : 0] : x[ts][k >= KP ? k - KP : 0];
+            const h4 b1 = k + 1 < KP ? pts[ts][k + 1 < KP ? k + 1 : 0] : x[ts][k + 1 >= KP ? k + 1 - KP : 0];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[ts][nt] = mfma_k32(a0[nt], a1[nt], b0, b1, acc[ts][nt]);
+        }
+        if (k + 2 < KS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) { a0[nt] = n0[nt]; a1[nt] = n1[nt]; }
+        }
+    }
+#pragma unroll
+    for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) out[ts][nt] = RELU ? relu_h4(to_h4(acc[ts][nt])) : to_h4(acc[ts][nt]);
+}
+
+// The chunk pipeline: chunk q is computed from buffer q % 3 while chunks q + 1 and q + 2 are landing in the other two (one chunk
+// of compute, ~0.7 us, is shorter than the ~1-2 us an LDS-DMA batch takes to arrive from L2).  Hand-made barrier: __syncthreads()
+// would wait for EVERY outstanding load (vmcnt(0)), i.e. also for the chunks that were just requested.
+template <int N>
+__device__ __forceinline__ void mlp_wait_barrier() {
+    // own DMA pieces up to the wanted chunk have landed (memory operations complete in order: at most N younger ones may still
+    // be in flight), own LDS reads of the buffer about to be refilled are done; then meet the other waves
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t mlp_dma_count(int halfs, uint32_t wave) {  // LDS-DMA instructions THIS wave issues for a chunk
+    const int pieces = (halfs * 2 + 1023) / 1024;
+    return pieces > (int)wave ? (uint32_t)(pieces - (int)wave + 3) / 4u : 0u;
+}
+struct MlpStream {
+    half_t *buf[3];
+    const half_t *next;  // source of the next chunk to FETCH
+    uint32_t q;          // chunks computed so far
+    uint32_t young;      // this wave's DMA instructions of the most recently requested chunk (q + 1)
+    // make chunk q usable, request chunk q + 2 (`next2_halfs`: its size, 0 = none)
+    __device__ __forceinline__ const half_t *acquire(int next2_halfs, uint32_t tid) {
+        // chunk q is complete once at most `young` younger DMA instructions of this wave are outstanding (rounded down to a
+        // value that exists as an immediate: waiting for more is always safe)
+        if (young >= 10u) mlp_wait_barrier<10>();
+        else if (young >= 8u) mlp_wait_barrier<8>();
+        else if (young >= 4u) mlp_wait_barrier<4>();
+        else if (young >= 2u) mlp_wait_barrier<2>();
+        else mlp_wait_barrier<0>();
+        // every wave is past its reads of buffer (q + 2) % 3 (chunk q - 1): refill it
+        young = 0u;
+        if (next2_halfs > 0) {
+            mlp_dma(buf[(q + 2u) % 3u], next, next2_halfs, tid);
+            next += next2_halfs;
+            young = mlp_dma_count(next2_halfs, tid >> 6);
+        }
+        const half_t *cur = buf[q % 3u];
+        q++;
+        return cur;
+    }
+};
+
+// one 256-wide layer = 4 chunks; `after1` / `after2`: sizes of the first two chunks of what FOLLOWS this layer (0: none) -- the
+// requests run two chunks ahead of the compute
+template <int KP, int KX>
+__device__ __forceinline__ void mlp_layer(MlpStream &st, const h4 (&pts)[kMlpTS][kMlpIn / 16], const h4 (&x)[kMlpTS][kMlpW / 16],
+                                          h4 (&y)[kMlpTS][kMlpW / 16], int after1, int after2, uint32_t tid, uint32_t lane) {
+    constexpr int own = mlp_chunk_halfs(kMlpChunkRows, 16 * (KP + KX));
+    constexpr int nc = kMlpW / kMlpChunkRows;
+#pragma unroll
+    for (int c = 0; c < nc; c++) {
+        const half_t *cur = st.acquire(c + 2 < nc ? own : (c + 2 == nc ? after1 : after2), tid);
+        h4 o[kMlpTS][4];
+        mlp_chunk<KP, KX, 4, true>(cur, pts, x, o, lane);
+#pragma unroll
+        for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) y[ts][4 * c + nt] = o[ts][nt];
+    }
+}
+
+__global__ void __launch_bounds__(kHeadBlock, 1) k_mlp_fwd_fused(HeadArgs a, MlpArgs m) {
+    extern __shared__ __align__(16) half_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
+    constexpr int kBufHalfs = (kMlpMaxChunkHalfs + 7) & ~7;
+    MlpStream st;
+    st.buf[0] = lds; st.buf[1] = lds + kBufHalfs; st.buf[2] = lds + 2 * kBufHalfs; st.q = 0;
+    half_t *headw = lds + 3 * kBufHalfs;
+    HeadLds<KIND_HASH> W;
+    W.carve(headw);
+    // the first chunk of the first layer and the head's weights start moving now
+    constexpr int h_first = mlp_chunk_halfs(kMlpChunkRows, kMlpIn), h_hidden = mlp_chunk_halfs(kMlpChunkRows, kMlpW),
+                  h_skip = mlp_chunk_halfs(kMlpChunkRows, kMlpIn + kMlpW), h_last = mlp_chunk_halfs(32, kMlpW);
+    st.next = m.wstream;
+    if (a.image) copy_image_dma(headw, a.image, HeadLds<KIND_HASH>::halfs, tid);  // (older than every chunk: complete by the first acquire)
+    else W.load(a, tid, kHeadBlock);
+    mlp_dma(st.buf[0], st.next, h_first, tid);
+    st.next += h_first;
+    mlp_dma(st.buf[1], st.next, h_first, tid);
+    st.next += h_first;
+    st.young = mlp_dma_count(h_first, wave);
+    // ---- inputs of this wave's kMlpTS tiles
+    const size_t base = ((size_t)blockIdx.x * (kHeadBlock / 64) + wave) * (16 * kMlpTS);
+    h4 pts[kMlpTS][kMlpIn / 16];
+    float dir[kMlpTS][3];
+    const h4 hz = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+#pragma unroll
+    for (int ts = 0; ts < kMlpTS; ts++) {
+        const size_t b = base + 16 * ts + (lane & 15u);
+        const bool valid = b < a.M;
+#pragma unroll
+        for (int k = 0; k < kMlpIn / 16; k++) pts[ts][k] = valid ? *reinterpret_cast<const h4 *>(m.pts + b * kMlpIn + 16 * k + 4 * hi) : hz;
+#pragma unroll
+        for (int c = 0; c < 3; c++) dir[ts][c] = valid ? a.dirs[3 * b + c] : 0.f;
+    }
+    h4 xa[kMlpTS][kMlpW / 16], xb[kMlpTS][kMlpW / 16];
+#pragma unroll
+    for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+        for (int k = 0; k < kMlpW / 16; k++) xa[ts][k] = hz;
+    // ---- the trunk.  (`after` = size of the chunk that follows each layer: what its last acquire must start fetching)
+    // (sizes of the two chunks after each layer: the next layer's first two, all of one kind -- every 256-row layer has four)
+    mlp_layer<kMlpIn / 16, 0>(st, pts, xa, xb, m.n_before > 0 ? h_hidden : h_skip, m.n_before > 0 ? h_hidden : h_skip, tid, lane);  // 64 -> 256
+    for (uint32_t l = 0; l < m.n_before; l++) {
+#pragma unroll
+        for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+            for (int k = 0; k < kMlpW / 16; k++) xa[ts][k] = xb[ts][k];
+        mlp_layer<0, kMlpW / 16>(st, pts, xa, xb, l + 1 < m.n_before ? h_hidden : h_skip, l + 1 < m.n_before ? h_hidden : h_skip, tid, lane);
+    }
+#pragma unroll
+    for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+        for (int k = 0; k < kMlpW / 16; k++) xa[ts][k] = xb[ts][k];
+    mlp_layer<kMlpIn / 16, kMlpW / 16>(st, pts, xa, xb, m.n_after > 0 ? h_hidden : h_last, m.n_after > 0 ? h_hidden : 0, tid, lane);  // [pts | x] 320 -> 256
+    for (uint32_t l = 0; l < m.n_after; l++) {
+#pragma unroll
+        for (int ts = 0; ts < kMlpTS; ts++)
+#pragma unroll
+            for (int k = 0; k < kMlpW / 16; k++) xa[ts][k] = xb[ts][k];
+        mlp_layer<0, kMlpW / 16>(st, pts, xa, xb, l + 1 < m.n_after ? h_hidden : h_last, l + 1 < m.n_after ? h_hidden : 0, tid, lane);
+    }
+    // ---- last layer: 256 -> 28 (two tiles, no ReLU) = the head's input fragments
+    const half_t *cur = st.acquire(0, tid);
+    h4 feat[kMlpTS][2];
+    mlp_chunk<0, kMlpW / 16, 2, false>(cur, pts, xb, feat, lane);
+    // ---- sigma / colour head on each tile (weights: DMA'd at the start, visible since the first acquire's barrier)
+#pragma unroll
+    for (int ts = 0; ts < kMlpTS; ts++) {
+        const size_t b = base + 16 * ts + (lane & 15u);
+        const bool valid = b < a.M;
+        TileIn<KIND_HASH> in;
+        in.x[0] = feat[ts][0]; in.x[1] = feat[ts][1];
+        in.sraw = 0.f; in.dx = dir[ts][0]; in.dy = dir[ts][1]; in.dz = dir[ts][2];
+        TileFwd t;
+        head_forward_tile<KIND_HASH>(a, W, in, lane, t);
+        if (valid) {
+            *reinterpret_cast<f4 *>(a.feat16 + b * 16 + 4 * hi) = t.F;
+            if (hi == 0) {
+                a.sigma[b] = __expf(t.F.x);
+                a.rgb[3 * b] = sigmoid_h(t.out.x);
+                a.rgb[3 * b + 1] = sigmoid_h(t.out.y);
+                a.rgb[3 * b + 2] = sigmoid_h(t.out.z);
+            }
+        }
+    }
+}
+
+static int launch_mlp_fwd_fused(const HeadArgs &a, const MlpArgs &m, hipStream_t s) {
+    const uint32_t per_wg = (kHeadBlock / 64) * 16 * kMlpTS;
+    const uint32_t blocks = div_up(a.M, per_wg);
+    constexpr int kBufHalfs = (kMlpMaxChunkHalfs + 7) & ~7;
+    const size_t lds_bytes = (3 * (size_t)kBufHalfs + (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7)) * sizeof(half_t);
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return PVD_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_fwd_fused, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, m);
+    return check_launch();
+}
+
 static int launch_hash_fwd_fused(const HeadArgs &a, const FusedLookup &g, hipStream_t s) {
     const uint32_t nchunks = div_up(a.M, kFusedTile);
     uint32_t blocks = nchunks;
@@ -1023,6 +1275,23 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
     g.xyz = xyz; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
     g.scales = make_scales(14, S, H); g.gridtype = gridtype; g.align_corners = align_corners != 0;
     return launch_hash_fwd_fused(a, g, (hipStream_t)stream);
+}
+
+int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstream_f16, uint32_t n_before, uint32_t n_after, const float *dirs,
+                               const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
+                               float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, pvd_stream_t stream) {
+    if (M == 0) return PVD_OK;
+    if (!pts_f16 || !wstream_f16 || !dirs || !Wa1 || !Wa2 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
+    if (n_before > 16 || n_after > 16) return PVD_ERR_UNSUPPORTED;
+    HeadArgs a;
+    a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = dirs; a.M = M;
+    a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_sigma_min; a.clip_max = clip_max;
+    a.sigma = sigma; a.rgb = rgb; a.feat16 = feat16; a.image = (const half_t *)image;
+    a.rows_dev = nullptr;
+    MlpArgs m;
+    m.pts = (const half_t *)pts_f16; m.wstream = (const half_t *)wstream_f16; m.n_before = n_before; m.n_after = n_after;
+    return launch_mlp_fwd_fused(a, m, (hipStream_t)stream);
 }
 
 static uint32_t head_bwd_waves(int kind, uint32_t M) {

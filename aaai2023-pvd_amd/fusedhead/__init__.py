@@ -78,6 +78,63 @@ def hash_head_infer(model, x, d, rows_dev=None):
     return sigma, rgb, feat
 
 
+def mlp_supported(model):
+    """The layer structure pvd_mlp_head_forward_fused implements: 63 -> 256, hidden 256s with one skip concatenation, -> 28."""
+    mlp = getattr(model, "nerf_mlp", None)
+    if mlp is None or getattr(model, "in_dim_nerf", 0) != 63 or len(mlp) < 3:
+        return False
+    s = model.skips
+    shapes = [tuple(l.weight.shape) for l in mlp]
+    want = [(256, 63)] + [(256, 319 if i == s + 1 else 256) for i in range(1, len(mlp) - 1)] + [(28, 256)]
+    return shapes == want and 0 <= s and s + 1 <= len(mlp) - 2 and all(l.bias is not None for l in mlp) \
+        and tuple(model.sigma_net[0].weight.shape) == (64, 28)
+
+
+@torch.no_grad()
+def mlp_weight_stream(model):
+    """The trunk's weights in the order and layout k_mlp_fwd_fused streams them through LDS (cached until the weights change):
+    per layer, chunks of 64 output rows, each rows x (K + 16) halfs (input columns padded 63 -> 64) followed by the rows' biases."""
+    params = [p for layer in model.nerf_mlp for p in (layer.weight, layer.bias)]
+    key = _cache_key(params)
+    cache = getattr(model, "_mlp_stream_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    import torch.nn.functional as F
+    parts = []
+    last = len(model.nerf_mlp) - 1
+    for i, layer in enumerate(model.nerf_mlp):
+        w, b = layer.weight.detach().to(torch.float16), layer.bias.detach().to(torch.float16)
+        if i == 0:
+            w = F.pad(w, (0, 1))                                           # [256, 64]
+        elif i == model.skips + 1:
+            w = torch.cat([F.pad(w[:, :63], (0, 1)), w[:, 63:]], dim=1)    # [256, 64 + 256]
+        if i == last:
+            w, b = F.pad(w, (0, 0, 0, 4)), F.pad(b, (0, 4))                # 28 -> 32 rows
+        w = F.pad(w, (0, 16))                                              # 16 halfs of row padding (LDS bank spread, kMlpPad)
+        for c in range(0, w.shape[0], 64):
+            parts += [w[c:c + 64].reshape(-1), b[c:c + 64]]
+    stream = torch.cat(parts).contiguous()
+    model._mlp_stream_cache = (key, stream)
+    return stream
+
+
+@torch.no_grad()
+def mlp_head_infer(model, x, d):
+    """(sigma, rgb, feature_sigma_color) of a frozen `mlp` model: positional encoding (one launch) + trunk and head (one launch)."""
+    enc = model.encoder_nerf_pe
+    M = x.shape[0]
+    pts = pvd_hip.freq_encode(x.reshape(-1, 3).float().contiguous(), enc.freq_bands, enc.include_input, torch.float16, 64)
+    sigma, rgb, feat = _outputs(M, x.device)
+    a = model.args
+    ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight]
+    n_before = model.skips
+    n_after = len(model.nerf_mlp) - 3 - n_before
+    pvd_hip.mlp_head_forward_fused(pts, mlp_weight_stream(model), n_before, n_after, d.float().contiguous(), M, *ws, a.sigma_clip_min,
+                                   a.sigma_clip_max, sigma, rgb, feat, image=_cached_image(model, KIND_HASH, ws, ps))
+    return sigma, rgb, feat
+
+
 @torch.no_grad()
 def features_head_infer(model, h, d):
     """sigma_net / color_net head of a frozen model on features that are already there -- the `mlp` model, whose 28 features

@@ -321,7 +321,11 @@ class NeRFNetwork(NeRFRenderer):
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student
             elif (self.model_type == "mlp" and not torch.is_grad_enabled() and hasattr(fh, "features_head_infer")
                   and self.in_dim == 28 and self.sigma_net[0].weight.shape == (64, 28) and getattr(self.ops, "freq_encode", None) is not None):
-                out = fh.features_head_infer(self, self.forward_nerf_mlp(x), d)  # frozen NeRF-MLP teacher: trunk, then the fused head
+                if hasattr(fh, "mlp_head_infer") and fh.mlp_supported(self) and len(self.encoder_nerf_pe.freq_bands) == 10 \
+                        and os.environ.get("PVD_MLP_FUSED", "1") != "0":
+                    out = fh.mlp_head_infer(self, x, d)  # frozen NeRF-MLP teacher: positional encoding, then trunk + head in one launch
+                else:
+                    out = fh.features_head_infer(self, self.forward_nerf_mlp(x), d)  # library GEMMs for the trunk, then the fused head
             if out is not None:
                 sigma, color, feat = out[:3]
                 self.feature_sigma_color = feat

@@ -51,7 +51,7 @@ ENTRY_POINTS = (
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -599,6 +599,25 @@ def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, grid
                      _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
                      _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev), meta=(M, 3, 2, 14, PVD_F16))
     _check(status, "pvd_hash_head_forward_fused")
+
+
+def mlp_head_forward_fused(pts16, wstream, n_before, n_after, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_max, sigma, rgb, feat16,
+                           image=None):
+    """pvd_mlp_head_forward_fused: the frozen NeRF-MLP model (trunk + head) in one launch; see include/pvd_hip.h."""
+    dev = _dev(pts16, wstream, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
+    _want(pts16, torch.float16, "pts16"), _want(wstream, torch.float16, "wstream")
+    _f32_all(dirs=dirs, Wa1=Wa1, Wa2=Wa2, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
+    if pts16.shape != (M, 64) or not pts16.is_contiguous() or not wstream.is_contiguous():
+        raise PvdHipError("pts16 must be a contiguous [M, 64] f16 tensor")
+    need = 4 * (64 * 80 + 64) + (n_before + n_after) * 4 * (64 * 272 + 64) + 4 * (64 * 336 + 64) + (32 * 272 + 32)  # rows x (K + 16) + biases
+    if wstream.numel() != need:
+        raise PvdHipError("weight stream has %d halfs, the layer structure needs %d" % (wstream.numel(), need))
+    _check_image(KIND_HASH_CONST, image)
+    _call("pvd_mlp_head_forward_fused", dev, _p(pts16), _u32(M), _p(wstream), _u32(n_before), _u32(n_after), _p(dirs), _p(Wa1), _p(Wa2),
+          _p(Wc1), _p(Wc2), _p(Wc3), _p(image), _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16))
+
+
+KIND_HASH_CONST = 0
 
 
 # Kernels that rewrite parameters behind autograd's back (the flat optimizer, a graph replay) do not bump the tensors'

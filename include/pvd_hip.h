@@ -295,6 +295,21 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
                                 float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
                                 pvd_stream_t stream);
 
+/* The frozen `mlp` model (NeRF trunk + sigma / colour head; NeRFNetwork.forward with model_type "mlp", network.py:154-182 and
+ * :413-437, under no_grad + fp16 autocast) in one launch.
+ *   pts_f16 [M][64] f16: positional encoding padded to 64 columns (pvd_freq_encode(out_dtype = PVD_F16, row_stride = 64));
+ *   trunk: Linear(63,256) ReLU, n_before x [Linear(256,256) ReLU], skip layer Linear(63+256, 256) ReLU on [pts | x],
+ *          n_after x [Linear(256,256) ReLU], Linear(256,28); all with bias -- the reference's nerf_mlp with
+ *          nerf_layer_num = n_before + n_after + 3, skip = n_before, nerf_layer_wide = 256, PE = 10;
+ *   wstream_f16: the weights as the kernel streams them through LDS -- layer after layer, each in chunks of 64 output rows
+ *          (the last layer: one chunk of 32 rows, rows 28..31 zero): rows x (K + 16) halfs row-major (K = 64 / 256 / 320, input
+ *          columns zero-padded 63 -> 64; 16 halfs of padding per row), then `rows` bias halfs (fusedhead.mlp_weight_stream builds it);
+ *   the head arguments and outputs as in pvd_head_forward(kind = PVD_HEAD_HASH). */
+int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstream_f16, uint32_t n_before, uint32_t n_after,
+                               const float *dirs, const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2,
+                               const float *Wc3, const void *image, float clip_sigma_min, float clip_max, float *sigma,
+                               float *rgb, float *feat16, pvd_stream_t stream);
+
 /* Optional weight image.  Every workgroup of the head kernels stages all weights in LDS; converting and
  * (for the backward) transposing the fp32 masters there is the kernels' fixed cost.  pvd_head_pack_weights does it
  * once into `image` (pvd_head_image_halfs(kind) f16 elements, device memory), and pvd_head_forward /

@@ -66,3 +66,40 @@ def test_frozen_mlp_model_matches_the_layerwise_autocast_formulation(layers, ski
     assert ((sig.float() - sig_r.float()).abs() <= 2e-2 * sig_r.float().abs() + 1e-3).all()
     assert ((dens - dens_r).abs() <= 2e-2 * dens_r.abs() + 1e-3).all()
     assert torch.equal(sl, fea[:, 0]) and cl.shape == (20011, 3)
+
+
+@pytest.mark.parametrize("M", [1, 191, 192, 20011])
+def test_fused_trunk_kernel_matches_the_library_gemm_path(M, monkeypatch):
+    """pvd_mlp_head_forward_fused (trunk streamed through LDS, activations in registers) vs the same frozen model through
+    library GEMMs + the fused head: both are f16 GEMMs with f32 accumulation and a rounding per layer; accumulation order
+    differs."""
+    import fusedhead
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import make_model
+    opt = PVDConfig(model_type="mlp", fp16=True)
+    opt.stage_iters = {"stage1": -1, "stage2": -1}
+    torch.manual_seed(7)
+    m = make_model(hip_ops(), opt, "mlp", True, torch.device(DEV)).train()
+    assert fusedhead.mlp_supported(m)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 2:
+                p.mul_(1.4)
+        for layer in m.nerf_mlp:
+            layer.bias.uniform_(-0.2, 0.2)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.rand(M, 3, device=DEV, generator=g) * 2 - 1
+    d = torch.randn(M, 3, device=DEV, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PVD_MLP_FUSED", fused)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            sig, rgb = m(x, d)
+        outs.append((sig.float().clone(), rgb.float().clone(), m.feature_sigma_color.float().clone()))
+    (sa, ra, fa), (sb, rb, fb) = outs
+    assert torch.isfinite(sa).all() and fa.abs().max().item() > 0.05
+    assert (ra - rb).abs().max().item() <= 3e-3
+    assert (fa - fb).abs().max().item() <= 1e-2 * (1 + fb.abs().max().item())
+    assert ((sa - sb).abs() <= 1.5e-2 * sb.abs() + 1e-3).all()
