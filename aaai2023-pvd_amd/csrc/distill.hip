@@ -34,7 +34,7 @@ __device__ __forceinline__ float block_sum(float v, float *__restrict__ sh) {
 __global__ void __launch_bounds__(kLossBlock) k_sumsq4(const float *__restrict__ img_s, const float *__restrict__ img_t, uint32_t n_img,
                                                       const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
                                                       const float *__restrict__ col_s, const float *__restrict__ col_t,
-                                                      float *__restrict__ S, float *__restrict__ rates_decay, float fea_decay) {
+                                                      float *__restrict__ S, float *__restrict__ rates_decay, float fea_decay, uint32_t fea_width) {
     __shared__ float sh[kLossBlock / 64];
     const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
     // the per-step decay of the feature rate (utils.py:1044) for callers that finish the objective with k_loss_final_bwd,
@@ -42,12 +42,16 @@ __global__ void __launch_bounds__(kLossBlock) k_sumsq4(const float *__restrict__
     if (rates_decay && tid == 0) rates_decay[1] *= fea_decay;
     float s_img = 0.f, s_fea = 0.f, s_sig = 0.f, s_col = 0.f;
     for (uint32_t i = tid; i < n_img; i += stride) { const float d = img_t[i] - img_s[i]; s_img += d * d; }
-    // feature rows as float4 quarters: quarter q of row m; column 0 (q == 0, .x) is also the sigma term
-    for (uint32_t i = tid; i < M * 4u; i += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
-        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-        s_fea += dx * dx + dy * dy + dz * dz + dw * dw;
-        if ((i & 3u) == 0) s_sig += dx * dx;
+    if (fea_width == 1u) {  // models without a feature vector (Plenoxel student): the rows hold sigma_l alone, no feature term
+        for (uint32_t i = tid; i < M; i += stride) { const float d = fea_s[i] - fea_t[i]; s_sig += d * d; }
+    } else {
+        // feature rows as float4 quarters: quarter q of row m; column 0 (q == 0, .x) is also the sigma term
+        for (uint32_t i = tid; i < M * 4u; i += stride) {
+            const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+            s_fea += dx * dx + dy * dy + dz * dz + dw * dw;
+            if ((i & 3u) == 0) s_sig += dx * dx;
+        }
     }
     for (uint32_t i = tid; i < M * 3u; i += stride) { const float d = col_s[i] - col_t[i]; s_col += d * d; }
     s_img = block_sum(s_img, sh); s_fea = block_sum(s_fea, sh); s_sig = block_sum(s_sig, sh); s_col = block_sum(s_col, sh);
@@ -107,16 +111,21 @@ __global__ void __launch_bounds__(kLossBlock) k_sumsq4_bwd(const float *__restri
                                                           const float *__restrict__ fea_s, const float *__restrict__ fea_t, uint32_t M,
                                                           const float *__restrict__ col_s, const float *__restrict__ col_t,
                                                           const float *__restrict__ coef, const float *__restrict__ upstream,
-                                                          float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col) {
+                                                          float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col,
+                                                          uint32_t fea_width) {
     const uint32_t tid = blockIdx.x * kLossBlock + threadIdx.x, stride = gridDim.x * kLossBlock;
     const float up = upstream[0];
     const float c_img = coef[0] * up, c_fea = coef[1] * up, c_sig = coef[2] * up, c_col = coef[3] * up;
     for (uint32_t i = tid; i < n_img; i += stride) g_img[i] = c_img * (img_s[i] - img_t[i]);
-    for (uint32_t i = tid; i < M * 4u; i += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
-        float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
-        if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
-        reinterpret_cast<float4 *>(g_fea)[i] = g;
+    if (fea_width == 1u) {
+        for (uint32_t i = tid; i < M; i += stride) g_fea[i] = c_sig * (fea_s[i] - fea_t[i]);
+    } else {
+        for (uint32_t i = tid; i < M * 4u; i += stride) {
+            const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+            float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
+            if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
+            reinterpret_cast<float4 *>(g_fea)[i] = g;
+        }
     }
     for (uint32_t i = tid; i < M * 3u; i += stride) g_col[i] = c_col * (col_s[i] - col_t[i]);
 }
@@ -132,7 +141,8 @@ __global__ void __launch_bounds__(kLossBlock) k_loss_final_bwd(const float *__re
                                                               const float *__restrict__ extra, uint32_t n_extra,
                                                               const float *__restrict__ upstream, float *__restrict__ loss,
                                                               float *__restrict__ coef_out, float *__restrict__ norms,
-                                                              float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col) {
+                                                              float *__restrict__ g_img, float *__restrict__ g_fea, float *__restrict__ g_col,
+                                                              uint32_t fea_width) {
     __shared__ float sh[kLossBlock / 64];
     float s4[4];
     if (reduce_blocks) {
@@ -167,11 +177,15 @@ __global__ void __launch_bounds__(kLossBlock) k_loss_final_bwd(const float *__re
     const float up = upstream[0];
     const float c_img = coef[0] * up, c_fea = coef[1] * up, c_sig = coef[2] * up, c_col = coef[3] * up;
     for (uint32_t i = tid; i < n_img; i += stride) g_img[i] = c_img * (img_s[i] - img_t[i]);
-    for (uint32_t i = tid; i < M * 4u; i += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
-        float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
-        if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
-        reinterpret_cast<float4 *>(g_fea)[i] = g;
+    if (fea_width == 1u) {
+        for (uint32_t i = tid; i < M; i += stride) g_fea[i] = c_sig * (fea_s[i] - fea_t[i]);
+    } else {
+        for (uint32_t i = tid; i < M * 4u; i += stride) {
+            const float4 a = reinterpret_cast<const float4 *>(fea_s)[i], b = reinterpret_cast<const float4 *>(fea_t)[i];
+            float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
+            if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
+            reinterpret_cast<float4 *>(g_fea)[i] = g;
+        }
     }
     for (uint32_t i = tid; i < M * 3u; i += stride) g_col[i] = c_col * (col_s[i] - col_t[i]);
 }
@@ -192,11 +206,11 @@ int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img
                       uint32_t fea_width, const float *col_stu, const float *col_tea, float *S4, int reduce, float *rates4_decay,
                       float fea_decay, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4) return PVD_ERR_INVALID;
-    if (fea_width != 16u) return PVD_ERR_INVALID;  // rows are read as four float4
+    if (fea_width != 16u && fea_width != 1u) return PVD_ERR_INVALID;  // rows are read as four float4, or hold sigma_l alone
     hipStream_t s = (hipStream_t)stream;
     const uint32_t blocks = sumsq_blocks(n_img, M);
     hipLaunchKernelGGL(k_sumsq4, dim3(blocks), dim3(kLossBlock), 0, s, img_stu, img_tea, n_img, fea_stu, fea_tea, M, col_stu, col_tea, S4,
-                       rates4_decay, fea_decay);
+                       rates4_decay, fea_decay, fea_width);
     if (reduce) hipLaunchKernelGGL(k_sumsq4_reduce, dim3(1), dim3(kLossBlock), 0, s, S4, blocks);
     return blocks > 0 ? check_launch() : PVD_ERR_INVALID;
 }
@@ -214,12 +228,12 @@ int pvd_distill_sumsq_backward(const float *img_stu, const float *img_tea, uint3
                                const float *upstream, float *g_img, float *g_fea, float *g_col, pvd_stream_t stream) {
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !coef4 || !upstream || !g_img || !g_fea || !g_col)
         return PVD_ERR_INVALID;
-    if (fea_width != 16u) return PVD_ERR_INVALID;
+    if (fea_width != 16u && fea_width != 1u) return PVD_ERR_INVALID;
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sumsq4_bwd, dim3(blocks), dim3(kLossBlock), 0, (hipStream_t)stream, img_stu, img_tea, n_img, fea_stu, fea_tea, M,
-                       col_stu, col_tea, coef4, upstream, g_img, g_fea, g_col);
+                       col_stu, col_tea, coef4, upstream, g_img, g_fea, g_col, fea_width);
     return check_launch();
 }
 
@@ -230,13 +244,13 @@ int pvd_distill_loss_backward(const float *img_stu, const float *img_tea, uint32
     if (!img_stu || !img_tea || !fea_stu || !fea_tea || !col_stu || !col_tea || !S4 || !rates4 || !upstream || !loss || !coef4 || !norms4 ||
         !g_img || !g_fea || !g_col || (n_extra && !extra))
         return PVD_ERR_INVALID;
-    if (fea_width != 16u) return PVD_ERR_INVALID;
+    if (fea_width != 16u && fea_width != 1u) return PVD_ERR_INVALID;
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_loss_final_bwd, dim3(blocks), dim3(kLossBlock), 0, (hipStream_t)stream, img_stu, img_tea, n_img, fea_stu, fea_tea, M,
                        col_stu, col_tea, S4, reduce ? sumsq_blocks(n_img, M) : 0u, rates4, extra, n_extra, upstream, loss, coef4, norms4, g_img,
-                       g_fea, g_col);
+                       g_fea, g_col, fea_width);
     return check_launch();
 }
 

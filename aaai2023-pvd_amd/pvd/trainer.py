@@ -537,8 +537,16 @@ class DistillTrainer(_TrainerBase):
                  # the fused objective reads [M,16] rows whose column 0 is sigma_l (geo_feat_dim = 15, the reference's default)
                  and stu.feature_sigma_color.dim() == 2 and stu.feature_sigma_color.shape[-1] == 16
                  and tea.feature_sigma_color.shape == stu.feature_sigma_color.shape)
+        # models without a feature vector (the Plenoxel student): the same fused objective with the rows holding sigma_l alone
+        # (rgb + sigma + colour terms; utils.py:1109-1176 with the feature term absent)
+        fused_nofea = (not fused and not have_fea and self.fused_loss is not None and o.loss_type == "normL2" and pred_stu is not None
+                       and pred_stu.is_cuda and "stage1" not in out_stu and "stage2" not in out_stu
+                       and min(o.loss_rate_color, o.loss_rate_sigma, o.loss_rate_rgb) > 0.0
+                       and getattr(stu, "sigma_l", None) is not None and getattr(tea, "sigma_l", None) is not None
+                       and stu.sigma_l.dim() == 1 and tea.sigma_l.shape == stu.sigma_l.shape
+                       and not (o.l1_reg_weight > 0.0 and o.model_type == "vm"))
         if not fused:
-            self.fea_rate.mul_(0.995)  # (the fused objective decays the device-side rate inside its own kernel)
+            self.fea_rate.mul_(0.995) if not fused_nofea else None  # (the fused objective decays the device-side rate inside its own kernel)
         info = {}
         loss = 0.0
         if "stage1" in out_stu and self.loss_rate_fea_sc > 0.0 and have_fea:
@@ -557,6 +565,11 @@ class DistillTrainer(_TrainerBase):
             info.update(color=l_col.detach(), sigma=l_sig.detach())
             return loss, info, None, None
 
+        if fused_nofea:
+            l3, norms = self.fused_loss(pred_stu, pred_tea, stu.sigma_l.float().unsqueeze(-1), tea.sigma_l.float().unsqueeze(-1),
+                                        stu.color_l.float(), tea.color_l.float(), self.rates, self.dp, fea_decay=0.995)
+            info["rgb"] = norms[0]
+            return l3, info, pred_stu, pred_tea
         if fused:
             # all four norm terms (utils.py:1109-1176), the feature-rate decay and the value of the L1 term: one objective
             extra = None

@@ -410,8 +410,9 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
  *   loss = sum_i rates4[i] * sqrt(S4[i]) + sum(extra);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
  * img [n_img] f32 (= N*3), fea [M,fea_width] f32 (16-byte aligned) with column 0 = the log-density feature, col [M,3] f32.
- * fea_width must be 16 (1 + geo_feat_dim of the reference's default models, network.py:30): anything else returns
- * PVD_ERR_INVALID -- the kernels read rows as four float4.  rates4 / upstream are DEVICE scalars.
+ * fea_width must be 16 (1 + geo_feat_dim of the reference's default models, network.py:30: the kernels read rows as four
+ * float4) or 1 (a model without a feature vector, e.g. the Plenoxel student: fea = sigma_l alone, S4[1] = 0, no feature
+ * term); anything else returns PVD_ERR_INVALID.  rates4 / upstream are DEVICE scalars.
  * S4 must hold 4 + 4*1024 floats: the four sums, followed by scratch for per-workgroup partials.
  * pvd_distill_sumsq: reduce != 0 finishes S4[0..3] itself (ray data parallelism: the host all-reduces them before
  *   pvd_distill_loss_final(reduce = 0)); reduce == 0 leaves the partials for pvd_distill_loss_final(reduce = 1, same

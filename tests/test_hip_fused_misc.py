@@ -83,6 +83,34 @@ def test_fused_distill_loss_matches_torch_norms():
     assert float(loss) == 0.0 and torch.count_nonzero(z.grad) == 0
 
 
+def test_fused_objective_without_a_feature_vector_matches_torch_norms():
+    """fea_width = 1 (the Plenoxel student has no feature_sigma_color): the rows hold sigma_l alone -- rgb + sigma + colour terms,
+    no feature term, as utils.py:1109-1176 does when the model has no features."""
+    from pvd.losses import distill_loss_normL2
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, M = 4096, 91003
+    img_t, sig_t, col_t = torch.rand(1, N, 3, device=dev, generator=g), torch.randn(M, device=dev, generator=g) * 3, torch.rand(M, 3, device=dev, generator=g)
+    rates = torch.tensor([1.0, 0.002, 0.003, 0.004], device=dev)
+    res = []
+    for fused in (True, False):
+        img_s = (img_t + 0.1 * torch.randn(1, N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3))).requires_grad_(True)
+        sig_s = (sig_t + 0.2 * torch.randn(M, device=dev, generator=torch.Generator(device=dev).manual_seed(4))).requires_grad_(True)
+        col_s = (col_t + 0.05 * torch.randn(M, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(5))).requires_grad_(True)
+        if fused:
+            loss, norms = distill_loss_normL2(img_s, img_t, sig_s.unsqueeze(-1), sig_t.unsqueeze(-1), col_s, col_t, rates.clone(), None, fea_decay=0.995)
+            assert float(norms[1]) == 0.0
+        else:
+            norms = torch.stack([torch.norm(img_t - img_s), torch.zeros((), device=dev), torch.norm(sig_s - sig_t), torch.norm(col_s - col_t)])
+            loss = (norms * rates).sum()
+        (loss * 1024.0).backward()
+        res.append((loss.detach(), norms.detach(), img_s.grad, sig_s.grad, col_s.grad))
+    a, b = res
+    assert torch.allclose(a[0], b[0], rtol=1e-5) and torch.allclose(a[1], b[1], rtol=1e-5)
+    for x, y in zip(a[2:], b[2:]):
+        assert x.shape == y.shape and (x - y).abs().max() <= 1e-5 * y.abs().max()
+
+
 def test_objective_finished_inside_the_backward_launch_is_bit_identical():
     """defer=True (pvd_distill_loss_backward: loss / norms / coefficients finished by every workgroup of the backward launch)
     vs the three-launch form: loss, norms, the decayed feature rate and all three gradients bit for bit, with a parameter-only
