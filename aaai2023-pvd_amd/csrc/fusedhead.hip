@@ -228,10 +228,11 @@ __device__ __forceinline__ void copy_image(half_t *__restrict__ lds, const half_
 // the same copy as LDS-DMA (gfx950 global_load_lds_dwordx4): wave w moves the 1-KB pieces w, w + 4, ... -- lane l's 16 bytes land
 // at piece base + 16 l, which is the linear order of the image -- without passing through registers; completion is the
 // caller's business (s_waitcnt vmcnt(0), which __syncthreads() carries while such a load is in flight)
+template <uint32_t BLOCK = kHeadBlock>
 __device__ __forceinline__ void copy_image_dma(half_t *__restrict__ lds, const half_t *__restrict__ image, int halfs, uint32_t tid) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const int bytes = halfs * 2;
-    for (int c = (int)wave; c * 1024 < bytes; c += (int)(kHeadBlock / 64)) {
+    for (int c = (int)wave; c * 1024 < bytes; c += (int)(BLOCK / 64)) {
         const int off = c * 1024 + (int)lane * 16;
         if (off + 16 <= bytes)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)image + off),
@@ -609,13 +610,20 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
 // through LDS in chunks of 64 output rows (<= 41.6 KB), double-buffered by LDS-DMA, so that every A fragment read from LDS
 // feeds kMlpTS MFMAs.  Bias in the accumulator's initial value, ReLU and the rounding to f16 on the accumulator: the
 // autocast formulation's arithmetic (f16 GEMM, f32 accumulation, f16 result per layer).
-constexpr int kMlpTS = 3;             // 16-sample tiles per wave: 48 samples; a workgroup = 192 samples
+#ifndef PVD_MLP_TS
+#define PVD_MLP_TS 3
+#endif
+#ifndef PVD_MLP_WAVES
+#define PVD_MLP_WAVES 4
+#endif
+constexpr int kMlpTS = PVD_MLP_TS;    // 16-sample tiles per wave (3: 48 samples; a workgroup of 4 waves = 192 samples)
+constexpr uint32_t kMlpBlock = 64u * PVD_MLP_WAVES;
 constexpr int kMlpW = 256;            // hidden width (the reference's nerf_layer_wide default, main_distill_mutual.py)
 constexpr int kMlpIn = 64;            // positional encoding, padded (63 -> 64)
 constexpr int kMlpChunkRows = 64;     // output rows per weight chunk = 4 MFMA tiles
-constexpr int kMlpPad = 16;           // halfs of row padding: row stride (K + 16) / 2 dwords = 8 mod 16 with an odd multiple of 8 mod 64 for K = 64,
-                                      // 256 and 320 -> the 64 lanes' 8-byte A-fragment reads spread two per bank (the minimum)
-constexpr int kMlpMaxChunkHalfs = kMlpChunkRows * (kMlpIn + kMlpW + kMlpPad) + kMlpChunkRows;  // the skip layer's chunk: 21568 halfs
+constexpr int kMlpPad = 8;            // halfs of row padding: row stride (K + 8) / 2 dwords = 4 x odd for K = 64, 256 and 320, so the 16 lanes of
+                                      // a 16-byte read pass (one row each) start on 16 different multiples of 4 banks: conflict-free
+constexpr int kMlpMaxChunkHalfs = kMlpChunkRows * (kMlpIn + kMlpW + kMlpPad) + kMlpChunkRows;  // the skip layer's chunk: 21056 halfs
 
 struct MlpArgs {
     const half_t *pts;     // [M][64] f16 positional encoding (zero-padded column 63)
@@ -628,7 +636,7 @@ __host__ __device__ constexpr int mlp_chunk_halfs(int rows, int K) { return rows
 
 // DMA of one chunk into an LDS buffer (lane-linear 16-byte pieces, like copy_image_dma)
 __device__ __forceinline__ void mlp_dma(half_t *__restrict__ buf, const half_t *__restrict__ src, int halfs, uint32_t tid) {
-    copy_image_dma(buf, src, halfs, tid);
+    copy_image_dma<kMlpBlock>(buf, src, halfs, tid);
 }
 
 // One chunk of NT output tiles: acc = bias; acc += W[chunk rows, :] . X^T over KP k-steps of `pts` then KX k-steps of `x`.
@@ -656,33 +664,28 @@ __device__ __forceinline__ void mlp_chunk(const half_t *__restrict__ buf, const 
 #pragma unroll
         for (int ts = 0; ts < kMlpTS; ts++) acc[ts][nt] = bf;
     }
-    const half_t *__restrict__ arow = buf + r * stride + 4 * hi;
-    h4 a0[NT], a1[NT];  // the pair of k-steps in flight; the next pair is requested before this one is consumed
+    // A operands: the weight stream stores, for every row and every pair of k-steps, the 8 halfs a lane feeds to one K = 32
+    // MFMA next to each other ([pair][hi][k-step of the pair][4]): one 16-byte LDS read per output tile and pair
+    const half_t *__restrict__ arow = buf + r * stride + 8 * hi;
+    h8 an[NT];  // the pair in flight; the next one is requested before this one is consumed
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        a0[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride);
-        a1[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16);
-    }
+    for (int nt = 0; nt < NT; nt++) an[nt] = *reinterpret_cast<const h8 *>(arow + 16 * nt * stride);
 #pragma unroll
     for (int k = 0; k < KS; k += 2) {
-        h4 n0[NT], n1[NT];
+        h8 ac[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) ac[nt] = an[nt];
         if (k + 2 < KS) {
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                n0[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16 * (k + 2));
-                n1[nt] = *reinterpret_cast<const h4 *>(arow + 16 * nt * stride + 16 * (k + 3));
-            }
+            for (int nt = 0; nt < NT; nt++) an[nt] = *reinterpret_cast<const h8 *>(arow + 16 * nt * stride + 16 * (k + 2));
         }
 #pragma unroll
         for (int ts = 0; ts < kMlpTS; ts++) {
             const h4 b0 = k < KP ? pts[ts][k < KP ? k : 0] : x[ts][k >= KP ? k - KP : 0];
             const h4 b1 = k + 1 < KP ? pts[ts][k + 1 < KP ? k + 1 : 0] : x[ts][k + 1 >= KP ? k + 1 - KP : 0];
+            const h8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[ts][nt] = mfma_k32(a0[nt], a1[nt], b0, b1, acc[ts][nt]);
-        }
-        if (k + 2 < KS) {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) { a0[nt] = n0[nt]; a1[nt] = n1[nt]; }
+            for (int nt = 0; nt < NT; nt++) acc[ts][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[nt], b, acc[ts][nt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -701,8 +704,8 @@ __device__ __forceinline__ void mlp_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ uint32_t mlp_dma_count(int halfs, uint32_t wave) {  // LDS-DMA instructions THIS wave issues for a chunk
-    const int pieces = (halfs * 2 + 1023) / 1024;
-    return pieces > (int)wave ? (uint32_t)(pieces - (int)wave + 3) / 4u : 0u;
+    const int pieces = (halfs * 2 + 1023) / 1024, nw = (int)(kMlpBlock / 64);
+    return pieces > (int)wave ? (uint32_t)(pieces - (int)wave + nw - 1) / (uint32_t)nw : 0u;
 }
 struct MlpStream {
     half_t *buf[3];
@@ -750,7 +753,7 @@ __device__ __forceinline__ void mlp_layer(MlpStream &st, const h4 (&pts)[kMlpTS]
     }
 }
 
-__global__ void __launch_bounds__(kHeadBlock, 1) k_mlp_fwd_fused(HeadArgs a, MlpArgs m) {
+__global__ void __launch_bounds__(kMlpBlock, 1) k_mlp_fwd_fused(HeadArgs a, MlpArgs m) {
     extern __shared__ __align__(16) half_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
     constexpr int kBufHalfs = (kMlpMaxChunkHalfs + 7) & ~7;
@@ -763,15 +766,15 @@ __global__ void __launch_bounds__(kHeadBlock, 1) k_mlp_fwd_fused(HeadArgs a, Mlp
     constexpr int h_first = mlp_chunk_halfs(kMlpChunkRows, kMlpIn), h_hidden = mlp_chunk_halfs(kMlpChunkRows, kMlpW),
                   h_skip = mlp_chunk_halfs(kMlpChunkRows, kMlpIn + kMlpW), h_last = mlp_chunk_halfs(32, kMlpW);
     st.next = m.wstream;
-    if (a.image) copy_image_dma(headw, a.image, HeadLds<KIND_HASH>::halfs, tid);  // (older than every chunk: complete by the first acquire)
-    else W.load(a, tid, kHeadBlock);
+    if (a.image) copy_image_dma<kMlpBlock>(headw, a.image, HeadLds<KIND_HASH>::halfs, tid);  // (older than every chunk: complete by the first acquire)
+    else W.load(a, tid, kMlpBlock);
     mlp_dma(st.buf[0], st.next, h_first, tid);
     st.next += h_first;
     mlp_dma(st.buf[1], st.next, h_first, tid);
     st.next += h_first;
     st.young = mlp_dma_count(h_first, wave);
     // ---- inputs of this wave's kMlpTS tiles
-    const size_t base = ((size_t)blockIdx.x * (kHeadBlock / 64) + wave) * (16 * kMlpTS);
+    const size_t base = ((size_t)blockIdx.x * (kMlpBlock / 64) + wave) * (16 * kMlpTS);
     h4 pts[kMlpTS][kMlpIn / 16];
     float dir[kMlpTS][3];
     const h4 hz = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
@@ -838,7 +841,7 @@ __global__ void __launch_bounds__(kHeadBlock, 1) k_mlp_fwd_fused(HeadArgs a, Mlp
 }
 
 static int launch_mlp_fwd_fused(const HeadArgs &a, const MlpArgs &m, hipStream_t s) {
-    const uint32_t per_wg = (kHeadBlock / 64) * 16 * kMlpTS;
+    const uint32_t per_wg = (kMlpBlock / 64) * 16 * kMlpTS;
     const uint32_t blocks = div_up(a.M, per_wg);
     constexpr int kBufHalfs = (kMlpMaxChunkHalfs + 7) & ~7;
     const size_t lds_bytes = (3 * (size_t)kBufHalfs + (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7)) * sizeof(half_t);
@@ -848,7 +851,7 @@ static int launch_mlp_fwd_fused(const HeadArgs &a, const MlpArgs &m, hipStream_t
             return PVD_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_fwd_fused, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, m);
+    hipLaunchKernelGGL(k_mlp_fwd_fused, dim3(blocks), dim3(kMlpBlock), lds_bytes, s, a, m);
     return check_launch();
 }
 

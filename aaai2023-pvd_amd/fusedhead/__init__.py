@@ -93,7 +93,7 @@ def mlp_supported(model):
 @torch.no_grad()
 def mlp_weight_stream(model):
     """The trunk's weights in the order and layout k_mlp_fwd_fused streams them through LDS (cached until the weights change):
-    per layer, chunks of 64 output rows, each rows x (K + 16) halfs (input columns padded 63 -> 64) followed by the rows' biases."""
+    per layer, chunks of 64 output rows, each rows x (K + 8) halfs (input columns padded 63 -> 64 and permuted inside groups of 32, see below) followed by the rows' biases."""
     params = [p for layer in model.nerf_mlp for p in (layer.weight, layer.bias)]
     key = _cache_key(params)
     cache = getattr(model, "_mlp_stream_cache", None)
@@ -110,7 +110,11 @@ def mlp_weight_stream(model):
             w = torch.cat([F.pad(w[:, :63], (0, 1)), w[:, 63:]], dim=1)    # [256, 64 + 256]
         if i == last:
             w, b = F.pad(w, (0, 0, 0, 4)), F.pad(b, (0, 4))                # 28 -> 32 rows
-        w = F.pad(w, (0, 16))                                              # 16 halfs of row padding (LDS bank spread, kMlpPad)
+        # within every group of 32 input columns (a pair of k-steps) store [hi][k-step][4]: the 8 halfs lane (row, hi) feeds to
+        # one K = 32 MFMA become one 16-byte LDS read (logical column 32 p + 16 s + 4 hi + j -> position 32 p + 8 hi + 4 s + j)
+        n, k = w.shape
+        w = w.view(n, k // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(n, k)
+        w = F.pad(w, (0, 8))                                               # 8 halfs of row padding (LDS bank spread, kMlpPad)
         for c in range(0, w.shape[0], 64):
             parts += [w[c:c + 64].reshape(-1), b[c:c + 64]]
     stream = torch.cat(parts).contiguous()

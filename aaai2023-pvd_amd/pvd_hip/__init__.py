@@ -609,7 +609,7 @@ def mlp_head_forward_fused(pts16, wstream, n_before, n_after, dirs, M, Wa1, Wa2,
     _f32_all(dirs=dirs, Wa1=Wa1, Wa2=Wa2, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
     if pts16.shape != (M, 64) or not pts16.is_contiguous() or not wstream.is_contiguous():
         raise PvdHipError("pts16 must be a contiguous [M, 64] f16 tensor")
-    need = 4 * (64 * 80 + 64) + (n_before + n_after) * 4 * (64 * 272 + 64) + 4 * (64 * 336 + 64) + (32 * 272 + 32)  # rows x (K + 16) + biases
+    need = 4 * (64 * 72 + 64) + (n_before + n_after) * 4 * (64 * 264 + 64) + 4 * (64 * 328 + 64) + (32 * 264 + 32)  # rows x (K + 8) + biases
     if wstream.numel() != need:
         raise PvdHipError("weight stream has %d halfs, the layer structure needs %d" % (wstream.numel(), need))
     _check_image(KIND_HASH_CONST, image)

@@ -302,8 +302,9 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
  *          n_after x [Linear(256,256) ReLU], Linear(256,28); all with bias -- the reference's nerf_mlp with
  *          nerf_layer_num = n_before + n_after + 3, skip = n_before, nerf_layer_wide = 256, PE = 10;
  *   wstream_f16: the weights as the kernel streams them through LDS -- layer after layer, each in chunks of 64 output rows
- *          (the last layer: one chunk of 32 rows, rows 28..31 zero): rows x (K + 16) halfs row-major (K = 64 / 256 / 320, input
- *          columns zero-padded 63 -> 64; 16 halfs of padding per row), then `rows` bias halfs (fusedhead.mlp_weight_stream builds it);
+ *          (the last layer: one chunk of 32 rows, rows 28..31 zero): rows x (K + 8) halfs row-major (K = 64 / 256 / 320, input
+ *          columns zero-padded 63 -> 64, then permuted inside every group of 32: logical column 32 p + 16 s + 4 h + j is stored
+ *          at 32 p + 8 h + 4 s + j; 8 halfs of padding per row), then `rows` bias halfs (fusedhead.mlp_weight_stream builds it);
  *   the head arguments and outputs as in pvd_head_forward(kind = PVD_HEAD_HASH). */
 int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstream_f16, uint32_t n_before, uint32_t n_after,
                                const float *dirs, const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2,

@@ -240,8 +240,8 @@ def test_dp_compact_run_table_covers_the_index_set_exactly():
 
 def test_mlp_weight_stream_layout_matches_the_kernels_chunk_order():
     """fusedhead.mlp_weight_stream (host side of pvd_mlp_head_forward_fused): per layer, chunks of 64 output rows, each
-    rows x (K + 16) halfs with the 63 positional-encoding columns padded to 64, followed by the rows' biases; the last
-    layer is one chunk of 32 rows (28 + 4 zero rows)."""
+    rows x (K + 8) halfs -- the 63 positional-encoding columns padded to 64, columns permuted inside groups of 32 so that a
+    lane's operand of one K = 32 MFMA is contiguous -- followed by the rows' biases; the last layer is one chunk of 32 rows."""
     import fusedhead
     opt = PVDConfig(model_type="mlp", fp16=False)
     opt.stage_iters = {"stage1": -1, "stage2": -1}
@@ -251,23 +251,30 @@ def test_mlp_weight_stream_layout_matches_the_kernels_chunk_order():
     assert fusedhead.mlp_supported(m)
     s = fusedhead.mlp_weight_stream(m)
     nb, na = m.skips, len(m.nerf_mlp) - 3 - m.skips
-    need = 4 * (64 * 80 + 64) + (nb + na) * 4 * (64 * 272 + 64) + 4 * (64 * 336 + 64) + (32 * 272 + 32)
+    need = 4 * (64 * 72 + 64) + (nb + na) * 4 * (64 * 264 + 64) + 4 * (64 * 328 + 64) + (32 * 264 + 32)
     assert s.dtype == torch.float16 and s.numel() == need
-    # first layer, chunk 1 (rows 64..127): [64, 80] then 64 biases
-    off = 64 * 80 + 64
-    blk = s[off:off + 64 * 80].view(64, 80)
+
+    def logical(blk, K):  # undo the permutation: stored position 32 p + 8 h + 4 s + j holds logical column 32 p + 16 s + 4 h + j
+        n = blk.shape[0]
+        return blk[:, :K].reshape(n, K // 32, 4, 2, 4).permute(0, 1, 3, 2, 4).reshape(n, K)
+
+    # first layer, chunk 1 (rows 64..127): [64, 72] then 64 biases
+    off = 64 * 72 + 64
+    blk = s[off:off + 64 * 72].view(64, 72)
     w0 = m.nerf_mlp[0].weight.detach().half()
-    assert torch.equal(blk[:, :63], w0[64:128]) and not blk[:, 63:].any()
-    assert torch.equal(s[off + 64 * 80:off + 64 * 80 + 64], m.nerf_mlp[0].bias.detach().half()[64:128])
-    # the skip layer's first chunk: columns [pts 63 | 0 | x 256 | 16 zeros]
-    off = 4 * (64 * 80 + 64) + nb * 4 * (64 * 272 + 64)
-    blk = s[off:off + 64 * 336].view(64, 336)
+    lg = logical(blk, 64)
+    assert torch.equal(lg[:, :63], w0[64:128]) and not lg[:, 63].any() and not blk[:, 64:].any()
+    assert torch.equal(s[off + 64 * 72:off + 64 * 72 + 64], m.nerf_mlp[0].bias.detach().half()[64:128])
+    # the skip layer's first chunk: logical columns [pts 63 | 0 | x 256], then 8 zeros
+    off = 4 * (64 * 72 + 64) + nb * 4 * (64 * 264 + 64)
+    blk = s[off:off + 64 * 328].view(64, 328)
     ws = m.nerf_mlp[m.skips + 1].weight.detach().half()
-    assert torch.equal(blk[:, :63], ws[:64, :63]) and not blk[:, 63].any() and torch.equal(blk[:, 64:320], ws[:64, 63:]) and not blk[:, 320:].any()
+    lg = logical(blk, 320)
+    assert torch.equal(lg[:, :63], ws[:64, :63]) and not lg[:, 63].any() and torch.equal(lg[:, 64:], ws[:64, 63:]) and not blk[:, 320:].any()
     # the last layer: 32 rows, rows 28.. zero
-    off = need - (32 * 272 + 32)
-    blk = s[off:off + 32 * 272].view(32, 272)
-    assert torch.equal(blk[:28, :256], m.nerf_mlp[-1].weight.detach().half()) and not blk[28:].any()
+    off = need - (32 * 264 + 32)
+    blk = s[off:off + 32 * 264].view(32, 264)
+    assert torch.equal(logical(blk, 256)[:28], m.nerf_mlp[-1].weight.detach().half()) and not blk[28:].any()
     assert torch.equal(s[-32:-4], m.nerf_mlp[-1].bias.detach().half()) and not s[-4:].any()
     # a model with another width is not taken by the fused kernel
     opt2 = PVDConfig(model_type="mlp", nerf_layer_wide=32, nerf_layer_num=4, skip=1, fp16=False)
