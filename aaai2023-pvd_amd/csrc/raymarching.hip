@@ -426,6 +426,21 @@ __device__ __forceinline__ float lattice_advance(float t, float dt, uint32_t n) 
     return t;
 }
 
+// dt_gamma > 0: the step grows with t, dt(t) = clamp(t * dt_gamma, dt_min, dt_max), but an occupied step and every trip of the
+// skip loop still advance t the SAME way, t <- fl(t + dt(t)) (raymarching.cu:368, 395-398): the points a ray can visit are
+// again one fixed sequence from t0, only not an arithmetic one.  Lane k's point of the chunk that starts at t_base: the
+// recurrence run k times -- 63 dependent steps per chunk, every lane the same, each keeping its own; nothing closed-form
+// reproduces the per-step roundings.  `far` lets the loop stop once the rest of the chunk is past the ray's end.
+__device__ __forceinline__ float lattice_points_gamma(float t_base, uint32_t lane, float dt_gamma, float dt_min, float dt_max, float far) {
+    float cur = t_base, mine = t_base;
+    for (uint32_t i = 1; i < 64; i++) {
+        cur = cur + clampf(cur * dt_gamma, dt_min, dt_max);
+        mine = lane >= i ? cur : mine;
+        if (!(cur < far)) break;  // lanes >= i hold a value >= far: invalid points, whatever they are exactly
+    }
+    return mine;
+}
+
 __device__ __forceinline__ uint64_t lanes_from(uint32_t lane) { return lane >= 64 ? 0ull : (~0ull << lane); }
 // __builtin_amdgcn_readlane is an INT builtin: a float argument would be value-converted (truncated)
 __device__ __forceinline__ float readlane_f(float v, uint32_t lane) {
@@ -452,7 +467,7 @@ template <bool WRITE>
 __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float far, uint32_t limit, uint32_t lane,
                                                   float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
                                                   uint32_t *n_chunks = nullptr, MarchRecord *__restrict__ rec = nullptr) {
-    const float dt = r.dt_min;
+    const bool grows = r.dt_gamma != 0.0f;  // (wave-uniform) dt = clamp(t * dt_gamma, ..): the lattice is not arithmetic
     float t_base = t0;
     bool pending = false;
     float pending_tt = 0.f;
@@ -465,9 +480,10 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
     for (;;) {
         if (n_chunks) (*n_chunks)++;
         const uint32_t bb = __float_as_uint(t_base);
-        const bool fast = lat_c != 0 && bb + 64u * lat_c < (((bb >> 23) + 1u) << 23);
-        const float t = fast ? __uint_as_float(bb + lane * lat_c) : lattice_advance(t_base, dt, lane);
-        const float t_after = t + dt;
+        const bool fast = !grows && lat_c != 0 && bb + 64u * lat_c < (((bb >> 23) + 1u) << 23);
+        const float t = grows ? lattice_points_gamma(t_base, lane, r.dt_gamma, r.dt_min, r.dt_max, far)
+                              : (fast ? __uint_as_float(bb + lane * lat_c) : lattice_advance(t_base, r.dt_min, lane));
+        const float t_after = t + clampf(t * r.dt_gamma, r.dt_min, r.dt_max);
         const bool valid = t < far;
         float x = 0, y = 0, z = 0, dtp = 0, tt = 0;
         bool occ = false;
@@ -555,7 +571,7 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
         }
         if (done) break;
         t_base = readlane_f(t_after, 63);
-        if (!fast) {
+        if (!fast && !grows) {
             // the last three lattice points in one binade: the one before last is at least the first step after
             // entering it, so the last difference is the binade's steady increment
             const uint32_t b61 = __float_as_uint(readlane_f(t_after, 61)), b62 = __float_as_uint(readlane_f(t_after, 62));
@@ -569,7 +585,7 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
 constexpr uint32_t kRaysPerBlock = kBlock / kWave;
 
 __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                             const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
+                                                             const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
                                                              uint32_t N, uint32_t C, uint32_t H, const float *__restrict__ nears,
                                                              const float *__restrict__ fars, int32_t *__restrict__ rays, uint32_t perturb,
                                                              MarchRayRecords *__restrict__ records, const int32_t *__restrict__ counter,
@@ -584,7 +600,7 @@ __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__rest
     uint32_t prof_chunks = 0;
 #endif
     Dda r;
-    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
     const float far = fars[n];
     uint32_t num;
@@ -613,7 +629,7 @@ __global__ void __launch_bounds__(kBlock) k_march_count_wave(const float *__rest
 }
 
 __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                             const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
+                                                             const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
                                                              uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                              const float *__restrict__ nears, const float *__restrict__ fars,
                                                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
@@ -627,7 +643,7 @@ __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__rest
     if (num == 0) return;
     if (off + num >= logical_budget(M, budget)) return;  // strict (:419)
     Dda r;
-    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
     const float far = fars[n];
     float *px = xyzs + 3 * (size_t)off, *pd = dirs + 3 * (size_t)off, *pl = deltas + 2 * (size_t)off;
@@ -655,7 +671,7 @@ __global__ void __launch_bounds__(kBlock) k_march_write_wave(const float *__rest
 // Write pass from the chunk records, with the exclusive scan of the counts folded in (N small: every workgroup sums the
 // counts of the rays before its own -- a few KB from L2 -- instead of a separate single-workgroup scan launch).
 __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                               const uint8_t *__restrict__ grid, float bound, uint32_t max_steps,
+                                                               const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
                                                                uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                                const float *__restrict__ nears, const float *__restrict__ fars,
                                                                float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
@@ -715,7 +731,7 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
         return;
     }
     Dda r;
-    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, 0.0f, max_steps, C, H, grid);
+    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
     const float t0 = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
     float *px = xyzs + 3 * (size_t)off, *pd = dirs + 3 * (size_t)off, *pl = deltas + 2 * (size_t)off;
     const MarchRayRecords &rr = records[n];
@@ -741,13 +757,13 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
         }
         return;
     }
-    const float dt = r.dt_min;
     float last_t = t0;
     uint32_t emitted = 0;
     for (uint32_t c = 0; c < rr.n; c++) {
         const uint64_t emit_mask = rr.chunk[c].mask;
-        const float t = lattice_advance(rr.chunk[c].t_base, dt, lane);
-        const float t_after = t + dt;
+        const float t = r.dt_gamma != 0.0f ? lattice_points_gamma(rr.chunk[c].t_base, lane, r.dt_gamma, r.dt_min, r.dt_max, 3.0e38f)
+                                           : lattice_advance(rr.chunk[c].t_base, r.dt_min, lane);
+        const float t_after = t + clampf(t * r.dt_gamma, r.dt_min, r.dt_max);
         const uint64_t below = emit_mask & ((1ull << lane) - 1ull);
         const int prev_lane = below ? 63 - __clzll((long long)below) : 0;
         const float prev_after = __shfl(t_after, prev_lane, 64);
@@ -1320,18 +1336,24 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
     }
     PVD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter);
     PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
-    MarchRayRecords *records = (dt_gamma == 0.0f && workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
+    // one wavefront per ray, for a constant step (dt_gamma = 0: all BASELINE configs with bound 1) and for a growing one alike
+    // (the lattice of dt_gamma > 0 is a recurrence instead of an arithmetic sequence; thread-per-ray left 94 % of the SIMDs idle
+    // at 4096 rays).  PVD_MARCH_THREAD_PER_RAY=1: the serial kernels for dt_gamma > 0 (A/B, tests).
+    static int serial_gamma = -1;
+    if (serial_gamma < 0) { const char *e = getenv("PVD_MARCH_THREAD_PER_RAY"); serial_gamma = (e && e[0] == '1') ? 1 : 0; }
+    const bool wave = dt_gamma == 0.0f || !serial_gamma;
+    MarchRayRecords *records = (wave && workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
                                    ? (MarchRayRecords *)workspace : nullptr;
     if (fresh && !records) {  // only the record path initialises what it does not write: do it up front for the others
         (void)hipMemsetAsync(xyzs, 0, 3 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(dirs, 0, 3 * (size_t)M * sizeof(float), s);
         (void)hipMemsetAsync(deltas, 0, 2 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), s);
     }
-    if (dt_gamma == 0.0f) {  // constant step: one wavefront per ray (all BASELINE configs)
+    if (wave) {
         const dim3 g(div_up(N, kRaysPerBlock)), b(kBlock);
-        hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb,
+        hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, perturb,
                            records, counter, records && fresh ? 1u : 0u);
         if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
-            hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs,
+            hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs,
                                dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u, budget_dev);
             return check_launch();
         }
@@ -1339,7 +1361,7 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
         return check_launch();
 #endif
         hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
-        hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+        hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
                            deltas, rays, perturb, budget_dev);
         return check_launch();
     }

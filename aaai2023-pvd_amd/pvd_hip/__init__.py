@@ -225,7 +225,7 @@ def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, 
         _want(budget_dev, torch.int32, "budget_dev")
     _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas)
     _want(grid, torch.uint8, "grid"), _want(rays, torch.int32, "rays"), _want(counter, torch.int32, "counter")
-    ws = _march_workspace(dev, N) if (dt_gamma == 0 and use_workspace) else None
+    ws = _march_workspace(dev, N) if use_workspace else None
     _call("pvd_march_rays_train_ws", dev, _p(rays_o), _p(rays_d), _p(grid), _f32(bound), _f32(dt_gamma), _u32(max_steps),
           _u32(N), _u32(C), _u32(H), _u32(M), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter),
           _u32(int(perturb)), _p(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _u32(1 if fresh else 0), _p(budget_dev))

@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --rays is the GLOBAL batch, split evenly across the ranks (default: weak, --rays per GPU)")
+    ap.add_argument("--bound", type=float, default=1.0, help="scene bound (> 1: more than one occupancy cascade, as for Tanks&Temples, configs[4])")
+    ap.add_argument("--dt-gamma", type=float, default=0.0, help="dt_gamma of the marcher (the reference uses 1/256 for unbounded scenes)")
+    ap.add_argument("--scene-scale", type=float, default=1.0, help="scale of the synthetic scene (with --bound > 1)")
     ap.add_argument("--workload", choices=["distill", "teacher"], default="distill",
                     help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
@@ -240,9 +243,9 @@ def main():
     from pvd.trainer import RayDP, psnr
     from pvd.workload import DistillWorkload
 
-    opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type="hash", fp16=not args.fp32)
+    opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type="hash", fp16=not args.fp32, bound=args.bound, dt_gamma=args.dt_gamma)
     dp = RayDP()
-    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp, scene_scale=args.scene_scale)
     if dp.enabled:  # replicas must start bit-identical (teacher pre-training uses float atomics)
         for m in (w.tea, w.stu):
             for t in list(m.parameters()) + list(m.buffers()):
@@ -365,7 +368,10 @@ def main():
         "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP, as the reference forces) / f32 marcher+compositor",
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
         "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
-                               "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps" % (args.student, args.rays, args.teacher_pretrain),
+                               "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps%s" % (
+                                   args.student, args.rays, args.teacher_pretrain,
+                                   "" if (args.bound == 1.0 and args.dt_gamma == 0.0) else "; bound %g (%d cascades), dt_gamma %g, scene scale %g"
+                                   % (args.bound, w.stu.cascade, args.dt_gamma, args.scene_scale)),
                    "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
                    "capture_fallback": (not args.eager) and not launch_mode.startswith("hipGraph replay"),  # True = the step fell back to eager launches (~5x the ms)
                    "samples_per_step_per_gpu": samples,
