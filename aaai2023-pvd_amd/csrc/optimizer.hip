@@ -49,6 +49,10 @@ struct AdamExtras {
     float *lazy_log;        // DEVICE [lazy_capacity][segments] or NULL
     uint32_t *lazy_count;   // DEVICE scalar: logged steps
     uint32_t lazy_capacity;
+    // with lazy_log: the groups that are NOT cold, ascending (DEVICE [n_warm]) -- the update then walks this list instead of all
+    // groups: full wavefronts of warm groups instead of wavefronts in which the cold lanes idle
+    const uint32_t *warm;
+    uint32_t n_warm;
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -115,8 +119,9 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
     const double t = (double)step[0] + 1.0;  // the tail kernel advances the stored count after the update
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, t));
-    const uint64_t n4 = n >> 2;
-    for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kOptBlock) {
+    const uint64_t n4 = ex.warm ? (uint64_t)ex.n_warm : n >> 2;
+    for (uint64_t j = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; j < n4; j += (uint64_t)gridDim.x * kOptBlock) {
+        const uint64_t i = ex.warm ? (uint64_t)ex.warm[j] : j;
         const uint64_t e = i << 2;
         uint32_t k = 0;
         while (k + 1 < seg.count && e >= seg.end[k]) k++;  // segments are multiples of 4 elements (see trainer)
@@ -345,7 +350,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -359,6 +364,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         if (h.lazy_log) {
             if (!h.cold_bits || !h.lazy_count || h.lazy_capacity < 1) return PVD_ERR_INVALID;
             ex.lazy_log = h.lazy_log; ex.lazy_count = h.lazy_count; ex.lazy_capacity = h.lazy_capacity;
+            if (h.warm_groups) { ex.warm = h.warm_groups; ex.n_warm = h.n_warm_groups; }
+        } else if (h.warm_groups) {
+            return PVD_ERR_INVALID;  // without the deferred decay the cold groups need their update every step
         }
         if (h.g16) {
             if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
@@ -366,8 +374,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    uint64_t blocks = (n / 4 + kOptBlock - 1) / kOptBlock;
+    uint64_t blocks = ((ex.warm ? (uint64_t)ex.n_warm : n / 4) + kOptBlock - 1) / kOptBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, lr, beta1, beta2, eps, weight_decay, step,
                        grad_scale, found_inf, ex);
     const bool amp = extras_host && extras_host->amp_scale;
@@ -444,7 +453,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -4,6 +4,8 @@ per parameter group, the gradient exchange of ray-DP is one all-reduce, and zero
 Drop-in for torch.optim.AdamW(betas, eps, weight_decay) as the reference constructs it
 (main_distill_mutual.py:334-339), including GradScaler's unscale / skip-on-inf protocol and tensor learning
 rates (LR schedulers fill them in place), so a captured HIP graph sees the schedule."""
+import os
+
 import torch
 
 import pvd_hip
@@ -67,7 +69,6 @@ class FlatAdamW(torch.optim.Optimizer):
     _lazy, _lazy_logged = None, 0
 
     def _lazy_state(self):
-        import os
         if os.environ.get("PVD_ADAMW_LAZY", "1") == "0":
             return None
         if self._lazy is None:
@@ -124,6 +125,12 @@ class FlatAdamW(torch.optim.Optimizer):
         packed = (bits.view(words, 32) << torch.arange(32, device=dev)).sum(1)
         packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
         self.cold_fraction = float(cold.float().mean()) if n4 else 0.0
+        # the warm groups as a list (the update kernel walks it when the cold groups' decay is deferred): full wavefronts of work
+        self._warm_groups = (~cold).nonzero().squeeze(1).to(torch.int32).contiguous()
+        st = getattr(self, "_l1_track", None)
+        if st is not None:  # per-workgroup partial sums: the launch shape changes with the list, start them afresh
+            st["buf"].zero_()
+            st["buf"][0] = self.l1_value(st["scale"])
         return packed if self.cold_fraction > 0.05 else None
 
     def zero_grad(self, set_to_none=False):
@@ -211,13 +218,14 @@ class FlatAdamW(torch.optim.Optimizer):
         st = getattr(self, "_l1_track", None)
         capturing = torch.cuda.is_current_stream_capturing()
         if self._cold_dirty and not capturing:
-            import os
             self.flush()  # with the old bitmap
             self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
             self._cold_dirty = False
         cold = self._cold_bits if (self.touched is not None and self._outside_is_zero and not self._cold_dirty
                                    and getattr(self, "_half_grad", None) is None) else None
         lazy = self._lazy_state() if cold is not None else None
+        if lazy is not None and os.environ.get("PVD_ADAMW_WARM_LIST", "1") != "0":
+            lazy = (lazy[0], lazy[1], self._warm_groups)
         if lazy is None and self._lazy_logged and not capturing:
             self.flush()  # this step decays the cold groups itself: the logged decays come first
         if lazy is not None:

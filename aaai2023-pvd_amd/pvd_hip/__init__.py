@@ -790,7 +790,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("amp_growth", ctypes.c_double), ("amp_backoff", ctypes.c_double), ("amp_interval", ctypes.c_int32),
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
                 ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p),
-                ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32)]
+                ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32),
+                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32)]
 
 
 def _u64_array(vals):
@@ -814,8 +815,13 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
             if cold_bits.numel() * 128 < p.numel() or not cold_bits.is_contiguous():
                 raise PvdHipError("cold_bits needs one bit per 4 parameters")
             ex.cold_bits = cold_bits.data_ptr()
-            if lazy is not None:  # (log f32 [capacity, segments], count int32 [1]): the cold groups' decay is deferred (pvd_adamw_lazy_flush)
-                log, count = lazy
+            if lazy is not None:  # (log f32 [capacity, segments], count int32 [1][, warm int32 [n_warm]]): the cold groups' decay is deferred
+                log, count = lazy[:2]
+                if len(lazy) > 2 and lazy[2] is not None:  # the groups that are not cold, ascending: the update walks only these
+                    warm = lazy[2]
+                    _dev(warm)
+                    _want(warm, torch.int32, "warm groups")
+                    ex.warm_groups, ex.n_warm_groups = warm.data_ptr(), int(warm.numel())
                 _dev(log, count)
                 _want(log, torch.float32, "lazy log"), _want(count, torch.int32, "lazy count")
                 if log.dim() != 2 or log.shape[1] != len(segment_ends) or not log.is_contiguous():

@@ -496,6 +496,10 @@ typedef struct pvd_adamw_extras {
     float *lazy_log;
     uint32_t *lazy_count;
     uint32_t lazy_capacity;
+    /* warm_groups != NULL (only with lazy_log): DEVICE uint32 [n_warm_groups], ascending -- exactly the groups whose cold bit is
+     * clear.  The update walks this list instead of every group (the cold ones have nothing to do). */
+    const uint32_t *warm_groups;
+    uint32_t n_warm_groups;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,

@@ -543,7 +543,8 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
     seg_ends = [n // 2 // 4 * 4, n]
     # dense; cold groups decayed on every step; cold groups' decay DEFERRED (lazy log) and replayed in one go at the end, and
     # in two goes (a flush after the third step)
-    for use_cold, lazy_flush_at in ((False, None), (True, None), (True, (6,)), (True, (3, 6))):
+    warm_list = (~cold4).nonzero().squeeze(1).to(torch.int32).contiguous()
+    for use_cold, lazy_flush_at in ((False, None), (True, None), (True, (6,)), (True, (3, 6)), (True, (2, 6, "list"))):
         p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         m_probe = m.clone()
         lr = torch.tensor([1e-2, 3e-3], device=dev)
@@ -551,6 +552,8 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
         step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
         scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
         lazy = (torch.zeros(16, 2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if lazy_flush_at else None
+        if lazy_flush_at and "list" in lazy_flush_at:  # the update walks the list of warm groups instead of testing every group's bit
+            lazy = lazy + (warm_list,)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         replayed = []
         for k, gr in enumerate(grads):
