@@ -117,3 +117,44 @@ def test_error_behaviour_matches_the_reference_checks():
     with pytest.raises(RuntimeError):  # plenoxel: C must be 3 * degree^2 + 1
         hip.plenoxel_forward(z(4, 3), None, (-1, -1, -1, 1, 1, 1), torch.zeros(1, 27, 4, 4, 4, device=dev).contiguous(
             memory_format=torch.channels_last_3d), 3, -2.0, 7.0, z(4, 27), None, None, None, None)
+
+
+def test_round_two_entry_points_reject_bad_arguments_and_accept_empty_inputs():
+    """pvd_freq_encode / pvd_mlp_head_forward_fused / pvd_distill_* (fea_width) / pvd_adamw_step_ex (warm list without the deferred
+    decay): empty inputs are no-ops, malformed ones are refused by the binding or by the library (never a launch on bad sizes)."""
+    import pvd_hip
+    dev = torch.device("cuda:0")
+    # positional encoding: empty batch, too many frequencies, a row stride shorter than the encoding
+    out = pvd_hip.freq_encode(torch.empty(0, 3, device=dev), [1.0, 2.0], True, torch.float16, 16)
+    assert out.shape == (0, 16)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.freq_encode(torch.zeros(4, 3, device=dev), [1.0] * 17)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.freq_encode(torch.zeros(4, 3, device=dev), [1.0, 2.0], True, torch.float32, 14)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.freq_encode(torch.zeros(4, 3, device=dev).half(), [1.0])
+    # fused NeRF-MLP forward: a weight stream of the wrong length for the stated layer structure
+    f = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.mlp_head_forward_fused(torch.zeros(8, 64, device=dev).half(), torch.zeros(1000, device=dev).half(), 4, 1, f(8, 3), 8,
+                                       f(64, 28), f(16, 64), f(64, 31), f(64, 64), f(3, 64), -2.0, 7.0, f(8), f(8, 3), f(8, 16))
+    # objective: feature rows must be 16 wide or 1 wide
+    S = torch.zeros(4 + 4 * 1024, device=dev)
+    img = f(1, 4, 3)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.distill_sumsq(img, img, f(8, 7), f(8, 7), f(8, 3), f(8, 3), S)
+    pvd_hip.distill_sumsq(img, img, f(8, 1), f(8, 1), f(8, 3), f(8, 3), S, reduce=True)
+    assert float(S[:4].abs().sum()) == 0.0
+    # optimizer: a list of warm groups only makes sense when the cold groups' decay is deferred
+    n = 1024
+    p, g, m, v = torch.randn(n, device=dev), f(n), f(n), f(n)
+    bits = torch.zeros(n // 128, dtype=torch.int32, device=dev)
+    step, lr = f(1), torch.tensor([1e-3], device=dev)
+    log, cnt = torch.zeros(4, 1, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.adamw_step(p, g, m, v, [n], lr, 0.9, 0.99, 1e-15, 0.01, step, cold_bits=bits, lazy=(torch.zeros(4, 2, device=dev), cnt))
+    warm = torch.arange(n // 4, dtype=torch.int32, device=dev)
+    p0 = p.clone()
+    pvd_hip.adamw_step(p, g, m, v, [n], lr, 0.9, 0.99, 1e-15, 0.01, step, cold_bits=bits, lazy=(log, cnt, warm))
+    ref = (p0.double() - 1e-3 * 0.01 * p0.double())
+    assert torch.allclose(p.double(), ref, rtol=1e-6) and int(cnt[0]) == 1 and float(step[0]) == 1.0
