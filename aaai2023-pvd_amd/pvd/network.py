@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from .activation import make_trunc_exp
 from .encoding import get_encoder
-from .linear import make_skinny_linear
+from .linear import make_skinny_linear, make_skinny_linear_bias
 from .renderer import NeRFRenderer
 
 
@@ -82,6 +82,7 @@ class NeRFNetwork(NeRFRenderer):
         self.model_type = model_type
         self.trunc_exp = make_trunc_exp(ops.device_type)
         self.linear = make_skinny_linear(ops.device_type)  # F.linear with a split-K weight gradient
+        self.linear_bias = make_skinny_linear_bias(ops.device_type)  # the same for the biased layers of the NeRF MLP trunk
         self.plenoxel_degree = args.plenoxel_degree
         self.plenoxel_res = ast.literal_eval(args.plenoxel_res) if isinstance(args.plenoxel_res, str) else list(args.plenoxel_res)
         assert len(self.plenoxel_res) == 3
@@ -276,7 +277,7 @@ class NeRFNetwork(NeRFRenderer):
                 w = F.pad(w, (0, pad))
             elif i == self.skips + 1:
                 w = torch.cat([F.pad(w[:, :n_in], (0, pad)), w[:, n_in:]], dim=1)
-            x = F.linear(x, w, layer.bias)
+            x = self.linear_bias(x, w, layer.bias) if x.dim() == 2 else F.linear(x, w, layer.bias)
             if i != last:
                 x = F.relu(x, inplace=True)
             if i == self.skips:
