@@ -109,3 +109,40 @@ def test_teacher_block_graph_follows_the_eager_run_across_grid_updates():
     assert np.allclose(la[16:], lb[16:], rtol=0.08), (la[16:], lb[16:])
     assert all(abs(a - b) <= 0.05 * a for a, b in zip(ca, cb)), (ca, cb)
     assert lra == lrb and lb[-1] < lb[0] and lb[-1] < lb[15]
+
+
+def test_teacher_block_recaptures_when_the_scene_outgrows_its_rows():
+    """train_block(): when update_extra_state's new mean_count no longer fits the rows the block was captured with (or has
+    shrunk far below them), the block is captured again with a fresh allocation; training goes on."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays
+    from pvd.trainer import TeacherTrainer
+    from pvd.workload import DistillWorkload, measure_mean_count
+    torch.manual_seed(0)
+    opt = PVDConfig(num_rays=1024, fp16=True)
+    w = DistillWorkload(hip_ops(), torch.device(DEV), opt, teacher_pretrain_steps=0, seed=0)
+    topt = PVDConfig(**{**opt.__dict__, "model_type": opt.teacher_type, "iters": 3000, "stage_iters": {"stage1": -1, "stage2": -1}})
+    tea = w.tea
+    tea.teacher_variant = True
+    tea.requires_grad_(True).train()
+    tea.args = tea.opt = topt
+    tr = TeacherTrainer(topt, tea, torch.device(DEV), fp16=True)
+    tea.mean_count = measure_mean_count(tea, w.poses, opt, generator=w.gen)
+    batches = []
+    for it in range(16):
+        r = get_rays(w.poses[it][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
+        bg = torch.rand(1, opt.num_rays, 3, device=DEV, generator=w.gen)
+        batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
+    for it in range(16):
+        tr.train_step(*batches[it])
+    tr.capture_block(batches)
+    first = tr._cap
+    loss_a, _ = tr.train_block()
+    assert tr._cap is first  # same graph: the budget moved on the device only
+    tea.sample_alloc = 2048  # pretend the block had been captured for a much smaller scene
+    loss_b, _ = tr.train_block()
+    assert tr._cap is not first and tea.sample_alloc >= tea.mean_count and not tea.budget_exceeded
+    loss_c, _ = tr.train_block()
+    assert all(np.isfinite(float(l)) for l in (loss_a, loss_b, loss_c)) and tr.global_step == 64
+    assert int(tea._budget_dev[0]) == tea.mean_count + (128 - tea.mean_count % 128)
