@@ -78,6 +78,11 @@ constexpr int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
 // move reloads / flushes everything.  Every texel a ray crosses is thus read about once and receives about one
 // atomic per contiguous visit instead of one per sample and tap.  Control flow is wave-uniform: every lane shares
 // the sample's texel coordinates.
+// element offset of texel t at texel stride R: a 24-bit multiply (one full-rate instruction; the 64-bit product the plain
+// expression asks for is a quarter-rate v_mad_u64_u32 per access -- 212 of them in the forward's code).  pvd_vm_* refuse tables
+// whose texel count or byte size does not fit (fill_tables).
+__device__ __forceinline__ uint32_t toff(int t, uint32_t R) { return __umul24((uint32_t)t, R); }
+
 __device__ __forceinline__ void atom(float *__restrict__ p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool GRAD>
@@ -89,12 +94,12 @@ struct PlaneWin {
 
     __device__ __forceinline__ void fetch(int k, const float *__restrict__ mat, int W, int H, uint32_t R) {
         const int x = x0 + (k & 1), y = y0 + (k >> 1);
-        v[k] = (x >= 0 && x < W && y >= 0 && y < H) ? mat[((long)y * W + x) * (long)R] : 0.f;
+        v[k] = (x >= 0 && x < W && y >= 0 && y < H) ? mat[toff(y * W + x, R)] : 0.f;
     }
     __device__ __forceinline__ void flush(int k, float *__restrict__ gm, int W, int H, uint32_t R) {
         if (GRAD) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
-            if (x >= 0 && x < W && y >= 0 && y < H) atom(gm + ((long)y * W + x) * (long)R, a[k]);
+            if (x >= 0 && x < W && y >= 0 && y < H) atom(gm + toff(y * W + x, R), a[k]);
             a[k] = 0.f;
         }
     }
@@ -140,14 +145,14 @@ struct PlaneWin {
     // ---- interior fast path: the move code comes precomputed with the sample (see WalkCtl), old and new footprints
     // are known to lie inside the table, so there are no comparisons and no bounds checks; `t` is a texel index.
     template <int K>
-    __device__ __forceinline__ void fetch_at(int t, const float *__restrict__ mat, uint32_t R) { v[K] = mat[(long)t * (long)R]; }
+    __device__ __forceinline__ void fetch_at(int t, const float *__restrict__ mat, uint32_t R) { v[K] = mat[toff(t, R)]; }
     template <int K>
     __device__ __forceinline__ void flush_at(int t, float *__restrict__ gm, uint32_t R) {
-        if (GRAD) { atom(gm + (long)t * (long)R, a[K]); a[K] = 0.f; }
+        if (GRAD) { atom(gm + toff(t, R), a[K]); a[K] = 0.f; }
     }
     // The entering texels are LOADED before the leaving ones are flushed: memory operations complete in issue order
     // (one vmcnt), so a load issued behind the atomics would make the next use of the values wait for the atomics.
-    __device__ __forceinline__ float ld(int t, const float *__restrict__ mat, uint32_t R) const { return mat[(long)t * (long)R]; }
+    __device__ __forceinline__ float ld(int t, const float *__restrict__ mat, uint32_t R) const { return mat[toff(t, R)]; }
     __device__ __forceinline__ void move_fast(uint32_t code, int nx, int ny, const float *__restrict__ mat, float *__restrict__ gm, int W, uint32_t R) {
         const int nb = ny * W + nx;  // new origin texel
         if (code == 1) {         // +x: column 0 leaves
@@ -187,12 +192,12 @@ struct LineWin {
     float v[2], a[2];
     __device__ __forceinline__ void fetch(int k, const float *__restrict__ vec, int L, uint32_t R) {
         const int l = l0 + k;
-        v[k] = (l >= 0 && l < L) ? vec[(long)l * R] : 0.f;
+        v[k] = (l >= 0 && l < L) ? vec[toff(l, R)] : 0.f;
     }
     __device__ __forceinline__ void flush(int k, float *__restrict__ gv, int L, uint32_t R) {
         if (GRAD) {
             const int l = l0 + k;
-            if (l >= 0 && l < L) atom(gv + (long)l * R, a[k]);
+            if (l >= 0 && l < L) atom(gv + toff(l, R), a[k]);
             a[k] = 0.f;
         }
     }
@@ -229,17 +234,17 @@ struct LineWin {
     // interior fast path (see PlaneWin::move_fast): code 1 = +1, 2 = -1, 3 = jump
     __device__ __forceinline__ void move_fast(uint32_t code, int nl, const float *__restrict__ vec, float *__restrict__ gv, uint32_t R) {
         if (code == 1) {
-            const float e = vec[(long)(nl + 1) * (long)R];
-            if (GRAD) { atom(gv + (long)(nl - 1) * (long)R, a[0]); a[0] = a[1]; a[1] = 0.f; }
+            const float e = vec[toff(nl + 1, R)];
+            if (GRAD) { atom(gv + toff(nl - 1, R), a[0]); a[0] = a[1]; a[1] = 0.f; }
             v[0] = v[1]; v[1] = e;
         } else if (code == 2) {
-            const float e = vec[(long)nl * (long)R];
-            if (GRAD) { atom(gv + (long)(nl + 2) * (long)R, a[1]); a[1] = a[0]; a[0] = 0.f; }
+            const float e = vec[toff(nl, R)];
+            if (GRAD) { atom(gv + toff(nl + 2, R), a[1]); a[1] = a[0]; a[0] = 0.f; }
             v[1] = v[0]; v[0] = e;
         } else {
-            const float e0 = vec[(long)nl * (long)R], e1 = vec[(long)(nl + 1) * (long)R];
+            const float e0 = vec[toff(nl, R)], e1 = vec[toff(nl + 1, R)];
             if (GRAD) {
-                atom(gv + (long)l0 * (long)R, a[0]); atom(gv + (long)(l0 + 1) * (long)R, a[1]);
+                atom(gv + toff(l0, R), a[0]); atom(gv + toff(l0 + 1, R), a[1]);
                 a[0] = 0.f; a[1] = 0.f;
             }
             v[0] = e0; v[1] = e1;
@@ -488,6 +493,7 @@ static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *
         tb.H[i] = res[kM1[i]];
         tb.L[i] = res[kV[i]];
         if (tb.W[i] < 1 || tb.H[i] < 1 || tb.L[i] < 1) return PVD_ERR_INVALID;
+        if ((uint64_t)tb.W[i] * tb.H[i] >= (1ull << 24) || tb.L[i] >= (1u << 24)) return PVD_ERR_UNSUPPORTED;  // toff(): 24-bit texel indices
         for (int k = 0; k < 2; k++) {
             tb.mat[k][i] = (const float *)tables[k * 6 + i];
             tb.vec[k][i] = (const float *)tables[k * 6 + 3 + i];
@@ -503,7 +509,7 @@ static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *
     for (int k = 0; k < 2; k++) {
         tb.ms[k] = stride[2 * k];
         tb.vs[k] = stride[2 * k + 1];
-        if (tb.ms[k] < dense[2 * k] || tb.vs[k] < dense[2 * k]) return PVD_ERR_INVALID;
+        if (tb.ms[k] < dense[2 * k] || tb.vs[k] < dense[2 * k] || tb.ms[k] > 4096u || tb.vs[k] > 4096u) return PVD_ERR_INVALID;
     }
     return PVD_OK;
 }
