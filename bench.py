@@ -291,6 +291,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if dp.enabled and dist.get_world_size() > 1:  # the slowest rank's clock (the barriers make them agree to a few us anyway)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
 
     # ---- roofline of the hash-grid lookup (the kernel north_star names).  HIP events cannot sit inside the replayed step,
     # so right after the timed region the SAME kernel is launched on the samples of one more step: the frozen teacher's
