@@ -643,7 +643,11 @@ class DistillTrainer(_TrainerBase):
             # recorded into a capture here (tools/probe_rccl_capture.py) -- which costs less than the ~60 us of fixed
             # overhead the three-graph form pays on every step
             try:
-                out = self.capture(body, steps_per_graph=steps_per_graph)
+                pipe = os.environ.get("PVD_DP_PIPELINE", "1")  # 0: off; 1: when there is more than one rank; 2: always (tests)
+                if stage == 3 and steps_per_graph > 1 and (pipe == "2" or (pipe == "1" and self.dp.world_size > 1)):
+                    out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
+                else:
+                    out = self.capture(body, steps_per_graph=steps_per_graph)
             except Exception:
                 import traceback
                 traceback.print_exc()
@@ -655,10 +659,75 @@ class DistillTrainer(_TrainerBase):
         elif not self.dp.enabled and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
             self._pipe_stream = torch.cuda.Stream()
             out = self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
+        elif (not self.dp.enabled and stage == 3 and steps_per_graph > 1 and os.environ.get("PVD_PIPELINE_INGRAPH", "1") != "0"
+              and bool(getattr(self.opt, "render_stu_first", True))):
+            # single GPU, several steps per graph: the same fork -- next step's batch / march / teacher forward (ALU- and
+            # latency-bound) recorded next to this step's inf check + AdamW (HBM-bound) inside the one graph
+            out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
         else:
             out = self.capture(body, steps_per_graph=steps_per_graph)
         self._captured_stage = self._stage_of(self.global_step)
         return out
+
+    def _capture_ingraph_pipelined(self, batch_fn, body, steps_per_graph):
+        """Ray-DP with the collectives recorded into the graph, several steps per graph: the parameter-independent prefix of
+        step k + 1 (batch, march, frozen teacher's forward) is recorded on a FORKED stream next to step k's gradient exchange
+        and update, and joined before step k + 1's student forward -- inside one graph, so that on more than one GPU the
+        ~0.1 ms prefix hides behind the all-reduce instead of following it.  Same batches in the same order, same update
+        rule as the sequential schedule (tests/test_hip_dp_graph.py)."""
+        assert self.device_type == "cuda" and (not self.dp.enabled or self.dp.ingraph)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up steps (communicators, compactor, caches), as in capture()
+            for _ in range(3):
+                self._zero_grads()
+                out = body()
+                self._backward(out[0])
+                self._exchange()
+                self._optimize()
+                self.scheduler.step()
+                self.global_step += 1
+                del out
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        cap = SegmentedCapture(self.device)
+        self.dp.capture = cap
+        branch = torch.cuda.Stream(self.device)
+        K = max(1, int(steps_per_graph))
+        try:
+            with cap:
+                main = torch.cuda.current_stream()
+                pre = self.prefetch(batch_fn)
+                for k in range(K):
+                    # where the next prefix branches off: before this step's backward (default) or before its exchange + update.
+                    # (Not before compute_loss: it reads tea.feature_sigma_color, which the prefix rebinds.)
+                    fork_at = os.environ.get("PVD_PIPELINE_FORK", "backward")
+                    pre_next = None
+
+                    def fork():
+                        branch.wait_stream(main)
+                        with torch.cuda.stream(branch):
+                            return self.prefetch(batch_fn)
+                    self._zero_grads()
+                    with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                        self._static_out = self.compute_loss(None, None, None, pre=pre)
+                    if k + 1 < K and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
+                        pre_next = fork()
+                    self._backward(self._static_out[0])
+                    if k + 1 < K and fork_at == "optimizer":
+                        pre_next = fork()
+                    self._exchange()
+                    self._optimize()
+                    if pre_next is not None:  # join
+                        main.wait_stream(branch)
+                        pre = pre_next
+        finally:
+            self.dp.capture = None
+        self._cap = cap
+        self.steps_per_replay = K
+        self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
+        self.pipelined_ingraph = True
+        return self._static_out
 
     def _capture_pipelined(self, batch_fn, body):
         """Ray-DP: the next step's batch / march / teacher forward do not depend on this step's update, so they are a

@@ -258,8 +258,8 @@ def main():
 
     torch.cuda.manual_seed(1234 + rank)  # in-graph ray / background sampling: different rays on every rank
     launch_mode = "eager"
-    # steps per graph launch: the largest of 10, 5, 4, 2 that divides both the timed and the warm-up step count (exactly K timed steps)
-    spg = next((k for k in (10, 5, 4, 2) if args.steps % k == 0 and args.warmup % k == 0), 1) if os.environ.get("PVD_STEPS_PER_GRAPH", "") == "" \
+    # steps per graph launch: the largest of 20, 10, 5, 4, 2 that divides both the timed and the warm-up step count (exactly K timed steps)
+    spg = next((k for k in (20, 10, 5, 4, 2) if args.steps % k == 0 and args.warmup % k == 0), 1) if os.environ.get("PVD_STEPS_PER_GRAPH", "") == "" \
         else int(os.environ["PVD_STEPS_PER_GRAPH"])
     if not args.eager:
         try:

@@ -76,8 +76,9 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
 
 
-def _rccl_worker(rank, port, out_path, ingraph):
-    os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", PVD_DP_INGRAPH="1" if ingraph else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1"):
+    os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", PVD_DP_INGRAPH="1" if ingraph else "0", PVD_DP_PIPELINE=pipeline,
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -93,14 +94,15 @@ def _rccl_worker(rank, port, out_path, ingraph):
     opt = PVDConfig(num_rays=1024, resolution0=64, iters=300)
     w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0, dp=dp)
     torch.cuda.manual_seed(100)
-    w.enable_graph()
+    w.enable_graph(steps_per_graph=steps_per_graph)
     cap = w.trainer._cap
     if ingraph:  # both collectives recorded into the one graph of the step
         assert dp.ingraph and len(cap.graphs) == 1 and len(cap.between) == 0
+        assert bool(getattr(w.trainer, "pipelined_ingraph", False)) == (pipeline == "2" and steps_per_graph > 1)
     else:
         assert len(cap.graphs) == 3 and len(cap.between) == 2
         assert getattr(w.trainer, "_g_prefix", None) is not None
-    losses = [float(w.step()[1]["rgb"]) for _ in range(40)]
+    losses = [float(w.step()[1]["rgb"]) for _ in range(40 // steps_per_graph)]
     torch.cuda.synchronize()
     torch.save({"losses": losses}, out_path)
     dist.destroy_process_group()
@@ -117,5 +119,20 @@ def test_rccl_collectives_with_the_captured_step(tmp_path):
         mp.spawn(_rccl_worker, args=(_free_port(), out, ingraph), nprocs=1, join=True)
         losses = torch.load(out)["losses"]
         assert len(losses) == 40 and all(l == l for l in losses) and losses[-1] < losses[0]
+        runs.append(losses)
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
+
+
+@pytest.mark.timeout(900)
+def test_rccl_in_graph_with_the_next_prefix_forked_under_the_exchange(tmp_path):
+    """Four steps per graph, collectives in the graph (one-rank RCCL world): the next step's prefix recorded on a forked stream
+    next to the exchange + update (PVD_DP_PIPELINE=2: forced; the default takes it with more than one rank) trains like the
+    sequential recording -- the same batches in the same order (every 4th loss is compared: the one a replay reports)."""
+    runs = []
+    for pipeline in ("0", "2"):
+        out = str(tmp_path / ("pipe%s.pt" % pipeline))
+        mp.spawn(_rccl_worker, args=(_free_port(), out, True, 4, pipeline), nprocs=1, join=True)
+        losses = torch.load(out)["losses"]
+        assert len(losses) == 10 and all(l == l for l in losses) and losses[-1] < losses[0]
         runs.append(losses)
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
