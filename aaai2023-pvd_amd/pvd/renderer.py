@@ -216,6 +216,7 @@ class NeRFRenderer(nn.Module):
                 counter = self.step_counter[self.local_step % 16]  # set to zero (renderer.py:374): the scratch_counter flag below
                 self.local_step += 1
             budget = self._budget() if not force_all_rays else None  # (single-model training: the model composites its own march)
+            own = i_march or bool(kwargs.get("own_march", False))  # the samples come from THIS model's march (budget applies)
             if i_march:
                 if budget is not None:
                     xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
@@ -242,7 +243,7 @@ class NeRFRenderer(nn.Module):
                 sigmas = self.density_scale * sigmas
             eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
             # compositing + `image += (1 - ws) * bg` + depth normalisation (renderer.py:442-446) as one op
-            if budget is not None and i_march:
+            if budget is not None and own:
                 weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True, budget[1])
             else:
                 weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True)  # rays: straight from the march
@@ -346,9 +347,11 @@ class NeRFRenderer(nn.Module):
         nears, fars = nears_fars if nears_fars is not None else rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         counter = self.step_counter[self.local_step % 16]  # "counter.zero_()" (renderer.py:374) = the scratch_counter flag below
         self.local_step += 1
+        budget = self._budget() if not force_all_rays else None  # fixed allocation + device-side budget (fix_sample_alloc)
+        extra = (budget,) if budget is not None else ()
         xyzs, dirs, deltas, rays = rm.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                        nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
-                                                       max_steps, True)
+                                                       max_steps, True, *extra)
         return [xyzs, dirs, deltas, rays], (nears, fars)
 
     def _cell_centres(self, coords, cas, jitter):

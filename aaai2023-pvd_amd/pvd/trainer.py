@@ -817,6 +817,57 @@ class TeacherTrainer(_TrainerBase):
             return loss, pred
         return body
 
+    def _capture_block_pipelined(self, batches):
+        """The block with step k + 1's march (near/far, count and write passes: ~50 us, instruction-bound, depends only on the
+        occupancy grid, which is fixed inside a block) recorded on a forked stream next to step k's backward (the hash-grid
+        scatter sits at the memory-side atomic rate) and update -- the same schedule as DistillTrainer's multi-step graph."""
+        o, m = self.opt, self.model
+        kw = dict(dt_gamma=o.dt_gamma, max_steps=o.max_steps)
+
+        def march(b):
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                return m.march(b[0], b[1], perturb=True, force_all_rays=False, **kw)
+
+        def loss_of(b, marched):
+            inh, nf = marched
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                out = m.render(b[0], b[1], staged=False, bg_color=b[3], perturb=True, force_all_rays=False, inherited_params=inh,
+                               nears_fars=nf, premarched=True, own_march=True, num_steps=o.num_steps, upsample_steps=o.upsample_steps, **kw)
+                pred = out["image"]
+                loss = self.dp.global_mean((pred.float() - b[2].float()) ** 2)
+                if o.l1_reg_weight > 0.0 and o.model_type == "vm":
+                    loss = loss + self._l1_term()
+            return loss, pred
+        torch.cuda.synchronize()
+        cap = SegmentedCapture(self.device)
+        self.dp.capture = cap
+        branch = torch.cuda.Stream(self.device)
+        K = len(batches)
+        try:
+            with cap:
+                main = torch.cuda.current_stream()
+                marched = march(batches[0])
+                for k in range(K):
+                    self._zero_grads()
+                    self._static_out = loss_of(batches[k], marched)
+                    nxt = None
+                    if k + 1 < K:
+                        branch.wait_stream(main)
+                        with torch.cuda.stream(branch):
+                            nxt = march(batches[k + 1])
+                    self._backward(self._static_out[0])
+                    self._exchange()
+                    self._optimize()
+                    if nxt is not None:
+                        main.wait_stream(branch)
+                        marched = nxt
+        finally:
+            self.dp.capture = None
+        self._cap = cap
+        self.steps_per_replay = K
+        self._captured_occ_epoch = None
+        self.pipelined_block = True
+
     def capture_block(self, batches):
         """Capture `update_extra_interval` consecutive training steps (one per entry of `batches`: STATIC device tensors
         (rays_o, rays_d, gt_rgb, bg) that the caller refills in place) as one HIP graph.  The teacher's sample budget moves
@@ -828,7 +879,10 @@ class TeacherTrainer(_TrainerBase):
         assert m.cuda_ray and m.mean_count > 0 and self.global_step % o.update_extra_interval == 0
         m.fix_sample_alloc()
         self._block_batches = batches
-        self.capture(self._block_body(batches), warmup=0, steps_per_graph=len(batches))
+        if not self.dp.enabled and os.environ.get("PVD_TEACHER_PIPELINE", "1") != "0":
+            self._capture_block_pipelined(batches)
+        else:
+            self.capture(self._block_body(batches), warmup=0, steps_per_graph=len(batches))
         self._block_alloc = m.sample_alloc
 
     def train_block(self):
