@@ -317,6 +317,10 @@ class NeRFNetwork(NeRFRenderer):
                 out = fh.vm_head_infer(self, sraw, prod, d)
             elif self.model_type == "vm" and hasattr(fh, "vm_head_train"):
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+                hook = getattr(self, "_between_backwards", None)  # (trainer: called between the head's and the lookup's backward)
+                if hook is not None and prod.requires_grad:
+                    prod.register_hook(hook)
+                    self._between_backwards = None  # taken
                 out = fh.vm_head_train(self, sraw, prod, d)
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student

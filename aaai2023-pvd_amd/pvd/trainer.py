@@ -699,22 +699,39 @@ class DistillTrainer(_TrainerBase):
                 main = torch.cuda.current_stream()
                 pre = self.prefetch(batch_fn)
                 for k in range(K):
-                    # where the next prefix branches off: before this step's backward (default) or before its exchange + update.
-                    # (Not before compute_loss: it reads tea.feature_sigma_color, which the prefix rebinds.)
-                    fork_at = os.environ.get("PVD_PIPELINE_FORK", "backward")
+                    # where the next prefix branches off: "mid" = between the student's head backward and its table scatter
+                    # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
+                    # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
+                    # prefix rebinds.)
+                    fork_at = os.environ.get("PVD_PIPELINE_FORK", "mid")
                     pre_next = None
 
                     def fork():
                         branch.wait_stream(main)
                         with torch.cuda.stream(branch):
                             return self.prefetch(batch_fn)
+                    held = {}
+                    if k + 1 < K and fork_at == "mid":  # between the student's head backward and its table scatter
+
+                        def between(grad, held=held):
+                            if "pre" not in held:
+                                held["pre"] = fork()
+                            return None
+                        self.model_stu._between_backwards = between
                     self._zero_grads()
-                    with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                        self._static_out = self.compute_loss(None, None, None, pre=pre)
+                    try:
+                        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                            self._static_out = self.compute_loss(None, None, None, pre=pre)
+                    finally:
+                        if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
+                            fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
+                        self.model_stu._between_backwards = None
                     if k + 1 < K and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
                         pre_next = fork()
                     self._backward(self._static_out[0])
-                    if k + 1 < K and fork_at == "optimizer":
+                    if k + 1 < K and fork_at == "mid":
+                        pre_next = held.get("pre")
+                    if k + 1 < K and pre_next is None:  # "optimizer", or a student without the hook point
                         pre_next = fork()
                     self._exchange()
                     self._optimize()

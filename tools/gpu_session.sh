@@ -1,8 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-run() { env "$@" timeout 300 python bench.py --workload teacher --steps 256 --warmup 320 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['config'].get('loss'), d['config'].get('launch'))"; }
-run PVD_TEACHER_PIPELINE=0
-run PVD_TEACHER_PIPELINE=1
-run PVD_TEACHER_PIPELINE=0
-run PVD_TEACHER_PIPELINE=1
-timeout 900 python -m pytest tests/test_hip_budget.py -x -q -m gpu 2>&1 | tail -3
+run() { env "$@" timeout 300 python bench.py --no-cpu-baseline --teacher-pretrain 100 $ARGS 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$ARGS $*', d['ms_per_step'], d['config']['loss'], d['config']['psnr_student_vs_teacher_db'], d['config']['launch'][:60])"; }
+ARGS="--student hash"
+run PVD_PIPELINE_INGRAPH=0
+run PVD_PIPELINE_INGRAPH=1
+run PVD_PIPELINE_INGRAPH=1 PVD_PIPELINE_FORK=optimizer
+run PVD_PIPELINE_INGRAPH=0 PVD_STEPS_PER_GRAPH=1
+run PVD_PIPELINE_INGRAPH=0
+run PVD_PIPELINE_INGRAPH=1
