@@ -479,15 +479,24 @@ class DistillTrainer(_TrainerBase):
         """The parameter-independent prefix of a step: batch, march, the frozen teacher's forward and compositing.  Its
         results feed compute_loss(pre=...); under ray-DP it is captured as its own graph and replayed for step k+1 while
         step k's gradient exchange is in flight."""
-        o, stu, tea = self.opt, self.model_stu, self.model_tea
+        return self.prefetch_teacher(self.prefetch_march(batch_fn))
+
+    def prefetch_march(self, batch_fn):
+        """First half of the prefix: the batch and the march (depend on the occupancy grid only)."""
         rays_o, rays_d, bg, *rest = batch_fn()
-        kw = self.render_kwargs()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
-            inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, nears_fars=rest[0] if rest else None, **kw)
-            with torch.no_grad():
-                out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False,
-                                     inherited_params=inh, nears_fars=nf, premarched=True, **kw)
-        return dict(rays_o=rays_o, rays_d=rays_d, bg=bg, inh=inh, nf=nf, out_tea=out_tea)
+            inh, nf = self.model_stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, nears_fars=rest[0] if rest else None,
+                                           **self.render_kwargs())
+        return dict(rays_o=rays_o, rays_d=rays_d, bg=bg, inh=inh, nf=nf)
+
+    def prefetch_teacher(self, part):
+        """Second half: the frozen teacher's forward and compositing on the marched samples (rebinds the teacher's
+        feature_sigma_color: not before the objective of the step in flight has been issued)."""
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"), torch.no_grad():
+            out_tea = self.model_tea.render(part["rays_o"], part["rays_d"], staged=False, bg_color=part["bg"], perturb=True,
+                                            force_all_rays=False, inherited_params=part["inh"], nears_fars=part["nf"], premarched=True,
+                                            **self.render_kwargs())
+        return dict(part, out_tea=out_tea)
 
     def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None, pre=None):
         o, stu, tea = self.opt, self.model_stu, self.model_tea
