@@ -24,6 +24,56 @@ def psnr(pred, truth):
     return -10.0 * torch.log10(mse)
 
 
+def _tree_map(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _tree_map(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tree_map(v, fn) for v in obj)
+    return obj
+
+
+def _tree_tensors(obj, out):
+    _tree_map(obj, lambda t: out.append(t) or t)
+    return out
+
+
+class CarriedPrefix:
+    """A static home for the results of DistillTrainer.prefetch across graph replays: the prefix recorded next to the LAST step
+    of a multi-step graph feeds the FIRST step of the next replay.  Storage by storage (views of one buffer stay views of one
+    buffer: sigma_l is column 0 of feature_sigma_color), same sizes / strides / offsets."""
+
+    def __init__(self, pre):
+        self._stores = {}  # data_ptr of a source storage -> flat uint8 tensor owning the static copy
+
+        def home(t):
+            st = t.untyped_storage()
+            if st.data_ptr() not in self._stores:
+                flat = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (st.nbytes(),), (1,))
+                self._stores[st.data_ptr()] = flat.clone()
+            dst = self._stores[st.data_ptr()].untyped_storage()
+            return torch.empty(0, dtype=t.dtype, device=t.device).set_(dst, t.storage_offset(), t.size(), t.stride())
+        self.pre = _tree_map(pre, home)
+        self._layout = [(t.dtype, tuple(t.size()), tuple(t.stride()), t.storage_offset()) for t in _tree_tensors(pre, [])]
+
+    def store(self, pre):
+        """Copy a new prefix (same structure and layout) into the static home: one multi-tensor copy on the current stream."""
+        new, old = _tree_tensors(pre, []), _tree_tensors(self.pre, [])
+        assert [(t.dtype, tuple(t.size()), tuple(t.stride()), t.storage_offset()) for t in new] == self._layout, \
+            "the prefix changed shape between steps of one capture"
+        srcs, dsts, seen = [], [], set()
+        for tn, to in zip(new, old):
+            sn, so = tn.untyped_storage(), to.untyped_storage()
+            if sn.data_ptr() in seen:
+                continue
+            seen.add(sn.data_ptr())
+            assert sn.nbytes() == so.nbytes()
+            srcs.append(torch.empty(0, dtype=torch.uint8, device=tn.device).set_(sn, 0, (sn.nbytes(),), (1,)))
+            dsts.append(torch.empty(0, dtype=torch.uint8, device=to.device).set_(so, 0, (so.nbytes(),), (1,)))
+        torch._foreach_copy_(dsts, srcs)
+
+
 class SegmentedCapture:
     """A step as a chain of HIP graphs with eager host calls between them.  `break_for(fn)` ends the graph being
     captured, runs fn() eagerly (and remembers it), and starts the next graph in the same memory pool; `replay()` replays
@@ -496,7 +546,9 @@ class DistillTrainer(_TrainerBase):
             out_tea = self.model_tea.render(part["rays_o"], part["rays_d"], staged=False, bg_color=part["bg"], perturb=True,
                                             force_all_rays=False, inherited_params=part["inh"], nears_fars=part["nf"], premarched=True,
                                             **self.render_kwargs())
-        return dict(part, out_tea=out_tea)
+        tea = self.model_tea
+        attrs = {k: getattr(tea, k, None) for k in ("feature_sigma_color", "sigma_l", "color_l")}
+        return dict(part, out_tea=out_tea, tea_attrs={k: v for k, v in attrs.items() if torch.is_tensor(v)})
 
     def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None, pre=None):
         o, stu, tea = self.opt, self.model_stu, self.model_tea
@@ -504,8 +556,10 @@ class DistillTrainer(_TrainerBase):
         kw = self.render_kwargs()
         kw_stu = dict(kw, nears_fars=nears_fars) if nears_fars is not None else kw  # the batch kernel already intersected the box
         if pre is not None:
+            for k, v in pre.get("tea_attrs", {}).items():  # what the teacher's forward left on the model (this prefix's, not the latest)
+                setattr(tea, k, v)
             out_tea = dict(pre["out_tea"])
-            if out_tea.get("image") is not None:
+            if out_tea.get("image") is not None and pre.get("replayed_ahead", False):
                 out_tea["image"] = out_tea["image"].clone()  # the prefix graph overwrites its outputs one step ahead
             out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
                                  inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, **kw)
@@ -699,15 +753,25 @@ class DistillTrainer(_TrainerBase):
                 del out
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        K = max(1, int(steps_per_graph))
+        # the prefix next to the LAST step of the graph feeds the FIRST step of the next replay through a static home, so that
+        # every step has its prefix overlapped, whatever the number of steps per graph (K >= 2: with one step per graph the
+        # step's own scatter would still be reading the samples the copy overwrites)
+        carried = None
+        if K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
+            with torch.cuda.stream(side):
+                carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)
-        K = max(1, int(steps_per_graph))
         try:
             with cap:
                 main = torch.cuda.current_stream()
-                pre = self.prefetch(batch_fn)
+                pre = carried.pre if carried is not None else self.prefetch(batch_fn)
                 for k in range(K):
+                    more = k + 1 < K or carried is not None  # a prefix to record next to this step
                     # where the next prefix branches off: "mid" = between the student's head backward and its table scatter
                     # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
                     # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
@@ -715,12 +779,15 @@ class DistillTrainer(_TrainerBase):
                     fork_at = os.environ.get("PVD_PIPELINE_FORK", "mid")
                     pre_next = None
 
-                    def fork():
+                    def fork(k=k):
                         branch.wait_stream(main)
                         with torch.cuda.stream(branch):
-                            return self.prefetch(batch_fn)
+                            nxt = self.prefetch(batch_fn)
+                            if k + 1 == K:  # for the next replay
+                                carried.store(nxt)
+                            return nxt
                     held = {}
-                    if k + 1 < K and fork_at == "mid":  # between the student's head backward and its table scatter
+                    if more and fork_at == "mid":  # between the student's head backward and its table scatter
 
                         def between(grad, held=held):
                             if "pre" not in held:
@@ -735,12 +802,12 @@ class DistillTrainer(_TrainerBase):
                         if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
                             fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
                         self.model_stu._between_backwards = None
-                    if k + 1 < K and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
+                    if more and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
                         pre_next = fork()
                     self._backward(self._static_out[0])
-                    if k + 1 < K and fork_at == "mid":
+                    if more and fork_at == "mid":
                         pre_next = held.get("pre")
-                    if k + 1 < K and pre_next is None:  # "optimizer", or a student without the hook point
+                    if more and pre_next is None:  # "optimizer", or a student without the hook point
                         pre_next = fork()
                     self._exchange()
                     self._optimize()
@@ -776,7 +843,7 @@ class DistillTrainer(_TrainerBase):
         torch.cuda.synchronize()
         self._g_prefix = torch.cuda.CUDAGraph()  # own memory pool: it is replayed out of capture order
         with torch.cuda.graph(self._g_prefix, capture_error_mode="thread_local"):
-            self._pre = self.prefetch(batch_fn)
+            self._pre = dict(self.prefetch(batch_fn), replayed_ahead=True)
 
         def body_pre():
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):

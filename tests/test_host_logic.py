@@ -280,3 +280,41 @@ def test_mlp_weight_stream_layout_matches_the_kernels_chunk_order():
     opt2 = PVDConfig(model_type="mlp", nerf_layer_wide=32, nerf_layer_num=4, skip=1, fp16=False)
     opt2.stage_iters = opt.stage_iters
     assert not fusedhead.mlp_supported(make_model(OPS, opt2, "mlp", True, "cpu"))
+
+
+def test_carried_prefix_keeps_views_and_copies_storage_by_storage():
+    """The static home of a prefix across graph replays (pvd/trainer.py CarriedPrefix): views of one buffer stay views of one
+    buffer, a store() brings every value across, aliases inside the structure stay aliases."""
+    from pvd.trainer import CarriedPrefix
+
+    def prefix(seed):
+        g = torch.Generator().manual_seed(seed)
+        feat = torch.rand(7, 16, generator=g)
+        xyz = torch.rand(7, 3, generator=g)
+        inh = [xyz, torch.rand(7, 3, generator=g), torch.rand(7, 2, generator=g), torch.arange(8, dtype=torch.int32).view(4, 2) + seed]
+        return dict(rays_o=torch.rand(4, 3, generator=g), bg=1, inh=inh, nf=(torch.rand(4, generator=g), torch.rand(4, generator=g)),
+                    out_tea=dict(image=torch.rand(4, 3, generator=g), depth=None, inherited_params=inh),
+                    tea_attrs=dict(feature_sigma_color=feat, sigma_l=feat[..., 0], color_l=feat[:, 1:4]))
+
+    a, b = prefix(1), prefix(2)
+    c = CarriedPrefix(a)
+    home = c.pre
+    assert home["bg"] == 1 and home["out_tea"]["depth"] is None
+    assert torch.equal(home["tea_attrs"]["feature_sigma_color"], a["tea_attrs"]["feature_sigma_color"])
+    assert home["tea_attrs"]["feature_sigma_color"].data_ptr() != a["tea_attrs"]["feature_sigma_color"].data_ptr()
+    # the view relation survives
+    assert home["tea_attrs"]["sigma_l"].data_ptr() == home["tea_attrs"]["feature_sigma_color"].data_ptr()
+    assert home["tea_attrs"]["sigma_l"].stride() == (16,)
+    assert home["out_tea"]["inherited_params"][0].data_ptr() == home["inh"][0].data_ptr()
+    ptrs = [t.data_ptr() for t in (home["inh"][0], home["tea_attrs"]["feature_sigma_color"], home["out_tea"]["image"])]
+    c.store(b)
+    assert ptrs == [t.data_ptr() for t in (c.pre["inh"][0], c.pre["tea_attrs"]["feature_sigma_color"], c.pre["out_tea"]["image"])]
+    for key in ("feature_sigma_color", "sigma_l", "color_l"):
+        assert torch.equal(c.pre["tea_attrs"][key], b["tea_attrs"][key])
+    for i in range(4):
+        assert torch.equal(c.pre["inh"][i], b["inh"][i])
+    assert torch.equal(c.pre["nf"][1], b["nf"][1]) and torch.equal(c.pre["out_tea"]["image"], b["out_tea"]["image"])
+    bad = prefix(3)
+    bad["inh"][0] = torch.rand(9, 3)
+    with pytest.raises(AssertionError):
+        c.store(bad)
