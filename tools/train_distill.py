@@ -60,14 +60,19 @@ def main():
     tr = w.trainer
     marks = sorted(set([0, a.stage1, a.stage2] + list(range(0, a.steps + 1, max(a.steps // 6, 1))) + [a.steps]))
     t_train = 0.0
+
+    def spg():
+        # stage 3 has no further boundary to respect: ten steps per graph launch, the next step's prefix next to the update
+        # (a mark may be overshot by up to 9 steps; the printed step count is the real one)
+        return 10 if tr._stage_of(tr.global_step + 3) == 3 else 1  # (+3: the capture's eager warm-up steps)
     for lo, hi in zip(marks[:-1], marks[1:]):
         if tr._stage_of(tr.global_step) != getattr(tr, "_captured_stage", None) or not getattr(w, "_graph", False):
-            w.enable_graph()  # (re-)capture: the set of loss terms changed
+            w.enable_graph(steps_per_graph=spg())  # (re-)capture: the set of loss terms changed
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         while tr.global_step < hi:
             if tr._stage_of(tr.global_step) != tr._captured_stage:
-                w.enable_graph()
+                w.enable_graph(steps_per_graph=spg())
             w.step()
         torch.cuda.synchronize()
         t_train += time.perf_counter() - t1
