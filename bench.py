@@ -352,7 +352,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps,
                 "samples_per_launch": B, "us_per_launch": us, "launches": n_launch,
-                "timing": "HIP events on the launch stream around %d launches (HIP graphs of %d), right after the timed region" % (n_launch, per_graph)}
+                "timing": "HIP events on the launch stream around %d launches (HIP graphs of %d), right after the timed region" % (n_launch, per_graph),
+                "in_step": "the kernel alone on the chip; inside the replayed step it runs on a forked branch of the graph next to the "
+                           "student's table scatter and update, where sharing the chip stretches it (rocprofv3: 45 us shared vs 28 us "
+                           "alone, profiles/r02_kernel_populations.txt) -- the step as a whole is shorter for it"}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
