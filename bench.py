@@ -24,6 +24,11 @@ import time
 # multi-process GPU work on this platform needs dmabuf IPC (the host driver does not support the legacy mode); the
 # environment exports it already -- keep it if the launcher dropped it
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The replayed step is a graph with two parallel chains (the next step's prefix on a forked branch).  How
+# the HIP runtime spreads the graph's internal streams over hardware queues decides whether the chains share the chip or
+# trip over each other: with 8 queues every run is slow (0.48-0.66 ms/step), with the default 4 one process in ~15 is, with 2
+# none was in 25 runs and the step is ~1 % shorter (profiles/r02_hw_queues_ab.txt).  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd")):

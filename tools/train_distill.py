@@ -4,8 +4,9 @@ teacher training on the analytic scene -> stage 1 (feature loss only) -> stage 2
 with PSNR of the student against the teacher and against the analytic ground truth on held-out views, rendered with the
 inference path (march_rays / composite_rays / compact_rays).
   python tools/train_distill.py [--teacher-steps 3000 --stage1 500 --stage2 1500 --steps 6000 --student vm]"""
-import argparse
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")  # forked graphs: see DESIGN section 6 (before the HIP runtime starts)
+import argparse
 import sys
 import time
 
