@@ -725,7 +725,7 @@ class DistillTrainer(_TrainerBase):
         elif (not self.dp.enabled and stage == 3 and steps_per_graph > 1 and os.environ.get("PVD_PIPELINE_INGRAPH", "1") != "0"
               and bool(getattr(self.opt, "render_stu_first", True))):
             # single GPU, several steps per graph: the same fork -- next step's batch / march / teacher forward (ALU- and
-            # latency-bound) recorded next to this step's inf check + AdamW (HBM-bound) inside the one graph
+            # latency-bound) recorded next to this step's table scatter + inf check + AdamW inside the one graph
             out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
         else:
             out = self.capture(body, steps_per_graph=steps_per_graph)
@@ -733,11 +733,13 @@ class DistillTrainer(_TrainerBase):
         return out
 
     def _capture_ingraph_pipelined(self, batch_fn, body, steps_per_graph):
-        """Ray-DP with the collectives recorded into the graph, several steps per graph: the parameter-independent prefix of
-        step k + 1 (batch, march, frozen teacher's forward) is recorded on a FORKED stream next to step k's gradient exchange
-        and update, and joined before step k + 1's student forward -- inside one graph, so that on more than one GPU the
-        ~0.1 ms prefix hides behind the all-reduce instead of following it.  Same batches in the same order, same update
-        rule as the sequential schedule (tests/test_hip_dp_graph.py)."""
+        """Several steps per graph (single GPU, or ray-DP with the collectives recorded into the graph): the parameter-
+        independent prefix of step k + 1 (batch, march, frozen teacher's forward and compositing) is recorded on a FORKED
+        stream next to step k's table scatter, gradient exchange and update, and joined before step k + 1's student forward --
+        inside one graph: no extra graph launches, one fork / join pair per step.  The scatter waits on the memory side, the
+        update on HBM and the exchange on xGMI while the prefix is instruction- and L2-bound, so the two chains share the chip
+        (0.379 -> 0.327 ms/step on one GPU).  Same batches in the same order, same update rule as the
+        back-to-back recording (tests/test_hip_graph.py, tests/test_hip_dp_graph.py)."""
         assert self.device_type == "cuda" and (not self.dp.enabled or self.dp.ingraph)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
