@@ -66,6 +66,8 @@ def test_several_steps_per_graph_launch_train_like_single_step_replays():
     torch.cuda.manual_seed(21)
     wb.enable_graph(steps_per_graph=3)
     assert wb.steps_per_call == 3 and wa.steps_per_call == 1
+    # several steps per graph: the next step's prefix rides on a forked branch, the last one feeds the next replay
+    assert getattr(wb.trainer, "pipelined_ingraph", False) and not getattr(wa.trainer, "pipelined_ingraph", False)
     g0 = wb.trainer.global_step
     lb = [float(wb.step()[0]) for _ in range(2)]
     assert wb.trainer.global_step == g0 + 6 and wb.trainer.scheduler.last_epoch == wa.trainer.scheduler.last_epoch
