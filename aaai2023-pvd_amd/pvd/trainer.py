@@ -726,7 +726,14 @@ class DistillTrainer(_TrainerBase):
               and bool(getattr(self.opt, "render_stu_first", True))):
             # single GPU, several steps per graph: the same fork -- next step's batch / march / teacher forward (ALU- and
             # latency-bound) recorded next to this step's table scatter + inf check + AdamW inside the one graph
-            out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
+            try:
+                out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                torch.cuda.synchronize()
+                self.pipelined_ingraph = False
+                out = self.capture(body, steps_per_graph=steps_per_graph)  # the same steps recorded back to back
         else:
             out = self.capture(body, steps_per_graph=steps_per_graph)
         self._captured_stage = self._stage_of(self.global_step)
@@ -772,50 +779,57 @@ class DistillTrainer(_TrainerBase):
             with cap:
                 main = torch.cuda.current_stream()
                 pre = carried.pre if carried is not None else self.prefetch(batch_fn)
-                for k in range(K):
-                    more = k + 1 < K or carried is not None  # a prefix to record next to this step
-                    # where the next prefix branches off: "mid" = between the student's head backward and its table scatter
-                    # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
-                    # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
-                    # prefix rebinds.)
-                    fork_at = os.environ.get("PVD_PIPELINE_FORK", "mid")
-                    pre_next = None
+                try:
+                    for k in range(K):
+                        more = k + 1 < K or carried is not None  # a prefix to record next to this step
+                        # where the next prefix branches off: "mid" = between the student's head backward and its table scatter
+                        # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
+                        # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
+                        # prefix rebinds.)
+                        fork_at = os.environ.get("PVD_PIPELINE_FORK", "mid")
+                        pre_next = None
 
-                    def fork(k=k):
-                        branch.wait_stream(main)
-                        with torch.cuda.stream(branch):
-                            nxt = self.prefetch(batch_fn)
-                            if k + 1 == K:  # for the next replay
-                                carried.store(nxt)
-                            return nxt
-                    held = {}
-                    if more and fork_at == "mid":  # between the student's head backward and its table scatter
+                        def fork(k=k):
+                            branch.wait_stream(main)
+                            with torch.cuda.stream(branch):
+                                nxt = self.prefetch(batch_fn)
+                                if k + 1 == K:  # for the next replay
+                                    carried.store(nxt)
+                                return nxt
+                        held = {}
+                        if more and fork_at == "mid":  # between the student's head backward and its table scatter
 
-                        def between(grad, held=held):
-                            if "pre" not in held:
-                                held["pre"] = fork()
-                            return None
-                        self.model_stu._between_backwards = between
-                    self._zero_grads()
-                    try:
-                        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                            self._static_out = self.compute_loss(None, None, None, pre=pre)
-                    finally:
-                        if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
-                            fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
-                        self.model_stu._between_backwards = None
-                    if more and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
-                        pre_next = fork()
-                    self._backward(self._static_out[0])
-                    if more and fork_at == "mid":
-                        pre_next = held.get("pre")
-                    if more and pre_next is None:  # "optimizer", or a student without the hook point
-                        pre_next = fork()
-                    self._exchange()
-                    self._optimize()
-                    if pre_next is not None:  # join
-                        main.wait_stream(branch)
-                        pre = pre_next
+                            def between(grad, held=held):
+                                if "pre" not in held:
+                                    held["pre"] = fork()
+                                return None
+                            self.model_stu._between_backwards = between
+                        self._zero_grads()
+                        try:
+                            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                                self._static_out = self.compute_loss(None, None, None, pre=pre)
+                        finally:
+                            if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
+                                fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
+                            self.model_stu._between_backwards = None
+                        if more and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
+                            pre_next = fork()
+                        self._backward(self._static_out[0])
+                        if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
+                            raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
+                        if more and fork_at == "mid":
+                            pre_next = held.get("pre")
+                        if more and pre_next is None:  # "optimizer", or a student without the hook point
+                            pre_next = fork()
+                        self._exchange()
+                        self._optimize()
+                        if pre_next is not None:  # join
+                            main.wait_stream(branch)
+                            pre = pre_next
+                except Exception:
+                    self.model_stu._between_backwards = None
+                    main.wait_stream(branch)  # a capture can only be ended with its forked work joined
+                    raise
         finally:
             self.dp.capture = None
         self._cap = cap

@@ -269,7 +269,9 @@ def main():
     if not args.eager:
         try:
             w.enable_graph(steps_per_graph=spg)  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
-            launch_mode = "hipGraph replay" + (" (%d steps per graph launch)" % w.steps_per_call if w.steps_per_call > 1 else "")
+            launch_mode = "hipGraph replay" + (" (%d steps per graph launch%s)" % (
+                w.steps_per_call, ", next step's march + teacher forward on a forked branch" if getattr(w.trainer, "pipelined_ingraph", False) else "")
+                if w.steps_per_call > 1 else "")
         except Exception as e:  # never lose the measurement to a capture problem: fall back to eager launches
             import traceback
             traceback.print_exc(file=sys.stderr)
