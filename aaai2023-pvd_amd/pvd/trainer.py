@@ -577,6 +577,7 @@ class DistillTrainer(_TrainerBase):
             main.wait_stream(self._side)
         else:
             join = self.__dict__.pop("_prologue_join", None)
+            out_tea = None
             if join is not None and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
                 # the step's prologue (zero_grad, weight image) was forked onto a side stream: march first, join, then the forward
                 inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, **kw_stu)
@@ -586,10 +587,18 @@ class DistillTrainer(_TrainerBase):
             else:
                 if join is not None:
                     join()
-                out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
-            with torch.no_grad():
-                out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                     inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
+                if not bool(getattr(o, "render_stu_first", True)) and stu.cuda_ray:
+                    # the TEACHER marches and the student inherits its samples (utils.py:1020-1043, renderer.py:392-411)
+                    with torch.no_grad():
+                        out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
+                    out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                                         inherited_params=out_tea["inherited_params"], nears_fars=out_tea.get("nears_fars"), **kw)
+                else:
+                    out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
+            if out_tea is None:
+                with torch.no_grad():
+                    out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
+                                         inherited_params=out_stu["inherited_params"], nears_fars=out_stu.get("nears_fars"), **kw)
         self.loss_rate_fea_sc *= 0.995  # decays every step (utils.py:1044)
         have_fea = stu.feature_sigma_color is not None and tea.feature_sigma_color is not None
         pred_stu, pred_tea = out_stu.get("image"), out_tea.get("image")

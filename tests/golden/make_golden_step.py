@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_step.npz: the REFERENCE's own distillation step -- `Trainer.train_step`
+(distill_mutual/utils.py:954-1189) driving `NeRFRenderer.run_cuda` (distill_mutual/renderer.py:319-448) of two of its
+`NeRFNetwork`s (hash teacher, VM student) -- run HERE on the CPU, in its three stages, on fixed rays / weights / occupancy.
+
+Everything that is Python / torch in the reference on that path is the reference's own code and arithmetic in these numbers:
+the stage gating, which model marches and which inherits, `sigmas * density_scale`, the background mix, the four loss terms
+with their rates and the 0.995 decay, the VM L1 term, and autograd through all of it.  The native operators underneath
+(march_rays_train, composite_rays_train, grid_encode, sh_encode) are the CPU oracle standing in for the reference's CUDA
+extensions (they cannot be built here: no cuda.h, stand-ins are not allowed), exactly as in make_golden.py, and `Tensor.cuda()` is
+made the identity for the run (the wrappers call it; there is no GPU here) -- so this pins the repo's renderer / trainer
+restatement, not kernel arithmetic.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden_step.py
+Only data (inputs + what the reference computed) is written; no reference source is copied."""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import oracle_backend as ob  # the CPU oracle dressed as the three _backend modules
+
+for name, be in (("_raymarching", ob.raymarching_backend), ("_gridencoder", ob.gridencoder_backend), ("_shencoder", ob.shencoder_backend)):
+    m = types.ModuleType(name)
+    m.__dict__.update(be.__dict__)
+    sys.modules[name] = m
+for name in ("cv2", "trimesh", "mcubes", "lpips", "tensorboardX", "torch_ema", "imageio", "IPython", "torch_efficient_distloss"):
+    sys.modules[name] = MagicMock()
+for k in list(sys.modules):
+    if k.split(".")[0] in ("gridencoder", "shencoder", "raymarching"):
+        sys.modules.pop(k)
+sys.path.insert(0, REF)
+from distill_mutual.network import NeRFNetwork as RefNet  # noqa: E402
+from distill_mutual import utils as ref_utils  # noqa: E402
+import raymarching as ref_rm  # noqa: E402
+
+assert ref_rm.__file__.startswith(REF) and ref_utils.__file__.startswith(REF)
+# the reference's raymarching wrappers move their inputs with `.cuda()` (raymarching/raymarching.py:36, :221): there is no GPU
+# in this container and the operators underneath are the CPU oracle, so `.cuda()` is the identity for this run
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+N_RAYS, GRID, MAX_STEPS = 96, 16, 96
+RATES = dict(loss_rate_rgb=1.0, loss_rate_fea_sc=0.02, loss_rate_color=0.03, loss_rate_sigma=0.05)
+out = {}
+
+
+def make_args(student, stu_first=True):
+    a = dict(plenoxel_degree=3, plenoxel_res="[12,12,12]", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+             sigma_clip_min=-2, sigma_clip_max=7, global_step=0,
+             stage_iters={"stage1": -1 if student == "tensors" else 2000, "stage2": 5000},  # no feature head: main_distill_mutual.py:243-246
+             enable_edit_plenoxel=False, render_stu_first=stu_first, loss_type="normL2", l1_reg_weight=1e-3, model_type=student,
+             dt_gamma=0, max_steps=MAX_STEPS, **RATES)
+    return types.SimpleNamespace(**a)
+
+
+def occupancy():
+    """128-cell-wide would be 2 MB; a 16^3 grid: a ball of radius 0.62 plus a slab, in Morton order, packed to bits."""
+    import oracle
+    c = (np.arange(GRID) + 0.5) / GRID * 2 - 1
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    occ = (X ** 2 + Y ** 2 + Z ** 2 < 0.62 ** 2) | ((np.abs(Z + 0.7) < 0.1) & (np.abs(X) < 0.8))
+    idx = np.stack(np.nonzero(occ), axis=1).astype(np.int32)
+    mort = oracle.morton3D(idx) if hasattr(oracle, "morton3D") else None
+    if mort is None:
+        def part(v):
+            v = v.astype(np.uint32) & 0x3ff
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            v = (v | (v << 2)) & 0x09249249
+            return v
+        mort = part(idx[:, 0]) | (part(idx[:, 1]) << 1) | (part(idx[:, 2]) << 2)
+    bits = np.zeros(GRID ** 3, dtype=np.uint8)
+    bits[np.asarray(mort, dtype=np.int64)] = 1
+    return np.packbits(bits.reshape(-1, 8)[:, ::-1], axis=1).reshape(-1)  # bit k of byte j = cell 8 j + k
+
+
+def rays(rs):
+    o = rs.standard_normal((N_RAYS, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * rs.uniform(1.6, 2.4, size=(N_RAYS, 1))
+    target = rs.uniform(-0.7, 0.7, size=(N_RAYS, 3))
+    target[:6] = o[:6] * 1.5 + rs.standard_normal((6, 3))  # a few rays that miss the box
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o.astype(np.float32)[None], d.astype(np.float32)[None]
+
+
+def build(mt, args, is_teacher, seed):
+    torch.manual_seed(seed)
+    net = RefNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=GRID, model_type=mt, args=args, is_teacher=is_teacher)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "embeddings" in n:
+                torch.manual_seed(777)
+                p.copy_((torch.rand(p.shape) - 0.5) * 0.6)  # 42 MB: regenerated from this seed by the test, not stored
+            elif p.dim() >= 2:
+                p.mul_(3.0 if mt == "vm" and p.dim() == 4 else 1.6)
+    return net
+
+
+RefTrainer = ref_utils.Trainer
+rs = np.random.RandomState(5)
+ro, rd = rays(rs)
+images = rs.uniform(0, 1, size=(1, N_RAYS, 4)).astype(np.float32)  # 4 channels: the step draws a random background
+bitfield = torch.from_numpy(occupancy())
+out.update(rays_o=ro, rays_d=rd, images=images, bitfield=bitfield.numpy(), mean_count=np.int64(3000), grid_size=np.int64(GRID),
+           max_steps=np.int64(MAX_STEPS), l1_reg_weight=np.float64(1e-3))
+for k, v in RATES.items():
+    out[k] = np.float64(v)
+data = dict(rays_o=torch.from_numpy(ro), rays_d=torch.from_numpy(rd), images=torch.from_numpy(images))
+
+# (name, teacher, student, student renders first, stages)
+CASES = [("hash_vm", "hash", "vm", True, (1, 2, 3)),
+         ("hash_vm_teafirst", "hash", "vm", False, (3,)),      # renderer.py:392-411: the teacher marches, the student inherits
+         ("mlp_tensors", "mlp", "tensors", True, (2, 3)),       # configs[3]; stage 1 does not exist without a feature vector
+         ("hash_hash", "hash", "hash", True, (1, 3))]           # configs[4]
+GSTEP = {1: 100, 2: 3000, 3: 9000}
+out["cases"] = np.array([c[0] for c in CASES])
+for case, tea_type, stu_type, stu_first, stages in CASES:
+    args = make_args(stu_type, stu_first)
+    tea = build(tea_type, args, True, 11)
+    stu = build(stu_type, args, False, 12)
+    assert bitfield.numel() == stu.density_bitfield.numel()
+    for net in (tea, stu):
+        net.density_bitfield.copy_(bitfield)
+        net.mean_count = 3000
+        net.train()  # (the reference trainer keeps both models in train mode during train_one_epoch; run_cuda branches on it)
+    out[case + "__cfg"] = np.array([tea_type, stu_type, str(int(stu_first))])
+    out[case + "__stages"] = np.array(stages)
+    for role, net in (("tea", tea), ("stu", stu)):
+        keys = []
+        for k, v in net.state_dict().items():
+            keys.append(k)
+            if "embeddings" not in k:
+                out["%s__%s_sd__%s" % (case, role, k)] = v.detach().numpy().copy()
+        out["%s__%s_keys" % (case, role)] = np.array(keys)
+    me = types.SimpleNamespace(model_stu=stu, model_tea=tea, model=stu, opt=args, error_map=None, criterion=torch.nn.MSELoss(reduction="none"))
+    me.get_loss = lambda pred, gt, me=me: RefTrainer.get_loss(me, pred, gt)
+    for stage in stages:
+        args.global_step = GSTEP[stage]
+        rate0 = args.loss_rate_fea_sc
+        for p in stu.parameters():
+            p.grad = None
+        torch.manual_seed(1000 + stage)
+        res = RefTrainer.train_step(me, data)
+        loss = res[2]
+        loss.backward()
+        pre = "%s__s%d__" % (case, stage)
+        out[pre + "global_step"] = np.int64(GSTEP[stage])
+        out[pre + "seed"] = np.int64(1000 + stage)
+        out[pre + "fea_rate_before"] = np.float64(rate0)
+        out[pre + "fea_rate_after"] = np.float64(args.loss_rate_fea_sc)
+        out[pre + "loss"] = np.float64(loss.item())
+        out[pre + "parts"] = np.array([float(x) for x in res[3:]], dtype=np.float64)  # rgb (mse, shown), fea, color, sigma
+        if res[0] is not None:
+            out[pre + "pred_stu"] = res[0].detach().numpy().copy()
+            out[pre + "pred_tea"] = res[1].detach().numpy().copy()
+        marcher = stu if stu_first else tea
+        out[pre + "samples"] = marcher.step_counter[(marcher.local_step - 1) % 16].numpy().copy()
+        for n, p in stu.named_parameters():
+            g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
+            if "embeddings" in n:  # 42 MB of mostly zeros: keep the non-zero rows
+                rows = g.abs().sum(1).nonzero().squeeze(1)
+                out[pre + "grad_rows__" + n] = rows.numpy()
+                out[pre + "grad_vals__" + n] = g[rows].numpy().copy()
+            else:
+                out[pre + "grad__" + n] = g.numpy().copy()
+        print(case, "stage", stage, "loss", loss.item(), "parts", res[3:], "samples", out[pre + "samples"], "fea rate", rate0, "->", args.loss_rate_fea_sc)
+
+np.savez_compressed(os.path.join(HERE, "reference_step.npz"), **out)
+print("wrote reference_step.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "reference_step.npz")), "bytes")

@@ -1,0 +1,109 @@
+"""The REFERENCE's own distillation step -- `Trainer.train_step` (distill_mutual/utils.py:954-1189) over `run_cuda`
+(distill_mutual/renderer.py:319-448) of two of its `NeRFNetwork`s, run on the CPU in tests/golden/make_golden_step.py with the
+CPU oracle underneath as the native operators -- reproduced by this repo's renderer + DistillTrainer on the same rays, weights,
+occupancy grid and background draw: loss, the fea-rate decay, both rendered images and every gradient of the student, for
+
+    hash -> vm        stages 1, 2, 3   (the bench's pair, BASELINE configs[2])
+    hash -> vm        stage 3 with the TEACHER marching first (render_stu_first = False, renderer.py:392-411)
+    mlp  -> tensors   stages 2, 3      (configs[3]; no feature vector, so no stage 1)
+    hash -> hash      stages 1, 3      (configs[4])
+
+Pins the Python restatement of the path: stage gating, who marches / who inherits, density_scale, background mix, the four
+terms and their rates, the VM L1 term, autograd through the wrappers.  Kernel arithmetic is the oracle's on both sides."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_ops import oracle_ops
+from pvd.config import PVDConfig
+from pvd.trainer import DistillTrainer
+from pvd.workload import make_model
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_step.npz"), allow_pickle=False)
+CASES = [(str(c), int(s)) for c in G["cases"] for s in G[str(c) + "__stages"]]
+
+
+def config(case):
+    tea_type, stu_type, stu_first = [str(v) for v in G[case + "__cfg"]]
+    return PVDConfig(model_type=stu_type, teacher_type=tea_type, PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+                     plenoxel_res="[12,12,12]", grid_size=int(G["grid_size"]), density_thresh=10.0, fp16=False,
+                     stage_iters={"stage1": 2000, "stage2": 5000}, global_step=0, num_rays=G["rays_o"].shape[1],
+                     max_steps=int(G["max_steps"]), dt_gamma=0.0, loss_type="normL2", l1_reg_weight=float(G["l1_reg_weight"]),
+                     loss_rate_rgb=float(G["loss_rate_rgb"]), loss_rate_fea_sc=float(G["loss_rate_fea_sc"]),
+                     loss_rate_color=float(G["loss_rate_color"]), loss_rate_sigma=float(G["loss_rate_sigma"]),
+                     render_stu_first=stu_first == "1")
+
+
+def load(net, case, role):
+    sd = {}
+    for k in [str(k) for k in G["%s__%s_keys" % (case, role)]]:
+        if "embeddings" in k:
+            torch.manual_seed(777)  # the 42 MB table is regenerated, as in make_golden_step.py
+            sd[k] = (torch.rand(net.state_dict()[k].shape) - 0.5) * 0.6
+        else:
+            sd[k] = torch.from_numpy(G["%s__%s_sd__%s" % (case, role, k)])
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    net.density_bitfield.copy_(torch.from_numpy(G["bitfield"]))
+    net.mean_count = int(G["mean_count"])
+    net.note_occupancy_changed()
+
+
+_trainers = {}
+
+
+def trainer_of(case):
+    if case not in _trainers:
+        ops, opt, dev = oracle_ops(), config(case), torch.device("cpu")
+        torch.manual_seed(0)
+        tea = make_model(ops, opt, opt.teacher_type, True, dev)
+        stu = make_model(ops, opt, opt.model_type, False, dev)
+        load(tea, case, "tea"), load(stu, case, "stu")
+        _trainers[case] = DistillTrainer(opt, tea, stu, dev, fp16=False)
+    return _trainers[case]
+
+
+@pytest.mark.parametrize("case,stage", CASES)
+def test_distillation_step_matches_the_references_own_train_step(case, stage):
+    tr = trainer_of(case)
+    pre = "%s__s%d__" % (case, stage)
+    tr.global_step = tr.opt.global_step = int(G[pre + "global_step"])
+    tr.loss_rate_fea_sc = float(G[pre + "fea_rate_before"])
+    rays_o, rays_d = torch.from_numpy(G["rays_o"]), torch.from_numpy(G["rays_d"])
+    for p in tr.model_stu.parameters():
+        p.grad = None
+    tr.model_stu.train(), tr.model_tea.train()
+    torch.manual_seed(int(G[pre + "seed"]))
+    bg = torch.rand([1, rays_o.shape[1], 3], dtype=torch.float32)  # the step's random background (utils.py:989-996): first draw
+    loss, info, pred_stu, pred_tea = tr.compute_loss(rays_o, rays_d, bg)
+    loss.backward()
+    assert tr.loss_rate_fea_sc == pytest.approx(float(G[pre + "fea_rate_after"]), rel=1e-12)
+    marcher = tr.model_stu if tr.opt.render_stu_first else tr.model_tea
+    assert marcher.step_counter[(marcher.local_step - 1) % 16].tolist() == G[pre + "samples"].tolist()  # same samples, same rays kept
+    assert float(loss.detach()) == pytest.approx(float(G[pre + "loss"]), rel=2e-5), (float(loss.detach()), float(G[pre + "loss"]))
+    if stage == 3:
+        for got, name in ((pred_stu, "pred_stu"), (pred_tea, "pred_tea")):
+            np.testing.assert_allclose(got.detach().numpy().reshape(G[pre + name].shape), G[pre + name], rtol=0, atol=2e-6)
+    reached = 0
+    for n, p in tr.model_stu.named_parameters():
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
+        if "embeddings" in n:  # the fixture keeps the non-zero rows of the 42 MB table gradient
+            rows, ref = torch.from_numpy(G[pre + "grad_rows__" + n]), G[pre + "grad_vals__" + n]
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got[rows].numpy() - ref).max() <= 5e-5 * scale, (case, stage, n)
+            mask = torch.ones(got.shape[0], dtype=torch.bool)
+            mask[rows] = False
+            assert got[mask].abs().max().item() <= 5e-5 * scale, (case, stage, n)
+            reached += 1
+            continue
+        ref = G[pre + "grad__" + n]
+        got = got.numpy()
+        assert got.shape == ref.shape, n
+        scale = max(np.abs(ref).max(), 1e-12)
+        assert np.abs(got - ref).max() <= 5e-5 * scale, (case, stage, n, np.abs(got - ref).max(), scale)
+        reached += int(np.abs(ref).max() > 0)
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, (case, stage, n)  # a parameter the stage does not reach stays untouched
+    assert reached >= 1, reached
