@@ -178,5 +178,56 @@ for case, tea_type, stu_type, stu_first, stages in CASES:
                 out[pre + "grad__" + n] = g.numpy().copy()
         print(case, "stage", stage, "loss", loss.item(), "parts", res[3:], "samples", out[pre + "samples"], "fea rate", rate0, "->", args.loss_rate_fea_sc)
 
+# ---- occupancy-grid maintenance: the reference's own mark_untrained_grid / update_extra_state (renderer.py:561-775) of a hash
+# model, one and two cascades: full sweeps (iter_density < 16), partial updates (uniform + occupied cells), the EMA maximum, the
+# mean / threshold, packbits, and the refresh of mean_count from the step counter -- torch's generator seeded before each call
+for bound in (1, 2):
+    args = make_args("hash")
+    torch.manual_seed(21)
+    net = RefNet(encoding="hashgrid", bound=bound, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=GRID, model_type="hash", args=args, is_teacher=True)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "embeddings" in n:
+                torch.manual_seed(777)
+                p.copy_((torch.rand(p.shape) - 0.5) * 0.6)
+            elif p.dim() >= 2:
+                p.mul_(1.6)
+    pre = "occ_b%d__" % bound
+    keys = []
+    for k, v in net.state_dict().items():
+        keys.append(k)
+        if "embeddings" not in k:
+            out[pre + "sd__" + k] = v.detach().numpy().copy()
+    out[pre + "keys"] = np.array(keys)
+    poses = np.stack([ref_utils.nerf_matrix_to_ngp(ref_utils.pose_spherical(th, ph, 4.0), scale=0.8)
+                      for th, ph in ((30.0, -20.0), (-100.0, -35.0), (170.0, -5.0))]).astype(np.float32)
+    intrinsic = np.array([1111.1, 1111.1, 400.0, 400.0])
+    out[pre + "poses"], out[pre + "intrinsic"] = poses, intrinsic
+    net.mark_untrained_grid(poses, intrinsic)
+    out[pre + "marked"] = net.density_grid.numpy().copy()
+    calls = []
+    for i, (it, counts) in enumerate(((0, None), (1, [(700, 96), (900, 96), (650, 90)]), (16, None), (17, [(1200, 96)] * 16))):
+        net.iter_density = it
+        if counts is not None:  # the marcher filled these slots of the step counter since the last update
+            net.step_counter.zero_()
+            for j, c in enumerate(counts):
+                net.step_counter[j, 0], net.step_counter[j, 1] = c
+            net.local_step = len(counts)
+        torch.manual_seed(500 + i)
+        net.update_extra_state()
+        c = pre + "u%d__" % i
+        out[c + "iter_density"] = np.int64(it)
+        out[c + "seed"] = np.int64(500 + i)
+        out[c + "counts"] = np.array(counts if counts is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+        out[c + "grid"] = net.density_grid.numpy().copy()
+        out[c + "bitfield"] = net.density_bitfield.numpy().copy()
+        out[c + "mean_density"] = np.float64(net.mean_density)
+        out[c + "mean_count"] = np.int64(net.mean_count)
+        calls.append(i)
+        print("occupancy bound", bound, "call", i, "iter", it, "mean density", net.mean_density, "occupied", int((net.density_grid > 0).sum()),
+              "bits", int(np.unpackbits(net.density_bitfield.numpy()).sum()), "mean_count", net.mean_count)
+    out[pre + "calls"] = np.array(calls)
+
 np.savez_compressed(os.path.join(HERE, "reference_step.npz"), **out)
 print("wrote reference_step.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "reference_step.npz")), "bytes")
