@@ -172,11 +172,59 @@ for case, tea_type, stu_type, stu_first, stages in CASES:
             g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
             if "embeddings" in n:  # 42 MB of mostly zeros: keep the non-zero rows
                 rows = g.abs().sum(1).nonzero().squeeze(1)
-                out[pre + "grad_rows__" + n] = rows.numpy()
+                out[pre + "grad_rows__" + n] = rows.numpy().astype(np.int32)
                 out[pre + "grad_vals__" + n] = g[rows].numpy().copy()
             else:
                 out[pre + "grad__" + n] = g.numpy().copy()
         print(case, "stage", stage, "loss", loss.item(), "parts", res[3:], "samples", out[pre + "samples"], "fea rate", rate0, "->", args.loss_rate_fea_sc)
+
+# ---- the reference's teacher-training step (just_train_tea/utils.py:746-846 over just_train_tea/renderer.py's run_cuda): one
+# model, MSE against alpha-composited ground-truth pixels on a random background, plus the VM L1 term for a VM model
+from just_train_tea.network import NeRFNetwork as TeaNet  # noqa: E402
+from just_train_tea import utils as tea_utils  # noqa: E402
+
+assert tea_utils.__file__.startswith(REF)
+out["teacher_cases"] = np.array(["teacher_hash", "teacher_vm"])
+for case, mt in (("teacher_hash", "hash"), ("teacher_vm", "vm")):
+    args = make_args(mt)
+    args.just_train_a_model, args.color_space = True, "srgb"
+    torch.manual_seed(31)
+    net = TeaNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=GRID, model_type=mt, args=args, is_teacher=False)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "embeddings" in n:
+                torch.manual_seed(777)
+                p.copy_((torch.rand(p.shape) - 0.5) * 0.6)
+            elif p.dim() >= 2:
+                p.mul_(3.0 if mt == "vm" and p.dim() == 4 else 1.6)
+    net.density_bitfield.copy_(bitfield)
+    net.mean_count = 3000
+    net.train()
+    keys = []
+    for k, v in net.state_dict().items():
+        keys.append(k)
+        if "embeddings" not in k:
+            out["%s__sd__%s" % (case, k)] = v.detach().numpy().copy()
+    out[case + "__keys"] = np.array(keys)
+    me = types.SimpleNamespace(model_stu=net, model_tea=None, model=net, opt=args, criterion=torch.nn.MSELoss(reduction="none"))
+    torch.manual_seed(2000)
+    loss, pred, gt = tea_utils.Trainer.train_step(me, dict(rays_o=torch.from_numpy(ro), rays_d=torch.from_numpy(rd), images=torch.from_numpy(images.copy())))
+    loss.backward()
+    pre = case + "__"
+    out[pre + "seed"] = np.int64(2000)
+    out[pre + "loss"] = np.float64(loss.item())
+    out[pre + "pred"], out[pre + "gt"] = pred.detach().numpy().copy(), gt.detach().numpy().copy()
+    out[pre + "samples"] = net.step_counter[(net.local_step - 1) % 16].numpy().copy()
+    for n, p in net.named_parameters():
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
+        if "embeddings" in n:
+            rows = g.abs().sum(1).nonzero().squeeze(1)
+            out[pre + "grad_rows__" + n] = rows.numpy().astype(np.int32)
+            out[pre + "grad_vals__" + n] = g[rows].numpy().copy()
+        else:
+            out[pre + "grad__" + n] = g.numpy().copy()
+    print(case, "loss", loss.item(), "samples", out[pre + "samples"])
 
 # ---- occupancy-grid maintenance: the reference's own mark_untrained_grid / update_extra_state (renderer.py:561-775) of a hash
 # model, one and two cascades: full sweeps (iter_density < 16), partial updates (uniform + occupied cells), the EMA maximum, the

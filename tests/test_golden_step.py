@@ -90,7 +90,7 @@ def test_distillation_step_matches_the_references_own_train_step(case, stage):
     for n, p in tr.model_stu.named_parameters():
         got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
         if "embeddings" in n:  # the fixture keeps the non-zero rows of the 42 MB table gradient
-            rows, ref = torch.from_numpy(G[pre + "grad_rows__" + n]), G[pre + "grad_vals__" + n]
+            rows, ref = torch.from_numpy(G[pre + "grad_rows__" + n]).long(), G[pre + "grad_vals__" + n]
             scale = max(np.abs(ref).max(), 1e-12)
             assert np.abs(got[rows].numpy() - ref).max() <= 5e-5 * scale, (case, stage, n)
             mask = torch.ones(got.shape[0], dtype=torch.bool)
@@ -107,3 +107,54 @@ def test_distillation_step_matches_the_references_own_train_step(case, stage):
         if np.abs(ref).max() == 0:
             assert np.abs(got).max() == 0, (case, stage, n)  # a parameter the stage does not reach stays untouched
     assert reached >= 1, reached
+
+
+@pytest.mark.parametrize("case", [str(c) for c in G["teacher_cases"]])
+def test_teacher_training_step_matches_the_references_own_train_step(case):
+    """just_train_tea/utils.py:746-846 over just_train_tea/renderer.py's run_cuda, run on the CPU by make_golden_step.py: one model,
+    MSE against alpha-composited pixels on a random background (+ the VM L1 term), reproduced by TeacherTrainer's step body."""
+    from pvd.trainer import TeacherTrainer
+    mt = case.split("_")[1]
+    opt = PVDConfig(model_type=mt, teacher_type=mt, PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+                    plenoxel_res="[12,12,12]", grid_size=int(G["grid_size"]), density_thresh=10.0, fp16=False, num_rays=G["rays_o"].shape[1],
+                    max_steps=int(G["max_steps"]), dt_gamma=0.0, l1_reg_weight=float(G["l1_reg_weight"]), stage_iters={"stage1": -1, "stage2": -1})
+    dev = torch.device("cpu")
+    torch.manual_seed(0)
+    net = make_model(oracle_ops(), opt, mt, False, dev, teacher_variant=True)
+    sd = {}
+    for k in [str(k) for k in G[case + "__keys"]]:
+        if "embeddings" in k:
+            torch.manual_seed(777)
+            sd[k] = (torch.rand(net.state_dict()[k].shape) - 0.5) * 0.6
+        else:
+            sd[k] = torch.from_numpy(G["%s__sd__%s" % (case, k)])
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    net.density_bitfield.copy_(torch.from_numpy(G["bitfield"]))
+    net.mean_count = int(G["mean_count"])
+    net.note_occupancy_changed()
+    net.train()
+    tr = TeacherTrainer(opt, net, dev, fp16=False)
+    images = torch.from_numpy(G["images"])
+    torch.manual_seed(int(G[case + "__seed"]))
+    bg = torch.rand_like(images[..., :3])  # pixel-wise random background: the step's first draw (just_train_tea/utils.py:782)
+    gt = images[..., :3] * images[..., 3:] + bg * (1 - images[..., 3:])
+    np.testing.assert_allclose(gt.numpy(), G[case + "__gt"], rtol=0, atol=1e-7)
+    loss, pred = tr._block_body([(torch.from_numpy(G["rays_o"]), torch.from_numpy(G["rays_d"]), gt, bg)])()
+    loss.backward()
+    assert net.step_counter[(net.local_step - 1) % 16].tolist() == G[case + "__samples"].tolist()
+    np.testing.assert_allclose(pred.detach().numpy().reshape(G[case + "__pred"].shape), G[case + "__pred"], rtol=0, atol=2e-6)
+    assert float(loss.detach()) == pytest.approx(float(G[case + "__loss"]), rel=2e-5)
+    for n, p in net.named_parameters():
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
+        if "embeddings" in n:
+            rows, ref = torch.from_numpy(G[case + "__grad_rows__" + n]).long(), G[case + "__grad_vals__" + n]
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got[rows].numpy() - ref).max() <= 5e-5 * scale, (case, n)
+            mask = torch.ones(got.shape[0], dtype=torch.bool)
+            mask[rows] = False
+            assert got[mask].abs().max().item() <= 5e-5 * scale, (case, n)
+            continue
+        ref = G[case + "__grad__" + n]
+        scale = max(np.abs(ref).max(), 1e-12)
+        assert np.abs(got.numpy() - ref).max() <= 5e-5 * scale, (case, n, np.abs(got.numpy() - ref).max(), scale)
