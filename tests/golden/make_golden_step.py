@@ -177,6 +177,36 @@ for case, tea_type, stu_type, stu_first, stages in CASES:
             else:
                 out[pre + "grad__" + n] = g.numpy().copy()
         print(case, "stage", stage, "loss", loss.item(), "parts", res[3:], "samples", out[pre + "samples"], "fea rate", rate0, "->", args.loss_rate_fea_sc)
+    if case in ("hash_vm", "mlp_tensors"):
+        # ---- the inference branch of run_cuda (renderer.py:450-543: rounds of march_rays / composite_rays / compact_rays over the
+        # alive rays, n_step = clamp(N // n_alive, 1, 8)) of both models, white background, no perturbation
+        for role, net in (("tea", tea), ("stu", stu)):
+            net.eval()
+            with torch.no_grad():
+                res = net.render(data["rays_o"], data["rays_d"], staged=False, bg_color=None, perturb=False, **vars(args))
+            out["%s__eval_%s_image" % (case, role)] = res["image"].numpy().copy()
+            out["%s__eval_%s_depth" % (case, role)] = res["depth"].numpy().copy()
+            net.train()
+            print(case, "eval", role, "image mean", float(res["image"].mean()), "depth mean", float(res["depth"].mean()))
+    if case == "hash_vm":
+        # ---- VM utilities of the reference network: density_loss (network.py:549-558), upsample_model (:560-587), and the
+        # optimizer's parameter groups of every model type (get_params, :646-700) as (lr, parameter names)
+        out["vm__density_loss"] = np.float64(stu.density_loss().item())
+        stu.upsample_model([20, 16, 24])
+        out["vm__upsampled_to"] = np.array([20, 16, 24])
+        for k, v in stu.state_dict().items():
+            if "_mat." in k or "_vec." in k:
+                out["vm__up__" + k] = v.detach().numpy().copy()
+        out["vm__density_loss_up"] = np.float64(stu.density_loss().item())
+
+for mt in ("hash", "mlp", "vm", "tensors"):
+    net = build(mt, make_args(mt), False, 5)
+    names = {id(p): n for n, p in net.named_parameters()}
+    groups = []
+    for g in net.get_params(0.02):
+        groups.append("%r|%s" % (float(g["lr"]), ",".join(names[id(p)] for p in g["params"])))
+    out["groups__" + mt] = np.array(groups)
+    print("get_params", mt, [g.split("|")[0] for g in groups])
 
 # ---- the reference's teacher-training step (just_train_tea/utils.py:746-846 over just_train_tea/renderer.py's run_cuda): one
 # model, MSE against alpha-composited ground-truth pixels on a random background, plus the VM L1 term for a VM model

@@ -158,3 +158,51 @@ def test_teacher_training_step_matches_the_references_own_train_step(case):
         ref = G[case + "__grad__" + n]
         scale = max(np.abs(ref).max(), 1e-12)
         assert np.abs(got.numpy() - ref).max() <= 5e-5 * scale, (case, n, np.abs(got.numpy() - ref).max(), scale)
+
+
+@pytest.mark.parametrize("case", ["hash_vm", "mlp_tensors"])
+def test_inference_rounds_match_the_references_own_loop(case):
+    """The inference branch of run_cuda (renderer.py:450-543: rounds of march_rays / composite_rays / compact_rays over the rays
+    still alive) of both models of the pair, as the reference's own loop computed it on the CPU: image and depth per ray (rays that
+    miss the box have depth 0/0 there, and here)."""
+    tr = trainer_of(case)
+    rays_o, rays_d = torch.from_numpy(G["rays_o"]), torch.from_numpy(G["rays_d"])
+    for role, net in (("tea", tr.model_tea), ("stu", tr.model_stu)):
+        net.eval()
+        with torch.no_grad():
+            res = net.render(rays_o, rays_d, staged=False, bg_color=None, perturb=False, dt_gamma=0, max_steps=int(G["max_steps"]))
+        net.train()
+        ref_i, ref_d = G["%s__eval_%s_image" % (case, role)], G["%s__eval_%s_depth" % (case, role)]
+        np.testing.assert_allclose(res["image"].numpy().reshape(ref_i.shape), ref_i, rtol=0, atol=3e-6)
+        np.testing.assert_allclose(res["depth"].numpy().reshape(ref_d.shape), ref_d, rtol=1e-5, atol=3e-6, equal_nan=True)
+        assert np.isnan(ref_d).any() and np.isfinite(ref_d).sum() > 60
+
+
+def test_vm_utilities_and_parameter_groups_match_the_reference():
+    """density_loss (network.py:549-558), upsample_model (:560-587) of the reference's VM student, and the optimizer parameter
+    groups of all four model types (get_params, :646-700) as (lr, parameter names)."""
+    from pvd.checkpoint import upsample_vm
+    ops, opt, dev = oracle_ops(), config("hash_vm"), torch.device("cpu")
+    torch.manual_seed(0)
+    stu = make_model(ops, opt, "vm", False, dev)
+    load(stu, "hash_vm", "stu")
+    assert float(stu.density_loss().detach()) == pytest.approx(float(G["vm__density_loss"]), rel=1e-6)
+    upsample_vm(stu, [int(v) for v in G["vm__upsampled_to"]])
+    sd = stu.state_dict()
+    n = 0
+    for k in G.files:
+        if k.startswith("vm__up__"):
+            got = sd[k[len("vm__up__"):]].detach().numpy()
+            assert got.shape == G[k].shape, k
+            np.testing.assert_allclose(got, G[k], rtol=0, atol=1e-6)
+            n += 1
+    assert n >= 12, n  # 3 x (sigma_mat, sigma_vec, color_mat, color_vec) (+ basis_mat.weight: untouched)
+    assert float(stu.density_loss().detach()) == pytest.approx(float(G["vm__density_loss_up"]), rel=1e-6)
+    for mt in ("hash", "mlp", "vm", "tensors"):
+        o = PVDConfig(**{**opt.__dict__, "model_type": mt})
+        net = make_model(ops, o, mt, False, dev)
+        names = {id(p): n for n, p in net.named_parameters()}
+        groups = ["%r|%s" % (float(g["lr"]), ",".join(names[id(p)] for p in g["params"])) for g in net.get_params(0.02)]
+        groups = [g for g in groups if g.split("|")[1]]  # (the reference lists the parameter-free direction encoder as a group)
+        ref = [str(g) for g in G["groups__" + mt] if str(g).split("|")[1]]
+        assert groups == ref, (mt, groups, ref)
