@@ -71,6 +71,7 @@ def test_distillation_step_matches_the_references_own_train_step(case, stage):
     pre = "%s__s%d__" % (case, stage)
     tr.global_step = tr.opt.global_step = int(G[pre + "global_step"])
     tr.loss_rate_fea_sc = float(G[pre + "fea_rate_before"])
+    tr.rates[1] = tr.loss_rate_fea_sc  # (the rate the objective multiplies with lives next to the other three, on the device)
     rays_o, rays_d = torch.from_numpy(G["rays_o"]), torch.from_numpy(G["rays_d"])
     for p in tr.model_stu.parameters():
         p.grad = None
