@@ -54,12 +54,12 @@ RATES = dict(loss_rate_rgb=1.0, loss_rate_fea_sc=0.02, loss_rate_color=0.03, los
 out = {}
 
 
-def make_args(student, stu_first=True):
+def make_args(student, stu_first=True, dt_gamma=0):
     a = dict(plenoxel_degree=3, plenoxel_res="[12,12,12]", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
              sigma_clip_min=-2, sigma_clip_max=7, global_step=0,
              stage_iters={"stage1": -1 if student == "tensors" else 2000, "stage2": 5000},  # no feature head: main_distill_mutual.py:243-246
              enable_edit_plenoxel=False, render_stu_first=stu_first, loss_type="normL2", l1_reg_weight=1e-3, model_type=student,
-             dt_gamma=0, max_steps=MAX_STEPS, **RATES)
+             dt_gamma=dt_gamma, max_steps=MAX_STEPS, **RATES)
     return types.SimpleNamespace(**a)
 
 
@@ -85,6 +85,39 @@ def occupancy():
     return np.packbits(bits.reshape(-1, 8)[:, ::-1], axis=1).reshape(-1)  # bit k of byte j = cell 8 j + k
 
 
+def occupancy2():
+    """Two cascades (bound 2): the ball of `occupancy()` in the inner level, a thick shell 1.1 < |x| < 1.7 in the outer one."""
+    inner = np.unpackbits(occupancy().reshape(-1, 1), axis=1)[:, ::-1].reshape(-1)
+    c = ((np.arange(GRID) + 0.5) / GRID * 2 - 1) * 2
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
+    occ = (r > 1.1) & (r < 1.7) & (Z > -0.5)
+    idx = np.stack(np.nonzero(occ), axis=1).astype(np.uint32)
+
+    def part(v):
+        v = v & 0x3ff
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    mort = part(idx[:, 0]) | (part(idx[:, 1]) << 1) | (part(idx[:, 2]) << 2)
+    outer = np.zeros(GRID ** 3, dtype=np.uint8)
+    outer[mort.astype(np.int64)] = 1
+    bits = np.concatenate([inner, outer])
+    return np.packbits(bits.reshape(-1, 8)[:, ::-1], axis=1).reshape(-1)
+
+
+def save_table_grad(out, pre, name, g):
+    rows = g.abs().sum(1).nonzero().squeeze(1)
+    sub = rows[::7]
+    out[pre + "grad_rows__" + name] = sub.numpy().astype(np.int32)
+    out[pre + "grad_vals__" + name] = g[sub].numpy().copy()
+    out[pre + "grad_nrows__" + name] = np.int64(rows.numel())
+    out[pre + "grad_colsum__" + name] = g.double().sum(0).numpy()
+    out[pre + "grad_abssum__" + name] = np.float64(g.double().abs().sum().item())
+
+
 def rays(rs):
     o = rs.standard_normal((N_RAYS, 3))
     o = o / np.linalg.norm(o, axis=1, keepdims=True) * rs.uniform(1.6, 2.4, size=(N_RAYS, 1))
@@ -95,9 +128,9 @@ def rays(rs):
     return o.astype(np.float32)[None], d.astype(np.float32)[None]
 
 
-def build(mt, args, is_teacher, seed):
+def build(mt, args, is_teacher, seed, bound=1):
     torch.manual_seed(seed)
-    net = RefNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+    net = RefNet(encoding="hashgrid", bound=bound, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
                  grid_size=GRID, model_type=mt, args=args, is_teacher=is_teacher)
     with torch.no_grad():
         for n, p in net.named_parameters():
@@ -121,22 +154,31 @@ for k, v in RATES.items():
 data = dict(rays_o=torch.from_numpy(ro), rays_d=torch.from_numpy(rd), images=torch.from_numpy(images))
 
 # (name, teacher, student, student renders first, stages)
-CASES = [("hash_vm", "hash", "vm", True, (1, 2, 3)),
-         ("hash_vm_teafirst", "hash", "vm", False, (3,)),      # renderer.py:392-411: the teacher marches, the student inherits
-         ("mlp_tensors", "mlp", "tensors", True, (2, 3)),       # configs[3]; stage 1 does not exist without a feature vector
-         ("hash_hash", "hash", "hash", True, (1, 3))]           # configs[4]
+CASES = [("hash_vm", "hash", "vm", True, (1, 2, 3), 1, 0),
+         ("hash_vm_teafirst", "hash", "vm", False, (3,), 1, 0),      # renderer.py:392-411: the teacher marches, the student inherits
+         ("mlp_tensors", "mlp", "tensors", True, (2, 3), 1, 0),       # configs[3]; stage 1 does not exist without a feature vector
+         ("hash_hash", "hash", "hash", True, (1, 3), 1, 0),           # configs[4]
+         ("hash_hash_b2", "hash", "hash", True, (3,), 2, 1 / 256)]    # configs[4] as on Tanks&Temples: two cascades, growing step
 GSTEP = {1: 100, 2: 3000, 3: 9000}
 out["cases"] = np.array([c[0] for c in CASES])
-for case, tea_type, stu_type, stu_first, stages in CASES:
-    args = make_args(stu_type, stu_first)
-    tea = build(tea_type, args, True, 11)
-    stu = build(stu_type, args, False, 12)
-    assert bitfield.numel() == stu.density_bitfield.numel()
+bitfield2 = torch.from_numpy(occupancy2())
+out["bitfield2"] = bitfield2.numpy()
+ro2, rd2 = rays(np.random.RandomState(6))
+ro2 = (ro2 * 1.6).astype(np.float32)  # cameras outside the outer shell
+out.update(rays_o2=ro2, rays_d2=rd2)
+data2 = dict(rays_o=torch.from_numpy(ro2), rays_d=torch.from_numpy(rd2), images=torch.from_numpy(images))
+for case, tea_type, stu_type, stu_first, stages, bound, dt_gamma in CASES:
+    args = make_args(stu_type, stu_first, dt_gamma)
+    tea = build(tea_type, args, True, 11, bound)
+    stu = build(stu_type, args, False, 12, bound)
+    bf = bitfield if bound == 1 else bitfield2
+    data_c = data if bound == 1 else data2
+    assert bf.numel() == stu.density_bitfield.numel(), (bf.numel(), stu.density_bitfield.numel())
     for net in (tea, stu):
-        net.density_bitfield.copy_(bitfield)
+        net.density_bitfield.copy_(bf)
         net.mean_count = 3000
         net.train()  # (the reference trainer keeps both models in train mode during train_one_epoch; run_cuda branches on it)
-    out[case + "__cfg"] = np.array([tea_type, stu_type, str(int(stu_first))])
+    out[case + "__cfg"] = np.array([tea_type, stu_type, str(int(stu_first)), str(bound), repr(float(dt_gamma))])
     out[case + "__stages"] = np.array(stages)
     for role, net in (("tea", tea), ("stu", stu)):
         keys = []
@@ -153,7 +195,7 @@ for case, tea_type, stu_type, stu_first, stages in CASES:
         for p in stu.parameters():
             p.grad = None
         torch.manual_seed(1000 + stage)
-        res = RefTrainer.train_step(me, data)
+        res = RefTrainer.train_step(me, data_c)
         loss = res[2]
         loss.backward()
         pre = "%s__s%d__" % (case, stage)
@@ -170,20 +212,18 @@ for case, tea_type, stu_type, stu_first, stages in CASES:
         out[pre + "samples"] = marcher.step_counter[(marcher.local_step - 1) % 16].numpy().copy()
         for n, p in stu.named_parameters():
             g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
-            if "embeddings" in n:  # 42 MB of mostly zeros: keep the non-zero rows
-                rows = g.abs().sum(1).nonzero().squeeze(1)
-                out[pre + "grad_rows__" + n] = rows.numpy().astype(np.int32)
-                out[pre + "grad_vals__" + n] = g[rows].numpy().copy()
+            if "embeddings" in n:  # 42 MB of mostly zeros: every 7th non-zero row, the column sums and the non-zero row count
+                save_table_grad(out, pre, n, g)
             else:
                 out[pre + "grad__" + n] = g.numpy().copy()
         print(case, "stage", stage, "loss", loss.item(), "parts", res[3:], "samples", out[pre + "samples"], "fea rate", rate0, "->", args.loss_rate_fea_sc)
-    if case in ("hash_vm", "mlp_tensors"):
+    if case in ("hash_vm", "mlp_tensors", "hash_hash_b2"):
         # ---- the inference branch of run_cuda (renderer.py:450-543: rounds of march_rays / composite_rays / compact_rays over the
         # alive rays, n_step = clamp(N // n_alive, 1, 8)) of both models, white background, no perturbation
         for role, net in (("tea", tea), ("stu", stu)):
             net.eval()
             with torch.no_grad():
-                res = net.render(data["rays_o"], data["rays_d"], staged=False, bg_color=None, perturb=False, **vars(args))
+                res = net.render(data_c["rays_o"], data_c["rays_d"], staged=False, bg_color=None, perturb=False, **vars(args))
             out["%s__eval_%s_image" % (case, role)] = res["image"].numpy().copy()
             out["%s__eval_%s_depth" % (case, role)] = res["depth"].numpy().copy()
             net.train()
@@ -249,9 +289,7 @@ for case, mt in (("teacher_hash", "hash"), ("teacher_vm", "vm")):
     for n, p in net.named_parameters():
         g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
         if "embeddings" in n:
-            rows = g.abs().sum(1).nonzero().squeeze(1)
-            out[pre + "grad_rows__" + n] = rows.numpy().astype(np.int32)
-            out[pre + "grad_vals__" + n] = g[rows].numpy().copy()
+            save_table_grad(out, pre, n, g)
         else:
             out[pre + "grad__" + n] = g.numpy().copy()
     print(case, "loss", loss.item(), "samples", out[pre + "samples"])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_golden_step import CASES, G, config, load
+from test_golden_step import CASES, G, check_table_grad, config, load, rays_of
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +30,7 @@ def test_hip_distillation_step_matches_the_references_own_train_step(case, stage
     tr.global_step = tr.opt.global_step = int(G[pre + "global_step"])
     tr.loss_rate_fea_sc = float(G[pre + "fea_rate_before"])
     tr.rates[1] = tr.loss_rate_fea_sc  # (the rate the objective multiplies with lives next to the other three, on the device)
-    rays_o, rays_d = torch.from_numpy(G["rays_o"]).to(dev), torch.from_numpy(G["rays_d"]).to(dev)
+    rays_o, rays_d = [t.to(dev) for t in rays_of(case)]
     stu.train(), tea.train()
     tr._zero_grads()
     torch.manual_seed(int(G[pre + "seed"]))
@@ -47,12 +47,7 @@ def test_hip_distillation_step_matches_the_references_own_train_step(case, stage
     for n, p in stu.named_parameters():
         got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().cpu()
         if "embeddings" in n:
-            rows, ref = torch.from_numpy(G[pre + "grad_rows__" + n]).long(), G[pre + "grad_vals__" + n]
-            scale = max(np.abs(ref).max(), 1e-12)
-            assert np.abs(got[rows].numpy() - ref).max() <= 1e-3 * scale, (case, stage, n, np.abs(got[rows].numpy() - ref).max(), scale)
-            mask = torch.ones(got.shape[0], dtype=torch.bool)
-            mask[rows] = False
-            assert got[mask].abs().max().item() <= 1e-3 * scale, (case, stage, n)
+            check_table_grad(got, pre, n, 1e-3, (case, stage))
             continue
         ref = G[pre + "grad__" + n]
         assert tuple(got.shape) == ref.shape, n
