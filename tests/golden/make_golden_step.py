@@ -294,6 +294,56 @@ for case, mt in (("teacher_hash", "hash"), ("teacher_vm", "vm")):
             out[pre + "grad__" + n] = g.numpy().copy()
     print(case, "loss", loss.item(), "samples", out[pre + "samples"])
 
+# ---- configs[0]: the fixed-step sampler `run` (just_train_tea/renderer.py, the non-cuda_ray branch of render) of an `mlp` model:
+# uniform steps between the box intersections, perturbation, importance resampling through the reference's own sample_pdf, sort /
+# gather, alpha compositing by cumprod, depth, background mix -- all the reference's code.  Its `color()` asserts out before doing
+# anything (network.py:515-516), so for this run the masked colour query is the model's own forward on the selected rows (zeros
+# elsewhere), which is what the dead body computes.
+def masked_color(self, x, d, mask=None, **kwargs):
+    rgbs = torch.zeros(x.shape[0], 3, dtype=x.dtype, device=x.device)
+    if mask is None:
+        return self.forward(x, d)[1]
+    if mask.any():
+        rgbs[mask] = self.forward(x[mask], d[mask])[1].to(rgbs.dtype)
+    return rgbs
+
+
+args = make_args("mlp")
+args.just_train_a_model, args.color_space = True, "srgb"
+torch.manual_seed(41)
+net = TeaNet(encoding="hashgrid", bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+             grid_size=GRID, model_type="mlp", args=args, is_teacher=False)
+with torch.no_grad():
+    for n, p in net.named_parameters():
+        if p.dim() >= 2:
+            p.mul_(1.6)
+        if n == "sigma_net.1.weight":
+            p[0].add_(0.35)  # denser medium: compositing weights above the 1e-4 colour threshold on most rays
+net.color = types.MethodType(masked_color, net)
+keys = []
+for k, v in net.state_dict().items():
+    keys.append(k)
+    out["run_mlp__sd__" + k] = v.detach().numpy().copy()
+out["run_mlp__keys"] = np.array(keys)
+rs3 = np.random.RandomState(9)
+g_img = rs3.standard_normal((1, N_RAYS, 3)).astype(np.float32)
+g_dep = rs3.standard_normal((1, N_RAYS)).astype(np.float32)
+out.update(run_mlp__g_image=g_img, run_mlp__g_depth=g_dep, run_mlp__num_steps=np.int64(24), run_mlp__upsample_steps=np.int64(12))
+for mode, perturb, seed in (("train", True, 3000), ("eval", False, 3001)):
+    net.train(mode == "train")
+    for p in net.parameters():
+        p.grad = None
+    torch.manual_seed(seed)
+    res = net.render(torch.from_numpy(ro), torch.from_numpy(rd), staged=False, bg_color=None, perturb=perturb, num_steps=24, upsample_steps=12)
+    pre = "run_mlp__%s__" % mode
+    out[pre + "seed"] = np.int64(seed)
+    out[pre + "image"], out[pre + "depth"] = res["image"].detach().numpy().copy(), res["depth"].detach().numpy().copy()
+    if mode == "train":
+        (res["image"] * torch.from_numpy(g_img)).sum().backward()  # (depth is 0/0 on the rays that miss the box: left out of the objective)
+        for n, p in net.named_parameters():
+            out[pre + "grad__" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+    print("run()", mode, "image mean", float(res["image"].mean()), "min", float(res["image"].min()), "depth nan", int(torch.isnan(res["depth"]).sum()))
+
 # ---- occupancy-grid maintenance: the reference's own mark_untrained_grid / update_extra_state (renderer.py:561-775) of a hash
 # model, one and two cascades: full sweeps (iter_density < 16), partial updates (uniform + occupied cells), the EMA maximum, the
 # mean / threshold, packbits, and the refresh of mean_count from the step counter -- torch's generator seeded before each call

@@ -212,3 +212,38 @@ def test_vm_utilities_and_parameter_groups_match_the_reference():
         groups = [g for g in groups if g.split("|")[1]]  # (the reference lists the parameter-free direction encoder as a group)
         ref = [str(g) for g in G["groups__" + mt] if str(g).split("|")[1]]
         assert groups == ref, (mt, groups, ref)
+
+
+def test_fixed_step_sampler_matches_the_references_own_run():
+    """configs[0]: the reference's fixed-step sampler `run` (just_train_tea/renderer.py:139-317 shape) of an `mlp` model, run on the
+    CPU by make_golden_step.py with its dead `color()` replaced by the model's forward on the rows above the weight threshold:
+    uniform steps, perturbation and importance resampling (torch's generator consumed in the reference's order), sort / gather,
+    cumprod compositing, depth, white background -- train mode with gradients of every parameter, eval mode (deterministic
+    resampling)."""
+    opt = PVDConfig(model_type="mlp", teacher_type="mlp", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+                    plenoxel_res="[12,12,12]", grid_size=int(G["grid_size"]), density_thresh=10.0, fp16=False, cuda_ray=False,
+                    stage_iters={"stage1": -1, "stage2": -1})
+    torch.manual_seed(0)
+    net = make_model(oracle_ops(), opt, "mlp", False, torch.device("cpu"), teacher_variant=True)
+    sd = {k: torch.from_numpy(G["run_mlp__sd__" + k]) for k in [str(k) for k in G["run_mlp__keys"]]}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    rays_o, rays_d = torch.from_numpy(G["rays_o"]), torch.from_numpy(G["rays_d"])
+    T, t = int(G["run_mlp__num_steps"]), int(G["run_mlp__upsample_steps"])
+    for mode, perturb in (("train", True), ("eval", False)):
+        pre = "run_mlp__%s__" % mode
+        net.train(mode == "train")
+        for p in net.parameters():
+            p.grad = None
+        torch.manual_seed(int(G[pre + "seed"]))
+        res = net.render(rays_o, rays_d, staged=False, bg_color=None, perturb=perturb, num_steps=T, upsample_steps=t)
+        np.testing.assert_allclose(res["image"].detach().numpy(), G[pre + "image"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(res["depth"].detach().numpy(), G[pre + "depth"], rtol=1e-5, atol=2e-6, equal_nan=True)
+        if mode == "train":
+            (res["image"] * torch.from_numpy(G["run_mlp__g_image"])).sum().backward()
+            for n, p in net.named_parameters():
+                ref = G[pre + "grad__" + n]
+                got = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+                assert np.isfinite(ref).all(), n
+                scale = max(np.abs(ref).max(), 1e-12)
+                assert np.abs(got - ref).max() <= 5e-5 * scale, (n, np.abs(got - ref).max(), scale)
