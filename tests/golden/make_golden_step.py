@@ -30,6 +30,15 @@ import torch
 
 import oracle_backend as ob  # the CPU oracle dressed as the three _backend modules
 
+# this repo's own stack (for the reverse-direction checkpoint check below) is imported FIRST and bound to this repo's
+# `gridencoder` / `shencoder` / `raymarching` packages; those names are then handed over to the reference's packages
+from oracle_ops import oracle_ops as _our_oracle_ops  # noqa: E402
+from pvd.checkpoint import save_checkpoint as our_save_checkpoint, upsample_vm as our_upsample_vm  # noqa: E402
+from pvd.config import PVDConfig as OurConfig  # noqa: E402
+from pvd.workload import make_model as our_make_model  # noqa: E402
+
+OUR_OPS = _our_oracle_ops()
+
 for name, be in (("_raymarching", ob.raymarching_backend), ("_gridencoder", ob.gridencoder_backend), ("_shencoder", ob.shencoder_backend)):
     m = types.ModuleType(name)
     m.__dict__.update(be.__dict__)
@@ -143,6 +152,13 @@ def build(mt, args, is_teacher, seed, bound=1):
 
 
 RefTrainer = ref_utils.Trainer
+
+
+def tea_trainer():
+    from just_train_tea import utils as tu
+    return tu.Trainer
+
+
 rs = np.random.RandomState(5)
 ro, rd = rays(rs)
 images = rs.uniform(0, 1, size=(1, N_RAYS, 4)).astype(np.float32)  # 4 channels: the step draws a random background
@@ -228,6 +244,22 @@ for case, tea_type, stu_type, stu_first, stages, bound, dt_gamma in CASES:
             out["%s__eval_%s_depth" % (case, role)] = res["depth"].numpy().copy()
             net.train()
             print(case, "eval", role, "image mean", float(res["image"].mean()), "depth mean", float(res["depth"].mean()))
+    if case in ("hash_vm", "mlp_tensors"):
+        # ---- checkpoints written by the reference's own Trainer.save_checkpoint (utils.py:1405-1475 / just_train_tea's): the VM
+        # student of hash->vm as the distillation trainer saves it, the mlp teacher of mlp->tensors as the teacher trainer does
+        import tempfile
+        for trainer_cls, role, net, fname in ((RefTrainer, "stu", stu, "reference_ckpt_vm_student.pth"), (tea_trainer(), "tea", tea, "reference_ckpt_mlp_teacher.pth")):
+            if (case, role) not in (("hash_vm", "stu"), ("mlp_tensors", "tea")):
+                continue
+            net.mean_density = 0.125
+            with tempfile.TemporaryDirectory() as d:
+                saver = types.SimpleNamespace(name="ngp", epoch=7, global_step=4321, opt=types.SimpleNamespace(model_type=net.model_type),
+                                              stats={"loss": [0.5], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None},
+                                              model_stu=net, ckpt_path=d, max_keep_ckpt=2, ema=None)
+                trainer_cls.save_checkpoint(saver, name="golden")
+                import shutil
+                shutil.copy(os.path.join(d, "golden.pth"), os.path.join(HERE, fname))
+            print("checkpoint", fname, os.path.getsize(os.path.join(HERE, fname)), "bytes")
     if case == "hash_vm":
         # ---- VM utilities of the reference network: density_loss (network.py:549-558), upsample_model (:560-587), and the
         # optimizer's parameter groups of every model type (get_params, :646-700) as (lr, parameter names)
@@ -293,6 +325,48 @@ for case, mt in (("teacher_hash", "hash"), ("teacher_vm", "vm")):
         else:
             out[pre + "grad__" + n] = g.numpy().copy()
     print(case, "loss", loss.item(), "samples", out[pre + "samples"])
+
+# ---- the other direction: a checkpoint written by THIS repo (pvd/checkpoint.py, a VM student resampled to a non-cubic
+# resolution, channels-last tables in memory) read by the reference's own Trainer.load_student_checkpoint (utils.py:1529-1556) into
+# the reference's NeRFNetwork: no missing / unexpected key, and the reference's model then renders what this repo's model renders
+def reverse_direction():
+    import tempfile
+    save_checkpoint, upsample_vm, make_model = our_save_checkpoint, our_upsample_vm, our_make_model
+    opt = OurConfig(model_type="vm", teacher_type="hash", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
+                    plenoxel_res="[12,12,12]", grid_size=GRID, density_thresh=10.0, fp16=False, max_steps=MAX_STEPS)
+    torch.manual_seed(77)
+    mine = make_model(OUR_OPS, opt, "vm", False, torch.device("cpu"))
+    with torch.no_grad():
+        for n, p in mine.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0 if p.dim() == 4 else 1.6)
+    upsample_vm(mine, [14, 12, 16])
+    mine.density_bitfield.copy_(bitfield)
+    mine.mean_count, mine.mean_density = 2816, 0.3
+    mine.note_occupancy_changed()
+    logs = []
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "mine.pth")
+        save_checkpoint(path, mine, epoch=3, global_step=999)
+        a = make_args("vm")
+        ref = build("vm", a, False, 99)
+        loader = types.SimpleNamespace(opt=types.SimpleNamespace(ckpt_student=path, ckpt_teacher=None, model_type="vm"), model_stu=ref,
+                                       device="cpu", ema=None, log=lambda *m, **k: logs.append(" ".join(str(x) for x in m)))
+        RefTrainer.load_student_checkpoint(loader)
+    assert not any("WARN" in m for m in logs), logs
+    assert ref.mean_count == 2816 and list(ref.resolution) == [14, 12, 16], (ref.mean_count, ref.resolution)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        r = ref.render(data["rays_o"], data["rays_d"], staged=False, bg_color=None, perturb=False, **vars(a))["image"]
+        m = mine.render(data["rays_o"], data["rays_d"], staged=False, bg_color=None, perturb=False, dt_gamma=0, max_steps=MAX_STEPS)["image"]
+    err = float((r - m.view_as(r)).abs().max())
+    assert err <= 3e-6, err
+    out["reverse__logs"] = np.array(logs)
+    out["reverse__image_reference_model"], out["reverse__image_this_repo"] = r.numpy().copy(), m.numpy().copy()
+    print("reverse direction: reference loader took this repo's checkpoint:", logs, "max |image difference|", err)
+
+
+reverse_direction()
 
 # ---- configs[0]: the fixed-step sampler `run` (just_train_tea/renderer.py, the non-cuda_ray branch of render) of an `mlp` model:
 # uniform steps between the box intersections, perturbation, importance resampling through the reference's own sample_pdf, sort /

@@ -247,3 +247,43 @@ def test_fixed_step_sampler_matches_the_references_own_run():
                 assert np.isfinite(ref).all(), n
                 scale = max(np.abs(ref).max(), 1e-12)
                 assert np.abs(got - ref).max() <= 5e-5 * scale, (n, np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("fname,case,role", [("reference_ckpt_vm_student.pth", "hash_vm", "stu"), ("reference_ckpt_mlp_teacher.pth", "mlp_tensors", "tea")])
+def test_checkpoints_written_by_the_references_own_trainer_load_and_render(fname, case, role):
+    """.pth files written by the REFERENCE's `Trainer.save_checkpoint` (utils.py:1405-1475; just_train_tea's for the teacher) in
+    make_golden_step.py, read by this repo's loaders (pvd/checkpoint.py, the reference's strict=False rules): every key lands,
+    the bookkeeping comes along, and the loaded model renders the image the reference's model rendered (inference rounds)."""
+    from pvd.checkpoint import load_student_checkpoint, load_teacher_checkpoint
+    path = os.path.join(os.path.dirname(__file__), "golden", fname)
+    opt = config(case)
+    torch.manual_seed(123)  # (different initial weights: everything must come from the file)
+    mt = opt.model_type if role == "stu" else opt.teacher_type
+    net = make_model(oracle_ops(), opt, mt, role == "tea", torch.device("cpu"))
+    if role == "stu":
+        missing, unexpected = load_student_checkpoint(net, ckpt_teacher=None, ckpt_student=path)
+    else:
+        missing, unexpected = load_teacher_checkpoint(net, path)
+    assert not missing and not unexpected, (missing, unexpected)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 7 and ck["global_step"] == 4321 and ("resolution" in ck) == (mt == "vm")
+    assert net.mean_count == ck["mean_count"] == int(G["mean_count"]) and net.mean_density == pytest.approx(0.125)
+    np.testing.assert_array_equal(net.density_bitfield.numpy(), G["bitfield"])  # the occupancy grid travels in the state-dict
+    net.note_occupancy_changed()
+    rays_o, rays_d = rays_of(case)
+    net.eval()
+    with torch.no_grad():
+        res = net.render(rays_o, rays_d, staged=False, bg_color=None, perturb=False, dt_gamma=0, max_steps=int(G["max_steps"]))
+    ref = G["%s__eval_%s_image" % (case, role)]
+    np.testing.assert_allclose(res["image"].numpy().reshape(ref.shape), ref, rtol=0, atol=3e-6)
+
+
+def test_reverse_direction_record_the_reference_loader_took_this_repos_checkpoint():
+    """Recorded by make_golden_step.py (it can only run where the reference is): a VM student of THIS repo, resampled to a
+    non-cubic resolution and saved by pvd/checkpoint.py, was read by the reference's own `Trainer.load_student_checkpoint`
+    (utils.py:1529-1556) into the reference's `NeRFNetwork` without a missing / unexpected key, and the two models then rendered
+    the same image."""
+    logs = [str(m) for m in G["reverse__logs"]]
+    assert logs == ["[INFO] loaded student model."], logs
+    np.testing.assert_array_equal(G["reverse__image_reference_model"].reshape(-1), G["reverse__image_this_repo"].reshape(-1))
+    assert G["reverse__image_this_repo"].std() > 0.05
