@@ -197,3 +197,37 @@ def test_ray_dp_ranks_with_different_masks_fall_back_to_the_dense_exchange(tmp_p
     agreement check (size + checksum, all-reduced) makes ALL ranks use the dense all-reduce -- no mismatched collective."""
     _setup_paths()
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path / "skew.pt"), OPT_COMPACT, False, 1), nprocs=2, join=True)
+
+
+@pytest.mark.timeout(600)
+def test_ray_dp_with_the_teacher_marching_first(tmp_path):
+    """render_stu_first = False (utils.py:1020-1043, renderer.py:392-411): the TEACHER marches on its occupancy grid and the student
+    inherits the samples; the compact exchange then takes its footprint from the teacher's grid.  Two ranks against one process."""
+    _setup_paths()
+    opt = dict(OPT_COMPACT, render_stu_first=False)
+    out = str(tmp_path / "dpt.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, opt, True), nprocs=2, join=True)
+    dp_res = torch.load(out)
+    w = _make(opt)
+    base = _make(opt)
+    rays_o, rays_d, bg = base.next_batch()
+    tr, stu, tea = w.trainer, w.stu, w.tea
+    tr.opt.global_step = tr.global_step
+    tr.flat.zero_()
+    diffs = []
+    half = opt["num_rays"] // 2
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        o, d, b = rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous()
+        with torch.no_grad():
+            out_t = tea.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024)
+        out_s = stu.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False,
+                           inherited_params=out_t["inherited_params"], dt_gamma=0, max_steps=1024)
+        diffs.append(out_t["image"] - out_s["image"])
+    l_rgb = torch.norm(torch.cat(diffs, dim=1))
+    (l_rgb * tr.opt.loss_rate_rgb).backward()
+    assert abs(float(l_rgb.detach()) - dp_res["rgb"]) <= 1e-5 * abs(dp_res["rgb"]), (float(l_rgb), dp_res["rgb"])
+    flat = tr.flat.flat
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
