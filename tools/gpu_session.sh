@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 2: the evidence run (tests, smoke, bench line, rocprofv3 stats + PMC, the other workloads)
+# the evidence run (tests, smoke, bench line, rocprofv3 stats + launch populations + hardware queues + PMC, the other workloads);
+# TAG names the output directory under gpurun_out/, PMC=0 / RENDER=0 skip the counter passes / the render and fused-MLP lines
 TAG=${TAG:-r02final}
 PMC=${PMC:-1}   # 0: skip the counter passes (profiles/r02_pmc_traffic.json stays valid while the lookup kernels' sources are unchanged)
 OUT=gpurun_out/$TAG
@@ -21,7 +22,10 @@ timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cut -c1-30
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > /tmp/prof_b.log 2>&1)
 cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 python tools/step_timeline.py $(find /tmp/prof_b -name "*kernel_trace.csv" | head -1) "k_adamw(" 22 > $OUT/step_timeline.txt; tail -3 $OUT/step_timeline.txt
-tail -1 /tmp/prof_b.log > $OUT/bench_profiled_line.json
+T=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1)
+python tools/kernel_populations.py $T k_hash_fwd_fused > $OUT/kernel_populations.txt; python tools/kernel_populations.py $T k_vm_bwd_split >> $OUT/kernel_populations.txt; cat $OUT/kernel_populations.txt
+python tools/step_queues.py $T "k_adamw(" 22 > $OUT/step_queues.txt; tail -1 $OUT/step_queues.txt
+grep '^{' /tmp/prof_b.log | tail -1 > $OUT/bench_profiled_line.json
 [ "$PMC" = 1 ] && for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 5 --teacher-pretrain 20 --no-cpu-baseline --eager > /tmp/pmcs_$n.log 2>&1)
