@@ -63,10 +63,10 @@ RATES = dict(loss_rate_rgb=1.0, loss_rate_fea_sc=0.02, loss_rate_color=0.03, los
 out = {}
 
 
-def make_args(student, stu_first=True, dt_gamma=0):
+def make_args(student, stu_first=True, dt_gamma=0, teacher="hash"):
     a = dict(plenoxel_degree=3, plenoxel_res="[12,12,12]", PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32, resolution0=12,
              sigma_clip_min=-2, sigma_clip_max=7, global_step=0,
-             stage_iters={"stage1": -1 if student == "tensors" else 2000, "stage2": 5000},  # no feature head: main_distill_mutual.py:243-246
+             stage_iters={"stage1": -1 if "tensors" in (student, teacher) else 2000, "stage2": 5000},  # no feature head: main_distill_mutual.py:243-246
              enable_edit_plenoxel=False, render_stu_first=stu_first, loss_type="normL2", l1_reg_weight=1e-3, model_type=student,
              dt_gamma=dt_gamma, max_steps=MAX_STEPS, **RATES)
     return types.SimpleNamespace(**a)
@@ -174,7 +174,10 @@ CASES = [("hash_vm", "hash", "vm", True, (1, 2, 3), 1, 0),
          ("hash_vm_teafirst", "hash", "vm", False, (3,), 1, 0),      # renderer.py:392-411: the teacher marches, the student inherits
          ("mlp_tensors", "mlp", "tensors", True, (2, 3), 1, 0),       # configs[3]; stage 1 does not exist without a feature vector
          ("hash_hash", "hash", "hash", True, (1, 3), 1, 0),           # configs[4]
-         ("hash_hash_b2", "hash", "hash", True, (3,), 2, 1 / 256)]    # configs[4] as on Tanks&Temples: two cascades, growing step
+         ("hash_hash_b2", "hash", "hash", True, (3,), 2, 1 / 256),    # configs[4] as on Tanks&Temples: two cascades, growing step
+         ("hash_mlp", "hash", "mlp", True, (1, 3), 1, 0),             # a NeRF-MLP student (gradients through FreqEncoder + trunk)
+         ("vm_tensors", "vm", "tensors", True, (3,), 1, 0),           # a VM teacher
+         ("tensors_vm", "tensors", "vm", True, (3,), 1, 0)]           # a Plenoxel teacher (no feature vector on the teacher's side)
 GSTEP = {1: 100, 2: 3000, 3: 9000}
 out["cases"] = np.array([c[0] for c in CASES])
 bitfield2 = torch.from_numpy(occupancy2())
@@ -184,7 +187,7 @@ ro2 = (ro2 * 1.6).astype(np.float32)  # cameras outside the outer shell
 out.update(rays_o2=ro2, rays_d2=rd2)
 data2 = dict(rays_o=torch.from_numpy(ro2), rays_d=torch.from_numpy(rd2), images=torch.from_numpy(images))
 for case, tea_type, stu_type, stu_first, stages, bound, dt_gamma in CASES:
-    args = make_args(stu_type, stu_first, dt_gamma)
+    args = make_args(stu_type, stu_first, dt_gamma, tea_type)
     tea = build(tea_type, args, True, 11, bound)
     stu = build(stu_type, args, False, 12, bound)
     bf = bitfield if bound == 1 else bitfield2

@@ -6,7 +6,9 @@ occupancy grid and background draw: loss, the fea-rate decay, both rendered imag
     hash -> vm        stages 1, 2, 3   (the bench's pair, BASELINE configs[2])
     hash -> vm        stage 3 with the TEACHER marching first (render_stu_first = False, renderer.py:392-411)
     mlp  -> tensors   stages 2, 3      (configs[3]; no feature vector, so no stage 1)
-    hash -> hash      stages 1, 3      (configs[4])
+    hash -> hash      stages 1, 3      (configs[4]; and stage 3 with bound 2 / two cascades / dt_gamma 1/256)
+    hash -> mlp       stages 1, 3      (a NeRF-MLP student)
+    vm -> tensors, tensors -> vm       stage 3 (the other two teacher families)
 
 Pins the Python restatement of the path: stage gating, who marches / who inherits, density_scale, background mix, the four
 terms and their rates, the VM L1 term, autograd through the wrappers.  Kernel arithmetic is the oracle's on both sides."""
