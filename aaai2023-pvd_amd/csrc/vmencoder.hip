@@ -510,6 +510,9 @@ static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *
         tb.ms[k] = stride[2 * k];
         tb.vs[k] = stride[2 * k + 1];
         if (tb.ms[k] < dense[2 * k] || tb.vs[k] < dense[2 * k] || tb.ms[k] > 4096u || tb.vs[k] > 4096u) return PVD_ERR_INVALID;
+        // toff() returns a 32-bit ELEMENT offset: texels x stride of every plane and line must fit
+        for (int i = 0; i < 3; i++)
+            if ((uint64_t)tb.W[i] * tb.H[i] * tb.ms[k] >= (1ull << 32) || (uint64_t)tb.L[i] * tb.vs[k] >= (1ull << 32)) return PVD_ERR_UNSUPPORTED;
     }
     return PVD_OK;
 }

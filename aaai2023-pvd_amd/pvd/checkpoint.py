@@ -66,6 +66,9 @@ def upsample_vm(model, resolution):
 
 def _load_model(model, ckpt):
     """load_state_dict(strict=False), as both loaders do; returns (missing, unexpected)."""
+    # a flat optimizer's deferred decays are applied BEFORE the parameters are overwritten: a later flush would otherwise
+    # decay the freshly loaded rows by steps they never took
+    getattr(model, "_pvd_flush_params", lambda: None)()
     missing, unexpected = model.load_state_dict(ckpt["model"], strict=False)
     import sys
     hip = sys.modules.get("pvd_hip")  # derived caches (packed head weights, f16 table shadows) key on this

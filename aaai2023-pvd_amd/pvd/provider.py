@@ -125,8 +125,11 @@ def training_target(images, generator=None, bg_radius=-1):
     """Ground-truth pixels and the background they were blended over (reference train_step, utils.py:980-1001):
     RGB images train against a white background; RGBA images against a random colour per ray, blended by alpha."""
     C = images.shape[-1]
-    if C == 3 or bg_radius > 0:
-        return images[..., :3], 1
+    if C == 3:
+        return images, 1
+    if bg_radius > 0:  # a background model supplies the colour; the target is still blended by alpha, over white
+        # (bg_color = 1 and `gt = rgb * a + bg * (1 - a)` whenever C == 4: just_train_tea/utils.py:778-788, distill utils.py:1383)
+        return images[..., :3] * images[..., 3:] + (1 - images[..., 3:]), 1
     bg = torch.rand(images.shape[:-1] + (3,), dtype=images.dtype, device=images.device, generator=generator)
     gt = images[..., :3] * images[..., 3:] + bg * (1 - images[..., 3:])
     return gt, bg

@@ -404,6 +404,7 @@ class NeRFRenderer(nn.Module):
         (reference: renderer.py:647-775)."""
         if not self.cuda_ray:
             return
+        self._flush_deferred_updates()  # the density sweep reads table rows no training sample touches
         occ = getattr(self.ops, "occupancy", None)
         if occ is not None and self.density_grid.is_cuda:
             return self._update_extra_state_device(occ, decay)
@@ -515,8 +516,19 @@ class NeRFRenderer(nn.Module):
             return None
         return (self.sample_alloc, self._budget_dev)
 
+    def _flush_deferred_updates(self):
+        """A flat optimizer may hold deferred weight decay for table rows the training samples never touch
+        (FlatAdamW.flush, installed by the trainer as `_pvd_flush_params`).  Whoever reads tables OUTSIDE the training
+        samples -- the occupancy sweep, an evaluation render, a checkpoint -- brings them up to date first; free when
+        nothing is pending."""
+        fl = getattr(self, "_pvd_flush_params", None)
+        if fl is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            fl()
+
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """reference: render, renderer.py:777-814 (`staged` is ignored on the cuda_ray path)."""
+        if not self.training:
+            self._flush_deferred_updates()  # evaluation marches on this model's own grid, not the training marcher's
         if self.cuda_ray:
             return self.run_cuda(rays_o, rays_d, **kwargs)
         kwargs = {k: v for k, v in kwargs.items() if k in ("num_steps", "upsample_steps", "bg_color", "perturb")}

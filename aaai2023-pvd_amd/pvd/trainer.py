@@ -10,12 +10,21 @@ Ray data parallelism (new work, the reference has none -- tools/details.md:24): 
 its own rays against replicated models; one flat-bucket all-reduce (SUM) of the student gradient per
 step over RCCL/xGMI; norm-type losses are made global by all-reducing the sum of squares first.
 """
+import gc
 import math
-
 import os
 
 import torch
 import torch.distributed as dist
+
+
+def pvd_forked_graphs_ok():
+    """May a step be recorded as a hipGraph with two PARALLEL chains (next step's march / teacher forward forked next to
+    this step's scatter + update)?  Only when the HIP runtime spreads its streams over the number of hardware queues the
+    schedule was validated with (pvd_hip settles GPU_MAX_HW_QUEUES before the runtime starts, DESIGN section 6);
+    otherwise the steps are recorded back to back."""
+    import pvd_hip
+    return pvd_hip.forked_graphs_ok()
 
 
 def psnr(pred, truth):
@@ -100,12 +109,32 @@ class SegmentedCapture:
         self.graphs[-1].capture_end()
 
     def __enter__(self):
+        # as torch.cuda.graph.__enter__ does: collect garbage and return cached blocks BEFORE the capture begins, and keep the
+        # cyclic collector off while it is under way -- an earlier trainer's graphs (reference cycles: collected whenever the
+        # collector happens to run) would otherwise be destroyed, and their private pools released, in the middle of this
+        # capture.  PVD_CAPTURE_GC=0 restores the old behaviour (tools/flake_hunt.sh).
+        self._gc_was_enabled = None
         torch.cuda.synchronize()
+        if os.environ.get("PVD_CAPTURE_GC", "1") != "0":
+            gc.collect()
+            torch.cuda.empty_cache()
+            self._gc_was_enabled = gc.isenabled()
+            gc.disable()
         self._stream.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(self._stream)
         self._ctx.__enter__()
-        self._begin()
+        try:
+            self._begin()
+        except BaseException:
+            self._ctx.__exit__(None, None, None)
+            self._restore_gc()
+            raise
         return self
+
+    def _restore_gc(self):
+        if self._gc_was_enabled:
+            gc.enable()
+        self._gc_was_enabled = None
 
     def __exit__(self, exc_type, exc, tb):
         try:
@@ -113,6 +142,7 @@ class SegmentedCapture:
                 self._end()
         finally:
             self._ctx.__exit__(exc_type, exc, tb)
+            self._restore_gc()
         torch.cuda.current_stream().wait_stream(self._stream)
         return False
 
@@ -473,6 +503,19 @@ class _TrainerBase:
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         return self._static_out  # the warm-up steps above are real steps; the capture itself records without running
 
+    def _after_failed_capture(self):
+        """A recording that raised left nothing on the device (nothing runs while capturing) but may have left host-side
+        bookkeeping half way through a step: settle it before recording again."""
+        import traceback
+        traceback.print_exc()
+        torch.cuda.synchronize()
+        self.dp.capture = None
+        if self.flat_opt:
+            self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
+        for mdl in (getattr(self, "model_stu", None), self.model):
+            if mdl is not None and getattr(mdl, "_between_backwards", None) is not None:
+                mdl._between_backwards = None
+
     def replay(self):
         assert getattr(self, "_captured_occ_epoch", None) in (None, self._marching_model().occ_epoch), \
             "the occupancy grid changed since the step was captured (touched-row set is stale): capture again"
@@ -709,6 +752,10 @@ class DistillTrainer(_TrainerBase):
         stage = self._stage_of(self.global_step)
         assert self._stage_of(self.global_step + warm) == stage, \
             "capture_step: the %d warm-up steps cross a stage boundary (global_step %d); step eagerly past it first" % (warm, self.global_step)
+        # the pipelined recordings march ahead with the STUDENT (prefetch_march); when the teacher marches
+        # (render_stu_first = False) the touched-row set, the compact exchange and the cold bitmap belong to the teacher's
+        # grid, so those steps are recorded back to back through compute_loss, which honours the flag
+        stu_marches = bool(getattr(self.opt, "render_stu_first", True))
         if self.dp.enabled and self.dp.ingraph:
             # ONE graph for the whole step, both collectives recorded into it (no graph cuts, no eager calls per step); the
             # gradient exchange is then not overlapped with the next step's prefix -- a replayed child graph cannot be
@@ -716,33 +763,32 @@ class DistillTrainer(_TrainerBase):
             # overhead the three-graph form pays on every step
             try:
                 pipe = os.environ.get("PVD_DP_PIPELINE", "1")  # 0: off; 1: when there is more than one rank; 2: always (tests)
-                if stage == 3 and steps_per_graph > 1 and (pipe == "2" or (pipe == "1" and self.dp.world_size > 1)):
+                if stu_marches and stage == 3 and steps_per_graph > 1 and (pipe == "2" or (pipe == "1" and self.dp.world_size > 1)):
                     out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
                 else:
                     out = self.capture(body, steps_per_graph=steps_per_graph)
             except Exception:
-                import traceback
-                traceback.print_exc()
-                torch.cuda.synchronize()
-                self.dp.ingraph, self.dp.capture = False, None  # fall back to graphs cut at the collectives
-                return self.capture_step(batch_fn)
-        elif self.dp.enabled and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
+                self._after_failed_capture()
+                self.dp.ingraph = False  # fall back to graphs cut at the collectives
+                # (the failed attempt's warm-up steps were real steps and are not repeated; one step per chain)
+                out = self.capture(body, warmup=0, steps_per_graph=1)
+                self.capture_fallback = "segmented"
+        elif self.dp.enabled and stu_marches and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
             out = self._capture_pipelined(batch_fn, body)
-        elif not self.dp.enabled and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
+        elif not self.dp.enabled and stu_marches and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
             self._pipe_stream = torch.cuda.Stream()
             out = self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
         elif (not self.dp.enabled and stage == 3 and steps_per_graph > 1 and os.environ.get("PVD_PIPELINE_INGRAPH", "1") != "0"
-              and bool(getattr(self.opt, "render_stu_first", True))):
+              and stu_marches and pvd_forked_graphs_ok()):
             # single GPU, several steps per graph: the same fork -- next step's batch / march / teacher forward (ALU- and
             # latency-bound) recorded next to this step's table scatter + inf check + AdamW inside the one graph
             try:
                 out = self._capture_ingraph_pipelined(batch_fn, body, steps_per_graph)
             except Exception:
-                import traceback
-                traceback.print_exc()
-                torch.cuda.synchronize()
+                self._after_failed_capture()
                 self.pipelined_ingraph = False
-                out = self.capture(body, steps_per_graph=steps_per_graph)  # the same steps recorded back to back
+                self.capture_fallback = "back-to-back"
+                out = self.capture(body, warmup=0, steps_per_graph=steps_per_graph)  # the same steps recorded back to back (warm-ups done)
         else:
             out = self.capture(body, steps_per_graph=steps_per_graph)
         self._captured_stage = self._stage_of(self.global_step)
@@ -965,20 +1011,26 @@ class TeacherTrainer(_TrainerBase):
             with cap:
                 main = torch.cuda.current_stream()
                 marched = march(batches[0])
-                for k in range(K):
-                    self._zero_grads()
-                    self._static_out = loss_of(batches[k], marched)
-                    nxt = None
-                    if k + 1 < K:
-                        branch.wait_stream(main)
-                        with torch.cuda.stream(branch):
-                            nxt = march(batches[k + 1])
-                    self._backward(self._static_out[0])
-                    self._exchange()
-                    self._optimize()
-                    if nxt is not None:
-                        main.wait_stream(branch)
-                        marched = nxt
+                try:
+                    for k in range(K):
+                        self._zero_grads()
+                        self._static_out = loss_of(batches[k], marched)
+                        nxt = None
+                        if k + 1 < K:
+                            branch.wait_stream(main)
+                            with torch.cuda.stream(branch):
+                                nxt = march(batches[k + 1])
+                        self._backward(self._static_out[0])
+                        if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-back
+                            raise RuntimeError("forced failure inside the forked teacher block (PVD_TEST_FAIL_IN_CAPTURE)")
+                        self._exchange()
+                        self._optimize()
+                        if nxt is not None:
+                            main.wait_stream(branch)
+                            marched = nxt
+                except Exception:
+                    main.wait_stream(branch)  # a capture can only be ended with its forked work joined
+                    raise
         finally:
             self.dp.capture = None
         self._cap = cap
@@ -997,9 +1049,18 @@ class TeacherTrainer(_TrainerBase):
         assert m.cuda_ray and m.mean_count > 0 and self.global_step % o.update_extra_interval == 0
         m.fix_sample_alloc()
         self._block_batches = batches
-        if not self.dp.enabled and os.environ.get("PVD_TEACHER_PIPELINE", "1") != "0":
-            self._capture_block_pipelined(batches)
-        else:
+        self.pipelined_block = False
+        if not self.dp.enabled and os.environ.get("PVD_TEACHER_PIPELINE", "1") != "0" and pvd_forked_graphs_ok():
+            step0, local0 = self.global_step, m.local_step
+            try:
+                self._capture_block_pipelined(batches)
+            except Exception:
+                # the same join-and-fall-back DistillTrainer.capture_step has: the 16 steps recorded back to back (nothing ran
+                # during the failed recording, so the step counters are put back and no training step is lost or repeated)
+                self._after_failed_capture()
+                self.global_step, m.local_step = step0, local0
+                self.pipelined_block = False
+        if not self.pipelined_block:
             self.capture(self._block_body(batches), warmup=0, steps_per_graph=len(batches))
         self._block_alloc = m.sample_alloc
 

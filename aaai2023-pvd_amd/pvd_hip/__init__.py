@@ -14,9 +14,39 @@ Kernels are enqueued on torch's *current* stream of the tensor's device.
 """
 import ctypes
 import os
+import sys
 import types
 
+# ---- hardware queues.  A training step recorded as a hipGraph with two PARALLEL chains (the next step's march / teacher
+# forward forked next to this step's scatter + update) is validated with the HIP runtime spreading its streams over TWO
+# hardware queues (profiles/r02_hw_queues_ab.txt: at the runtime's default of 4, one process in ~25 replays the graph 50 %
+# slower; at 8 every process does; at 1 the forked graph does not run).  The runtime reads GPU_MAX_HW_QUEUES when it
+# starts, i.e. at the first HIP call of the process, so the package -- not a benchmark script -- settles it here, before
+# the library below is loaded and before torch touches the device.  A value the caller exported wins; if the runtime is
+# already up without one, the forked schedule is refused (forked_graphs_ok) and steps are recorded back to back.
+_HWQ = "GPU_MAX_HW_QUEUES"
+_torch_loaded = sys.modules.get("torch")
+if _HWQ in os.environ:
+    HW_QUEUES, HW_QUEUES_SOURCE = os.environ[_HWQ], "caller"
+elif _torch_loaded is not None and _torch_loaded.cuda.is_initialized():
+    HW_QUEUES, HW_QUEUES_SOURCE = None, "runtime started before pvd_hip was imported"
+else:
+    os.environ[_HWQ] = "2"
+    HW_QUEUES, HW_QUEUES_SOURCE = "2", "package default"
+
 import torch
+
+
+def forked_graphs_ok():
+    """True when hipGraphs with parallel chains may be recorded (see above); PVD_FORKED_GRAPHS=0/1 overrides."""
+    force = os.environ.get("PVD_FORKED_GRAPHS")
+    if force in ("0", "1"):
+        return force == "1"
+    try:
+        return HW_QUEUES is not None and int(HW_QUEUES) == 2
+    except ValueError:
+        return False
+
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PVD_HIP_LIB") or os.path.join(_PKG_ROOT, "libpvd_hip.so")  # PVD_HIP_LIB: an A/B build of the same ABI

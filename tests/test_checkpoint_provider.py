@@ -188,6 +188,9 @@ def test_blender_scene_reader(tmp_path, alpha):
     if alpha:
         a = b["images"][..., 3:]
         assert torch.allclose(gt, b["images"][..., :3] * a + bg * (1 - a)) and bg.shape == (1, 40, 3)
+        # with a background model: bg_color = 1, and the RGBA target is STILL blended by alpha (over white)
+        gt1, bg1 = training_target(b["images"], bg_radius=32.0)
+        assert bg1 == 1 and torch.allclose(gt1, b["images"][..., :3] * a + (1 - a))
     else:
         assert bg == 1 and torch.equal(gt, b["images"])
     # evaluation split: whole images, all rays in pixel order; trainval = both files

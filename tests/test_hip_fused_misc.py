@@ -614,3 +614,60 @@ def test_trainer_cold_bitmap_covers_only_unreachable_unregularised_groups():
     assert ((o.flat_p[:n][cold] != p0[:n][cold]) == live).all()  # decayed (AdamW's default weight decay), zeros stay zeros
     ratio = (o.flat_p[:n][cold][live] / p0[:n][cold][live]).double()
     assert (ratio < 1).all() and (ratio > 0.99).all() and float(ratio.max() - ratio.min()) < 1e-5  # one common decay factor per lr group
+
+
+def test_whole_table_readers_see_the_deferred_decay():
+    """FlatAdamW defers the weight decay of table rows no training sample touches.  Readers that go OUTSIDE the training
+    samples -- an evaluation render, checkpoint loading, update_extra_state's density sweep (DistillTrainer.train_step with
+    update_stu_extra) -- must find those rows decayed: after each of them nothing is pending, and the rows that were cold hold,
+    bit for bit, what the per-step decay (PVD_ADAMW_LAZY=0) leaves after the same sequence of calls."""
+    import os
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    from pvd.checkpoint import _load_model, checkpoint_dict
+    dev = torch.device("cuda:0")
+    runs = {}
+    for lazy in (True, False):
+        old = os.environ.get("PVD_ADAMW_LAZY")
+        os.environ["PVD_ADAMW_LAZY"] = "1" if lazy else "0"
+        try:
+            torch.manual_seed(0)
+            opt = PVDConfig(num_rays=1024, resolution0=96, iters=200)
+            w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0)
+            tr, o = w.trainer, w.trainer.optimizer
+            pending = lambda: o._lazy_logged if lazy else 1
+            for _ in range(3):
+                tr.train_step(*w.next_batch())
+            assert pending() >= 1
+            w.stu.eval()  # reader 1: an evaluation render (marches on the model's own grid)
+            with torch.no_grad():
+                b = w.next_batch()
+                w.stu.render(b[0][:, :64].contiguous(), b[1][:, :64].contiguous(), bg_color=1, perturb=False)
+            w.stu.train()
+            assert o._lazy_logged == 0
+            tr.train_step(*w.next_batch())
+            ck = checkpoint_dict(w.stu)  # (state_dict flushes too)
+            tr.train_step(*w.next_batch())
+            assert pending() >= 1
+            _load_model(w.stu, ck)  # reader 2: pending decays are applied BEFORE the rows are overwritten, not after
+            assert o._lazy_logged == 0
+            for k, v in w.stu.state_dict().items():
+                assert torch.equal(v.float().cpu(), ck["model"][k].float().cpu()), k
+            tr.train_step(*w.next_batch())
+            assert pending() >= 1
+            n4 = o.flat_p.numel() // 4
+            words = o._cold_bits.to(torch.int64) & 0xFFFFFFFF
+            cold = ((words[:, None] >> torch.arange(32, device=dev)) & 1).reshape(-1)[:n4].bool().repeat_interleave(4)
+            with torch.autocast("cuda", dtype=torch.float16):
+                w.stu.update_extra_state()  # reader 3: the sweep over the whole grid
+            assert o._lazy_logged == 0 and (not lazy or int(o._lazy[1][0]) == 0)
+            runs[lazy] = (cold, o.flat_p[:cold.numel()][cold].clone())
+        finally:
+            if old is None:
+                os.environ.pop("PVD_ADAMW_LAZY", None)
+            else:
+                os.environ["PVD_ADAMW_LAZY"] = old
+    (ca, pa), (cb, pb) = runs[True], runs[False]
+    assert ca.any() and torch.equal(ca, cb)  # the same rows are cold either way (the touched set comes from the frozen grid)
+    assert torch.equal(pa, pb)  # the decays deferred and flushed == applied step by step

@@ -12,12 +12,10 @@ from test_golden_step import CASES, G, check_table_grad, config, load, rays_of
 pytestmark = pytest.mark.gpu
 
 
-# the cases that have been through the GPU (MI355X, 9 passed); pairs added to the fixture later are CPU-only until a GPU session
-# has run them here
-ON_GPU = ("hash_vm", "hash_vm_teafirst", "mlp_tensors", "hash_hash", "hash_hash_b2")
+# every pair and stage of the fixture (all eight pairs: each student family, each teacher family, either marching order)
 
 
-@pytest.mark.parametrize("case,stage", [c for c in CASES if c[0] in ON_GPU])
+@pytest.mark.parametrize("case,stage", CASES)
 def test_hip_distillation_step_matches_the_references_own_train_step(case, stage):
     from pvd.ops import hip_ops
     from pvd.trainer import DistillTrainer

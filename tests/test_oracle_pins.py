@@ -113,36 +113,64 @@ def test_march_rays_train_invariants():
             assert np.array_equal(again[0], xyzs)
 
 
-def test_march_counts_match_bruteforce_fixed_step_walk():
-    """dt_gamma = 0, bound = 1: an independent numpy walk in float32 reproduces num_steps per ray."""
+def _bruteforce_walk(o, d, near, far, bits, t0):
+    """One ray, dt_gamma = 0, bound = 1, one cascade, H = 128: the reference's loop (raymarching.cu:430-481) restated in numpy
+    float32 scalar arithmetic, one operation at a time -- independent of oracle/pvd_oracle.c (no shared code, no lattice /
+    probe restructuring).  Returns the samples' (xyz, dt, t - last_t)."""
+    f32 = np.float32
+    dt = f32(2) * f32(1.7320508075688772) / f32(1024)
+    rd = f32(1) / d
+    t, last_t, out = f32(t0), f32(t0), []
+    while t < far and len(out) < 1024:
+        p = np.clip((np.float64(t) * d.astype(np.float64) + o).astype(np.float32), -1, 1)  # fmaf == exact product then ONE rounding
+        cell = np.clip((0.5 * (p.astype(np.float64) + 1.0).astype(np.float32).astype(np.float64) * 128).astype(np.float32), 0, 127).astype(np.int32)
+        m = int(oracle.morton3D(cell[None])[0])
+        if (bits[m // 8] >> (m % 8)) & 1:
+            t = f32(t + dt)
+            out.append((p.copy(), dt, f32(t - last_t)))
+            last_t = t
+        else:
+            sgn = np.copysign(f32(1), d).astype(np.float32)
+            face = ((cell.astype(np.float32) + f32(0.5) + f32(0.5) * sgn) * f32(1 / 128) * f32(2) - f32(1)).astype(np.float32)
+            tt = t + max(f32(0), ((face - p).astype(np.float32) * rd).astype(np.float32).min())
+            while True:
+                t = f32(t + dt)
+                if not t < tt:
+                    break
+    return out
+
+
+@pytest.mark.parametrize("perturb", [0, 1])
+def test_march_samples_match_bruteforce_fixed_step_walk(perturb):
+    """dt_gamma = 0, bound = 1: an independent numpy walk in float32 reproduces, per ray, num_steps AND every sample's
+    clamped position, dt and `t - last_t` (bit for bit), with and without the per-ray start jitter
+    t0 = near + dt_min * pcg32{42}.advance(n).next_float() (raymarching.cu:346-352; the generator is pinned by its published
+    known-answer vector above)."""
     o, d, bits, _ = _scene(256, 1)
     aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
     n, f = oracle.near_far_from_aabb(o, d, aabb, 0.2)
-    _, _, _, rays, _ = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n, f, 256 * 1024)
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, bits, 1.0, 1, 128, n, f, 256 * 1024, perturb=perturb)
     f32 = np.float32
     dt = f32(2) * f32(1.7320508075688772) / f32(1024)
+    checked = 0
     for ray in range(256):
         if f[ray] == np.finfo(np.float32).max:
             assert rays[ray, 2] == 0
             continue
-        t, cnt = f32(n[ray]), 0
-        rd = f32(1) / d[ray]
-        while t < f[ray] and cnt < 1024:
-            p = np.clip((np.float64(t) * d[ray].astype(np.float64) + o[ray]).astype(np.float32), -1, 1)  # fma == exact product then one rounding
-            cell = np.clip((0.5 * (p.astype(np.float64) + 1.0).astype(np.float32).astype(np.float64) * 128).astype(np.float32), 0, 127).astype(np.int32)
-            m = int(oracle.morton3D(cell[None])[0])
-            if (bits[m // 8] >> (m % 8)) & 1:
-                cnt += 1
-                t = f32(t + dt)
-            else:
-                sgn = np.copysign(f32(1), d[ray]).astype(np.float32)
-                face = ((cell.astype(np.float32) + f32(0.5) + f32(0.5) * sgn) * f32(1 / 128) * f32(2) - f32(1)).astype(np.float32)
-                tt = t + max(f32(0), ((face - p).astype(np.float32) * rd).astype(np.float32).min())
-                while True:
-                    t = f32(t + dt)
-                    if not t < tt:
-                        break
-        assert cnt == rays[ray, 2], ray
+        t0 = f32(n[ray])
+        if perturb:
+            _, noise = oracle.pcg32_stream(42, ray, 1)
+            t0 = f32(t0 + f32(dt * f32(noise[0])))
+        walk = _bruteforce_walk(o[ray], d[ray], n[ray], f[ray], bits, t0)
+        s, c = int(rays[ray, 1]), int(rays[ray, 2])
+        assert c == len(walk), ray
+        if c:
+            assert np.array_equal(xyzs[s:s + c], np.stack([w[0] for w in walk])), ray
+            assert np.array_equal(deltas[s:s + c, 0], np.array([w[1] for w in walk], np.float32)), ray
+            assert np.array_equal(deltas[s:s + c, 1], np.array([w[2] for w in walk], np.float32)), ray
+            assert np.array_equal(dirs[s:s + c], np.repeat(d[ray][None], c, 0))
+            checked += c
+    assert checked == int(counter[0]) and checked > 2000
 
 
 def test_march_overflow_rule():
@@ -577,7 +605,8 @@ def test_polar_from_ray_closed_form_sphere_hit():
     np.testing.assert_allclose(oracle.polar_from_ray(z3, ax, 2.0), [[-1, 0], [0, 0], [0, 0.5], [1, 0]], atol=1e-7)
 
 
-def test_fma_contraction_sensitivity_of_the_marcher_with_a_non_power_of_two_bound(tmp_path):
+@pytest.mark.parametrize("bound,C", [(1.5, 2), (3.0, 3), (2.0, 2), (1.0, 1)])
+def test_fma_contraction_sensitivity_of_the_marcher_with_a_non_power_of_two_bound(tmp_path, bound, C):
     """The canonical arithmetic fuses a product into an add only where the source says fmaf().  A CUDA
     build of the reference contracts more (nvcc -fmad=true): `x * mip_rbound + 1` and `(..) * mip_bound - x` in the marcher,
     which is exact for power-of-two bounds only.  How much can that matter?  The same oracle source built with
@@ -600,7 +629,7 @@ def test_fma_contraction_sensitivity_of_the_marcher_with_a_non_power_of_two_boun
         import pytest
         pytest.skip("this host cannot build the -mfma variant")
     rs = np.random.RandomState(5)
-    bound, C, H, N, M = 1.5, 2, 64, 3000, 3000 * 400
+    H, N, M = 64, 3000, 3000 * 400  # (bound, C): 1.5 and 3 are the non-power-of-two cases; 2 and 1 the controls
     # occupancy: a thick spherical shell in both cascades
     ax = (np.arange(H) + 0.5) / H * 2 - 1
     grid = np.zeros((C, H ** 3), np.float32)
@@ -608,12 +637,12 @@ def test_fma_contraction_sensitivity_of_the_marcher_with_a_non_power_of_two_boun
         b = min(2 ** c, bound)
         X, Y, Z = np.meshgrid(ax * b, ax * b, ax * b, indexing="ij")
         r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
-        occ = ((r > 0.45) & (r < 1.3)).astype(np.float32)
+        occ = ((r > 0.45 * min(bound, 1.5) / 1.5) & (r < 1.3 * bound / 1.5)).astype(np.float32)
         coords = np.stack(np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
         grid[c, oracle.morton3D(coords)] = occ.reshape(-1)
     bits = oracle.packbits(grid, 0.5)
     o = rs.standard_normal((N, 3)).astype(np.float32)
-    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 3.0
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * (3.0 * max(bound, 1.5) / 1.5)
     d = (-o + rs.standard_normal((N, 3)).astype(np.float32) * 0.6)
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
