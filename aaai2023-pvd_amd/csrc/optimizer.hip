@@ -53,6 +53,8 @@ struct AdamExtras {
     // groups: full wavefronts of warm groups instead of wavefronts in which the cold lanes idle
     const uint32_t *warm;
     uint32_t n_warm;
+    // two-part update (include/pvd_hip.h): the tail records {found_inf, step before, scale before, 0, lr used ...} here
+    float *snapshot;
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -75,6 +77,13 @@ __global__ void k_adamw_tail(float *__restrict__ step, float *__restrict__ found
                              float *__restrict__ scale, int32_t *__restrict__ tracker, double growth, double backoff, int32_t interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool inf = found_inf && found_inf[0] != 0.f;
+    if (ex.snapshot) {  // what the update above used, for the deferred part of a two-part update
+        ex.snapshot[0] = inf ? 1.f : 0.f;
+        ex.snapshot[1] = step[0];
+        ex.snapshot[2] = scale ? scale[0] : 1.f;
+        ex.snapshot[3] = 0.f;
+        for (uint32_t k = 0; k < n_segments; k++) ex.snapshot[4 + k] = scheduled_lr(ex, lr, k);
+    }
     if (!inf) step[0] += 1.0f;
     if (ex.sched_kind != 0)
         for (uint32_t k = 0; k < n_segments; k++) lr[k] = scheduled_lr(ex, lr, k);
@@ -350,7 +359,8 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
+    const float *replay = nullptr;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
         if (h.sched_kind < 0 || h.sched_kind > 2) return PVD_ERR_UNSUPPORTED;
@@ -372,8 +382,21 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
             if ((h.g16_begin & 3u) || (h.g16_end & 3u) || h.g16_end < h.g16_begin || h.g16_end > n) return PVD_ERR_UNSUPPORTED;
             ex.g16 = (const _Float16 *)h.g16; ex.g16_begin = h.g16_begin; ex.g16_end = h.g16_end;
         }
+        ex.snapshot = h.snapshot;
+        replay = h.replay;
+        if (replay && (!ex.warm || h.snapshot || h.g16)) return PVD_ERR_INVALID;  // the deferred part walks a list and records nothing
     }
     hipStream_t s = (hipStream_t)stream;
+    if (replay) {
+        // the deferred part: the scalars of the recorded step (found_inf, step count, scale, learning rates as published), no tail
+        ex.sched_kind = 0;
+        uint64_t blocks_a = ((uint64_t)ex.n_warm + kOptBlock - 1) / kOptBlock;
+        if (blocks_a > 256 * 16) blocks_a = 256 * 16;
+        if (blocks_a < 1) blocks_a = 1;
+        hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks_a), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, replay + 4, beta1, beta2, eps, weight_decay,
+                           replay + 1, grad_scale ? replay + 2 : nullptr, replay, ex);
+        return check_launch();
+    }
     uint64_t blocks = ((ex.warm ? (uint64_t)ex.n_warm : n / 4) + kOptBlock - 1) / kOptBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
@@ -453,7 +476,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

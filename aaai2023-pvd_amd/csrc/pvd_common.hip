@@ -8,7 +8,7 @@ void set_last_error(hipError_t e) { g_last_error = e; }
 
 extern "C" {
 
-int pvd_abi_version(void) { return 1; }
+int pvd_abi_version(void) { return 2; }  // 2: pvd_adamw_extras gained snapshot / replay
 
 const char *pvd_status_string(int status) {
     switch (status) {

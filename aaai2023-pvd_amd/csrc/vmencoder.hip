@@ -374,11 +374,16 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     for (uint32_t m = s0; m < s1; m++) {
         const SampleTaps st = bcast_sample(pre, m - s0);
         float sig = 0.f;
+        // all three factor sets move their windows FIRST (the entering texels' loads of all sets are in flight together: one
+        // memory round trip per sample), then the products are formed; with move and product interleaved per set the wave
+        // waited for three round trips in a row -- it has few companions on its SIMD to hide them
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            walk_move<false>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, nullptr, tb.vec[kind][i] + ch, nullptr, (int)tb.W[i], (int)tb.H[i],
+                             (int)tb.L[i], R, Rv);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const Tap1 tx = st.ax[kM0[i]], ty = st.ax[kM1[i]], tl = st.ax[kV[i]];
-            walk_move<false>(pw[i], lw[i], st, i, tb.mat[kind][i] + ch, nullptr, tb.vec[kind][i] + ch, nullptr, (int)tb.W[i], (int)tb.H[i],
-                             (int)tb.L[i], R, Rv);
             const float prod = plane_value(pw[i], tx, ty) * line_value(lw[i], tl);
             if (kind) color_prod[(size_t)m * (3 * kRc) + i * kRc + ch] = (T)prod;
             else sig += prod;

@@ -51,6 +51,62 @@ class FlatAdamW(torch.optim.Optimizer):
         for k, g in enumerate(self.param_groups):
             g["lr"] = self.lr_dev[k:k + 1]  # LRScheduler.step() fills tensor lrs in place
 
+    # ---- two-part update (pvd_adamw_extras.snapshot / replay): set by the trainer while it records a pipelined multi-step graph
+    two_part = False      # step() updates part B (+ tail) and owes part A
+    defer_part_a = False  # ... and leaves it to the caller to run it (run_part_a) where it overlaps latency-bound kernels
+    _part_a_owed = None
+    _snapshot = None
+
+    @torch.no_grad()
+    def run_part_a(self):
+        """The owed second part of a two-part update (no-op when nothing is owed): the groups whose gradient is structurally zero,
+        with the scalars of the step that owes them.  Launched on the CURRENT stream."""
+        owed = self._part_a_owed
+        if owed is None:
+            return False
+        self._part_a_owed = None
+        cold, log, count, warm_a, scaled, l1n = owed
+        d = self.defaults
+        pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
+                           d["eps"], d["weight_decay"], self.step_count, self._snapshot[2:3] if scaled else None, None,
+                           l1_ranges=getattr(self, "_l1", None), l1_next=l1n, cold_bits=cold, lazy=(log, count, warm_a), replay=self._snapshot)
+        if torch.cuda.is_current_stream_capturing():
+            self._graph_is_two_part = True  # (note_device_steps: what a replay leaves in the L1 partial sums)
+        pvd_hip.note_weights_changed(self.params)
+        return True
+
+    def _two_part_now(self, lazy):
+        return bool(self.two_part and lazy is not None and len(lazy) == 3 and getattr(self, "_half_grad", None) is None
+                    and getattr(self, "_warm_A", None) is not None and self._warm_A.numel() > 0 and self._warm_B.numel() > 0)
+
+    _l1_layout, _graph_is_two_part = "one", False
+
+    def _l1_layout_is(self, layout, capturing=False):
+        """The L1 term's partial sums (l1_partials) are one entry per workgroup of whatever launch shape wrote them last: when the
+        shape changes (one launch <-> two parts) they are started afresh, as after a change of the warm list."""
+        if layout == self._l1_layout:
+            return
+        assert not capturing, "the form of the update must be settled before a capture begins (FlatAdamW.begin_two_part)"
+        self._l1_layout = layout
+        st = getattr(self, "_l1_track", None)
+        if st is not None:
+            st["buf"].zero_()
+            st["buf"][0] = self.l1_value(st["scale"])
+
+    def begin_two_part(self, defer):
+        """Called by the trainer BEFORE it records steps whose update is split (eagerly: may launch)."""
+        self.flush()
+        self.two_part, self.defer_part_a = True, bool(defer)
+        if self._cold_dirty:  # the lists are built by the first step after the touched set changed; the recording needs them now
+            self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
+            self._cold_dirty = False
+        if getattr(self, "_warm_A", None) is not None and self._warm_A.numel() > 0 and self._cold_bits is not None:
+            self._l1_layout_is("two")
+
+    def end_two_part(self):
+        """After the recording: eager steps go back to the single launch (the recorded graph keeps the two parts)."""
+        self.two_part = self.defer_part_a = False
+
     touched = None  # set_touched(): the only entries of flat_g anything ever writes (pvd/dp_compact.py), or None = all
     _outside_is_zero = False
 
@@ -80,6 +136,8 @@ class FlatAdamW(torch.optim.Optimizer):
     def note_device_steps(self, n):
         """n update steps ran on the device without step() being called (a graph replay): keep the host's idea of the log's
         fill level current, and empty the log well before it is full."""
+        if self._graph_is_two_part:
+            self._l1_layout = "two"  # the replayed steps wrote the partial sums in two regions
         if self._lazy is not None and self._cold_bits is not None:
             self._lazy_logged += int(n)
             if self._lazy_logged > self.LAZY_CAPACITY - 1024 and not torch.cuda.is_current_stream_capturing():
@@ -90,6 +148,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """Apply the deferred decays: after this every parameter holds what per-step updates would have left.  Called before
         anything reads whole tables (state_dict, checkpoints, a change of the touched set) -- and by whoever compares
         parameters."""
+        self.run_part_a()  # (a two-part update whose second part is still owed)
         if self._lazy is None or self._cold_bits is None or self._lazy_logged == 0:
             return
         status = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)
@@ -127,6 +186,13 @@ class FlatAdamW(torch.optim.Optimizer):
         self.cold_fraction = float(cold.float().mean()) if n4 else 0.0
         # the warm groups as a list (the update kernel walks it when the cold groups' decay is deferred): full wavefronts of work
         self._warm_groups = (~cold).nonzero().squeeze(1).to(torch.int32).contiguous()
+        # the two parts of a two-part update (step(): `two_part`): B = warm groups the step's backward can write (touched rows,
+        # the MLP heads -- everything in the touched set), A = the other warm groups (L1-only rows, rows whose moments are still
+        # decaying): their gradient is structurally zero and nothing reads them before the next step's objective
+        in_touched = torch.zeros(n4 + 1, dtype=torch.bool, device=dev)
+        in_touched[self.touched.idx >> 2] = True
+        self._warm_B = ((~cold) & in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
+        self._warm_A = ((~cold) & ~in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
         st = getattr(self, "_l1_track", None)
         if st is not None:  # per-workgroup partial sums: the launch shape changes with the list, start them afresh
             st["buf"].zero_()
@@ -207,7 +273,7 @@ class FlatAdamW(torch.optim.Optimizer):
         extra pass over the regularised tables."""
         st = getattr(self, "_l1_track", None)
         if st is None or st["scale"] != scale:
-            buf = torch.zeros(4096, dtype=torch.float32, device=self.flat_p.device)
+            buf = torch.zeros(8192, dtype=torch.float32, device=self.flat_p.device)  # [0, 4096): the update's workgroups (part B of a two-part update), [4096, 8192): part A's
             buf[0] = self.l1_value(scale)  # once; every update that goes through overwrites one entry per workgroup
             st = self._l1_track = dict(buf=buf, scale=scale)
         return st["buf"]
@@ -232,11 +298,28 @@ class FlatAdamW(torch.optim.Optimizer):
             if self._lazy_logged > self.LAZY_CAPACITY - 1024 and not capturing:
                 self.flush()
             self._lazy_logged += 1
-        pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
-                           d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
-                           schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
-                           amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
-                           l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy)
+        self.run_part_a()  # (never two steps' worth owed)
+        self._l1_layout_is("two" if self._two_part_now(lazy) else "one", capturing)
+        two = self._two_part_now(lazy)
+        if two:
+            # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
+            if self._snapshot is None:
+                self._snapshot = torch.zeros(4 + len(self.segment_ends), dtype=torch.float32, device=self.flat_p.device)
+            pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
+                               d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
+                               schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
+                               amp_update=getattr(self, "amp_update", None), l1_next=(st["buf"], st["scale"]) if st is not None else None,
+                               cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B), snapshot=self._snapshot)
+            self._part_a_owed = (cold, lazy[0], lazy[1], self._warm_A, getattr(self, "grad_scale", None) is not None,
+                                 (st["buf"][4096:], st["scale"]) if st is not None else None)
+            if not self.defer_part_a:
+                self.run_part_a()
+        else:
+            pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
+                               d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
+                               schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
+                               amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
+                               l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy)
         self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)

@@ -510,8 +510,11 @@ class _TrainerBase:
         traceback.print_exc()
         torch.cuda.synchronize()
         self.dp.capture = None
+        self.__dict__.pop("_before_objective", None)
         if self.flat_opt:
             self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
+            self.optimizer._part_a_owed = None  # (a two-part update recorded half way: nothing of it ran)
+            self.optimizer.end_two_part()
         for mdl in (getattr(self, "model_stu", None), self.model):
             if mdl is not None and getattr(mdl, "_between_backwards", None) is not None:
                 mdl._between_backwards = None
@@ -680,6 +683,9 @@ class DistillTrainer(_TrainerBase):
             info.update(color=l_col.detach(), sigma=l_sig.detach())
             return loss, info, None, None
 
+        wait_l1 = self.__dict__.pop("_before_objective", None)
+        if wait_l1 is not None:
+            wait_l1()  # a deferred part of the previous step's update refreshes the L1 term's partial sums (see _capture_ingraph_pipelined)
         if fused_nofea:
             l3, norms = self.fused_loss(pred_stu, pred_tea, stu.sigma_l.float().unsqueeze(-1), tea.sigma_l.float().unsqueeze(-1),
                                         stu.color_l.float(), tea.color_l.float(), self.rates, self.dp, fea_decay=0.995)
@@ -822,11 +828,64 @@ class DistillTrainer(_TrainerBase):
         # every step has its prefix overlapped, whatever the number of steps per graph (K >= 2: with one step per graph the
         # step's own scatter would still be reading the samples the copy overwrites)
         carried = None
+        # (default "start": 0.322 vs 0.330 ms/step at 20 steps per graph, level at 5, profiles/r03_fork_modes.txt)
+        fork_mode = os.environ.get("PVD_PIPELINE_FORK", "start")
+        per_graph = fork_mode == "graph" and K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0"
+        if per_graph:
+            # ONE fork / join pair per GRAPH instead of one per step (a pair costs the main chain ~10 us at the fork and ~9 us at
+            # the join, profiles/r03_step_timeline.txt): the branch records the prefixes of all K steps of the NEXT replay back to
+            # back, the main chain records the K steps of this replay on the prefixes carried over from the previous one; after
+            # the join the K new prefixes move into the static homes (one multi-tensor copy per prefix).
+            with torch.cuda.stream(side):
+                homes = [CarriedPrefix(self.prefetch(batch_fn)) for _ in range(K)]  # prologue: the first replay's prefixes, eagerly
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            cap = SegmentedCapture(self.device)
+            self.dp.capture = cap
+            branch = torch.cuda.Stream(self.device)
+            try:
+                with cap:
+                    main = torch.cuda.current_stream()
+                    branch.wait_stream(main)
+                    try:
+                        with torch.cuda.stream(branch):
+                            nxts = [self.prefetch(batch_fn) for _ in range(K)]
+                        for k in range(K):
+                            self._zero_grads()
+                            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                                self._static_out = self.compute_loss(None, None, None, pre=homes[k].pre)
+                            self._backward(self._static_out[0])
+                            if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
+                                raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
+                            self._exchange()
+                            self._optimize()
+                    finally:
+                        main.wait_stream(branch)  # a capture can only be ended with its forked work joined
+                    for k in range(K):
+                        homes[k].store(nxts[k])
+            finally:
+                self.dp.capture = None
+            self._cap = cap
+            self.steps_per_replay = K
+            self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
+            self.pipelined_ingraph = True
+            self.pipeline_fork = "graph"
+            return self._static_out
         if K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
             with torch.cuda.stream(side):
                 carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+        # Two-part AdamW (PVD_ADAMW_SPLIT=1; FlatAdamW.two_part, single GPU, fork at "start"): the update behind the table scatter
+        # covers only what the backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the
+        # update's bytes, read by nobody before the next objective -- are updated first thing on the NEXT step's forked branch, next
+        # to the student's instruction-bound forward, with the scalars the step recorded.  Bit-identical parameters
+        # (tests/test_hip_fused_misc.py, tests/test_hip_graph.py).  MEASURED SLOWER and therefore off: 0.340 vs 0.325 ms/step
+        # (profiles/r03_adamw_split_ab.txt) -- the update is a pure HBM stream (~190 MB); moved next to the forward it takes the
+        # bandwidth the forward's gathers wait on, and the second launch + the cross-branch wait cost what the shorter tail saves.
+        split = (self.flat_opt and not self.dp.enabled and fork_mode == "start" and K >= 2 and os.environ.get("PVD_ADAMW_SPLIT", "0") == "1")
+        if split:
+            self.optimizer.begin_two_part(defer=True)
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)
@@ -841,12 +900,19 @@ class DistillTrainer(_TrainerBase):
                         # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
                         # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
                         # prefix rebinds.)
-                        fork_at = os.environ.get("PVD_PIPELINE_FORK", "mid")
+                        # "start" = before this step's forward: compute_loss re-installs the teacher outputs of ITS prefix first
+                        # thing, so the rebinding is harmless once the fork's host code has run before it.
+                        fork_at = fork_mode if fork_mode in ("mid", "backward", "optimizer", "start") else "start"
                         pre_next = None
 
                         def fork(k=k):
                             branch.wait_stream(main)
                             with torch.cuda.stream(branch):
+                                if split and self.optimizer.run_part_a():  # what the previous step's update still owes
+                                    done = torch.cuda.Event()
+                                    done.record(branch)
+                                    # (the objective adds up the L1 term from the partial sums this launch refreshes)
+                                    self._before_objective = lambda: main.wait_event(done)
                                 nxt = self.prefetch(batch_fn)
                                 if k + 1 == K:  # for the next replay
                                     carried.store(nxt)
@@ -859,6 +925,10 @@ class DistillTrainer(_TrainerBase):
                                     held["pre"] = fork()
                                 return None
                             self.model_stu._between_backwards = between
+                        if more and fork_at == "start":
+                            pre_next = fork()
+                        elif split:
+                            self.optimizer.run_part_a()  # no branch to put it on
                         self._zero_grads()
                         try:
                             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
@@ -881,16 +951,22 @@ class DistillTrainer(_TrainerBase):
                         if pre_next is not None:  # join
                             main.wait_stream(branch)
                             pre = pre_next
+                    if split:
+                        self.optimizer.run_part_a()  # the last step's: a replay leaves nothing owed
                 except Exception:
                     self.model_stu._between_backwards = None
+                    self.__dict__.pop("_before_objective", None)
                     main.wait_stream(branch)  # a capture can only be ended with its forked work joined
                     raise
         finally:
             self.dp.capture = None
+            if split:
+                self.optimizer.end_two_part()
         self._cap = cap
         self.steps_per_replay = K
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         self.pipelined_ingraph = True
+        self.pipeline_fork = fork_mode
         return self._static_out
 
     def _capture_pipelined(self, batch_fn, body):

@@ -138,10 +138,15 @@ class KernelTimer:
         ms_per_launch = kt.mean_ms("pvd_grid_encode_forward")
     """
 
-    def __init__(self, names):
+    def __init__(self, names, external=False):
+        """external=True: events that may be recorded while a stream is CAPTURING (hipEventRecordWithFlags(hipEventRecordExternal)):
+        they become event-record nodes of the hipGraph and are stamped on every replay, so a kernel can be timed where it
+        runs inside a replayed step; `captured[name][i]` says whether pair i was recorded into a graph."""
         self.names = set(names)
+        self.external = bool(external)
         self.events = {n: [] for n in self.names}
         self.meta = {n: [] for n in self.names}
+        self.captured = {n: [] for n in self.names}
 
     def __enter__(self):
         global _timer
@@ -163,6 +168,11 @@ class KernelTimer:
         n = self.launches(name)
         return self.total_ms(name) / n if n else float("nan")
 
+    def captured_ms(self, name):
+        """Durations (ms) of the pairs recorded into a graph, as stamped by the LAST replay."""
+        torch.cuda.synchronize()
+        return [float(a.elapsed_time(b)) for (a, b), c in zip(self.events[name], self.captured[name]) if c]
+
 
 _timer = None
 
@@ -171,12 +181,14 @@ def _invoke(fn_name, dev, *args, meta=None):
     with torch.cuda.device(dev):
         t = _timer
         if t is not None and fn_name in t.names:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            kw = {"external": True} if t.external else {}
+            a, b = torch.cuda.Event(enable_timing=True, **kw), torch.cuda.Event(enable_timing=True, **kw)
             a.record()
             status = getattr(_lib, fn_name)(*args, _stream(dev))
             b.record()
             t.events[fn_name].append((a, b))
             t.meta[fn_name].append(meta)
+            t.captured[fn_name].append(bool(torch.cuda.is_current_stream_capturing()))
             return status
         return getattr(_lib, fn_name)(*args, _stream(dev))
 
@@ -821,7 +833,7 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
                 ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p),
                 ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32),
-                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32)]
+                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p)]
 
 
 def _u64_array(vals):
@@ -829,10 +841,12 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None, snapshot=None, replay=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer.
-    cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good."""
+    cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good.
+    snapshot / replay: f32 [4 + segments] device: the two-part update of include/pvd_hip.h (snapshot: this launch records the
+    scalars it used; replay: this launch is the deferred part and uses a recorded step's scalars, no tail)."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
@@ -857,6 +871,13 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
                 if log.dim() != 2 or log.shape[1] != len(segment_ends) or not log.is_contiguous():
                     raise PvdHipError("the lazy-decay log must be a contiguous [capacity, segments] f32 tensor")
                 ex.lazy_log, ex.lazy_count, ex.lazy_capacity = log.data_ptr(), count.data_ptr(), int(log.shape[0])
+        for name_, t_ in (("snapshot", snapshot), ("replay", replay)):
+            if t_ is not None:
+                _dev(t_)
+                _want(t_, torch.float32, name_)
+                if t_.numel() < 4 + len(segment_ends):
+                    raise PvdHipError("%s needs 4 + segments floats" % name_)
+                setattr(ex, name_, t_.data_ptr())
         if l1_next is not None:  # (buffer [>= 4096] f32, scale)
             buf, sc = l1_next
             _dev(buf)

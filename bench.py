@@ -270,7 +270,9 @@ def main():
         try:
             w.enable_graph(steps_per_graph=spg)  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
             launch_mode = "hipGraph replay" + (" (%d steps per graph launch%s)" % (
-                w.steps_per_call, ", next step's march + teacher forward on a forked branch" if getattr(w.trainer, "pipelined_ingraph", False) else "")
+                w.steps_per_call, (", the next replay's marches + teacher forwards on ONE forked branch per graph" if getattr(w.trainer, "pipeline_fork", "") == "graph" else
+                                           ", next step's march + teacher forward on a forked branch (fork at %s)" % getattr(w.trainer, "pipeline_fork", "mid"))
+                if getattr(w.trainer, "pipelined_ingraph", False) else "")
                 if w.steps_per_call > 1 else "")
         except Exception as e:  # never lose the measurement to a capture problem: fall back to eager launches
             import traceback
@@ -336,33 +338,55 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         n_launch = per_graph * reps
-        us = ev_a.elapsed_time(ev_b) / n_launch * 1e3
+        us_alone = ev_a.elapsed_time(ev_b) / n_launch * 1e3
         B = int(xyzs.shape[0])
         fused = bool(getattr(fusedhead, "FUSED_LOOKUP", False)) and opt.fp16
-        # algorithmic bytes per sample: position 12 + 14 levels x 8 corners x 4 B (f16 pair) = 448; the two-launch
-        # form adds the [14][M][2] f16 write (56: 516 B/sample in total); the fused launch adds instead what the head reads and
-        # writes: dirs 12 + sigma 4 + rgb 12 + feature_sigma_color 64 = 92 (552 B/sample)
-        bps = 552 if fused else 516 + 56 + 92
-        achieved = bps * B / (us * 1e-6) / 1e9
+        # ALGORITHMIC bytes per sample: SURVEY.md section 8(d)'s figure for the f16 lookup -- position 12 + 14 levels x 8 corners x 4 B
+        # (f16 pair) = 448 gathered + 14 x 2 x 2 = 56 of features = 516 B/sample.  (The fused launch does not write the 56 B of
+        # features to HBM and instead moves what the head reads and writes -- dirs 12 + sigma 4 + rgb 12 + feature_sigma_color 64:
+        # 552 B/sample -- kept as `bytes_per_sample_fused` for reference; `achieved` is priced at 516.)
+        bps = grid_fwd_bytes_per_sample(3, 2, 14, 2 if opt.fp16 else 4)
+        gbs = lambda us_: bps * B / (us_ * 1e-6) / 1e9  # noqa: E731
+        alone = {"us_per_launch": us_alone, "launches": n_launch, "achieved": gbs(us_alone), "frac": gbs(us_alone) / HBM_PEAK_GBS,
+                 "timing": "HIP events on the launch stream around %d back-to-back launches (HIP graphs of %d), nothing else on the chip, right "
+                           "after the timed region" % (n_launch, per_graph)}
+        # ---- the same kernel WHERE IT RUNS: inside the replayed step it sits on the forked branch of the graph next to the student's
+        # table scatter and update and is stretched by sharing the chip.  That duration cannot be taken live: this runtime has no
+        # way to stamp an event inside a replayed hipGraph (torch refuses external events on ROCm, plain event-record nodes return
+        # hipErrorInvalidHandle from hipEventElapsedTime: tools/probe_graph_events.py, profiles/r03_graph_events_probe.txt).  It is
+        # measured by rocprofv3 over the driver's command and committed (profiles/r03_kernel_populations.txt); the record is
+        # QUOTED here, labelled as such, when it was taken on this build of the kernel.
+        in_step = None
+        rec_path = os.path.join(REPO, "profiles", "r03_in_step.json")
+        if fused and os.path.exists(rec_path):
+            rec = json.load(open(rec_path))
+            if rec.get("source_sha16") == kernel_source_sha16():
+                us_in, Bi = float(rec["median_us"]), int(rec["samples_per_launch"])
+                in_step = {"us_per_launch": us_in, "mean_us": rec.get("mean_us"), "launches": rec.get("launches"), "samples_per_launch": Bi,
+                           "achieved": bps * Bi / (us_in * 1e-6) / 1e9, "frac": bps * Bi / (us_in * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "timing": "NOT live: rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5` on the builder's lease, launches that "
+                                     "overlap the student's scatter / update (profiles/r03_kernel_populations.txt), same kernel source hash"}
+        head = alone  # the headline figure is the live one
         traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
-        pmc_path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc_path):  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
+        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(q)), None)
+        if pmc_path:  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
             pmc = json.load(open(pmc_path))
             if pmc.get("source_sha16") == kernel_source_sha16() and fused:
-                traffic = (pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0 / pmc["samples_per_launch"] * B
-                traffic_note = "bytes/launch, rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes, tools/pmc_teacher_fwd.py), scaled by samples; " \
-                               "gather pattern, uncorrected (the guide's x2 FETCH_SIZE correction is for wide coalesced streams)"
+                traffic = (pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0 / pmc["samples_per_launch"] * head.get("samples_per_launch", B)
+                traffic_note = "bytes/launch, rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes, tools/pmc_teacher_fwd.py; %s), scaled by " \
+                               "samples; gather pattern, uncorrected (the guide's x2 FETCH_SIZE correction is for wide coalesced streams)" % os.path.basename(pmc_path)
             else:
-                traffic_note = "profiles/r02_pmc_traffic.json was taken on a different build of the kernel (source hash differs)"
+                traffic_note = "%s was taken on a different build of the kernel (source hash differs)" % os.path.basename(pmc_path)
+        Bh = head.get("samples_per_launch", B)
         roof = {"kernel": ("k_hash_fwd_fused (pvd_hash_head_forward_fused: hash-grid lookup f16 3x2x14 + sigma/colour head, one launch)" if fused
                            else "pvd_grid_encode_forward_affine + pvd_head_forward (two launches)"),
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * B, "bytes_per_sample": bps,
-                "samples_per_launch": B, "us_per_launch": us, "launches": n_launch,
-                "timing": "HIP events on the launch stream around %d launches (HIP graphs of %d), right after the timed region" % (n_launch, per_graph),
-                "in_step": "the kernel alone on the chip; inside the replayed step it runs on a forked branch of the graph next to the "
-                           "student's table scatter and update, where sharing the chip stretches it (rocprofv3: 45 us shared vs 28 us "
-                           "alone, profiles/r02_kernel_populations.txt) -- the step as a whole is shorter for it"}
+                "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+                "where": "alone on the chip (live HIP events); inside the replayed step: see in_step",
+                "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * Bh, "bytes_per_sample": bps,
+                "bytes_per_sample_fused": 552 if fused else None,
+                "samples_per_launch": Bh, "us_per_launch": head["us_per_launch"], "launches": head["launches"],
+                "alone": alone, "in_step": in_step,
+                "rederive": "python tools/roofline_from_profile.py  (profiles/r03_kernel_populations.txt + r03_bench_profiled_line.json + r03_kernel_stats.csv)"}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 

@@ -500,6 +500,16 @@ typedef struct pvd_adamw_extras {
      * clear.  The update walks this list instead of every group (the cold ones have nothing to do). */
     const uint32_t *warm_groups;
     uint32_t n_warm_groups;
+    /* Two-part update.  The groups of a step fall into (B) those whose gradient the step's backward may have written (table
+     * rows a sample can reach, the MLP heads) and (A) those whose gradient is structurally zero (L1-only rows of the sigma
+     * planes, rows whose moments are still decaying): nothing reads an A parameter before the next step's objective adds up
+     * the L1 term, so part A can run LATER, next to latency-bound kernels, instead of behind the table scatter on the step's
+     * critical chain.  The B launch (warm_groups = B, with tail) records the scalars the step used in
+     * snapshot = {found_inf, step count before the step, grad scale, 0, lr[0..n_segments)} (DEVICE, 4 + n_segments floats);
+     * the A launch (warm_groups = A) passes that record as `replay`: it uses the recorded scalars instead of the live ones
+     * (no schedule evaluation, no tail kernel, nothing logged), leaving bit for bit what a single launch would have. */
+    float *snapshot;
+    const float *replay;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,

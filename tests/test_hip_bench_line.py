@@ -1,0 +1,66 @@
+"""bench.py's contract, end to end, on the one GPU of the box: the JSON line of the single-GPU run (metric, config, roofline
+and -- when asked for -- cpu_baseline objects), and the N > 1 launch exactly as the driver issues it
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ...`) with both ranks sharing the GPU
+over gloo (PVD_DIST_BACKEND=gloo): ray-DP capture, gradient exchange, max-over-ranks timing, weak and strong scaling.
+Short runs of a small batch -- what is checked is the plumbing and the line, not the number."""
+import json
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _line(cmd, env=None, timeout=600):
+    p = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, (p.returncode, out[-2000:], p.stderr.decode(errors="replace")[-4000:])
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]  # ONE JSON line (rank 0 only)
+    return json.loads(lines[0])
+
+
+COMMON = ["--steps", "10", "--warmup", "5", "--rays", "1024", "--teacher-pretrain", "20"]
+
+
+def test_single_gpu_line_carries_the_contract():
+    d = _line([sys.executable, "bench.py", *COMMON, "--cpu-steps", "1"])
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "rays/s" and d["vs_baseline"] is None and d["data"].startswith("synthetic")
+    assert abs(d["value"] - 10 * 1024 / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
+    cfg = d["config"]
+    assert "workload" in cfg and "model" not in cfg and cfg["capture_fallback"] is False and cfg["launch"].startswith("hipGraph replay")
+    assert math.isfinite(cfg["loss"]) and cfg["samples_per_step_per_gpu"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bytes_per_sample"] == 516  # SURVEY section 8(d)'s algorithmic figure for the f16 lookup
+    assert abs(r["achieved"] - r["bytes_per_sample"] * r["samples_per_launch"] / (r["us_per_launch"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["alone"]["us_per_launch"] > 0 and r["alone"]["launches"] >= 20
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+
+
+@pytest.mark.parametrize("strong", [False, True])
+def test_two_ranks_as_the_driver_launches_them(strong):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", *COMMON] + (["--strong"] if strong else [])
+    d = _line(cmd, env={"PVD_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == ("strong" if strong else "weak")
+    per_gpu = 512 if strong else 1024
+    assert d["config"]["rays_per_gpu"] == per_gpu and d["config"]["parallelism"] == "ray-dp2"
+    total = 10 * (1024 if strong else 2048)  # whole-job rays over the timed steps
+    assert abs(d["value"] - total / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
+    assert "all-reduce" in d["config"]["exchange"] and math.isfinite(d["config"]["loss"]) and d["config"]["capture_fallback"] is False
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only

@@ -539,8 +539,28 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
         if s == 3:
             gr[(~cold_el).nonzero()[7]] = float("inf")
         grads.append(gr)
-    res = []
+    res, res_two = [], []
     seg_ends = [n // 2 // 4 * 4, n]
+    a_el = torch.zeros(n, dtype=torch.bool, device=dev)
+    a_el[30000:] = True
+    grads_two = [torch.where(a_el, torch.zeros_like(gr), gr) for gr in grads]  # (the inf of step 3 sits in a B group: element < 30000)
+    assert not torch.isfinite(grads_two[3]).all()
+    # (part A's moments are still decaying: rows that used to be reachable -- so the recorded step count and rates matter)
+    m_init, v_init = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    decaying = a_el & ~cold_el
+    m_init[decaying] = torch.randn(int(decaying.sum()), device=dev, generator=g) * 0.1
+    v_init[decaying] = torch.rand(int(decaying.sum()), device=dev, generator=g) * 0.01
+    if True:  # the single dense launch on those gradients: what both two-part runs must reproduce bit for bit
+        p, m, v = p0.clone(), m_init.clone(), v_init.clone()
+        lr = torch.tensor([1e-2, 3e-3], device=dev)
+        base = lr.clone()
+        step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        for gr in grads_two:
+            pvd_hip.check_finite(gr, flag)
+            pvd_hip.adamw_step(p, gr, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag, schedule=(1, 100.0, 5e-5, base, sched),
+                               l1_ranges=[(0, 4096, 1e-3)], amp_update=(scale, tracker, 2.0, 0.5, 2000))
+        res_two.append((p, m, v, step.clone(), scale.clone()))
     # dense; cold groups decayed on every step; cold groups' decay DEFERRED (lazy log) and replayed in one go at the end, and
     # in two goes (a flush after the third step)
     warm_list = (~cold4).nonzero().squeeze(1).to(torch.int32).contiguous()
@@ -570,8 +590,47 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
         if lazy is not None:
             assert sum(replayed) == 5  # the skipped (inf) step logs nothing
         res.append((p, m, v, step.clone(), scale.clone()))
+    # the TWO-PART update (pvd_adamw_extras.snapshot / replay): the warm groups split into B (may hold a gradient) and A (gradient
+    # structurally zero: here the warm groups past the first 30 000 elements, whose gradients are zeroed for every run of this
+    # comparison below); B runs with the tail and records the step's scalars, A runs LATER -- here after the next step's
+    # gradient check has already raised the live inf flag / the tail has moved on -- from the record
+    for part_a_late in (False, True):
+        p, m, v = p0.clone(), m_init.clone(), v_init.clone()
+        lr = torch.tensor([1e-2, 3e-3], device=dev)
+        base = lr.clone()
+        step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        log, count = torch.zeros(16, 2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        snap = torch.zeros(4 + 2, device=dev)
+        is_a = torch.zeros(n4, dtype=torch.bool, device=dev)
+        is_a[30000 // 4:] = True
+        warm_b = ((~cold4) & ~is_a).nonzero().squeeze(1).to(torch.int32).contiguous()
+        warm_a = ((~cold4) & is_a).nonzero().squeeze(1).to(torch.int32).contiguous()
+        assert warm_a.numel() > 1000 and warm_b.numel() > 1000
+        owed = False
+
+        def part_a():
+            pvd_hip.adamw_step(p, gr_prev, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, snap[2:3], None, l1_ranges=[(0, 4096, 1e-3)],
+                               cold_bits=packed, lazy=(log, count, warm_a), replay=snap)
+        for k, gr in enumerate(grads_two):
+            pvd_hip.check_finite(gr, flag)
+            if owed and part_a_late:
+                part_a()  # the previous step's part A, with the NEXT step's inf flag already live: it must use the record
+            pvd_hip.adamw_step(p, gr, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag, schedule=(1, 100.0, 5e-5, base, sched),
+                               l1_ranges=[(0, 4096, 1e-3)], amp_update=(scale, tracker, 2.0, 0.5, 2000), cold_bits=packed,
+                               lazy=(log, count, warm_b), snapshot=snap)
+            gr_prev, owed = gr, True
+            if not part_a_late:
+                part_a()
+        if part_a_late:
+            part_a()
+        pvd_hip.adamw_lazy_flush(p, seg_ends, packed, log, count, 0.01, status)
+        res_two.append((p, m, v, step.clone(), scale.clone()))
     for other in res[1:]:
         for a, b in zip(res[0], other):
+            assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    for other in res_two[1:]:
+        for a, b in zip(res_two[0], other):
             assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
     p, m, v = res[1][:3]
     assert float(res[1][3]) == 5.0  # one of the six steps was skipped

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 evidence run (lean: the GPU budget is 90 minutes a round).  TAG names the output directory under gpurun_out/.
+#   bench line (default arguments, with cpu_baseline) -> rocprofv3 --kernel-trace --stats of the DRIVER's command
+#   (bench.py --steps 20 --warmup 5) -> kernel stats, launch populations of the roofline kernel and of the scatter, step
+#   timeline -> PMC passes of the roofline kernel (FETCH_SIZE, WRITE_SIZE; TCC request / miss counters) -> re-derivation.
+TAG=${TAG:-r03ev}
+PMC=${PMC:-1}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench_line.json
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_b.log 2>&1)
+T=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1)
+cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+grep '^{' /tmp/prof_b.log | tail -1 > $OUT/bench_profiled_line.json
+python tools/kernel_populations.py $T k_hash_fwd_fused > $OUT/kernel_populations.txt
+for k in k_vm_bwd_split k_vm_fwd "k_adamw(" k_head_bwd; do python tools/kernel_populations.py $T "$k" >> $OUT/kernel_populations.txt; done
+cat $OUT/kernel_populations.txt
+python tools/step_timeline.py $T "k_adamw(" 22 > $OUT/step_timeline.txt 2>&1; tail -30 $OUT/step_timeline.txt
+python tools/in_step_record.py $OUT/kernel_populations.txt $OUT/bench_profiled_line.json > $OUT/in_step.json; cat $OUT/in_step.json
+python tools/roofline_from_profile.py $OUT/kernel_populations.txt $OUT/bench_profiled_line.json $OUT/kernel_stats.csv | tee $OUT/roofline_rederived.txt
+if [ "$PMC" = 1 ]; then
+  for c in FETCH_SIZE WRITE_SIZE "TCC_REQ_sum TCC_MISS_sum TCC_HIT_sum"; do
+    n=$(echo $c | cut -d' ' -f1)
+    (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -- python "$GRAFT_REPO_ROOT/tools/pmc_teacher_fwd.py" > /tmp/pmc_$n.log 2>&1)
+  done
+  n=$(grep samples_per_launch /tmp/pmc_FETCH_SIZE.log | awk '{print $2}')
+  python tools/pmc_traffic_json.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $n > $OUT/pmc_traffic.json; cat $OUT/pmc_traffic.json
+  f=$(find /tmp/pmc_TCC_REQ_sum -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python tools/pmc_summary.py $f | grep -i "k_hash_fwd_fused\|^kernel" > $OUT/pmc_tcc.csv; cat $OUT/pmc_tcc.csv
+fi
+true
