@@ -55,6 +55,14 @@ struct AdamExtras {
     uint32_t n_warm;
     // two-part update (include/pvd_hip.h): the tail records {found_inf, step before, scale before, 0, lr used ...} here
     float *snapshot;
+    // fewer launches (include/pvd_hip.h): zero every visited gradient group after reading it; the last workgroup to arrive does the tail
+    uint32_t zero_g;
+    uint32_t *arrivals;
+    float *tail_scale;      // GradScaler state for the in-kernel tail (NULL: no scaler)
+    int32_t *tail_tracker;
+    double tail_growth, tail_backoff;
+    int32_t tail_interval;
+    uint32_t tail_segments;
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -73,9 +81,19 @@ __device__ __forceinline__ float scheduled_lr(const AdamExtras &ex, const float 
 // the learning rates the update used; then GradScaler.update() on the device (torch's amp_update_scale_cuda_kernel: back
 // off on inf, grow after `interval` clean steps) and clear the inf flag for the next step -- one launch instead of a
 // counting launch before the update plus four host-issued scaler ops after it.
+__device__ __forceinline__ void adamw_tail_body(float *__restrict__ step, float *__restrict__ found_inf, const AdamExtras &ex,
+                                                float *__restrict__ lr, uint32_t n_segments, float *__restrict__ scale,
+                                                int32_t *__restrict__ tracker, double growth, double backoff, int32_t interval);
+
 __global__ void k_adamw_tail(float *__restrict__ step, float *__restrict__ found_inf, AdamExtras ex, float *__restrict__ lr, uint32_t n_segments,
                              float *__restrict__ scale, int32_t *__restrict__ tracker, double growth, double backoff, int32_t interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    adamw_tail_body(step, found_inf, ex, lr, n_segments, scale, tracker, growth, backoff, interval);
+}
+
+__device__ __forceinline__ void adamw_tail_body(float *__restrict__ step, float *__restrict__ found_inf, const AdamExtras &ex,
+                                                float *__restrict__ lr, uint32_t n_segments, float *__restrict__ scale,
+                                                int32_t *__restrict__ tracker, double growth, double backoff, int32_t interval) {
     const bool inf = found_inf && found_inf[0] != 0.f;
     if (ex.snapshot) {  // what the update above used, for the deferred part of a two-part update
         ex.snapshot[0] = inf ? 1.f : 0.f;
@@ -114,24 +132,52 @@ __global__ void k_adamw_tail(float *__restrict__ step, float *__restrict__ found
     found_inf[0] = 0.f;
 }
 
-__global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                    float *__restrict__ v, uint64_t n, AdamSegments seg, const float *__restrict__ lr,
+// The tail inside the update (ex.arrivals): a workgroup announces itself when it is DONE (all of them read the step's scalars
+// first thing, long before); the last one to be done knows that nobody will read them again and advances them.  Relaxed
+// counters: nothing but the order of each workgroup's own reads and its increment matters.  Returning atomics on ONE address
+// serialise at the memory side (~12 ns each: 4096 workgroups announcing on one counter made the launch 16-20 us longer, at
+// the start of the workgroups as well as at their end, profiles/r03_fold_launches_ab.txt), so the count is kept in two levels:
+// kArriveGroups counters, each on a 128-byte line of its own, for the workgroups of one residue class, and a top counter
+// that the last workgroup of every class bumps.  ex.arrivals = (1 + kArriveGroups) x 32 uint32, zero before the first call.
+constexpr uint32_t kArriveGroups = 64, kArriveStride = 32;
+__device__ __forceinline__ void adamw_announce(const AdamExtras &ex, float *__restrict__ step, float *__restrict__ found_inf, float *__restrict__ lr) {
+    if (!ex.arrivals || threadIdx.x != 0) return;
+    const uint32_t grp = blockIdx.x % kArriveGroups;
+    const uint32_t in_grp = (gridDim.x - grp + kArriveGroups - 1) / kArriveGroups;  // workgroups of this residue class
+    uint32_t *c = ex.arrivals + (size_t)(1 + grp) * kArriveStride;
+    if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_grp - 1) return;
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t groups = gridDim.x < kArriveGroups ? gridDim.x : kArriveGroups;
+    if (__hip_atomic_fetch_add(ex.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != groups - 1) return;
+    __hip_atomic_store(ex.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    adamw_tail_body(step, found_inf, ex, lr, ex.tail_segments, ex.tail_scale, ex.tail_tracker, ex.tail_growth, ex.tail_backoff, ex.tail_interval);
+}
+
+__global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, uint64_t n, AdamSegments seg, float *__restrict__ lr,
                                                     double beta1, double beta2, double eps, double weight_decay,
-                                                    const float *__restrict__ step, const float *__restrict__ grad_scale,
-                                                    const float *__restrict__ found_inf, AdamExtras ex) {
-    if (found_inf && found_inf[0] != 0.f) return;  // GradScaler: skip the whole step (l1_next keeps describing the parameters)
+                                                    float *__restrict__ step, const float *__restrict__ grad_scale,
+                                                    float *__restrict__ found_inf, AdamExtras ex) {
+    // GradScaler: an inf skips the whole step (l1_next keeps describing the parameters)
+    const bool skip = found_inf && found_inf[0] != 0.f;
     __shared__ float l1_sh[kOptBlock / 64];
     __shared__ float lr_sh[kMaxSegments];
     if (threadIdx.x < seg.count) lr_sh[threadIdx.x] = scheduled_lr(ex, lr, threadIdx.x);
-    __syncthreads();
+    const double t = (double)step[0] + 1.0;  // the tail advances the stored count after the update
+    const float gscale = grad_scale ? grad_scale[0] : 1.0f;
+    __syncthreads();  // (every scalar of the step has been READ by this workgroup beyond this point)
+    if (skip && !ex.zero_g) { adamw_announce(ex, step, found_inf, lr); return; }
     float l1_acc = 0.f;
-    const double t = (double)step[0] + 1.0;  // the tail kernel advances the stored count after the update
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, t));
     const uint64_t n4 = ex.warm ? (uint64_t)ex.n_warm : n >> 2;
     for (uint64_t j = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; j < n4; j += (uint64_t)gridDim.x * kOptBlock) {
         const uint64_t i = ex.warm ? (uint64_t)ex.warm[j] : j;
         const uint64_t e = i << 2;
+        if (skip) {  // (zero_g) the skipped step's gradients must not reach the next step
+            if (!(ex.cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         uint32_t k = 0;
         while (k + 1 < seg.count && e >= seg.end[k]) k++;  // segments are multiples of 4 elements (see trainer)
         float l1 = 0.f;  // ranges are multiples of 4 elements too
@@ -154,6 +200,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         // the parameters and gradients the other kernels of the step come back to
         typedef float f4v __attribute__((ext_vector_type(4)));
         float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<const float4 *>(g)[i];
+        if (ex.zero_g) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const f4v Mn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(m) + i);
         const f4v Vn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v) + i);
         float4 M = make_float4(Mn.x, Mn.y, Mn.z, Mn.w), V = make_float4(Vn.x, Vn.y, Vn.z, Vn.w);
@@ -167,7 +214,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         for (int c = 0; c < 4; c++) {
             // torch's fused kernel keeps the hyper-parameters in double, so these expressions evaluate in fp64
             // and round once into the fp32 state (ATen fused_adam_utils.cuh: adam_math, ADAMW mode)
-            float grad = grad_scale ? (float)((double)gg[c] / (double)grad_scale[0]) : gg[c];
+            float grad = grad_scale ? (float)((double)gg[c] / (double)gscale) : gg[c];
             if (l1 != 0.f) grad += l1 * (pp[c] > 0.f ? 1.0f : (pp[c] < 0.f ? -1.0f : 0.0f));  // d(l1 * |p|)/dp
             float param = (float)((double)pp[c] - lrk * (double)weight_decay * (double)pp[c]);
             const float ea = (float)((double)mm[c] + (1.0 - (double)beta1) * ((double)grad - (double)mm[c]));
@@ -181,7 +228,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
         __builtin_nontemporal_store((f4v){M.x, M.y, M.z, M.w}, reinterpret_cast<f4v *>(m) + i);
         __builtin_nontemporal_store((f4v){V.x, V.y, V.z, V.w}, reinterpret_cast<f4v *>(v) + i);
     }
-    if (ex.l1_next) {
+    if (ex.l1_next && !skip) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) l1_acc += __shfl_xor(l1_acc, off, 64);
         if ((threadIdx.x & 63u) == 0) l1_sh[threadIdx.x >> 6] = l1_acc;
@@ -192,6 +239,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, cons
             ex.l1_next[blockIdx.x] = sacc * ex.l1_next_scale;
         }
     }
+    adamw_announce(ex, step, found_inf, lr);
 }
 
 // Replay of the deferred weight decay: every cold group takes the logged steps one after the other, p <- (float)(p - lr wd p)
@@ -360,6 +408,8 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
     ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
+    ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
+    ex.tail_interval = 1; ex.tail_segments = n_segments;
     const float *replay = nullptr;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
@@ -384,7 +434,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         }
         ex.snapshot = h.snapshot;
         replay = h.replay;
-        if (replay && (!ex.warm || h.snapshot || h.g16)) return PVD_ERR_INVALID;  // the deferred part walks a list and records nothing
+        if (replay && (!ex.warm || h.snapshot || h.g16 || h.arrivals)) return PVD_ERR_INVALID;  // the deferred part walks a list and records nothing
+        ex.zero_g = h.zero_grad_after ? 1u : 0u;
+        ex.arrivals = h.arrivals;
     }
     hipStream_t s = (hipStream_t)stream;
     if (replay) {
@@ -393,17 +445,24 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         uint64_t blocks_a = ((uint64_t)ex.n_warm + kOptBlock - 1) / kOptBlock;
         if (blocks_a > 256 * 16) blocks_a = 256 * 16;
         if (blocks_a < 1) blocks_a = 1;
-        hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks_a), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, replay + 4, beta1, beta2, eps, weight_decay,
-                           replay + 1, grad_scale ? replay + 2 : nullptr, replay, ex);
+        hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks_a), dim3(kOptBlock), 0, s, p, const_cast<float *>(g), m, v, n, seg,
+                           const_cast<float *>(replay + 4), beta1, beta2, eps, weight_decay, const_cast<float *>(replay + 1),
+                           grad_scale ? replay + 2 : nullptr, const_cast<float *>(replay), ex);
         return check_launch();
     }
     uint64_t blocks = ((ex.warm ? (uint64_t)ex.n_warm : n / 4) + kOptBlock - 1) / kOptBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, g, m, v, n, seg, lr, beta1, beta2, eps, weight_decay, step,
-                       grad_scale, found_inf, ex);
     const bool amp = extras_host && extras_host->amp_scale;
     if (amp && (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1)) return PVD_ERR_INVALID;
+    if (ex.arrivals) {  // the tail runs inside the update (last workgroup to arrive)
+        ex.tail_scale = amp ? extras_host->amp_scale : nullptr; ex.tail_tracker = amp ? extras_host->amp_growth_tracker : nullptr;
+        ex.tail_growth = amp ? extras_host->amp_growth : 0.0; ex.tail_backoff = amp ? extras_host->amp_backoff : 0.0;
+        ex.tail_interval = amp ? extras_host->amp_interval : 1; ex.tail_segments = n_segments;
+    }
+    hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(kOptBlock), 0, s, p, const_cast<float *>(g), m, v, n, seg, lr, beta1, beta2, eps,
+                       weight_decay, step, grad_scale, const_cast<float *>(found_inf), ex);
+    if (ex.arrivals) return check_launch();
     hipLaunchKernelGGL(k_adamw_tail, dim3(1), dim3(64), 0, s, step, const_cast<float *>(found_inf), ex, lr, n_segments,
                        amp ? extras_host->amp_scale : nullptr, amp ? extras_host->amp_growth_tracker : nullptr,
                        amp ? extras_host->amp_growth : 0.0, amp ? extras_host->amp_backoff : 0.0, amp ? extras_host->amp_interval : 1);
@@ -477,6 +536,8 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
     ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
+    ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
+    ex.tail_interval = 1; ex.tail_segments = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

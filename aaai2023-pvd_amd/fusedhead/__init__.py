@@ -224,6 +224,9 @@ def vm_head_train(model, sigma_raw, prod, d):
     """-> (sigma, rgb, feature_sigma_color, rgb_l): rgb_l is rgb again, for the colour term of the objective (see above)."""
     a = model.args
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
+    wait = model.__dict__.pop("_before_head", None)
+    if wait is not None:
+        wait()  # the weight image was packed on another stream (prepack_train_image): this stream waits for it here
     return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
                               model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max, model.__dict__.pop("_train_image_ready", None))
 

@@ -51,6 +51,19 @@ class FlatAdamW(torch.optim.Optimizer):
         for k, g in enumerate(self.param_groups):
             g["lr"] = self.lr_dev[k:k + 1]  # LRScheduler.step() fills tensor lrs in place
 
+    # ---- fewer launches around the update (pvd_adamw_extras.zero_grad_after / arrivals)
+    zero_in_step = False     # set by the trainer while it records several steps into one graph: the update zeroes what it read, so
+    _zeroed_by_step = False  # ... the NEXT step's zero_grad() has nothing to launch
+    _arrivals = None
+
+    def _tail_in_kernel(self):
+        """The arrival counter of the in-kernel tail (PVD_ADAMW_TAIL_KERNEL=1 keeps the separate one-thread launch)."""
+        if os.environ.get("PVD_ADAMW_TAIL_KERNEL", "0") == "1":
+            return None
+        if self._arrivals is None:
+            self._arrivals = torch.zeros(65 * 32, dtype=torch.int32, device=self.flat_p.device)
+        return self._arrivals
+
     # ---- two-part update (pvd_adamw_extras.snapshot / replay): set by the trainer while it records a pipelined multi-step graph
     two_part = False      # step() updates part B (+ tail) and owes part A
     defer_part_a = False  # ... and leaves it to the caller to run it (run_part_a) where it overlaps latency-bound kernels
@@ -201,9 +214,13 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self._half_grad = None
-        if self.touched is not None and self._outside_is_zero:
+        if self._zeroed_by_step and self.touched is not None and self._outside_is_zero:
+            self._zeroed_by_step = False  # the previous step's update zeroed every group it read: the touched set is clean
+        elif self.touched is not None and self._outside_is_zero:
+            self._zeroed_by_step = False
             self.touched.zero(self.flat_g)
         else:
+            self._zeroed_by_step = False
             self.flat_g.zero_()
             self._outside_is_zero = self.touched is not None
         self.reattach()
@@ -301,6 +318,11 @@ class FlatAdamW(torch.optim.Optimizer):
         self.run_part_a()  # (never two steps' worth owed)
         self._l1_layout_is("two" if self._two_part_now(lazy) else "one", capturing)
         two = self._two_part_now(lazy)
+        # zero what the update reads (zero_in_step): only when everything that can be non-zero IS read -- the warm list contains
+        # the touched set, outside of which the gradient buffer is known to be zero; a pending half-precision gradient lives in
+        # its own buffer
+        zero_after = bool(self.zero_in_step and getattr(self, "_half_grad", None) is None
+                          and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) == 3)
         if two:
             # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
             if self._snapshot is None:
@@ -309,7 +331,8 @@ class FlatAdamW(torch.optim.Optimizer):
                                d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                                schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                                amp_update=getattr(self, "amp_update", None), l1_next=(st["buf"], st["scale"]) if st is not None else None,
-                               cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B), snapshot=self._snapshot)
+                               cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B), snapshot=self._snapshot, zero_after=zero_after,
+                               arrivals=self._tail_in_kernel())
             self._part_a_owed = (cold, lazy[0], lazy[1], self._warm_A, getattr(self, "grad_scale", None) is not None,
                                  (st["buf"][4096:], st["scale"]) if st is not None else None)
             if not self.defer_part_a:
@@ -319,7 +342,9 @@ class FlatAdamW(torch.optim.Optimizer):
                                d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                                schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                                amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
-                               l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy)
+                               l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy, zero_after=zero_after,
+                               arrivals=self._tail_in_kernel())
+        self._zeroed_by_step = zero_after
         self._half_grad = None
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)

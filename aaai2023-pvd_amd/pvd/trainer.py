@@ -485,6 +485,9 @@ class _TrainerBase:
         self.dp.capture = cap
         if self.dp.enabled and not self.dp.ingraph:
             steps_per_graph = 1  # graphs cut at the collectives: one step per chain
+        self._graph_zeroes = False
+        if max(1, int(steps_per_graph)) >= 2 and not self.dp.enabled:
+            self._fold_launches(True)
         try:
             with cap:
                 for _ in range(max(1, int(steps_per_graph))):
@@ -497,11 +500,23 @@ class _TrainerBase:
                     self._optimize()
         finally:
             self.dp.capture = None
+            self._fold_launches(False)
         self._cap = cap
         self.steps_per_replay = max(1, int(steps_per_graph))
         # (only a step that relies on a touched-row set is tied to the occupancy grid it was captured with)
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         return self._static_out  # the warm-up steps above are real steps; the capture itself records without running
+
+    def _fold_launches(self, on):
+        """While several steps are recorded into one graph the update zeroes the gradients it has read (FlatAdamW.zero_in_step), so
+        only the first step of the graph launches a zero_grad.  What the host knows about the gradients after such a recording
+        is settled by replay() (a recording runs nothing)."""
+        if self.flat_opt:
+            self.optimizer.zero_in_step = bool(on) and os.environ.get("PVD_ADAMW_ZERO_IN_STEP", "1") != "0"
+            if on:
+                self._graph_zeroes = self.optimizer.zero_in_step
+            else:
+                self.optimizer._zeroed_by_step = False
 
     def _after_failed_capture(self):
         """A recording that raised left nothing on the device (nothing runs while capturing) but may have left host-side
@@ -511,6 +526,8 @@ class _TrainerBase:
         torch.cuda.synchronize()
         self.dp.capture = None
         self.__dict__.pop("_before_objective", None)
+        self._fold_launches(False)
+        self._graph_zeroes = False
         if self.flat_opt:
             self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
             self.optimizer._part_a_owed = None  # (a two-part update recorded half way: nothing of it ran)
@@ -531,6 +548,8 @@ class _TrainerBase:
         self._cap.replay()
         if self.flat_opt:
             self.optimizer.note_device_steps(self.steps_per_replay)
+            if getattr(self, "_graph_zeroes", False):
+                self.optimizer._zeroed_by_step = True  # the graph's last update left the touched set clean
         for _ in range(self.steps_per_replay):
             self.scheduler.step()
         self.global_step += self.steps_per_replay
@@ -831,6 +850,9 @@ class DistillTrainer(_TrainerBase):
         # (default "start": 0.322 vs 0.330 ms/step at 20 steps per graph, level at 5, profiles/r03_fork_modes.txt)
         fork_mode = os.environ.get("PVD_PIPELINE_FORK", "start")
         per_graph = fork_mode == "graph" and K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0"
+        self._graph_zeroes = False
+        if K >= 2 and not self.dp.enabled:
+            self._fold_launches(True)
         if per_graph:
             # ONE fork / join pair per GRAPH instead of one per step (a pair costs the main chain ~10 us at the fork and ~9 us at
             # the join, profiles/r03_step_timeline.txt): the branch records the prefixes of all K steps of the NEXT replay back to
@@ -865,6 +887,7 @@ class DistillTrainer(_TrainerBase):
                         homes[k].store(nxts[k])
             finally:
                 self.dp.capture = None
+                self._fold_launches(False)
             self._cap = cap
             self.steps_per_replay = K
             self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
@@ -884,6 +907,8 @@ class DistillTrainer(_TrainerBase):
         # (profiles/r03_adamw_split_ab.txt) -- the update is a pure HBM stream (~190 MB); moved next to the forward it takes the
         # bandwidth the forward's gathers wait on, and the second launch + the cross-branch wait cost what the shorter tail saves.
         split = (self.flat_opt and not self.dp.enabled and fork_mode == "start" and K >= 2 and os.environ.get("PVD_ADAMW_SPLIT", "0") == "1")
+        fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
+        pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
         if split:
             self.optimizer.begin_two_part(defer=True)
         cap = SegmentedCapture(self.device)
@@ -908,6 +933,12 @@ class DistillTrainer(_TrainerBase):
                         def fork(k=k):
                             branch.wait_stream(main)
                             with torch.cuda.stream(branch):
+                                if fork_at == "start" and pack_ahead is not None and pack_ahead(self.model_stu):
+                                    # the student's f16 weight image for THIS step's head (5 us on the main chain otherwise): the
+                                    # weights are final (the fork follows the previous update), the head waits for it
+                                    packed = torch.cuda.Event()
+                                    packed.record(branch)
+                                    self.model_stu._before_head = lambda: main.wait_event(packed)
                                 if split and self.optimizer.run_part_a():  # what the previous step's update still owes
                                     done = torch.cuda.Event()
                                     done.record(branch)
@@ -955,11 +986,14 @@ class DistillTrainer(_TrainerBase):
                         self.optimizer.run_part_a()  # the last step's: a replay leaves nothing owed
                 except Exception:
                     self.model_stu._between_backwards = None
+                    self.model_stu.__dict__.pop("_before_head", None)
+                    self.model_stu.__dict__.pop("_train_image_ready", None)
                     self.__dict__.pop("_before_objective", None)
                     main.wait_stream(branch)  # a capture can only be ended with its forked work joined
                     raise
         finally:
             self.dp.capture = None
+            self._fold_launches(False)
             if split:
                 self.optimizer.end_two_part()
         self._cap = cap

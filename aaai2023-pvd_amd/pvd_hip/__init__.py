@@ -833,7 +833,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
                 ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p),
                 ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32),
-                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p)]
+                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p),
+                ("zero_grad_after", ctypes.c_uint32), ("arrivals", ctypes.c_void_p)]
 
 
 def _u64_array(vals):
@@ -841,18 +842,27 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None, snapshot=None, replay=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None, snapshot=None, replay=None, zero_after=False, arrivals=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer.
     cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good.
     snapshot / replay: f32 [4 + segments] device: the two-part update of include/pvd_hip.h (snapshot: this launch records the
-    scalars it used; replay: this launch is the deferred part and uses a recorded step's scalars, no tail)."""
+    scalars it used; replay: this launch is the deferred part and uses a recorded step's scalars, no tail).
+    zero_after: the update zeroes every gradient group it has read (the next step needs no zero_grad launch); arrivals: uint32 [1]
+    device, zero -- the tail's work is done inside the update kernel by the last workgroup to arrive (no tail launch)."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
     ex = None
-    if schedule is not None or l1_ranges or amp_update is not None or half_grad is not None or cold_bits is not None:
+    if (schedule is not None or l1_ranges or amp_update is not None or half_grad is not None or cold_bits is not None or zero_after
+            or arrivals is not None or snapshot is not None):
         ex = _AdamwExtras()
+        ex.zero_grad_after = 1 if zero_after else 0
+        if arrivals is not None:
+            _dev(arrivals)
+            if arrivals.dtype != torch.int32 or arrivals.numel() < 65 * 32:
+                raise PvdHipError("arrivals must be an int32 tensor of 65 * 32 counters (zero)")
+            ex.arrivals = arrivals.data_ptr()
         if cold_bits is not None:
             _dev(cold_bits)
             _want(cold_bits, torch.int32, "cold_bits")

@@ -510,6 +510,17 @@ typedef struct pvd_adamw_extras {
      * (no schedule evaluation, no tail kernel, nothing logged), leaving bit for bit what a single launch would have. */
     float *snapshot;
     const float *replay;
+    /* Fewer launches around the update (both off = the three-launch form: zero_grad ... update, tail):
+     *  zero_grad_after != 0: every gradient group the update visits is ZEROED once it has been read (also on a skipped step), so
+     *    the next step needs no zero_grad launch -- the caller guarantees that whatever may be non-zero is visited (dense walk,
+     *    or a warm list that contains the touched set).  g is written although the signature says const.
+     *  arrivals != NULL (DEVICE uint32 [65 * 32] = 65 counters on 128-byte lines of their own, zero before the first call; left
+     *    zero): the tail's work -- step count, schedule tick,
+     *    published rates, lazy log, snapshot, GradScaler.update(), clearing found_inf -- is done by the LAST WORKGROUP TO ARRIVE
+     *    inside the update kernel (every workgroup reads the step's scalars first thing and announces itself with a
+     *    relaxed atomic when it is done: the last one knows nobody will read them again), and no tail kernel is launched. */
+    uint32_t zero_grad_after;
+    uint32_t *arrivals;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,

@@ -626,6 +626,29 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
             part_a()
         pvd_hip.adamw_lazy_flush(p, seg_ends, packed, log, count, 0.01, status)
         res_two.append((p, m, v, step.clone(), scale.clone()))
+    # fewer launches (pvd_adamw_extras.arrivals / zero_grad_after): the tail's work done inside the update kernel by the last
+    # workgroup to arrive, and every gradient group zeroed once it has been read (also on the skipped step) -- same bits, and
+    # the gradient buffer comes back clean wherever the update walks (cold groups hold no gradient to begin with)
+    for use_cold in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        lr = torch.tensor([1e-2, 3e-3], device=dev)
+        base = lr.clone()
+        step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        arrivals = torch.zeros(65 * 32, dtype=torch.int32, device=dev)
+        log, count = torch.zeros(16, 2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        for k, gr in enumerate(grads):
+            gk = gr.clone()
+            pvd_hip.check_finite(gk, flag)
+            pvd_hip.adamw_step(p, gk, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag, schedule=(1, 100.0, 5e-5, base, sched),
+                               l1_ranges=[(0, 4096, 1e-3)], amp_update=(scale, tracker, 2.0, 0.5, 2000),
+                               cold_bits=packed if use_cold else None, lazy=(log, count, warm_list) if use_cold else None,
+                               zero_after=True, arrivals=arrivals)
+            assert not arrivals.any() and float(flag[0]) == 0.0  # counters back at zero, inf flag cleared by the in-kernel tail
+            assert not gk[: n4 * 4].any(), k  # (also after the skipped step k = 3)
+        if use_cold:
+            pvd_hip.adamw_lazy_flush(p, seg_ends, packed, log, count, 0.01, status)
+        res.append((p, m, v, step.clone(), scale.clone()))
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
