@@ -9,6 +9,7 @@
 #include "pvd_device.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace pvd {
 
@@ -162,20 +163,34 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
     const bool skip = found_inf && found_inf[0] != 0.f;
     __shared__ float l1_sh[kOptBlock / 64];
     __shared__ float lr_sh[kMaxSegments];
+    __shared__ double bc_sh[2];
     if (threadIdx.x < seg.count) lr_sh[threadIdx.x] = scheduled_lr(ex, lr, threadIdx.x);
     const double t = (double)step[0] + 1.0;  // the tail advances the stored count after the update
     const float gscale = grad_scale ? grad_scale[0] : 1.0f;
+    // the bias corrections: two fp64 pow() per THREAD were ~7 us of the launch (a few hundred instructions each, every thread the
+    // same two values); one lane of the last wave computes them while the first lanes evaluate the schedule
+    if (threadIdx.x == kOptBlock - 1) {
+        bc_sh[0] = 1.0 - pow((double)beta1, t);
+        bc_sh[1] = sqrt(1.0 - pow((double)beta2, t));
+    }
     __syncthreads();  // (every scalar of the step has been READ by this workgroup beyond this point)
     if (skip && !ex.zero_g) { adamw_announce(ex, step, found_inf, lr); return; }
     float l1_acc = 0.f;
-    const double bc1 = 1.0 - pow((double)beta1, t);
-    const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, t));
+    const double bc1 = bc_sh[0];
+    const double bc2_sqrt = bc_sh[1];
     const uint64_t n4 = ex.warm ? (uint64_t)ex.n_warm : n >> 2;
-    for (uint64_t j = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; j < n4; j += (uint64_t)gridDim.x * kOptBlock) {
-        const uint64_t i = ex.warm ? (uint64_t)ex.warm[j] : j;
+    // walking the warm list: the NEXT group's index is fetched while this group is updated (index -> data is a dependent pair of
+    // round trips otherwise), and the cold bit is not looked up -- the list holds exactly the groups whose bit is clear
+    const uint64_t jstride = (uint64_t)gridDim.x * kOptBlock;
+    uint64_t j = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x;
+    uint64_t i_next = (ex.warm && j < n4) ? (uint64_t)ex.warm[j] : j;
+    const bool test_cold = ex.cold && !ex.warm;
+    for (; j < n4; j += jstride) {
+        const uint64_t i = i_next;
+        if (j + jstride < n4) i_next = ex.warm ? (uint64_t)ex.warm[j + jstride] : j + jstride;
         const uint64_t e = i << 2;
         if (skip) {  // (zero_g) the skipped step's gradients must not reach the next step
-            if (!(ex.cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
         uint32_t k = 0;
@@ -184,7 +199,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         for (uint32_t r = 0; r < ex.n_l1; r++)
             if (e >= ex.l1_begin[r] && e < ex.l1_end[r]) l1 = ex.l1_coef[r];
         const double lrk = (double)lr_sh[k];
-        if (ex.cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u)) {
+        if (test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u)) {
             if (ex.lazy_log) continue;  // decay deferred: logged by the tail kernel, replayed by pvd_adamw_lazy_flush
             // g = m = v = 0: ea = es = 0, denom = eps, param -= step_size * 0 / eps leaves param as decayed below
             float4 P = reinterpret_cast<float4 *>(p)[i];
@@ -451,7 +466,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         return check_launch();
     }
     uint64_t blocks = ((ex.warm ? (uint64_t)ex.n_warm : n / 4) + kOptBlock - 1) / kOptBlock;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    static int cap = -1;  // PVD_ADAMW_BLOCKS: workgroups of the update launch (measurement)
+    if (cap < 0) { const char *e = getenv("PVD_ADAMW_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > 65535) cap = 256 * 16; }
+    if (blocks > (uint64_t)cap) blocks = (uint64_t)cap;
     if (blocks < 1) blocks = 1;
     const bool amp = extras_host && extras_host->amp_scale;
     if (amp && (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1)) return PVD_ERR_INVALID;

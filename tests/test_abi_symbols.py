@@ -60,3 +60,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "pvd_oracle" not in txt, os.path.join(root, f)
+
+
+def test_the_binding_settles_the_hardware_queues_before_the_runtime_starts():
+    """pvd_hip/__init__.py: GPU_MAX_HW_QUEUES = 2 unless the caller exported a value (the HIP runtime reads it at its first
+    call); graphs with parallel chains are only recorded under the validated setting (forked_graphs_ok), with an override."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "aaai2023-pvd_amd")
+    code = ("import os, sys; sys.path.insert(0, %r); import torch, pvd_hip; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), pvd_hip.HW_QUEUES, pvd_hip.HW_QUEUES_SOURCE.split()[0], pvd_hip.forked_graphs_ok())" % pkg)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "PVD_FORKED_GRAPHS")}
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        return p.stdout.decode().split()
+    assert run() == ["2", "2", "package", "True"]
+    assert run(GPU_MAX_HW_QUEUES="4") == ["4", "4", "caller", "False"]
+    assert run(GPU_MAX_HW_QUEUES="4", PVD_FORKED_GRAPHS="1") == ["4", "4", "caller", "True"]
+    assert run(PVD_FORKED_GRAPHS="0") == ["2", "2", "package", "False"]

@@ -31,3 +31,23 @@ if [ "$PMC" = 1 ]; then
   [ -n "$f" ] && python tools/pmc_summary.py $f | grep -i "k_hash_fwd_fused\|^kernel" > $OUT/pmc_tcc.csv; cat $OUT/pmc_tcc.csv
 fi
 true
+# smoke + the other workloads' lines (documentation: BASELINE.md rows 2, 4, 5)
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_args.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_driver_args.json
+timeout 300 python bench.py --workload teacher --steps 256 --warmup 320 > $OUT/bench_teacher.json 2>> $OUT/bench.err; cut -c1-250 $OUT/bench_teacher.json
+timeout 300 python bench.py --student hash --no-cpu-baseline --teacher-pretrain 100 > $OUT/bench_hash_student.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_hash_student.json
+timeout 300 python bench.py --student tensors --no-cpu-baseline --teacher-pretrain 100 > $OUT/bench_tensors_student.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_tensors_student.json
+true
+# where k_head_bwd's time goes: wave-parked vs issue-stalled vs active quad-cycles, MFMA busy, LDS conflicts --
+# separate PMC passes over eager steps
+if [ "$PMC" = 1 ]; then
+  : > $OUT/pmc_head_bwd.csv
+  for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS"; do
+    n=$(echo $c | cut -d' ' -f1)
+    (cd /tmp && rm -rf /tmp/pmch_$n && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmch_$n -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 5 --teacher-pretrain 20 --no-cpu-baseline --eager > /tmp/pmch_$n.log 2>&1)
+    f=$(find /tmp/pmch_$n -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py $f | grep -E "k_head_bwd|k_head_fwd|k_vm_bwd_split|k_vm_fwd|k_adamw|^kernel" >> $OUT/pmc_head_bwd.csv
+  done
+  cat $OUT/pmc_head_bwd.csv
+fi
+true
