@@ -514,8 +514,11 @@ class _TrainerBase:
         if self.flat_opt:
             self.optimizer.zero_in_step = bool(on) and os.environ.get("PVD_ADAMW_ZERO_IN_STEP", "1") != "0"
             if on:
-                self._graph_zeroes = self.optimizer.zero_in_step
+                self._graph_zeroes = False
             else:
+                # what the LAST recorded update did (it zeroes only in the touched-set / warm-list form, FlatAdamW.step) is what
+                # a replay leaves behind; the recording itself ran nothing, so right now the host knows nothing
+                self._graph_zeroes = bool(self.optimizer._zeroed_by_step)
                 self.optimizer._zeroed_by_step = False
 
     def _after_failed_capture(self):

@@ -113,6 +113,38 @@ def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits():
     assert np.allclose(la, lb, rtol=2e-3) and abs(l1a - l1b) <= 1e-4 * abs(l1b) and abs(lea - leb) <= 2e-3 * abs(leb), (la, lb, l1a, l1b, lea, leb)
 
 
+def test_what_the_host_believes_about_the_gradients_after_a_replay_is_what_the_graph_did():
+    """Inside a multi-step graph the update zeroes the gradients it has read (touched-set / warm-list form), so only the first
+    step of the graph launches a zero_grad; after a replay the touched set IS clean and the next zero_grad has nothing to
+    launch.  When the update cannot take that form (here: PVD_ADAMW_LAZY=0, no warm list) every recorded step zeroes for itself
+    and the host must not assume a clean buffer afterwards."""
+    import os
+    for lazy in ("1", "0"):
+        old = os.environ.get("PVD_ADAMW_LAZY")
+        os.environ["PVD_ADAMW_LAZY"] = lazy
+        try:
+            w = _workload(13)
+            torch.cuda.manual_seed(41)
+            w.enable_graph(steps_per_graph=3)
+            tr, o = w.trainer, w.trainer.optimizer
+            assert o._zeroed_by_step is False  # (a recording runs nothing)
+            w.step()
+            torch.cuda.synchronize()
+            clean = not bool(o.flat_g[o.touched.idx].any())
+            assert tr._graph_zeroes == (lazy == "1") and o._zeroed_by_step == (lazy == "1") and clean == (lazy == "1")
+            loss = tr.train_step(*w.device_batch())[0]  # an eager step after the replay starts from zero either way ...
+            assert np.isfinite(float(loss)) and o._zeroed_by_step is False
+            g_eager = o.flat_g[o.touched.idx].clone()
+            assert bool(g_eager.any())  # ... and leaves its gradients in place for whoever wants to look at them
+            o.zero_grad()
+            assert not bool(o.flat_g[o.touched.idx].any())
+        finally:
+            if old is None:
+                os.environ.pop("PVD_ADAMW_LAZY", None)
+            else:
+                os.environ["PVD_ADAMW_LAZY"] = old
+
+
 _GARBAGE_DURING_CAPTURE = r'''
 import gc, os, sys
 sys.path[:0] = [%(repo)r, %(pkg)r]

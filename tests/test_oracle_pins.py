@@ -173,6 +173,90 @@ def test_march_samples_match_bruteforce_fixed_step_walk(perturb):
     assert checked == int(counter[0]) and checked > 2000
 
 
+def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_steps=1024):
+    """The reference's marching loop (raymarching.cu:44-56, 340-481) for ANY bound / cascade count / dt_gamma, one float32
+    operation at a time in numpy scalars (fp64 only where the C source promotes: `0.5 * (...) * H`), independent of
+    oracle/pvd_oracle.c.  Returns [(xyz, dt, t - last_t)]."""
+    f32 = np.float32
+    s3 = f32(1.7320508075688772)
+    dt_min = f32(f32(2) * s3) / f32(max_steps)
+    dt_max = f32(f32(f32(2) * s3) * f32(1 << (C - 1))) / f32(H)
+    rd = (f32(1) / d).astype(np.float32)
+    rH = f32(1) / f32(H)
+    bound = f32(bound)
+    gam = f32(dt_gamma)
+
+    def step_of(t):
+        return min(max(f32(t * gam), dt_min), dt_max)
+
+    def exponent(v):  # frexpf(v, &e): v = m * 2^e with m in [0.5, 1); 0 -> 0
+        return int(np.frexp(f32(v))[1])
+    t, last_t, out = f32(t0), f32(t0), []
+    while t < far and len(out) < max_steps:
+        p = np.clip((np.float64(t) * d.astype(np.float64) + o).astype(np.float32), -bound, bound)  # fmaf
+        dt = step_of(t)
+        lvl_pos = min(C - 1, max(0, exponent(np.abs(p).max())))
+        lvl_dt = min(C - 1, max(0, exponent(f32(f32(dt * f32(H)) * f32(0.5)))))
+        level = max(lvl_pos, lvl_dt)
+        mip_bound = min(f32(1 << level), bound)
+        mip_rbound = f32(1) / mip_bound
+        v = ((p * mip_rbound).astype(np.float32) + f32(1)).astype(np.float32)
+        cell = np.clip((0.5 * v.astype(np.float64) * H).astype(np.float32), 0, H - 1).astype(np.int32)
+        m = level * H ** 3 + int(oracle.morton3D(cell[None])[0])
+        if (bits[m // 8] >> (m % 8)) & 1:
+            t = f32(t + dt)
+            out.append((p.copy(), dt, f32(t - last_t)))
+            last_t = t
+        else:
+            sgn = np.copysign(f32(1), d).astype(np.float32)
+            a = (cell.astype(np.float32) + f32(0.5) + (f32(0.5) * sgn).astype(np.float32)).astype(np.float32)
+            face = (((a * rH).astype(np.float32) * f32(2)).astype(np.float32) - f32(1)).astype(np.float32)
+            txyz = (((face * mip_bound).astype(np.float32) - p).astype(np.float32) * rd).astype(np.float32)
+            tt = f32(t + max(f32(0), txyz.min()))
+            while True:
+                t = f32(t + step_of(t))
+                if not t < tt:
+                    break
+    return out
+
+
+@pytest.mark.parametrize("bound,C,dt_gamma", [(2.0, 2, 1.0 / 256), (1.5, 2, 1.0 / 256), (2.0, 2, 0.0), (4.0, 3, 1.0 / 128)])
+def test_march_samples_match_bruteforce_walk_with_cascades_and_growing_steps(bound, C, dt_gamma):
+    """configs[4]'s marcher (bound > 1: several cascades, mip level from position AND from step size, dt = clamp(t * dt_gamma)):
+    the independent numpy walk reproduces every ray's samples -- positions, dt, t - last_t -- bit for bit, for a power-of-two and
+    a non-power-of-two bound, with the start jitter on."""
+    from pvd.scene import ChairScene, packbits_torch
+    H = 128
+    o, d, _, _ = _scene(96, 2, bound=bound)
+    # the scene scaled into the outer cascades (as tests/test_hip_workloads.py does for configs[4]), thickened so that the
+    # coarse cells of the outer cascades hold it
+    bits = packbits_torch(ChairScene(thicken=0.1, scale=1.9 if bound <= 2 else 0.95 * bound).density_grid(H, bound, C), 10.0).numpy()
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    n, f = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, bits, bound, C, H, n, f, 96 * 1024, perturb=1, dt_gamma=dt_gamma)
+    f32 = np.float32
+    dt_min = f32(f32(2) * f32(1.7320508075688772)) / f32(1024)
+    checked, outer = 0, 0
+    for ray in range(96):
+        if f[ray] == np.finfo(np.float32).max:
+            assert rays[ray, 2] == 0
+            continue
+        _, noise = oracle.pcg32_stream(42, ray, 1)
+        t0 = f32(f32(n[ray]) + f32(dt_min * f32(noise[0])))
+        walk = _bruteforce_walk_general(o[ray], d[ray], f[ray], bits, t0, bound, C, H, dt_gamma)
+        s, c = int(rays[ray, 1]), int(rays[ray, 2])
+        assert c == len(walk), (ray, c, len(walk))
+        if c:
+            assert np.array_equal(xyzs[s:s + c], np.stack([w[0] for w in walk])), ray
+            assert np.array_equal(deltas[s:s + c, 0], np.array([w[1] for w in walk], np.float32)), ray
+            assert np.array_equal(deltas[s:s + c, 1], np.array([w[2] for w in walk], np.float32)), ray
+            checked += c
+            outer += int((np.abs(xyzs[s:s + c]).max(1) > 1.0).sum())
+    assert checked == int(counter[0]) and checked > 500 and outer > 50, (checked, outer)
+    if dt_gamma > 0:
+        assert np.unique(deltas[:checked, 0]).size > 3  # the step does grow with t
+
+
 def test_march_overflow_rule():
     o, d, bits, _ = _scene(512, 2)
     aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
