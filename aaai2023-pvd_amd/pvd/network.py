@@ -322,6 +322,10 @@ class NeRFNetwork(NeRFRenderer):
                     prod.register_hook(hook)
                     self._between_backwards = None  # taken
                 out = fh.vm_head_train(self, sraw, prod, d)
+                hook = getattr(self, "_before_head_backward", None)  # (trainer: called when sigma's gradient arrives, i.e. after the
+                if hook is not None and out[0].requires_grad:        #  compositing backward and right before the head's backward)
+                    out[0].register_hook(hook)
+                    self._before_head_backward = None  # taken
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student
             elif (self.model_type == "mlp" and not torch.is_grad_enabled() and hasattr(fh, "features_head_infer")

@@ -930,7 +930,12 @@ class DistillTrainer(_TrainerBase):
                         # prefix rebinds.)
                         # "start" = before this step's forward: compute_loss re-installs the teacher outputs of ITS prefix first
                         # thing, so the rebinding is harmless once the fork's host code has run before it.
-                        fork_at = fork_mode if fork_mode in ("mid", "backward", "optimizer", "start") else "start"
+                        # "headbwd" = right before the student's head backward (after the objective's and the compositing backward).
+                        # "start2" = two stages: the batch and the march (instruction-bound) fork at the start, next to the student's
+                        # forward; the frozen teacher's forward (gathers) is held back until the student's head backward begins, so
+                        # that it does not sit on top of the short latency-bound launches of the objective in between.
+                        two_stage = fork_mode == "start2"
+                        fork_at = "start" if two_stage else (fork_mode if fork_mode in ("mid", "backward", "optimizer", "start", "headbwd") else "start")
                         pre_next = None
 
                         def fork(k=k):
@@ -947,8 +952,18 @@ class DistillTrainer(_TrainerBase):
                                     done.record(branch)
                                     # (the objective adds up the L1 term from the partial sums this launch refreshes)
                                     self._before_objective = lambda: main.wait_event(done)
+                                if two_stage:
+                                    return self.prefetch_march(batch_fn)  # stage 1; stage 2 (teacher) follows from the hook below
                                 nxt = self.prefetch(batch_fn)
                                 if k + 1 == K:  # for the next replay
+                                    carried.store(nxt)
+                                return nxt
+
+                        def teacher_stage(part, k=k):
+                            branch.wait_stream(main)  # not before the main chain has come this far
+                            with torch.cuda.stream(branch):
+                                nxt = self.prefetch_teacher(part)
+                                if k + 1 == K:
                                     carried.store(nxt)
                                 return nxt
                         held = {}
@@ -959,7 +974,22 @@ class DistillTrainer(_TrainerBase):
                                     held["pre"] = fork()
                                 return None
                             self.model_stu._between_backwards = between
-                        if more and fork_at == "start":
+                        if more and fork_at == "headbwd":
+
+                            def before_head(grad, held=held):
+                                if "pre" not in held:
+                                    held["pre"] = fork()
+                                return None
+                            self.model_stu._before_head_backward = before_head
+                        if more and two_stage:
+                            held["part"] = fork()
+
+                            def before_head2(grad, held=held):
+                                if "pre" not in held:
+                                    held["pre"] = teacher_stage(held["part"])
+                                return None
+                            self.model_stu._before_head_backward = before_head2
+                        elif more and fork_at == "start":
                             pre_next = fork()
                         elif split:
                             self.optimizer.run_part_a()  # no branch to put it on
@@ -970,13 +1000,22 @@ class DistillTrainer(_TrainerBase):
                         finally:
                             if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
                                 fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
+                            if fork_at == "headbwd" and getattr(self.model_stu, "_before_head_backward", None) is not None:
+                                fork_at = "backward"
+                            if two_stage and getattr(self.model_stu, "_before_head_backward", None) is not None:
+                                held["pre"] = teacher_stage(held["part"])  # hook not taken: the teacher stage before the backward
                             self.model_stu._between_backwards = None
+                            self.model_stu._before_head_backward = None
                         if more and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
                             pre_next = fork()
                         self._backward(self._static_out[0])
                         if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
                             raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
-                        if more and fork_at == "mid":
+                        if more and two_stage:
+                            pre_next = held.get("pre")
+                            if pre_next is None:  # the forward did not take the hook (not a fused VM student): stage 2 now
+                                pre_next = teacher_stage(held["part"])
+                        if more and fork_at in ("mid", "headbwd"):
                             pre_next = held.get("pre")
                         if more and pre_next is None:  # "optimizer", or a student without the hook point
                             pre_next = fork()
@@ -989,6 +1028,7 @@ class DistillTrainer(_TrainerBase):
                         self.optimizer.run_part_a()  # the last step's: a replay leaves nothing owed
                 except Exception:
                     self.model_stu._between_backwards = None
+                    self.model_stu._before_head_backward = None
                     self.model_stu.__dict__.pop("_before_head", None)
                     self.model_stu.__dict__.pop("_train_image_ready", None)
                     self.__dict__.pop("_before_objective", None)
