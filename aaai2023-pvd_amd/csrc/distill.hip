@@ -218,7 +218,10 @@ int pvd_distill_sumsq(const float *img_stu, const float *img_tea, uint32_t n_img
 int pvd_distill_loss_final(float *S4, uint32_t n_img, uint32_t M, int reduce, float *rates4, float fea_decay, const float *extra,
                            uint32_t n_extra, float *loss, float *coef4, float *norms4, pvd_stream_t stream) {
     if (!S4 || !rates4 || !loss || !coef4 || !norms4 || (n_extra && !extra)) return PVD_ERR_INVALID;
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kLossBlock), 0, (hipStream_t)stream, S4, reduce ? sumsq_blocks(n_img, M) : 0u, rates4,
+    // reduce: 0 = S4[0..4) are final, 1 = pvd_distill_sumsq's partials (their count follows from n_img / M), >= 2 = that many
+    // partials as they are (pvd_composite_objective_forward: pvd_composite_objective_blocks(N, rows))
+    const uint32_t nparts = reduce >= 2 ? (uint32_t)reduce : (reduce ? sumsq_blocks(n_img, M) : 0u);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kLossBlock), 0, (hipStream_t)stream, S4, nparts, rates4,
                        fea_decay, extra, n_extra, loss, coef4, norms4);
     return check_launch();
 }

@@ -823,18 +823,121 @@ struct CompositeEpilogue {
     const int32_t *budget;  // logical sample budget in device memory (see logical_budget), or NULL
 };
 
+// The stage-3 distillation objective riding on the student's compositing launches (pvd_composite_objective_*): the forward
+// launch also forms the four sums of squares of Trainer.train_step's normL2 terms (utils.py:1109-1176) -- the image term by
+// the workgroups that composite the rays, the feature / sigma / colour terms by extra workgroups of the same launch -- and the
+// backward launch forms the image gradient coef * (I_stu - I_tea) on the fly and writes the feature / colour gradients from
+// extra workgroups.  Two of the five short dependent launches between the student's head forward and head backward go away;
+// the arithmetic per element is that of k_sumsq4 / k_sumsq4_bwd (distill.hip).
+struct CompositeObjective {
+    const float *img_t;           // [N,3] teacher image, by ray index
+    const float *fea_s, *fea_t;   // [rows,16] feature_sigma_color (column 0 = sigma_l)
+    const float *col_s, *col_t;   // [rows,3] color_l
+    uint32_t rows;
+    uint32_t ray_blocks;          // workgroups [0, ray_blocks) composite rays, the others walk the feature rows
+    float *partials;              // forward: float4 per workgroup {sum (I_t - I_s)^2, sum dF^2, sum dsigma^2, sum dc^2}
+    const float *coef, *upstream; // backward: r_i / ||.||_i [4] (k_loss_final), upstream gradient [1]
+    float *g_fea, *g_col;         // backward outputs [rows,16], [rows,3]
+    // the objective FINISHED by the backward launch (no k_loss_final between the passes): every workgroup reduces the forward
+    // launch's partial sums for itself and forms the coefficients; workgroup 0 publishes loss / norms / coefficients / sums.
+    // The feature rate's per-step decay (utils.py:1044) is then applied by ONE thread of the forward launch (rates_decay),
+    // which nothing else reads meanwhile.
+    float *rates_decay;           // forward: rates_decay[1] *= fea_decay (or NULL)
+    float fea_decay;
+    const float *rates;           // backward: != NULL = finish here (coef is then an OUTPUT)
+    const float *extra;           // partial sums of a parameter-only term of the loss value (L1 regulariser), or NULL
+    uint32_t n_extra, nparts;
+    float *sums, *loss, *coef_out, *norms;
+};
+
+__device__ __forceinline__ float objective_block_sum(float v, float *__restrict__ sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / kWave; w++) r += sh[w];
+    return r;
+}
+
+// (backward, ob.rates != NULL) the four coefficients from the partial sums; same arithmetic as k_loss_final
+__device__ __forceinline__ void objective_finish(const CompositeObjective &ob, float (&c4)[4], float *__restrict__ sh) {
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    for (uint32_t i = threadIdx.x; i < ob.nparts; i += kBlock) {
+        const float4 v = reinterpret_cast<const float4 *>(ob.partials)[i];
+        a += v.x; b += v.y; c += v.z; d += v.w;
+    }
+    float s4[4] = {objective_block_sum(a, sh), objective_block_sum(b, sh), objective_block_sum(c, sh), objective_block_sum(d, sh)};
+    float nrm[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        nrm[i] = sqrtf(s4[i]);
+        c4[i] = nrm[i] > 0.f ? ob.rates[i] / nrm[i] : 0.f;  // d (r ||x||) / dx = r x / ||x||
+    }
+    if (blockIdx.x == 0) {  // the value of the objective (k_loss_final's summation order: parameter-only term first)
+        float e = 0.f;
+        for (uint32_t i = threadIdx.x; i < ob.n_extra; i += kBlock) e += ob.extra[i];
+        e = objective_block_sum(e, sh);
+        if (threadIdx.x == 0) {
+            float t = e;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { t += ob.rates[i] * nrm[i]; ob.sums[i] = s4[i]; ob.norms[i] = nrm[i]; ob.coef_out[i] = c4[i]; }
+            ob.loss[0] = t;
+        }
+    }
+}
+
+// workgroup `blk` of `nblk` over the feature rows: the sums of k_sumsq4 without its image term
+__device__ __forceinline__ void objective_row_sums(const CompositeObjective &ob, uint32_t blk, uint32_t nblk, float *__restrict__ sh) {
+    const uint32_t tid = blk * kBlock + threadIdx.x, stride = nblk * kBlock;
+    float s_fea = 0.f, s_sig = 0.f, s_col = 0.f;
+    for (uint32_t i = tid; i < ob.rows * 4u; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(ob.fea_s)[i], b = reinterpret_cast<const float4 *>(ob.fea_t)[i];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        s_fea += dx * dx + dy * dy + dz * dz + dw * dw;
+        if ((i & 3u) == 0) s_sig += dx * dx;
+    }
+    for (uint32_t i = tid; i < ob.rows * 3u; i += stride) { const float d = ob.col_s[i] - ob.col_t[i]; s_col += d * d; }
+    s_fea = objective_block_sum(s_fea, sh); s_sig = objective_block_sum(s_sig, sh); s_col = objective_block_sum(s_col, sh);
+    if (threadIdx.x == 0) reinterpret_cast<float4 *>(ob.partials)[ob.ray_blocks + blk] = make_float4(0.f, s_fea, s_sig, s_col);
+}
+
+// ... and the gradients of k_sumsq4_bwd without the image's
+__device__ __forceinline__ void objective_row_grads(const CompositeObjective &ob, const float (&c4)[4], uint32_t blk, uint32_t nblk) {
+    const uint32_t tid = blk * kBlock + threadIdx.x, stride = nblk * kBlock;
+    const float up = ob.upstream[0];
+    const float c_fea = c4[1] * up, c_sig = c4[2] * up, c_col = c4[3] * up;
+    for (uint32_t i = tid; i < ob.rows * 4u; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(ob.fea_s)[i], b = reinterpret_cast<const float4 *>(ob.fea_t)[i];
+        float4 g = make_float4(c_fea * (a.x - b.x), c_fea * (a.y - b.y), c_fea * (a.z - b.z), c_fea * (a.w - b.w));
+        if ((i & 3u) == 0) g.x += c_sig * (a.x - b.x);
+        reinterpret_cast<float4 *>(ob.g_fea)[i] = g;
+    }
+    for (uint32_t i = tid; i < ob.rows * 3u; i += stride) ob.g_col[i] = c_col * (ob.col_s[i] - ob.col_t[i]);
+}
+
 // reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
-template <bool EPI>
+template <bool EPI, bool OBJ = false>
 __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
                                                                uint32_t M, uint32_t N, float *__restrict__ weights_sum,
-                                                               float *__restrict__ depth, float *__restrict__ image, CompositeEpilogue ep) {
+                                                               float *__restrict__ depth, float *__restrict__ image, CompositeEpilogue ep,
+                                                               CompositeObjective ob = CompositeObjective{}) {
+    __shared__ float obj_sh[kBlock / kWave];
+    if (OBJ && blockIdx.x >= ob.ray_blocks) {
+        if (ob.rates_decay && blockIdx.x == ob.ray_blocks && threadIdx.x == 0) ob.rates_decay[1] *= ob.fea_decay;
+        objective_row_sums(ob, blockIdx.x - ob.ray_blocks, gridDim.x - ob.ray_blocks, obj_sh);
+        return;
+    }
     const uint32_t n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[3 * (size_t)n];
-    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
-    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
+    if (!OBJ && n >= N) return;
+    const bool live = n < N;  // (OBJ: the whole workgroup stays for the reduction of the image term)
+    const uint32_t index = live ? (uint32_t)rays[3 * (size_t)n] : 0u;
+    const uint32_t offset = live ? (uint32_t)rays[3 * (size_t)n + 1] : 0u;
+    const uint32_t num = live ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
     float r = 0, g = 0, b = 0, ws = 0, d = 0;
     if (!(num == 0 || offset + num >= logical_budget(M, EPI ? ep.budget : nullptr))) {
         float T_carry = 1.0f, t_carry = 0.0f;
@@ -862,7 +965,8 @@ __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__re
         }
         r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
     }
-    if (lane == 0) {
+    float d2 = 0.f;  // (OBJ) this ray's share of sum (I_tea - I_stu)^2
+    if (lane == 0 && live) {
         if (EPI) {
             const float t = 1.0f - ws;
             const float b0 = ep.bg ? ep.bg[3 * (size_t)index] : ep.bg_scalar, b1 = ep.bg ? ep.bg[3 * (size_t)index + 1] : ep.bg_scalar,
@@ -874,18 +978,37 @@ __global__ void __launch_bounds__(kBlock) k_composite_fwd_wave(const float *__re
         weights_sum[index] = ws;
         depth[index] = d;
         image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+        if (OBJ) {
+            const float e0 = ob.img_t[3 * (size_t)index] - r, e1 = ob.img_t[3 * (size_t)index + 1] - g, e2 = ob.img_t[3 * (size_t)index + 2] - b;
+            d2 = e0 * e0 + e1 * e1 + e2 * e2;
+        }
+    }
+    if (OBJ) {
+        const float s_img = objective_block_sum(d2, obj_sh);
+        if (threadIdx.x == 0) reinterpret_cast<float4 *>(ob.partials)[blockIdx.x] = make_float4(s_img, 0.f, 0.f, 0.f);
     }
 }
 
 // reference: kernel_composite_rays_train_backward, raymarching.cu:606-686.  With EPI the incoming gradient is
 // w.r.t. the blended image: d blended / d ws = -bg, and `image` holds the blended colours (un-blended here).
-template <bool EPI>
+template <bool EPI, bool OBJ = false>
 __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
                                                                const float *__restrict__ sigmas, const float *__restrict__ rgbs,
                                                                const float *__restrict__ deltas, const int32_t *__restrict__ rays,
                                                                const float *__restrict__ weights_sum, const float *__restrict__ image,
                                                                uint32_t M, uint32_t N, float *__restrict__ grad_sigmas,
-                                                               float *__restrict__ grad_rgbs, CompositeEpilogue ep) {
+                                                               float *__restrict__ grad_rgbs, CompositeEpilogue ep,
+                                                               CompositeObjective ob = CompositeObjective{}) {
+    float c4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (OBJ) {
+        __shared__ float fin_sh[kBlock / kWave];
+        if (ob.rates) objective_finish(ob, c4, fin_sh);  // (all threads of every workgroup: before anybody leaves)
+        else { c4[0] = ob.coef[0]; c4[1] = ob.coef[1]; c4[2] = ob.coef[2]; c4[3] = ob.coef[3]; }
+    }
+    if (OBJ && blockIdx.x >= ob.ray_blocks) {
+        objective_row_grads(ob, c4, blockIdx.x - ob.ray_blocks, gridDim.x - ob.ray_blocks);
+        return;
+    }
     const uint32_t n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (n >= N) return;
@@ -906,8 +1029,15 @@ __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__re
     }
     if (num == 0 || offset + num >= logical_budget(M, EPI ? ep.budget : nullptr)) return;
     float gws = grad_ws ? grad_ws[index] : 0.0f;
-    const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
     float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
+    float g0, g1, g2;
+    if (OBJ) {  // d (r_rgb ||I_tea - I_stu||) / d I_stu, as k_sumsq4_bwd writes it: coef * upstream * (I_stu - I_tea)
+        const float c_img = c4[0] * ob.upstream[0];
+        g0 = c_img * (rF - ob.img_t[3 * (size_t)index]); g1 = c_img * (gF - ob.img_t[3 * (size_t)index + 1]);
+        g2 = c_img * (bF - ob.img_t[3 * (size_t)index + 2]);
+    } else {
+        g0 = grad_image[3 * (size_t)index]; g1 = grad_image[3 * (size_t)index + 1]; g2 = grad_image[3 * (size_t)index + 2];
+    }
     const float wsF = weights_sum[index];
     if (EPI) {
         const float b0 = ep.bg ? ep.bg[3 * (size_t)index] : ep.bg_scalar, b1 = ep.bg ? ep.bg[3 * (size_t)index + 1] : ep.bg_scalar,
@@ -1423,6 +1553,62 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
     const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f, fresh ? 1u : 0u, budget_dev};
     hipLaunchKernelGGL(k_composite_bwd_wave<true>, dim3(div_up(N, kBlock / kWave)), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, ep);
+    return check_launch();
+}
+
+// ---- the student's compositing with the stage-3 objective riding along (see CompositeObjective)
+static uint32_t objective_row_blocks(uint32_t rows, uint32_t cap) {
+    uint32_t b = div_up(rows * 4u, kBlock);
+    if (b > cap) b = cap;
+    return b < 1 ? 1 : b;
+}
+
+uint32_t pvd_composite_objective_blocks(uint32_t N, uint32_t rows) { return div_up(N, kBlock / kWave) + objective_row_blocks(rows, 256u); }
+
+int pvd_composite_objective_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
+                                    const float *bg, float bg_scalar, const float *nears, const float *fars, float depth_eps,
+                                    float *weights_sum, float *depth, float *image, const int32_t *budget_dev, const float *img_tea,
+                                    const float *fea_stu, const float *fea_tea, const float *col_stu, const float *col_tea, uint32_t rows,
+                                    float *S4, float *rates4_decay, float fea_decay, pvd_stream_t stream) {
+    PVD_REQUIRE(N > 0 && rows > 0);
+    PVD_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && weights_sum && depth && image);
+    PVD_REQUIRE(img_tea && fea_stu && fea_tea && col_stu && col_tea && S4);
+    const CompositeEpilogue ep{bg, bg_scalar, nears, fars, depth_eps, 0u, budget_dev};
+    CompositeObjective ob{};
+    ob.img_t = img_tea; ob.fea_s = fea_stu; ob.fea_t = fea_tea; ob.col_s = col_stu; ob.col_t = col_tea; ob.rows = rows;
+    ob.ray_blocks = div_up(N, kBlock / kWave);
+    ob.partials = S4 + 4;  // the layout pvd_distill_loss_final reduces: S4[0..4) the sums, then one float4 per workgroup
+    ob.rates_decay = rates4_decay; ob.fea_decay = fea_decay;
+    const uint32_t blocks = ob.ray_blocks + objective_row_blocks(rows, 256u);
+    hipLaunchKernelGGL((k_composite_fwd_wave<true, true>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
+                       weights_sum, depth, image, ep, ob);
+    return check_launch();
+}
+
+int pvd_composite_objective_backward(const float *grad_weights_sum, const float *sigmas, const float *rgbs, const float *deltas,
+                                     const int32_t *rays, const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                     const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs, uint32_t flags,
+                                     const int32_t *budget_dev, const float *img_tea, const float *fea_stu, const float *fea_tea,
+                                     const float *col_stu, const float *col_tea, uint32_t rows, float *coef4, const float *upstream,
+                                     float *g_fea, float *g_col, const float *rates4, const float *extra, uint32_t n_extra, float *S4,
+                                     float *loss, float *norms4, pvd_stream_t stream) {
+    PVD_REQUIRE(N > 0 && rows > 0);
+    PVD_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
+    PVD_REQUIRE(img_tea && fea_stu && fea_tea && col_stu && col_tea && coef4 && upstream && g_fea && g_col);
+    PVD_REQUIRE(!rates4 || (S4 && loss && norms4 && (!n_extra || extra)));
+    const bool fresh = (flags & PVD_MARCH_FRESH) != 0;
+    const CompositeEpilogue ep{bg, bg_scalar, nullptr, nullptr, 0.f, fresh ? 1u : 0u, budget_dev};
+    CompositeObjective ob{};
+    ob.img_t = img_tea; ob.fea_s = fea_stu; ob.fea_t = fea_tea; ob.col_s = col_stu; ob.col_t = col_tea; ob.rows = rows;
+    ob.ray_blocks = div_up(N, kBlock / kWave);
+    ob.coef = coef4; ob.upstream = upstream; ob.g_fea = g_fea; ob.g_col = g_col;
+    if (rates4) {  // finish the objective here: the forward launch's partial sums sit at S4 + 4
+        ob.rates = rates4; ob.extra = extra; ob.n_extra = n_extra; ob.nparts = pvd_composite_objective_blocks(N, rows);
+        ob.partials = S4 + 4; ob.sums = S4; ob.loss = loss; ob.coef_out = coef4; ob.norms = norms4;
+    }
+    const uint32_t blocks = ob.ray_blocks + objective_row_blocks(rows, 2048u);
+    hipLaunchKernelGGL((k_composite_bwd_wave<true, true>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, grad_weights_sum,
+                       (const float *)nullptr, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, ep, ob);
     return check_launch();
 }
 

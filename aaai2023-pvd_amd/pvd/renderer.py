@@ -243,10 +243,15 @@ class NeRFRenderer(nn.Module):
                 sigmas = self.density_scale * sigmas
             eps = 0.0 if self.teacher_variant else 1e-6  # renderer.py:446 vs just_train_tea/renderer.py
             # compositing + `image += (1 - ws) * bg` + depth normalisation (renderer.py:442-446) as one op
+            # (trainer) a stage-3 objective riding on the compositing launches: it needs this model's feature / colour rows
+            ride = kwargs.get("objective")
+            if ride is not None and not (torch.is_grad_enabled() and ride.with_student(getattr(self, "feature_sigma_color", None), getattr(self, "color_l", None))):
+                ride = None
+            okw = {} if ride is None else {"objective": ride}
             if budget is not None and own:
-                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True, budget[1])
+                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True, budget[1], **okw)
             else:
-                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True)  # rays: straight from the march
+                weights_sum, depth, image = rm.composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg_color, nears, fars, eps, True, **okw)  # rays: straight from the march
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             return {"depth": depth, "image": image, "inherited_params": inherited_params, "sigmas": sigmas, "rays": rays,

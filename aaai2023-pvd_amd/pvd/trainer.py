@@ -621,6 +621,7 @@ class DistillTrainer(_TrainerBase):
     def compute_loss(self, rays_o, rays_d, bg_color, nears_fars=None, pre=None):
         o, stu, tea = self.opt, self.model_stu, self.model_tea
         o.global_step = self.global_step
+        self.__dict__.pop("_ride", None)  # (an ObjectiveRide belongs to the step that created it)
         kw = self.render_kwargs()
         kw_stu = dict(kw, nears_fars=nears_fars) if nears_fars is not None else kw  # the batch kernel already intersected the box
         if pre is not None:
@@ -629,8 +630,23 @@ class DistillTrainer(_TrainerBase):
             out_tea = dict(pre["out_tea"])
             if out_tea.get("image") is not None and pre.get("replayed_ahead", False):
                 out_tea["image"] = out_tea["image"].clone()  # the prefix graph overwrites its outputs one step ahead
+            # the teacher's outputs exist already: the stage-3 objective can ride on the student's compositing launches
+            # (ObjectiveRide: two launches fewer on the chain; PVD_OBJECTIVE_RIDE=0 keeps the separate launches)
+            ride = None
+            if (self.fused_loss is not None and o.loss_type == "normL2" and not self.dp.enabled and torch.is_grad_enabled()
+                    and self._stage_of(self.global_step) == 3 and out_tea.get("image") is not None
+                    and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc * 0.995, o.loss_rate_rgb) > 0.0
+                    and torch.is_tensor(getattr(tea, "feature_sigma_color", None)) and torch.is_tensor(getattr(tea, "color_l", None))
+                    and tea.feature_sigma_color.dim() == 2 and tea.feature_sigma_color.shape[-1] == 16
+                    and tea.feature_sigma_color.dtype == torch.float32 and pre["rays_o"].is_cuda
+                    and os.environ.get("PVD_OBJECTIVE_RIDE", "1") != "0" and os.environ.get("PVD_LOSS_DEFER", "0") != "1"):
+                from .losses import ObjectiveRide
+                # PVD_OBJECTIVE_FINISH=0: k_loss_final stays a launch of its own between the passes
+                fin = os.environ.get("PVD_OBJECTIVE_FINISH", "1") != "0"
+                ride = ObjectiveRide(out_tea["image"], tea.feature_sigma_color, tea.color_l, rates_decay=self.rates if fin else None, fea_decay=0.995)
             out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
-                                 inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, **kw)
+                                 inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, objective=ride, **kw)
+            self._ride = ride if (ride is not None and ride.S is not None) else None
         elif self.overlap_teacher and rays_o.is_cuda and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
             # march once, then the frozen teacher's forward runs on a side stream next to the student's forward
             # (they share only the samples); in a captured step this becomes two parallel branches of the graph
@@ -685,6 +701,8 @@ class DistillTrainer(_TrainerBase):
                        and getattr(stu, "sigma_l", None) is not None and getattr(tea, "sigma_l", None) is not None
                        and stu.sigma_l.dim() == 1 and tea.sigma_l.shape == stu.sigma_l.shape
                        and not (o.l1_reg_weight > 0.0 and o.model_type == "vm"))
+        assert fused or not getattr(getattr(self, "_ride", None), "decayed", False), \
+            "the compositing launch applied the feature rate's decay for a fused objective that is not being formed"
         if not fused:
             self.fea_rate.mul_(0.995) if not fused_nofea else None  # (the fused objective decays the device-side rate inside its own kernel)
         info = {}
@@ -726,8 +744,10 @@ class DistillTrainer(_TrainerBase):
             # (tests/test_hip_fused_misc.py) and measured: 0.3945 vs 0.3930 ms/step -- the single-workgroup launch it removes
             # was hidden behind its neighbours in the replayed graph; off by default.
             defer = not add_l1 and torch.is_grad_enabled() and os.environ.get("PVD_LOSS_DEFER", "0") == "1"
+            ride = self.__dict__.pop("_ride", None)
+            rkw = {} if (ride is None or defer) else {"ride": ride}
             l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
-                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra, defer=defer)
+                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra, defer=defer, **rkw)
             loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
             if add_l1:
                 loss = loss + self._l1_term()

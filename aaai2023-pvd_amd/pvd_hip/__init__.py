@@ -80,6 +80,7 @@ ENTRY_POINTS = (
     "pvd_head_forward", "pvd_hash_head_forward_fused",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
+    "pvd_composite_objective_blocks", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
     "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
 )
@@ -87,6 +88,7 @@ for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
         getattr(_lib, _name).restype = ctypes.c_int
 _lib.pvd_march_workspace_bytes.restype = ctypes.c_size_t
+_lib.pvd_composite_objective_blocks.restype = ctypes.c_uint32
 
 
 class PvdHipError(RuntimeError):
@@ -760,6 +762,57 @@ def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs,
           _p(budget_dev))
 
 
+
+def composite_objective_blocks(N, rows):
+    return int(_lib.pvd_composite_objective_blocks(_u32(N), _u32(rows)))
+
+
+def composite_objective_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar, nears, fars, depth_eps, weights_sum, depth, image,
+                                img_t, fea_s, fea_t, col_s, col_t, S4, budget_dev=None, rates_decay=None, fea_decay=1.0):
+    """pvd_composite_objective_forward: composite_rays_train_bg_forward + the partial sums of the four squared norms of the
+    stage-3 objective in one launch (S4: 4 + 4 * composite_objective_blocks(N, rows) floats)."""
+    dev = _dev(sigmas, rgbs, deltas, rays, bg, nears, fars, weights_sum, depth, image, budget_dev, img_t, fea_s, fea_t, col_s, col_t, S4)
+    _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, nears=nears, fars=fars, weights_sum=weights_sum, depth=depth, image=image,
+             img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, S4=S4)
+    _want(rays, torch.int32, "rays")
+    rows = fea_s.shape[0]
+    if fea_s.dim() != 2 or fea_s.shape[1] != 16 or fea_t.shape != fea_s.shape or col_s.shape != (rows, 3) or col_t.shape != (rows, 3):
+        raise PvdHipError("feature rows must be [rows,16], colour rows [rows,3]")
+    if img_t.numel() != 3 * N or S4.numel() < 4 + 4 * composite_objective_blocks(N, rows):
+        raise PvdHipError("teacher image must be [N,3]; S4 must hold 4 + 4 * composite_objective_blocks floats")
+    if budget_dev is not None:
+        _want(budget_dev, torch.int32, "budget_dev")
+    _call("pvd_composite_objective_forward", dev, _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u32(M), _u32(N), _p(bg), _f32(bg_scalar),
+          _p(nears), _p(fars), _f32(depth_eps), _p(weights_sum), _p(depth), _p(image), _p(budget_dev), _p(img_t), _p(fea_s), _p(fea_t),
+          _p(col_s), _p(col_t), _u32(rows), _p(S4), _p(rates_decay), _f32(fea_decay))
+
+
+def composite_objective_backward(grad_ws, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, bg, bg_scalar, grad_sigmas, grad_rgbs,
+                                 img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_fea, g_col, fresh=False, budget_dev=None, finish=None):
+    """pvd_composite_objective_backward: sumsq_backward + composite_rays_train_bg_backward in one launch.
+    finish = (rates4, extra or None, S4, loss, norms4): the launch also finishes the objective (coef4 becomes an output)."""
+    dev = _dev(grad_ws, sigmas, rgbs, deltas, rays, weights_sum, image, bg, grad_sigmas, grad_rgbs, budget_dev, img_t, fea_s, fea_t, col_s,
+               col_t, coef4, upstream, g_fea, g_col)
+    _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, image=image, grad_sigmas=grad_sigmas, grad_rgbs=grad_rgbs,
+             img_t=img_t, fea_s=fea_s, fea_t=fea_t, col_s=col_s, col_t=col_t, coef4=coef4, upstream=upstream, g_fea=g_fea, g_col=g_col)
+    _want(rays, torch.int32, "rays")
+    rows = fea_s.shape[0]
+    if g_fea.shape != fea_s.shape or g_col.shape != col_s.shape or fea_s.shape[1] != 16:
+        raise PvdHipError("gradient buffers must have the shapes of the student tensors ([rows,16], [rows,3])")
+    rates4 = extra = S4 = loss = norms4 = None
+    if finish is not None:
+        rates4, extra, S4, loss, norms4 = finish
+        _dev(rates4, extra, S4, loss, norms4)
+        _f32_all(rates4=rates4, S4=S4, loss=loss, norms4=norms4)
+        if extra is not None:
+            _want(extra, torch.float32, "extra")
+        if S4.numel() < 4 + 4 * composite_objective_blocks(N, rows):
+            raise PvdHipError("S4 must be the buffer composite_objective_forward filled")
+    _call("pvd_composite_objective_backward", dev, _p(grad_ws), _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _p(weights_sum), _p(image),
+          _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32(1 if fresh else 0), _p(budget_dev), _p(img_t),
+          _p(fea_s), _p(fea_t), _p(col_s), _p(col_t), _u32(rows), _p(coef4), _p(upstream), _p(g_fea), _p(g_col), _p(rates4), _p(extra),
+          _u32(extra.numel() if extra is not None else 0), _p(S4), _p(loss), _p(norms4))
+
 def _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t):
     """img: same element count; fea [M, W] (the library accepts W = 16 only); col [M, 3]."""
     if fea_s.dim() != 2 or fea_t.shape != fea_s.shape:
@@ -804,11 +857,15 @@ def distill_loss_backward(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, rates4, 
 
 
 def distill_loss_final(S4, rates4, loss, coef4, norms4, n_img=0, M=0, reduce=False, fea_decay=1.0, extra=None):
+    """reduce: False / True as pvd_distill_sumsq left S4, or an int >= 2 = that many float4 partials (composite_objective_forward)."""
     dev = _dev(S4, rates4, loss, coef4, norms4, extra)
     _f32_all(S4=S4, rates4=rates4, loss=loss, coef4=coef4, norms4=norms4)
     if extra is not None:
         _want(extra, torch.float32, "extra")
-    _call("pvd_distill_loss_final", dev, _p(S4), _u32(n_img), _u32(M), _int(int(bool(reduce))), _p(rates4), _f32(fea_decay), _p(extra),
+    nred = int(reduce) if (not isinstance(reduce, bool) and int(reduce) >= 2) else int(bool(reduce))
+    if nred >= 2 and S4.numel() < 4 + 4 * nred:
+        raise PvdHipError("S4 too small for %d partials" % nred)
+    _call("pvd_distill_loss_final", dev, _p(S4), _u32(n_img), _u32(M), _int(nred), _p(rates4), _f32(fea_decay), _p(extra),
           _u32(extra.numel() if extra is not None else 0), _p(loss), _p(coef4), _p(norms4))
 
 
@@ -987,6 +1044,8 @@ def l1_ranges(p, ranges, scratch, out=None):
 
 raymarching_backend = types.SimpleNamespace(
     composite_rays_train_bg_forward=composite_rays_train_bg_forward, composite_rays_train_bg_backward=composite_rays_train_bg_backward,
+    composite_objective_forward=composite_objective_forward, composite_objective_backward=composite_objective_backward,
+    composite_objective_blocks=composite_objective_blocks,
     get_rays=get_rays, near_far_from_aabb=near_far_from_aabb, polar_from_ray=polar_from_ray, morton3D=morton3D,
     morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
     composite_rays_train_forward=composite_rays_train_forward,

@@ -182,7 +182,7 @@ def make_ops(backend, device_type="cuda"):
 
         @staticmethod
         @fwd32
-        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None):
+        def forward(ctx, sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None, objective=None):
             ctx.packed_rays = bool(packed_rays) and bool(getattr(backend, "MARCH_FRESH", False))
             ctx.budget_dev = budget_dev
             kw = {} if budget_dev is None else {"budget_dev": budget_dev}
@@ -193,8 +193,20 @@ def make_ops(backend, device_type="cuda"):
             weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
             depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
             image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
-            backend.composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum,
-                                                    depth, image, **kw)
+            # objective: a stage-3 distillation objective that rides on this launch and on the backward one (pvd/losses.py
+            # ObjectiveRide: teacher image / features / colours, the student's features / colours; receives the partial sums)
+            ctx.objective = objective if (objective is not None and hasattr(backend, "composite_objective_forward") and N > 0 and M > 0) else None
+            if ctx.objective is not None:
+                ob = ctx.objective
+                ob.S = torch.empty(4 + 4 * backend.composite_objective_blocks(N, ob.fea_s.shape[0]), dtype=torch.float32, device=sigmas.device)
+                dk = {} if getattr(ob, "rates_decay", None) is None else {"rates_decay": ob.rates_decay, "fea_decay": ob.fea_decay}
+                backend.composite_objective_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum, depth,
+                                                    image, ob.img_t, ob.fea_s, ob.fea_t, ob.col_s, ob.col_t, ob.S, **kw, **dk)
+                ob.decayed = bool(dk)
+                ob.nparts = backend.composite_objective_blocks(N, ob.fea_s.shape[0])
+            else:
+                backend.composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum,
+                                                        depth, image, **kw)
             ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
             ctx.bg = (bg_t, bg_s)
             ctx.dims = [M, N]
@@ -214,19 +226,28 @@ def make_ops(backend, device_type="cuda"):
             if grad_image is None:  # only weights_sum was used
                 grad_image = torch.zeros_like(image)
             kw = {} if ctx.budget_dev is None else {"budget_dev": ctx.budget_dev}
-            if ctx.packed_rays:
+            ob = ctx.objective
+            if ob is not None and getattr(ob, "armed", False):
+                # the objective's backward ran first and left its coefficients: the image gradient is formed inside this launch
+                # (grad_image is a placeholder), the feature / colour gradients are written by extra workgroups of it
+                ob.armed = False
+                backend.composite_objective_backward(gws, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, ctx.bg[0], ctx.bg[1], grad_sigmas,
+                                                     grad_rgbs, ob.img_t, ob.fea_s, ob.fea_t, ob.col_s, ob.col_t, ob.coef, ob.upstream, ob.g_fea,
+                                                     ob.g_col, fresh=bool(ctx.packed_rays), finish=getattr(ob, "finish", None), **kw)
+            elif ctx.packed_rays:
                 backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                          ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, fresh=True, **kw)
             else:
                 backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                          ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, **kw)
-            return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
+            return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None
 
-    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None):
+    def composite_rays_train_bg(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays=False, budget_dev=None, objective=None):
         """packed_rays: `rays` comes straight from march_rays_train (offsets in ray order from 0, no gaps).  budget_dev: the
-        device-side logical sample budget the march of these rays was given (march_rays_train(budget=...)), if any."""
+        device-side logical sample budget the march of these rays was given (march_rays_train(budget=...)), if any.
+        objective: see _CompositeTrainBg.forward (ignored by backends without the fused launches)."""
         if fused_bg:
-            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays, budget_dev)
+            return _CompositeTrainBg.apply(sigmas, rgbs, deltas, rays, bg, nears, fars, depth_eps, packed_rays, budget_dev, objective)
         assert budget_dev is None, "a device-side budget needs the fused compositing of the HIP backend"
         # reference formulation (used with the CPU oracle backend in the test-suite)
         weights_sum, depth, image = _CompositeTrain.apply(sigmas, rgbs, deltas, rays)

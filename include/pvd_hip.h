@@ -407,6 +407,34 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
                                          float *grad_sigmas, float *grad_rgbs, uint32_t flags, const int32_t *budget_dev,
                                          pvd_stream_t stream);
 
+/* The student's compositing of a stage-3 DISTILLATION step with the objective riding on its two launches (no counterpart in the
+ * reference's modules: Trainer.train_step's four normL2 terms, distill_mutual/utils.py:1109-1176, are torch code there).
+ * forward  = pvd_composite_rays_train_bg_forward + pvd_distill_sumsq: besides weights_sum / depth / image the launch leaves
+ *            the per-workgroup partial sums of the four squared norms in S4 + 4 (pvd_composite_objective_blocks(N, rows) float4
+ *            entries; S4 holds 4 + 4 * that many floats) for pvd_distill_loss_final(..., reduce = that block count, ...);
+ * backward = pvd_distill_sumsq_backward + pvd_composite_rays_train_bg_backward: the image gradient coef4[0] * upstream *
+ *            (image - img_tea) is formed per ray inside the compositing backward, g_fea / g_col are written by extra
+ *            workgroups of the same launch.
+ *            rates4 != NULL (DEVICE [4]): the backward launch also FINISHES the objective -- every workgroup reduces the
+ *            forward launch's partial sums (at S4 + 4) for itself, coef4 becomes an output, workgroup 0 publishes S4[0..3],
+ *            loss, norms4 (+ the parameter-only partial sums `extra`) -- so no pvd_distill_loss_final runs between the
+ *            passes; the forward launch then applies the feature rate's decay (rates4_decay[1] *= fea_decay, one thread).
+ * img_tea [N,3] by ray index, fea_* [rows,16] (column 0 = sigma_l), col_* [rows,3], all f32; rows > 0. */
+uint32_t pvd_composite_objective_blocks(uint32_t N, uint32_t rows);
+int pvd_composite_objective_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
+                                    uint32_t N, const float *bg, float bg_scalar, const float *nears, const float *fars,
+                                    float depth_eps, float *weights_sum, float *depth, float *image, const int32_t *budget_dev,
+                                    const float *img_tea, const float *fea_stu, const float *fea_tea, const float *col_stu,
+                                    const float *col_tea, uint32_t rows, float *S4, float *rates4_decay, float fea_decay,
+                                    pvd_stream_t stream);
+int pvd_composite_objective_backward(const float *grad_weights_sum, const float *sigmas, const float *rgbs, const float *deltas,
+                                     const int32_t *rays, const float *weights_sum, const float *image, uint32_t M, uint32_t N,
+                                     const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs, uint32_t flags,
+                                     const int32_t *budget_dev, const float *img_tea, const float *fea_stu, const float *fea_tea,
+                                     const float *col_stu, const float *col_tea, uint32_t rows, float *coef4,
+                                     const float *upstream, float *g_fea, float *g_col, const float *rates4, const float *extra,
+                                     uint32_t n_extra, float *S4, float *loss, float *norms4, pvd_stream_t stream);
+
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
  *   loss = sum_i rates4[i] * sqrt(S4[i]) + sum(extra);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)
@@ -418,7 +446,8 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  * pvd_distill_sumsq: reduce != 0 finishes S4[0..3] itself (ray data parallelism: the host all-reduces them before
  *   pvd_distill_loss_final(reduce = 0)); reduce == 0 leaves the partials for pvd_distill_loss_final(reduce = 1, same
  *   n_img / M), saving a launch.
- * pvd_distill_loss_final: fea_decay multiplies rates4[1] in place before it is used (the per-step 0.995 decay of the
+ * pvd_distill_loss_final: reduce 0 = S4[0..3] are final, 1 = reduce pvd_distill_sumsq's partials, >= 2 = reduce that many
+ *   float4 partials at S4 + 4 as they are (pvd_composite_objective_forward); fea_decay multiplies rates4[1] in place before it is used (the per-step 0.995 decay of the
  *   feature rate, utils.py:1044; 1.0 = leave it); extra [n_extra] are partial sums of a parameter-only term added
  *   to the loss value (pvd_l1_ranges partials), or NULL.
  * pvd_distill_loss_backward = pvd_distill_loss_final + pvd_distill_sumsq_backward in ONE launch (every workgroup finishes

@@ -753,3 +753,62 @@ def test_whole_table_readers_see_the_deferred_decay():
     (ca, pa), (cb, pb) = runs[True], runs[False]
     assert ca.any() and torch.equal(ca, cb)  # the same rows are cold either way (the touched set comes from the frozen grid)
     assert torch.equal(pa, pb)  # the decays deferred and flushed == applied step by step
+
+
+@pytest.mark.parametrize("n_rays", [1001, 4096])
+def test_objective_riding_on_the_compositing_launches_equals_the_separate_launches(n_rays):
+    """pvd_composite_objective_forward / _backward (ObjectiveRide): the student's compositing launch also forms the partial sums
+    of the four squared norms, the compositing backward launch forms the image gradient from the coefficients and writes the
+    feature / colour gradients -- against composite_rays_train_bg + distill_loss_normL2 as separate launches: images and every
+    gradient bit-identical (same per-element arithmetic), the loss to summation order."""
+    import raymarching
+    from pvd.losses import ObjectiveRide, distill_loss_normL2
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
+    bits = packbits_torch(ChairScene(thicken=0.08).density_grid(128, 1.0, 1, device=dev), 10.0)
+    r = get_rays(poses[1:2], BLENDER_INTRINSICS, 800, 800, n_rays, generator=torch.Generator(device=dev).manual_seed(2))
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, -1, True, 128, True)
+    M, N = xyzs.shape[0], n_rays
+    sig0 = torch.rand(M, device=dev, generator=g) * 20
+    rgb0 = torch.rand(M, 3, device=dev, generator=g)
+    fea0 = torch.randn(M, 16, device=dev, generator=g)
+    col0 = torch.rand(M, 3, device=dev, generator=g)
+    fea_t, col_t = torch.randn(M, 16, device=dev, generator=g), torch.rand(M, 3, device=dev, generator=g)
+    img_t = torch.rand(1, N, 3, device=dev, generator=g)
+    bg = torch.rand(1, N, 3, device=dev, generator=g)
+    rates = torch.tensor([1.0, 0.002, 0.002, 0.002], device=dev)
+    outs = []
+    extra = torch.rand(8192, device=dev, generator=g) * 1e-3  # partial sums of a parameter-only term (the L1 regulariser's value)
+    # separate launches; riding with k_loss_final between the passes; riding with the objective finished by the backward launch
+    for riding in (None, "final", "finish"):
+        sig, rgb, fea, col = [t.clone().requires_grad_(True) for t in (sig0, rgb0, fea0, col0)]
+        r4 = rates.clone()
+        ride = None
+        if riding:
+            ride = ObjectiveRide(img_t, fea_t, col_t, rates_decay=r4 if riding == "finish" else None, fea_decay=0.995)
+            assert ride.with_student(fea, col)
+        ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6, True, **({"objective": ride} if riding else {}))
+        assert (ride is not None and ride.S is not None and ride.nparts >= 2) == bool(riding)
+        loss, norms = distill_loss_normL2(img.view(1, N, 3), img_t, fea, fea_t, col, col_t, r4, None, fea_decay=0.995, extra=extra,
+                                          **({"ride": ride} if riding else {}))
+        assert (ride is not None and ride.finish is not None) == (riding == "finish")
+        (loss * 3.0).backward()  # (finish: loss / norms are filled in by the backward launch)
+        outs.append((img.detach(), ws.detach(), depth.detach(), float(loss), norms.clone(), sig.grad, rgb.grad, fea.grad, col.grad, r4.clone()))
+    a = outs[0]
+    assert a[9][1] == rates[1] * 0.995 and a[9][0] == rates[0]  # the per-step decay of the feature rate
+    for b in outs[1:]:
+        for k in (0, 1, 2, 9):
+            assert torch.equal(a[k], b[k])
+        assert abs(a[3] - b[3]) <= 2e-6 * abs(a[3]) and torch.allclose(a[4], b[4], rtol=2e-6)
+        # the coefficients are functions of the (differently ordered) sums: gradients agree to their rounding, element for element
+        for k in (5, 6, 7, 8):
+            assert a[k] is not None and b[k] is not None and torch.isfinite(b[k]).all()
+            assert torch.allclose(a[k], b[k], rtol=5e-6, atol=0.0), k
+    for k in (3, 4, 5, 6, 7, 8):  # the two riding forms reduce the same partial sums in the same order: identical
+        x, y = outs[1][k], outs[2][k]
+        assert (x == y) if isinstance(x, float) else torch.equal(x, y), k
+    assert float(a[5].abs().max()) > 0 and float(a[7].abs().max()) > 0
