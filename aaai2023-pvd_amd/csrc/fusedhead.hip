@@ -29,6 +29,7 @@
 // register tiles (through a 512-byte LDS scratch per wave); dW tiles live in accumulators for the whole
 // launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
 #include "grid_lookup.h"
+#include "head_dw_reduce.h"
 
 #include <stdlib.h>
 
@@ -1139,12 +1140,16 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
 // Sum the per-wave partials and ACCUMULATE into the fp32 gradient buffers (real, un-padded layouts).
 // blockIdx.x walks the real weight elements (consecutive threads read consecutive lanes of a tile:
 // coalesced), blockIdx.y a slice of the waves; every slice adds its sum with one atomic per element.
-constexpr uint32_t kReduceSlices = 16;
 template <int KIND>
 __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWa1,
                                                        float *__restrict__ gWa2, float *__restrict__ gW1, float *__restrict__ gW2,
                                                        float *__restrict__ gW3) {
     using LY = DwLayout<KIND>;
+    if (KIND == KIND_VM) {  // (the same code the table scatter's launch can run in extra workgroups: head_dw_reduce.h)
+        static_assert(KIND != KIND_VM || LY::floats == (int)kVmHeadTileFloats, "head_dw_reduce.h mirrors DwLayout<KIND_VM>");
+        head_vm_reduce_dw(partials, nwaves, gWa1, gW1, gW2, gW3, blockIdx.x, blockIdx.y);
+        return;
+    }
     const uint32_t nA1 = KIND == KIND_VM ? 15 * 144 : 64 * 28, nA2 = KIND == KIND_VM ? 0 : 16 * 64;
     const uint32_t n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1196,7 +1201,8 @@ static int head_bwd_occupancy(int kind) {
 }
 
 template <int KIND>
-static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s) {
+static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s,
+                           pvd_head_dw_rider *defer = nullptr) {
     size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 256;
     if (lds_halfs < 2 * (size_t)DwLayout<KIND>::floats) lds_halfs = 2 * (size_t)DwLayout<KIND>::floats;
     const uint32_t nblocks = nwaves / (kHeadBlock / 64);
@@ -1204,6 +1210,10 @@ static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, f
         hipLaunchKernelGGL((k_head_bwd<KIND, 2>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
     else
         hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
+    if (defer) {  // the reduction rides on the caller's next launch (pvd_vm_backward_rider)
+        defer->partials = a.partials; defer->nblocks = nblocks; defer->gWa1 = gWa1; defer->gWc1 = gW1; defer->gWc2 = gW2; defer->gWc3 = gW3;
+        return check_launch();
+    }
     const uint32_t nreal = (KIND == KIND_VM ? 15 * 144 : 64 * 28 + 16 * 64) + 64 * 31 + 64 * 64 + 3 * 64;
     hipLaunchKernelGGL((k_head_reduce_dw<KIND>), dim3(div_up(nreal, 256u), kReduceSlices), dim3(256), 0, s, a.partials, nblocks, gWa1, gWa2, gW1,
                        gW2, gW3);
@@ -1309,11 +1319,12 @@ int pvd_head_backward_workspace_floats(int kind, uint32_t M) {
     return (int)(head_bwd_waves(kind, M) / (kHeadBlock / 64) * (kind == KIND_VM ? DwLayout<KIND_VM>::floats : DwLayout<KIND_HASH>::floats));
 }
 
-int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
-                      const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
-                      float clip_max,
-                      const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16, float *g_sigma_raw, void *g_x0,
-                      float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
+static int head_backward_impl(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
+                              const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
+                              float clip_max, const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16,
+                              float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace,
+                              pvd_head_dw_rider *defer, pvd_stream_t stream) {
+    if (defer) { defer->partials = nullptr; defer->nblocks = 0; }
     if (M == 0) return PVD_OK;
     if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_x0 || !gWa1 || !gWc1 || !gWc2 || !gWc3 ||
         !workspace)
@@ -1329,13 +1340,33 @@ int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const fl
     const uint32_t nwaves = head_bwd_waves(kind, M);
     if (kind == KIND_VM) {
         if (!sigma_raw || !g_sigma_raw) return PVD_ERR_INVALID;
-        return launch_head_bwd<KIND_VM>(a, nwaves, gWa1, nullptr, gWc1, gWc2, gWc3, (hipStream_t)stream);
+        return launch_head_bwd<KIND_VM>(a, nwaves, gWa1, nullptr, gWc1, gWc2, gWc3, (hipStream_t)stream, defer);
     }
+    if (defer) return PVD_ERR_UNSUPPORTED;  // only the VM head's reduction has a launch to ride on
     if (kind == KIND_HASH) {
         if (!Wa2 || !gWa2) return PVD_ERR_INVALID;
         return launch_head_bwd<KIND_HASH>(a, nwaves, gWa1, gWa2, gWc1, gWc2, gWc3, (hipStream_t)stream);
     }
     return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_head_backward(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
+                      const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
+                      float clip_max,
+                      const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16, float *g_sigma_raw, void *g_x0,
+                      float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_stream_t stream) {
+    return head_backward_impl(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, image, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb,
+                              g_rgb2, g_feat16, g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, nullptr, stream);
+}
+
+int pvd_head_backward_defer(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1, const float *Wa2,
+                            const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
+                            float clip_max, const float *g_sigma, const float *g_rgb, const float *g_rgb2, const float *g_feat16,
+                            float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2, float *gWc1, float *gWc2, float *gWc3, float *workspace,
+                            pvd_head_dw_rider *rider_out, pvd_stream_t stream) {
+    if (!rider_out) return PVD_ERR_INVALID;
+    return head_backward_impl(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, image, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb,
+                              g_rgb2, g_feat16, g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, rider_out, stream);
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 // A wave walks a contiguous run of samples (samples of a ray are contiguous), so in the backward
 // consecutive samples that hit the same texel are merged in registers before touching memory.
 #include "pvd_device.h"
+#include "head_dw_reduce.h"
 
 #include <stdlib.h>
 
@@ -462,7 +463,14 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ x
 // blockIdx.y = factor set: three times the waves, a third of the serial work per sample in each
 template <typename T>
 __global__ void __launch_bounds__(kVmBlock) k_vm_bwd_split(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
-                                                           const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr) {
+                                                           const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr,
+                                                           pvd_head_dw_rider hd = pvd_head_dw_rider{}) {
+    if (blockIdx.y == 3) {  // (gridDim.y == 4) the VM head's weight-gradient reduction riding on this launch: head_dw_reduce.h
+        static_assert(kVmBlock == 256, "head_vm_reduce_dw is written for 256 threads");
+        for (uint32_t rb = blockIdx.x; rb < kVmHeadReduceBlocks * kReduceSlices; rb += gridDim.x)
+            head_vm_reduce_dw(hd.partials, hd.nblocks, hd.gWa1, hd.gWc1, hd.gWc2, hd.gWc3, rb % kVmHeadReduceBlocks, rb / kVmHeadReduceBlocks);
+        return;
+    }
     if (blockIdx.y == 0) vm_bwd_body<T, 0, 1>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
     else if (blockIdx.y == 1) vm_bwd_body<T, 1, 2>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
     else vm_bwd_body<T, 2, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
@@ -548,9 +556,29 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
     return check_launch();
 }
 
+static int vm_backward_impl(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                            const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype, void *const *grad_tables_host,
+                            const uint32_t *texel_stride_host, const pvd_head_dw_rider *rider, pvd_stream_t stream);
+
 int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
                     const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype, void *const *grad_tables_host,
                     const uint32_t *texel_stride_host, pvd_stream_t stream) {
+    return vm_backward_impl(xyz, M, aabb_host, tables_host, res_host, grad_sigma_feat, grad_color_prod, prod_dtype, grad_tables_host,
+                            texel_stride_host, nullptr, stream);
+}
+
+int pvd_vm_backward_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                          const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype, void *const *grad_tables_host,
+                          const uint32_t *texel_stride_host, const pvd_head_dw_rider *rider, pvd_stream_t stream) {
+    if (!rider || !rider->partials || !rider->nblocks || !rider->gWa1 || !rider->gWc1 || !rider->gWc2 || !rider->gWc3 || M == 0)
+        return PVD_ERR_INVALID;  // (an owed reduction cannot be dropped)
+    return vm_backward_impl(xyz, M, aabb_host, tables_host, res_host, grad_sigma_feat, grad_color_prod, prod_dtype, grad_tables_host,
+                            texel_stride_host, rider, stream);
+}
+
+static int vm_backward_impl(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                            const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype, void *const *grad_tables_host,
+                            const uint32_t *texel_stride_host, const pvd_head_dw_rider *rider, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !aabb_host || !tables_host || !res_host || !grad_sigma_feat || !grad_color_prod || !grad_tables_host) return PVD_ERR_INVALID;
     VmTables tb;
@@ -568,15 +596,17 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
     static int split = -1;  // PVD_VM_BWD_SPLIT=0/1 (measurement); default: split
     if (split < 0) { const char *e = getenv("PVD_VM_BWD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
-    const dim3 grid3(grid.x, 3);
+    const dim3 grid3(grid.x, rider ? 4 : 3);
+    const pvd_head_dw_rider hd = rider ? *rider : pvd_head_dw_rider{};
+    if (rider && !split) return PVD_ERR_UNSUPPORTED;
     if (prod_dtype == PVD_F32) {
         if (split) hipLaunchKernelGGL((k_vm_bwd_split<float>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                      (const float *)grad_color_prod, gr);
+                                      (const float *)grad_color_prod, gr, hd);
         else hipLaunchKernelGGL((k_vm_bwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
                                 (const float *)grad_color_prod, gr);
     } else if (prod_dtype == PVD_F16) {
         if (split) hipLaunchKernelGGL((k_vm_bwd_split<half_t>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                      (const half_t *)grad_color_prod, gr);
+                                      (const half_t *)grad_color_prod, gr, hd);
         else hipLaunchKernelGGL((k_vm_bwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
                                 (const half_t *)grad_color_prod, gr);
     }

@@ -176,7 +176,8 @@ class _VMHeadTrain(torch.autograd.Function):
     (sigma [M], rgb [M,3], feature_sigma_color [M,16]), all f32; one MFMA kernel each way."""
 
     @staticmethod
-    def forward(ctx, sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3, smin, fmin, cmax, image=None):
+    def forward(ctx, sigma_raw, prod, dirs, Wb, Wc1, Wc2, Wc3, smin, fmin, cmax, image=None, head_dw=None):
+        ctx.head_dw = head_dw  # (a dict shared with the lookup's autograd node: see backward)
         M = prod.shape[0]
         sigma_raw, prod, dirs = sigma_raw.float().contiguous(), prod.contiguous(), dirs.float().contiguous()
         sigma, rgb, feat = _outputs(M, prod.device)
@@ -213,14 +214,18 @@ class _VMHeadTrain(torch.autograd.Function):
         # accumulate straight into the leaves' gradient buffers when they exist (the trainer's flat bucket)
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
         grads = [p.grad for p in ctx.leaves] if direct else [torch.zeros_like(p, dtype=torch.float32) for p in ctx.leaves]
+        # the reduction of the weight-gradient tiles rides on the lookup's backward launch (which autograd runs next, on this stream)
+        # when the lookup's node shares a hand-over dict with this one, needs a gradient itself, and the weight gradients go
+        # straight into their final buffers; otherwise it is a launch of its own, here
+        defer = ctx.head_dw if (ctx.head_dw is not None and direct and ctx.needs_input_grad[1] and M > 0) else None
         pvd_hip.head_backward(KIND_VM, prod, sigma_raw, dirs, M, Wb.detach(), None, Wc1.detach(), Wc2.detach(), Wc3.detach(), *ctx.clips,
                               g_sigma, g_rgb, g_feat, g_sraw, g_prod, grads[0], None, grads[1], grads[2], grads[3], ws, image=ctx.image,
-                              g_rgb2=g_rgb_l)
+                              g_rgb2=g_rgb_l, **({"defer_reduce": defer} if defer is not None else {}))
         gw = (None, None, None, None) if direct else tuple(grads)
-        return (g_sraw, g_prod, None) + gw + (None, None, None, None)
+        return (g_sraw, g_prod, None) + gw + (None, None, None, None, None)
 
 
-def vm_head_train(model, sigma_raw, prod, d):
+def vm_head_train(model, sigma_raw, prod, d, head_dw=None):
     """-> (sigma, rgb, feature_sigma_color, rgb_l): rgb_l is rgb again, for the colour term of the objective (see above)."""
     a = model.args
     smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
@@ -228,7 +233,8 @@ def vm_head_train(model, sigma_raw, prod, d):
     if wait is not None:
         wait()  # the weight image was packed on another stream (prepack_train_image): this stream waits for it here
     return _VMHeadTrain.apply(sigma_raw, prod, d, model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight,
-                              model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max, model.__dict__.pop("_train_image_ready", None))
+                              model.color_net[2].weight, smin, a.sigma_clip_min, a.sigma_clip_max, model.__dict__.pop("_train_image_ready", None),
+                              head_dw)
 
 
 def prepack_train_image(model):

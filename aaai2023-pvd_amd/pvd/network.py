@@ -316,12 +316,16 @@ class NeRFNetwork(NeRFRenderer):
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
                 out = fh.vm_head_infer(self, sraw, prod, d)
             elif self.model_type == "vm" and hasattr(fh, "vm_head_train"):
-                sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec)
+                # a dict shared by the two autograd nodes: the head's weight-gradient reduction rides on the lookup's backward
+                # launch (PVD_HEAD_DW_RIDE=0: a launch of its own)
+                head_dw = {} if (torch.is_grad_enabled() and os.environ.get("PVD_HEAD_DW_RIDE", "1") != "0") else None
+                sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec,
+                                                *(() if head_dw is None else (head_dw,)))
                 hook = getattr(self, "_between_backwards", None)  # (trainer: called between the head's and the lookup's backward)
                 if hook is not None and prod.requires_grad:
                     prod.register_hook(hook)
                     self._between_backwards = None  # taken
-                out = fh.vm_head_train(self, sraw, prod, d)
+                out = fh.vm_head_train(self, sraw, prod, d, head_dw=head_dw if prod.requires_grad else None)
                 hook = getattr(self, "_before_head_backward", None)  # (trainer: called when sigma's gradient arrives, i.e. after the
                 if hook is not None and out[0].requires_grad:        #  compositing backward and right before the head's backward)
                     out[0].register_hook(hook)

@@ -76,7 +76,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
@@ -521,7 +521,9 @@ def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=Non
                    _int(dt), _rows_dev(rows_dev, dev), strides, meta=(xyz.shape[0], dt)), "pvd_vm_forward")
 
 
-def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, grad_tables):
+def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, grad_tables, head_dw=None):
+    """head_dw: the dict a head_backward(..., defer_reduce=dict) filled -- the VM head's weight-gradient reduction then runs in
+    extra workgroups of this launch (pvd_vm_backward_rider)."""
     dev, aabb, resa = _vm_common(xyz, aabb_host, tables, res)
     _dev(grad_sigma_feat, grad_color_prod)
     _want(grad_sigma_feat, torch.float32, "grad_sigma_feat")
@@ -532,6 +534,13 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
     strides, st = _vm_texel_strides(tables)
     if _vm_texel_strides(grad_tables, "VM gradient buffers")[1] != st:
         raise PvdHipError("VM gradient buffers must have the factors' own strides")
+    if head_dw is not None and head_dw.get("rider") is not None:
+        rider = head_dw.pop("rider")
+        _check(_invoke("pvd_vm_backward_rider", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
+                       _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), strides, ctypes.byref(rider), meta=(xyz.shape[0], dt)),
+               "pvd_vm_backward_rider")
+        head_dw.pop("keep", None)
+        return
     _check(_invoke("pvd_vm_backward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
                    _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), strides, meta=(xyz.shape[0], dt)), "pvd_vm_backward")
 
@@ -701,8 +710,10 @@ def head_backward_workspace_floats(kind, M):
 
 
 def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_feat_min, clip_max, g_sigma, g_rgb, g_feat16,
-                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, image=None, g_rgb2=None):
-    """kind 1 (vm): x0 = products [M,144], g_x0 same layout.  kind 0 (hash): x0 = encoder output [14,M,2], g_x0 same."""
+                  g_sigma_raw, g_x0, gWa1, gWa2, gWc1, gWc2, gWc3, workspace, image=None, g_rgb2=None, defer_reduce=None):
+    """kind 1 (vm): x0 = products [M,144], g_x0 same layout.  kind 0 (hash): x0 = encoder output [14,M,2], g_x0 same.
+    defer_reduce (a dict, VM head only): the launch that sums the per-workgroup weight-gradient tiles is NOT issued; the dict
+    receives what vm_backward(..., head_dw=dict) needs to run it inside the table scatter's launch (pvd_head_backward_defer)."""
     dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_x0, workspace)
     _want(x0, torch.float16, "x0"), _want(g_x0, torch.float16, "g_x0")
     _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb, g_feat16=g_feat16,
@@ -721,9 +732,22 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
         _f32_all(g_rgb2=g_rgb2)
         if g_rgb2.shape != g_rgb.shape:
             raise PvdHipError("g_rgb2 must have the shape of g_rgb")
+    if defer_reduce is not None:
+        rider = _HeadDwRider()
+        _call("pvd_head_backward_defer", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
+              _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_rgb2), _p(g_feat16),
+              _p(g_sigma_raw), _p(g_x0), _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace), ctypes.byref(rider))
+        # (the tensors are kept next to the record: the reduction reads / writes them later)
+        defer_reduce["rider"], defer_reduce["keep"] = rider, (workspace, gWa1, gWc1, gWc2, gWc3)
+        return
     _call("pvd_head_backward", dev, _int(kind), _p(x0), _p(sigma_raw), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3),
           _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(g_sigma), _p(g_rgb), _p(g_rgb2), _p(g_feat16), _p(g_sigma_raw), _p(g_x0),
           _p(gWa1), _p(gWa2), _p(gWc1), _p(gWc2), _p(gWc3), _p(workspace))
+
+
+class _HeadDwRider(ctypes.Structure):  # pvd_head_dw_rider, include/pvd_hip.h
+    _fields_ = [("partials", ctypes.c_void_p), ("nblocks", ctypes.c_uint32), ("gWa1", ctypes.c_void_p), ("gWc1", ctypes.c_void_p),
+                ("gWc2", ctypes.c_void_p), ("gWc3", ctypes.c_void_p)]
 
 
 def freq_encode(x, freq_bands, include_input=True, out_dtype=torch.float32, row_stride=None):

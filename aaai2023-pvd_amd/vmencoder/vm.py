@@ -44,6 +44,11 @@ def make_vm_encode(backend, device_type="cuda"):
         @staticmethod
         @custom_fwd(device_type=device_type)
         def forward(ctx, xyz, aabb_host, *tables):
+            # an optional trailing dict: the hand-over point of the VM head's weight-gradient reduction, which then rides on this
+            # lookup's backward launch (fusedhead._VMHeadTrain.backward fills it, pvd_hip.vm_backward(head_dw=) consumes it)
+            ctx.head_dw = None
+            if tables and isinstance(tables[-1], dict):
+                ctx.head_dw, tables = tables[-1], tables[:-1]
             xyz = xyz.contiguous().float()
             tabs = [t if is_channels_last(t) else to_channels_last_param(t.detach()) for t in tables]
             res = [0, 0, 0]
@@ -69,12 +74,14 @@ def make_vm_encode(backend, device_type="cuda"):
             # accumulate straight into it: no 69 MB of zero-fill + add per step.
             direct = all(p.is_leaf and p.grad is not None and p.grad.stride() == t.stride() and p.grad.dtype == torch.float32
                          for p, t in zip(ctx.leaves, tabs))
+            hkw = {"head_dw": ctx.head_dw} if (ctx.head_dw is not None and ctx.head_dw.get("rider") is not None) else {}
+            tail = (None,) if ctx.head_dw is not None else ()
             if direct:
                 backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(),
-                                    [p.grad for p in ctx.leaves])
-                return (None, None) + (None,) * len(tabs)
+                                    [p.grad for p in ctx.leaves], **hkw)
+                return (None, None) + (None,) * len(tabs) + tail
             grads = [torch.zeros_like(t) for t in tabs]  # preserves the channels-last strides
-            backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(), grads)
-            return (None, None, *grads)
+            backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(), grads, **hkw)
+            return (None, None, *grads) + tail
 
     return _VMEncode.apply

@@ -256,6 +256,27 @@ int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const 
                     const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
                     void *const *grad_tables_host, const uint32_t *texel_stride_host, pvd_stream_t stream);
 
+/* The VM head's weight-gradient reduction riding on the VM table scatter's launch (both depend only on the head's backward):
+ * pvd_head_backward_defer = pvd_head_backward (kind = PVD_HEAD_VM only) WITHOUT the launch that sums the per-workgroup
+ * accumulator tiles into gW*; it fills *rider_out instead, and pvd_vm_backward_rider = pvd_vm_backward + that reduction in
+ * extra workgroups of the scatter's launch.  The caller owes exactly one pvd_vm_backward_rider per deferral, on the same
+ * stream, before anything reads gW* (the gradients are incomplete until then); workspace must stay alive until it ran. */
+typedef struct pvd_head_dw_rider {
+    const float *partials;  /* DEVICE: the head backward's workspace */
+    uint32_t nblocks;
+    float *gWa1, *gWc1, *gWc2, *gWc3;
+} pvd_head_dw_rider;
+int pvd_vm_backward_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
+                          const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,
+                          void *const *grad_tables_host, const uint32_t *texel_stride_host, const pvd_head_dw_rider *rider,
+                          pvd_stream_t stream);
+int pvd_head_backward_defer(int kind, const void *x0, const float *sigma_raw, const float *dirs, uint32_t M, const float *Wa1,
+                            const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
+                            float clip_sigma_min, float clip_feat_min, float clip_max, const float *g_sigma, const float *g_rgb,
+                            const float *g_rgb2, const float *g_feat16, float *g_sigma_raw, void *g_x0, float *gWa1, float *gWa2,
+                            float *gWc1, float *gWc2, float *gWc3, float *workspace, pvd_head_dw_rider *rider_out,
+                            pvd_stream_t stream);
+
 /* NeRF positional encoding -- torch code in the reference: FreqEncoder.forward, tools/encoding.py:6-49.
  * x [M,D] f32 -> out [M, row_stride] (out_dtype PVD_F32 / PVD_F16): columns [x (if include_input), sin(f_0 x), cos(f_0 x),
  * sin(f_1 x), ...], each block D wide, f = freq_bands_host[n_freqs] (<= 16; the reference's 2^linspace(0, max_freq_log2, N));

@@ -307,3 +307,51 @@ def test_fused_lookup_and_head_is_bit_identical_to_the_two_launches(M, bound, mo
     s1, c1, f1 = fusedhead.hash_head_infer(m, x, d)
     assert torch.equal(s0, s1) and torch.equal(c0, c1) and torch.equal(f0, f1)
     assert torch.isfinite(s1).all() and f1.abs().max().item() > 0
+
+
+def test_vm_head_weight_gradient_reduction_riding_on_the_table_scatter():
+    """The reduction of the VM head's per-workgroup weight-gradient tiles inside the table scatter's launch
+    (pvd_head_backward_defer + pvd_vm_backward_rider, csrc/head_dw_reduce.h) against its own launch (PVD_HEAD_DW_RIDE=0): the same
+    device function over the same tiles, so head and table gradients agree to the order of their float atomics."""
+    import os
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import make_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    opt = PVDConfig(model_type="vm", resolution0=64)
+    opt.stage_iters = {"stage1": -1, "stage2": -1}
+    m = make_model(hip_ops(), opt, "vm", False, dev)
+    for p in m.parameters():
+        if p.dim() == 2:
+            p.data.mul_(2.0)
+    x, d = _inputs(16 * 1000 + 37)
+    x = x * 0.8
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    gs, gc, gf = (torch.randn(x.shape[0], device=dev, generator=gen), torch.randn(x.shape[0], 3, device=dev, generator=gen),
+                  torch.randn(x.shape[0], 16, device=dev, generator=gen))
+    res = {}
+    for ride in ("1", "0"):
+        old = os.environ.get("PVD_HEAD_DW_RIDE")
+        os.environ["PVD_HEAD_DW_RIDE"] = ride
+        try:
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)  # final buffers exist: the kernels accumulate straight into them (the trainer's situation)
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, color = m(x, d)
+                feat = m.feature_sigma_color
+            ((sigma.float() * gs).sum() + (color.float() * gc).sum() + (feat.float() * gf).sum()).backward()
+            torch.cuda.synchronize()
+            res[ride] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        finally:
+            if old is None:
+                os.environ.pop("PVD_HEAD_DW_RIDE", None)
+            else:
+                os.environ["PVD_HEAD_DW_RIDE"] = old
+    heads = [n for n in res["1"] if n.startswith(("basis_mat", "color_net"))]
+    assert len(heads) == 4
+    for n in res["1"]:
+        a, b = res["1"][n], res["0"][n]
+        scale = float(b.abs().max())
+        assert scale > 0 and torch.isfinite(a).all(), n
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()), scale)
