@@ -54,6 +54,7 @@ struct AdamExtras {
     // groups: full wavefronts of warm groups instead of wavefronts in which the cold lanes idle
     const uint32_t *warm;
     uint32_t n_warm;
+    uint32_t warm_nograd_from;  // list entries from here on have a structurally zero gradient (0 = none)
     // two-part update (include/pvd_hip.h): the tail records {found_inf, step before, scale before, 0, lr used ...} here
     float *snapshot;
     // fewer launches (include/pvd_hip.h): zero every visited gradient group after reading it; the last workgroup to arrive does the tail
@@ -189,8 +190,9 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         const uint64_t i = i_next;
         if (j + jstride < n4) i_next = ex.warm ? (uint64_t)ex.warm[j + jstride] : j + jstride;
         const uint64_t e = i << 2;
+        const bool no_grad = ex.warm_nograd_from && j >= (uint64_t)ex.warm_nograd_from;  // the buffer holds zeros there, for good
         if (skip) {  // (zero_g) the skipped step's gradients must not reach the next step
-            if (!(test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!no_grad && !(test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
         uint32_t k = 0;
@@ -214,8 +216,11 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         // the moments are touched exactly once per step: stream them past the caches (nt) so that the Infinity Cache keeps
         // the parameters and gradients the other kernels of the step come back to
         typedef float f4v __attribute__((ext_vector_type(4)));
-        float4 P = reinterpret_cast<float4 *>(p)[i], G = reinterpret_cast<const float4 *>(g)[i];
-        if (ex.zero_g) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 P = reinterpret_cast<float4 *>(p)[i], G = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!no_grad) {
+            G = reinterpret_cast<const float4 *>(g)[i];
+            if (ex.zero_g) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const f4v Mn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(m) + i);
         const f4v Vn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v) + i);
         float4 M = make_float4(Mn.x, Mn.y, Mn.z, Mn.w), V = make_float4(Vn.x, Vn.y, Vn.z, Vn.w);
@@ -422,7 +427,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr; ex.n_l1 = 0;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.warm_nograd_from = 0; ex.snapshot = nullptr;
     ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
     ex.tail_interval = 1; ex.tail_segments = n_segments;
     const float *replay = nullptr;
@@ -439,7 +444,10 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         if (h.lazy_log) {
             if (!h.cold_bits || !h.lazy_count || h.lazy_capacity < 1) return PVD_ERR_INVALID;
             ex.lazy_log = h.lazy_log; ex.lazy_count = h.lazy_count; ex.lazy_capacity = h.lazy_capacity;
-            if (h.warm_groups) { ex.warm = h.warm_groups; ex.n_warm = h.n_warm_groups; }
+            if (h.warm_groups) {
+                ex.warm = h.warm_groups; ex.n_warm = h.n_warm_groups;
+                ex.warm_nograd_from = (h.warm_zero_grad_from && h.warm_zero_grad_from < h.n_warm_groups) ? h.warm_zero_grad_from : 0u;
+            }
         } else if (h.warm_groups) {
             return PVD_ERR_INVALID;  // without the deferred decay the cold groups need their update every step
         }
@@ -552,7 +560,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     AdamExtras ex;
     ex.sched_kind = 0; ex.sched_T = 1.f; ex.sched_param = 0.f; ex.base_lr = nullptr; ex.sched_step = nullptr;
     ex.g16 = nullptr; ex.g16_begin = ex.g16_end = 0; ex.l1_next = nullptr; ex.l1_next_scale = 1.f; ex.cold = nullptr;
-    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.snapshot = nullptr;
+    ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.warm_nograd_from = 0; ex.snapshot = nullptr;
     ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
     ex.tail_interval = 1; ex.tail_segments = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);

@@ -89,7 +89,7 @@ class FlatAdamW(torch.optim.Optimizer):
         return True
 
     def _two_part_now(self, lazy):
-        return bool(self.two_part and lazy is not None and len(lazy) == 3 and getattr(self, "_half_grad", None) is None
+        return bool(self.two_part and lazy is not None and len(lazy) >= 3 and getattr(self, "_half_grad", None) is None
                     and getattr(self, "_warm_A", None) is not None and self._warm_A.numel() > 0 and self._warm_B.numel() > 0)
 
     _l1_layout, _graph_is_two_part = "one", False
@@ -206,6 +206,13 @@ class FlatAdamW(torch.optim.Optimizer):
         in_touched[self.touched.idx >> 2] = True
         self._warm_B = ((~cold) & in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
         self._warm_A = ((~cold) & ~in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
+        # the single launch walks B then A: the A run's gradient is structurally zero (outside the touched set the buffer holds
+        # zeros for good), so the update neither reads nor re-zeroes it there (pvd_adamw_extras.warm_zero_grad_from)
+        if os.environ.get("PVD_ADAMW_NOGRAD_RUN", "0") == "1" and self._warm_A.numel() > 0 and self._warm_B.numel() > 0:
+            self._warm_groups = torch.cat([self._warm_B, self._warm_A]).contiguous()
+            self._warm_nograd_from = int(self._warm_B.numel())
+        else:
+            self._warm_nograd_from = 0
         st = getattr(self, "_l1_track", None)
         if st is not None:  # per-workgroup partial sums: the launch shape changes with the list, start them afresh
             st["buf"].zero_()
@@ -309,6 +316,8 @@ class FlatAdamW(torch.optim.Optimizer):
         lazy = self._lazy_state() if cold is not None else None
         if lazy is not None and os.environ.get("PVD_ADAMW_WARM_LIST", "1") != "0":
             lazy = (lazy[0], lazy[1], self._warm_groups)
+            if getattr(self, "_warm_nograd_from", 0) and self._outside_is_zero:
+                lazy = lazy + (self._warm_nograd_from,)
         if lazy is None and self._lazy_logged and not capturing:
             self.flush()  # this step decays the cold groups itself: the logged decays come first
         if lazy is not None:
@@ -322,7 +331,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # the touched set, outside of which the gradient buffer is known to be zero; a pending half-precision gradient lives in
         # its own buffer
         zero_after = bool(self.zero_in_step and getattr(self, "_half_grad", None) is None
-                          and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) == 3)
+                          and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) >= 3)
         if two:
             # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
             if self._snapshot is None:

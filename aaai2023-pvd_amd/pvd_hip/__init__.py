@@ -914,7 +914,8 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("g16", ctypes.c_void_p), ("g16_begin", ctypes.c_uint64), ("g16_end", ctypes.c_uint64),
                 ("l1_next", ctypes.c_void_p), ("l1_next_scale", ctypes.c_float), ("cold_bits", ctypes.c_void_p),
                 ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32),
-                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p),
+                ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("warm_zero_grad_from", ctypes.c_uint32),
+                ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p),
                 ("zero_grad_after", ctypes.c_uint32), ("arrivals", ctypes.c_void_p)]
 
 
@@ -957,6 +958,8 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
                     _dev(warm)
                     _want(warm, torch.int32, "warm groups")
                     ex.warm_groups, ex.n_warm_groups = warm.data_ptr(), int(warm.numel())
+                    if len(lazy) > 3 and lazy[3]:  # list entries from this position on have a structurally zero gradient
+                        ex.warm_zero_grad_from = int(lazy[3])
                 _dev(log, count)
                 _want(log, torch.float32, "lazy log"), _want(count, torch.int32, "lazy count")
                 if log.dim() != 2 or log.shape[1] != len(segment_ends) or not log.is_contiguous():

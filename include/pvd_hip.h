@@ -550,6 +550,11 @@ typedef struct pvd_adamw_extras {
      * clear.  The update walks this list instead of every group (the cold ones have nothing to do). */
     const uint32_t *warm_groups;
     uint32_t n_warm_groups;
+    /* warm_zero_grad_from (0 = none; only with warm_groups): entries [warm_zero_grad_from, n_warm_groups) of the list are groups whose
+     * GRADIENT is structurally zero (warm through an L1 range or through moments that are still decaying, outside everything a
+     * backward pass can write): their g is neither read nor zeroed -- the update uses 0, the very value the buffer holds.  The list
+     * is then two ascending runs: first the groups that may hold a gradient, then these. */
+    uint32_t warm_zero_grad_from;
     /* Two-part update.  The groups of a step fall into (B) those whose gradient the step's backward may have written (table
      * rows a sample can reach, the MLP heads) and (A) those whose gradient is structurally zero (L1-only rows of the sigma
      * planes, rows whose moments are still decaying): nothing reads an A parameter before the next step's objective adds up

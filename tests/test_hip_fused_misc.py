@@ -649,6 +649,31 @@ def test_adamw_cold_groups_are_bit_identical_to_the_dense_update():
         if use_cold:
             pvd_hip.adamw_lazy_flush(p, seg_ends, packed, log, count, 0.01, status)
         res.append((p, m, v, step.clone(), scale.clone()))
+    # one launch over the list [B run | A run] with warm_zero_grad_from = |B|: the A run's gradient is structurally zero, so it is
+    # neither read nor zeroed -- poisoned with NaN here to prove it; same bits as the dense launch on the zero gradients
+    if True:
+        p, m, v = p0.clone(), m_init.clone(), v_init.clone()
+        lr = torch.tensor([1e-2, 3e-3], device=dev)
+        base = lr.clone()
+        step, sched = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        scale, tracker, flag = torch.tensor([64.0], device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        log, count = torch.zeros(16, 2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        is_a = torch.zeros(n4, dtype=torch.bool, device=dev)
+        is_a[30000 // 4:] = True
+        wb = ((~cold4) & ~is_a).nonzero().squeeze(1).to(torch.int32)
+        wa = ((~cold4) & is_a).nonzero().squeeze(1).to(torch.int32)
+        both = torch.cat([wb, wa]).contiguous()
+        a_warm_el = (wa.long()[:, None] * 4 + torch.arange(4, device=dev)).reshape(-1)
+        for gr in grads_two:
+            gk = gr.clone()
+            pvd_hip.check_finite(gk, flag)
+            gk[a_warm_el] = float("nan")
+            pvd_hip.adamw_step(p, gk, m, v, seg_ends, lr, 0.9, 0.99, 1e-15, 0.01, step, scale, flag, schedule=(1, 100.0, 5e-5, base, sched),
+                               l1_ranges=[(0, 4096, 1e-3)], amp_update=(scale, tracker, 2.0, 0.5, 2000), cold_bits=packed,
+                               lazy=(log, count, both, int(wb.numel())), zero_after=True)
+            assert torch.isnan(gk[a_warm_el]).all() and not gk[(wb.long()[:, None] * 4 + torch.arange(4, device=dev)).reshape(-1)].any()
+        pvd_hip.adamw_lazy_flush(p, seg_ends, packed, log, count, 0.01, status)
+        res_two.append((p, m, v, step.clone(), scale.clone()))
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
