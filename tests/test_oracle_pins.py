@@ -173,7 +173,7 @@ def test_march_samples_match_bruteforce_fixed_step_walk(perturb):
     assert checked == int(counter[0]) and checked > 2000
 
 
-def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_steps=1024):
+def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_steps=1024, limit=None):
     """The reference's marching loop (raymarching.cu:44-56, 340-481) for ANY bound / cascade count / dt_gamma, one float32
     operation at a time in numpy scalars (fp64 only where the C source promotes: `0.5 * (...) * H`), independent of
     oracle/pvd_oracle.c.  Returns [(xyz, dt, t - last_t)]."""
@@ -192,7 +192,8 @@ def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_ste
     def exponent(v):  # frexpf(v, &e): v = m * 2^e with m in [0.5, 1); 0 -> 0
         return int(np.frexp(f32(v))[1])
     t, last_t, out = f32(t0), f32(t0), []
-    while t < far and len(out) < max_steps:
+    limit = max_steps if limit is None else limit  # (the inference march stops after n_step samples; dt_min still comes from max_steps)
+    while t < far and len(out) < limit:
         p = np.clip((np.float64(t) * d.astype(np.float64) + o).astype(np.float32), -bound, bound)  # fmaf
         dt = step_of(t)
         lvl_pos = min(C - 1, max(0, exponent(np.abs(p).max())))
@@ -255,6 +256,49 @@ def test_march_samples_match_bruteforce_walk_with_cascades_and_growing_steps(bou
     assert checked == int(counter[0]) and checked > 500 and outer > 50, (checked, outer)
     if dt_gamma > 0:
         assert np.unique(deltas[:checked, 0]).size > 3  # the step does grow with t
+
+
+@pytest.mark.parametrize("bound,C,dt_gamma", [(1.0, 1, 0.0), (2.0, 2, 1.0 / 256)])
+def test_inference_march_matches_bruteforce_walk(bound, C, dt_gamma):
+    """march_rays (raymarching.cu:704-811; the inference rounds of run_cuda): from every alive ray's current t, at most n_step
+    samples into slots [n * n_step, ...) -- the same independent walk, stopped after n_step samples, reproduces positions, dt and
+    `t - last_t` bit for bit, for two consecutive rounds (the second from the t the first one ended at)."""
+    from pvd.scene import ChairScene, packbits_torch
+    H, N, n_step = 128, 256, 8
+    o, d, _, _ = _scene(N, 4, bound=bound)
+    bits = packbits_torch(ChairScene(thicken=0.1, scale=1.9 if bound > 1 else 1.0).density_grid(H, bound, C), 10.0).numpy()
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    alive = np.arange(N, dtype=np.int32)
+    t_now = nears.copy()
+    total = 0
+    for rnd in range(2):
+        xyzs, dirs, deltas = oracle.march_rays(N, n_step, alive, t_now, o, d, bound, bits, C, H, nears, fars, dt_gamma=dt_gamma)
+        t_next = t_now.copy()
+        for n in range(N):
+            if not t_now[n] < fars[n]:
+                assert not deltas[n * n_step:(n + 1) * n_step].any()
+                continue
+            walk = _bruteforce_walk_general(o[n], d[n], fars[n], bits, t_now[n], bound, C, H, dt_gamma, limit=n_step)
+            k = len(walk)
+            s = n * n_step
+            if k:
+                assert np.array_equal(xyzs[s:s + k], np.stack([w[0] for w in walk])), (rnd, n)
+                assert np.array_equal(deltas[s:s + k, 0], np.array([w[1] for w in walk], np.float32)), (rnd, n)
+                assert np.array_equal(deltas[s:s + k, 1], np.array([w[2] for w in walk], np.float32)), (rnd, n)
+                assert np.array_equal(dirs[s:s + k], np.repeat(d[n][None], k, 0))
+                # composite_rays advances the ray's t by deltas[:, 1], one float32 add per sample (raymarching.cu:858-870): where
+                # the next round starts
+                tt = np.float32(t_now[n])
+                for w in walk:
+                    tt = np.float32(tt + w[2])
+                t_next[n] = tt
+            assert not deltas[s + k:s + n_step].any() and not xyzs[s + k:s + n_step].any()  # unused slots stay zero
+            if k < n_step:
+                t_next[n] = fars[n]  # the ray left the box before filling its slots: nothing left to march
+            total += k
+        t_now = t_next
+    assert total > 300
 
 
 def test_march_overflow_rule():
