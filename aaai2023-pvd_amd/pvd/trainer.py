@@ -917,6 +917,8 @@ class DistillTrainer(_TrainerBase):
             self.pipelined_ingraph = True
             self.pipeline_fork = "graph"
             return self._static_out
+        if fork_mode == "deep" and K >= 3 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
+            return self._capture_deep(batch_fn, K, side)
         if K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
             with torch.cuda.stream(side):
                 carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
@@ -1064,6 +1066,65 @@ class DistillTrainer(_TrainerBase):
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         self.pipelined_ingraph = True
         self.pipeline_fork = fork_mode
+        return self._static_out
+
+    def _capture_deep(self, batch_fn, K, side):
+        """PVD_PIPELINE_FORK=deep: the fork at the start of the step, the branch TWO steps deep -- first the frozen teacher's forward
+        on the samples of step k + 1 (marched during step k - 1's branch: the gathers then run next to the student's
+        instruction-bound forward instead of on top of its table scatter), then the batch and the march of step k + 2
+        (instruction-bound, next to the atomics-bound scatter).  No additional edge in the graph: still one fork and one join per
+        step.  Two static homes carry the state across replays (the complete prefix of the next replay's step 1, the marched
+        samples of its step 2); K >= 3 so that nobody still reads a home when the last step's branch refills it."""
+        with torch.cuda.stream(side):
+            full_home = CarriedPrefix(self.prefetch(batch_fn))
+            part_home = CarriedPrefix(self.prefetch_march(batch_fn))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
+        pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
+        cap = SegmentedCapture(self.device)
+        self.dp.capture = cap
+        branch = torch.cuda.Stream(self.device)
+        try:
+            with cap:
+                main = torch.cuda.current_stream()
+                pre, part = full_home.pre, part_home.pre
+                try:
+                    for k in range(K):
+                        branch.wait_stream(main)
+                        with torch.cuda.stream(branch):
+                            if pack_ahead is not None and pack_ahead(self.model_stu):
+                                packed = torch.cuda.Event()
+                                packed.record(branch)
+                                self.model_stu._before_head = lambda packed=packed: main.wait_event(packed)
+                            nxt_full = self.prefetch_teacher(part)
+                            nxt_part = self.prefetch_march(batch_fn)
+                            if k + 1 == K:  # for the next replay
+                                full_home.store(nxt_full)
+                                part_home.store(nxt_part)
+                        self._zero_grads()
+                        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                            self._static_out = self.compute_loss(None, None, None, pre=pre)
+                        self._backward(self._static_out[0])
+                        if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
+                            raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
+                        self._exchange()
+                        self._optimize()
+                        main.wait_stream(branch)
+                        pre, part = nxt_full, nxt_part
+                except Exception:
+                    self.model_stu.__dict__.pop("_before_head", None)
+                    self.model_stu.__dict__.pop("_train_image_ready", None)
+                    main.wait_stream(branch)  # a capture can only be ended with its forked work joined
+                    raise
+        finally:
+            self.dp.capture = None
+            self._fold_launches(False)
+        self._cap = cap
+        self.steps_per_replay = K
+        self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
+        self.pipelined_ingraph = True
+        self.pipeline_fork = "deep"
         return self._static_out
 
     def _capture_pipelined(self, batch_fn, body):
