@@ -477,6 +477,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     static int cap = -1;  // PVD_ADAMW_BLOCKS: workgroups of the update launch (measurement)
     if (cap < 0) { const char *e = getenv("PVD_ADAMW_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > 65535) cap = 256 * 16; }
     if (blocks > (uint64_t)cap) blocks = (uint64_t)cap;
+    // every workgroup writes one partial into l1_next[blockIdx.x]; the buffer's contract is ">= 4096 floats" (pvd_hip.h), so the
+    // measurement knob above must not grow the grid past it while the L1 value is tracked
+    if (ex.l1_next && blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     const bool amp = extras_host && extras_host->amp_scale;
     if (amp && (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1)) return PVD_ERR_INVALID;

@@ -146,6 +146,12 @@ class FlatAdamW(torch.optim.Optimizer):
                           torch.zeros(1, dtype=torch.int32, device=dev))
         return self._lazy
 
+    def before_replay(self):
+        """A graph whose updates are split writes the L1 partial sums in two regions; entries an eager single-launch step wrote
+        outside them would be added to every replayed step's L1 value.  Start the sums afresh when the shape changes."""
+        if self._graph_is_two_part:
+            self._l1_layout_is("two")
+
     def note_device_steps(self, n):
         """n update steps ran on the device without step() being called (a graph replay): keep the host's idea of the log's
         fill level current, and empty the log well before it is full."""

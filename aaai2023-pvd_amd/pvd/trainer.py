@@ -515,6 +515,9 @@ class _TrainerBase:
             self.optimizer.zero_in_step = bool(on) and os.environ.get("PVD_ADAMW_ZERO_IN_STEP", "1") != "0"
             if on:
                 self._graph_zeroes = False
+                # the first recorded step must record its zero_grad whatever the previous replay left behind: a graph that
+                # relies on "the last replay zeroed the gradients" accumulates stale ones after any eager step
+                self.optimizer._zeroed_by_step = False
             else:
                 # what the LAST recorded update did (it zeroes only in the touched-set / warm-list form, FlatAdamW.step) is what
                 # a replay leaves behind; the recording itself ran nothing, so right now the host knows nothing
@@ -548,6 +551,8 @@ class _TrainerBase:
         if getattr(self, "_pipe_pending", False):  # the prefix forked during the previous step feeds this one
             torch.cuda.current_stream().wait_stream(self._pipe_stream)
             self._pipe_pending = False
+        if self.flat_opt:
+            self.optimizer.before_replay()  # (stale L1 partial sums of another launch shape)
         self._cap.replay()
         if self.flat_opt:
             self.optimizer.note_device_steps(self.steps_per_replay)
@@ -642,7 +647,10 @@ class DistillTrainer(_TrainerBase):
                     and os.environ.get("PVD_OBJECTIVE_RIDE", "1") != "0" and os.environ.get("PVD_LOSS_DEFER", "0") != "1"):
                 from .losses import ObjectiveRide
                 # PVD_OBJECTIVE_FINISH=0: k_loss_final stays a launch of its own between the passes
-                fin = os.environ.get("PVD_OBJECTIVE_FINISH", "1") != "0"
+                # (and never when the L1 value is added to the loss by the host afterwards -- L1 on, VM student, non-flat
+                # optimizer: the finished loss only exists after the backward launch, as with PVD_LOSS_DEFER)
+                l1_on_host = o.l1_reg_weight > 0.0 and o.model_type == "vm" and not self.flat_opt
+                fin = os.environ.get("PVD_OBJECTIVE_FINISH", "1") != "0" and not l1_on_host
                 ride = ObjectiveRide(out_tea["image"], tea.feature_sigma_color, tea.color_l, rates_decay=self.rates if fin else None, fea_decay=0.995)
             out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
                                  inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, objective=ride, **kw)

@@ -24,10 +24,14 @@ import types
 # starts, i.e. at the first HIP call of the process, so the package -- not a benchmark script -- settles it here, before
 # the library below is loaded and before torch touches the device.  A value the caller exported wins; if the runtime is
 # already up without one, the forked schedule is refused (forked_graphs_ok) and steps are recorded back to back.
+# An integrator who does not want the binding to touch a runtime-wide variable exports PVD_HW_QUEUES=keep (the forked
+# schedule is then refused unless GPU_MAX_HW_QUEUES=2 was exported by the caller); INTEGRATION.md says so.
 _HWQ = "GPU_MAX_HW_QUEUES"
 _torch_loaded = sys.modules.get("torch")
 if _HWQ in os.environ:
     HW_QUEUES, HW_QUEUES_SOURCE = os.environ[_HWQ], "caller"
+elif os.environ.get("PVD_HW_QUEUES", "") == "keep":
+    HW_QUEUES, HW_QUEUES_SOURCE = None, "left to the runtime (PVD_HW_QUEUES=keep)"
 elif _torch_loaded is not None and _torch_loaded.cuda.is_initialized():
     HW_QUEUES, HW_QUEUES_SOURCE = None, "runtime started before pvd_hip was imported"
 else:

@@ -19,8 +19,12 @@
  *     PVD_ERR_UNSUPPORTED corresponds to the reference's
  *     `throw std::runtime_error{"GridEncoding: C must be 1, 2, 4, or 8."}`
  *     (gridencoder.cu:355,370);
- *   - re-entrant, no global mutable state (the reference constructs its RNG per
- *     call, raymarching.cu:488,816 -- so do we, on the device).
+ *   - re-entrant: no entry point keeps state between calls (the reference constructs
+ *     its RNG per call, raymarching.cu:488,816 -- so do we, on the device).  The ONE
+ *     exception is the pair of measurement knobs pvd_grid_set_variant /
+ *     pvd_grid_set_fwd_kernel: they set a process-wide choice among kernels whose
+ *     results are identical (bit-identical forward), are read once per launch, are meant
+ *     to be set before any concurrent use and never need to be called at all.
  *
  * Buffers that the reference's Python zero-fills before the call (xyzs, dirs,
  * deltas, grad_sigmas, grad_rgbs, grad_embeddings, grad_inputs) must arrive
