@@ -480,7 +480,148 @@ struct FusedLookup {
     bool align_corners;
 };
 
-__global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g) {
+// Round 4.  What the round-3 kernel below (k_hash_fwd_fused_r3, kept for A/B: PVD_FUSED_VARIANT=0) really executed was
+// FOURTEEN dependent memory round trips per workgroup, not two: `g.offsets` is a pointer inside a by-value struct, so the
+// compiler cannot prove the table of level offsets invariant, fetches offsets[level + 1] with a VECTOR load in front of every
+// level and waits for it -- and vmcnt retires in order, so that wait (s_waitcnt vmcnt(1) / vmcnt(0) in the ISA) also drains
+// every gather of the levels before it.  On top, LevelIndex decided hashed / pow2 / wrap with three uniform branches in front
+// of every one of the 56 loads of a lane (~90 instructions per load, 428 branches in the kernel).  Here:
+//   * the 15 offsets are read ONCE per workgroup (lanes 0..14, one load) and broadcast into SGPRs with v_readlane;
+//   * a level's shape is decided once (Level3, grid_lookup.h): hashed power-of-two levels and dense levels that cannot wrap
+//     get straight-line index code (shared y P1 / z P2 terms: 3 VALU ops per corner), everything else goes out of line;
+//   * the fractions are recomputed after the loads return instead of being held in 3 G registers;
+// so the G levels of a group really are in flight together (G = 7: two round trips, 28 loads per lane; G = 14: one, 56).
+// Same rows, same blend order: outputs bit-identical to the round-3 kernel and to lookup + head as two launches.
+struct FusedRes {
+    uint32_t res[14];  // (uint32_t)ceil((double)scale) + 1, on the host (what the kernels compute per level on the device)
+};
+
+template <uint32_t G>
+__global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g, FusedRes gr) {
+    extern __shared__ __align__(16) half_t lds[];
+    constexpr uint32_t D = 3, L = 14;
+    if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
+    if (blockIdx.x * kFusedTile >= a.M) return;  // nothing for this workgroup: skip the weight staging too
+    HeadLds<KIND_HASH> W;
+    W.carve(lds);
+    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
+    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
+    // level offsets: one vector load per wave, then SGPRs for the rest of the kernel
+    const int32_t offs_v = lane <= L ? g.offsets[lane] : 0;
+    bool dma_pending = a.image != nullptr;  // issued behind the first group of gathers (below)
+    if (!dma_pending) W.load(a, threadIdx.x, kHeadBlock);
+    for (uint32_t i = threadIdx.x; i < kFusedTile * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
+        *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
+    const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
+    const uint32_t nchunks = div_up(a.M, kFusedTile);
+    const float half_or_0 = g.align_corners ? 0.0f : 0.5f;
+    uint32_t off[L + 1];
+#pragma unroll
+    for (uint32_t l = 0; l <= L; l++) off[l] = (uint32_t)__builtin_amdgcn_readlane(offs_v, (int)l);
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // ---------------- phase 1: 14-level lookup of sample b by the lane pair (b, xb)
+        const uint32_t b = chunk * kFusedTile + s_local;
+        float x01[D] = {0.f, 0.f, 0.f};
+        bool inside = b < a.M;
+        if (inside) {
+            const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)b * D);
+            x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if (g.aff.on) x01[d] = (x01[d] + g.aff.add) / g.aff.div;
+                inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
+            }
+        }
+        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
+        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
+        float dir_pre[kTilesPerWave][3];
+#pragma unroll
+        for (int ti = 0; ti < kTilesPerWave; ti++) {
+            const size_t bs = (size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15);
+            const bool valid = bs < a.M;
+#pragma unroll
+            for (int c = 0; c < 3; c++) dir_pre[ti][c] = valid ? a.dirs[3 * bs + c] : 0.f;
+        }
+        // a sample outside the box gathers the rows of cell (0, 0, 0) of every level and is zeroed afterwards (branch-free)
+#pragma unroll
+        for (uint32_t l0 = 0; l0 < L; l0 += G) {
+            uint32_t v[G][4];
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                const uint32_t level = l0 + j;
+                if (level >= L) break;
+                const float scale = g.scales.scale[level];
+                Level3 lv;
+                lv.init(off[level + 1] - off[level], gr.res[level], g.gridtype, g.align_corners);
+                const uint32_t *__restrict__ table = g.grid + off[level];
+                uint32_t cell[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) cell[d] = inside ? (uint32_t)floorf(fmaf(x01[d], scale, half_or_0)) : 0u;
+                uint32_t row[4];
+                level3_rows(lv, g.gridtype, g.align_corners, cell, xb, row);
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) v[j][k] = table[row[k]];
+            }
+            if (l0 == 0 && dma_pending) {
+                dma_pending = false;
+                copy_image_dma(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < G; j++) {
+                const uint32_t level = l0 + j;
+                if (level >= L) break;
+                const float scale = g.scales.scale[level];
+                float fr[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    const float p = fmaf(x01[d], scale, half_or_0);
+                    fr[d] = p - (float)(uint32_t)floorf(p);
+                }
+                uint32_t acc = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t yb = k & 1u, zb = k >> 1;
+                    float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
+                    wi *= xb ? fr[0] : 1 - fr[0];
+                    wi *= yb ? fr[1] : 1 - fr[1];
+                    wi *= zb ? fr[2] : 1 - fr[2];
+                    const uint32_t pr = weighted_pair(wi, v[j][k]);
+                    const uint32_t other = dpp_quad<0xB1>(pr);
+                    acc = pk_add(acc, xb ? other : pr);
+                    acc = pk_add(acc, xb ? pr : other);
+                }
+                if (xb == 0) *reinterpret_cast<uint32_t *>(feat + s_local * kFeatStride + 2 * level) = inside ? acc : 0u;
+            }
+        }
+        __syncthreads();  // (also covers the weights / zero columns on the first pass)
+        // ---------------- phase 2: the head on the tile, 16 samples per wave and pass
+        for (uint32_t t16 = wave; t16 < kFusedTile / 16; t16 += kHeadBlock / 64) {
+            const uint32_t row = t16 * 16 + (lane & 15);
+            const size_t bs = (size_t)chunk * kFusedTile + row;
+            const bool valid = bs < a.M;
+            TileIn<KIND_HASH> in;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + row * kFeatStride + 16 * s2 + 4 * hi);
+            in.sraw = 0.f;
+            const int tsel = (int)((t16 - wave) / (kHeadBlock / 64));
+            in.dx = dir_pre[tsel][0]; in.dy = dir_pre[tsel][1]; in.dz = dir_pre[tsel][2];
+            TileFwd t;
+            head_forward_tile<KIND_HASH>(a, W, in, lane, t);
+            if (valid) {
+                *reinterpret_cast<f4 *>(a.feat16 + bs * 16 + 4 * hi) = t.F;
+                if (hi == 0) {
+                    a.sigma[bs] = __expf(t.F.x);
+                    a.rgb[3 * bs] = sigmoid_h(t.out.x);
+                    a.rgb[3 * bs + 1] = sigmoid_h(t.out.y);
+                    a.rgb[3 * bs + 2] = sigmoid_h(t.out.z);
+                }
+            }
+        }
+        __syncthreads();  // the next chunk's lookup overwrites the tile
+    }
+}
+
+__global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused_r3(HeadArgs a, FusedLookup g) {
     extern __shared__ __align__(16) half_t lds[];
     constexpr uint32_t D = 3, L = 14;
     if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
@@ -861,7 +1002,15 @@ static int launch_hash_fwd_fused(const HeadArgs &a, const FusedLookup &g, hipStr
     uint32_t blocks = nchunks;
     if (blocks > 256u * 4u) blocks = 256u * 4u;  // persistent beyond 4 workgroups per CU
     const size_t lds_bytes = (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + kFusedTile * kFeatStride * sizeof(half_t);
-    hipLaunchKernelGGL(k_hash_fwd_fused, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g);
+    // PVD_FUSED_VARIANT (measurement; read per launch so that one process can A/B): 0 = the round-3 kernel, 7 / 14 = levels per
+    // memory round trip.  All three produce the same bits.
+    int variant = 7;
+    if (const char *e = getenv("PVD_FUSED_VARIANT")) { variant = atoi(e); if (variant != 0 && variant != 14) variant = 7; }
+    FusedRes gr;
+    for (uint32_t l = 0; l < 14; l++) gr.res[l] = (uint32_t)ceil((double)g.scales.scale[l]) + 1u;
+    if (variant == 0) hipLaunchKernelGGL(k_hash_fwd_fused_r3, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g);
+    else if (variant == 14) hipLaunchKernelGGL(k_hash_fwd_fused<14>, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else hipLaunchKernelGGL(k_hash_fwd_fused<7>, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
     return check_launch();
 }
 

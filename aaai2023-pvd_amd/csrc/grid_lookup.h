@@ -69,6 +69,64 @@ struct LevelIndex {
     }
 };
 
+// ---- lean per-level geometry for the D = 3 kernels that keep SEVERAL levels' gathers in flight (fusedhead.hip).
+// LevelIndex::operator() decides hashed / pow2 / wrap per CORNER (three uniform branches and a possible division in front of
+// every load); here the decision is taken once per level and the two shapes the PVD table consists of get straight-line code:
+//   kHashPow2   : hashed level, power-of-two size   -> ((x) ^ (y P1) ^ (z P2)) & (size - 1), y P1 and z P2 shared by the corners
+//   kDensePlain : dense level that cannot wrap      -> x + y s1 + z s2
+//   kGeneric    : everything else (tiled grids, non-power-of-two hash sizes, align_corners) through LevelIndex
+// Same integers as LevelIndex for every corner, hence the same rows and bit-identical outputs.
+enum : uint32_t { kLevelGeneric = 0, kLevelHashPow2 = 1, kLevelDensePlain = 2 };
+
+struct Level3 {
+    uint32_t size, s1, s2, mode, resolution;
+
+    __device__ __forceinline__ void init(uint32_t size_, uint32_t resolution_, uint32_t gridtype, bool align_corners) {
+        size = size_;
+        resolution = resolution_;
+        const uint32_t R = align_corners ? resolution_ : resolution_ + 1u;
+        uint32_t s = 1;
+        s1 = s2 = 0;
+        if (s <= size) s *= R;                 // x: stride 1
+        if (s <= size) { s1 = s; s *= R; }     // y
+        if (s <= size) { s2 = s; s *= R; }     // z
+        const bool hashed = gridtype == 0u && s > size;
+        const bool pow2 = (size & (size - 1u)) == 0u;
+        // dense and unable to wrap: all three strides real, R^3 <= size, and (no align_corners) every corner coordinate <= R - 1
+        const bool dense_plain = !hashed && s2 != 0u && s <= size && !align_corners;
+        mode = (hashed && pow2) ? kLevelHashPow2 : dense_plain ? kLevelDensePlain : kLevelGeneric;
+    }
+};
+
+// the general index of one corner, out of line (never taken by the PVD table; keeps the unrolled level loops small)
+__device__ __noinline__ uint32_t level3_generic_index(uint32_t size, uint32_t resolution, uint32_t gridtype, bool align_corners, uint32_t x,
+                                                      uint32_t y, uint32_t z) {
+    LevelIndex<3> index;
+    index.init(size, resolution, gridtype, align_corners);
+    const uint32_t pg[3] = {x, y, z};
+    return index(pg);
+}
+
+// rows of the four (y, z) corners k = yb + 2 zb of lane-corner x = cell[0] + xb
+__device__ __forceinline__ void level3_rows(const Level3 &lv, uint32_t gridtype, bool align_corners, const uint32_t (&cell)[3], uint32_t xb,
+                                            uint32_t (&row)[4]) {
+    const uint32_t x = cell[0] + xb;
+    if (lv.mode == kLevelHashPow2) {
+        const uint32_t mask = lv.size - 1u;
+        const uint32_t a0 = cell[1] * 2654435761u, a1 = a0 + 2654435761u;  // (y + 1) P1 = y P1 + P1 (mod 2^32)
+        const uint32_t b0 = cell[2] * 805459861u, b1 = b0 + 805459861u;
+        const uint32_t xa0 = x ^ a0, xa1 = x ^ a1;
+        row[0] = (xa0 ^ b0) & mask; row[1] = (xa1 ^ b0) & mask; row[2] = (xa0 ^ b1) & mask; row[3] = (xa1 ^ b1) & mask;
+    } else if (lv.mode == kLevelDensePlain) {
+        const uint32_t base = x + cell[1] * lv.s1 + cell[2] * lv.s2;
+        row[0] = base; row[1] = base + lv.s1; row[2] = base + lv.s2; row[3] = base + lv.s1 + lv.s2;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            row[k] = level3_generic_index(lv.size, lv.resolution, gridtype, align_corners, x, cell[1] + (k & 1u), cell[2] + (k >> 1));
+    }
+}
+
 // optional input mapping x01 = (x + add) / div applied while reading the positions: GridEncoder.forward's
 // (inputs + bound) / (2 * bound) (grid.py:211) without two elementwise launches; same two IEEE operations
 struct InputAffine {
