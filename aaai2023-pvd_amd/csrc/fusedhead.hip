@@ -241,6 +241,23 @@ __device__ __forceinline__ void copy_image_dma(half_t *__restrict__ lds, const h
     }
 }
 
+// the same DMA with a compile-time size, fully unrolled: a LOOP of LDS-DMA operations in front of other loads makes the
+// compiler's wait-count insertion give up on graded waits (every later `s_waitcnt vmcnt(N)` becomes vmcnt(0)), a straight
+// line of them does not
+template <int HALFS, uint32_t BLOCK = kHeadBlock>
+__device__ __forceinline__ void copy_image_dma_static(half_t *__restrict__ lds, const half_t *__restrict__ image, uint32_t tid) {
+    constexpr int bytes = HALFS * 2, pieces_per_round = (int)(BLOCK / 64), rounds = (bytes + 1024 * pieces_per_round - 1) / (1024 * pieces_per_round);
+    const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
+#pragma unroll
+    for (int r = 0; r < rounds; r++) {
+        const int c = r * pieces_per_round + wave;
+        const int off = c * 1024 + lane * 16;
+        if (off + 16 <= bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)image + off),
+                                             (__attribute__((address_space(3))) void *)((char *)lds + c * 1024), 16, 0, 0);
+    }
+}
+
 // the packed image: [HeadLds<KIND>][HeadLdsT<KIND>], exactly the backward kernel's LDS contents.  One image element per
 // thread and ONE round of loads: the ten matrices (five weights, plain and transposed) used to be ten loops one after the
 // other, i.e. ten dependent memory round trips for 43 k elements (7.6 us in the step's timeline).
@@ -496,20 +513,35 @@ struct FusedRes {
     uint32_t res[14];  // (uint32_t)ceil((double)scale) + 1, on the host (what the kernels compute per level on the device)
 };
 
-template <uint32_t G>
+template <uint32_t G, int DMA>
 __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g, FusedRes gr) {
     extern __shared__ __align__(16) half_t lds[];
     constexpr uint32_t D = 3, L = 14;
+#ifdef PVD_FUSED_PROFILE  // instrumented A/B build (tools/prof_fused_stamps.py): every 97th workgroup's waves leave 8 s_memtime stamps
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PVD_FSTAMP(k) do { stamp[k] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PVD_FSTAMP(k) do { } while (0)
+#endif
+    PVD_FSTAMP(0);
     if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
     if (blockIdx.x * kFusedTile >= a.M) return;  // nothing for this workgroup: skip the weight staging too
     HeadLds<KIND_HASH> W;
     W.carve(lds);
     half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
     const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
-    // level offsets: one vector load per wave, then SGPRs for the rest of the kernel
+    // level offsets: one vector load per wave (the FIRST load of the kernel: with the positions it is the critical path to the
+    // first gather), then SGPRs for the rest of the kernel
     const int32_t offs_v = lane <= L ? g.offsets[lane] : 0;
-    bool dma_pending = a.image != nullptr;  // issued behind the first group of gathers (below)
-    if (!dma_pending) W.load(a, threadIdx.x, kHeadBlock);
+    // The head's weights: with a packed image, 22 KB of L2 hits go straight into LDS (global_load_lds_dwordx4: no data
+    // registers).  WHERE the DMA is issued matters more than it looks: while a global_load_lds is outstanding the compiler turns
+    // every later `s_waitcnt vmcnt(N)` into vmcnt(0) (it does not assume DMA and register loads retire in order), so a DMA in
+    // flight during the lookup serialises its graded waits.  DMA = 0: issued first and drained together with the positions, in
+    // front of the first gather; DMA = 1: issued when the blend is done, its latency in front of the head.  (Register-staging
+    // the image instead -- loads behind the last gather, ds_write in front of the barrier -- costs 20 VGPRs and the third wave
+    // per SIMD.)  Without an image the fp32 masters are converted in place (tests).
+    if (!a.image) W.load(a, threadIdx.x, kHeadBlock);
+    else if (DMA == 0) copy_image_dma_static<HeadLds<KIND_HASH>::halfs>(lds, a.image, threadIdx.x);
     for (uint32_t i = threadIdx.x; i < kFusedTile * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
         *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
@@ -523,8 +555,19 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
         const uint32_t b = chunk * kFusedTile + s_local;
         float x01[D] = {0.f, 0.f, 0.f};
         bool inside = b < a.M;
-        if (inside) {
-            const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)b * D);
+        // (loads are unconditional on a clamped row: a select between a loaded value and a constant is a wait at the select)
+        const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)min(b, a.M - 1u) * D);
+        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
+        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
+        float dir_pre[kTilesPerWave][3];
+#pragma unroll
+        for (int ti = 0; ti < kTilesPerWave; ti++) {
+            const size_t bs = min((size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15), (size_t)a.M - 1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) dir_pre[ti][c] = a.dirs[3 * bs + c];  // (rows past M: computed on row M - 1, never stored)
+        }
+        // a sample outside the box gathers the rows of cell (0, 0, 0) of every level and is zeroed afterwards (branch-free)
+        if (inside) {  // (first use of the position: everything above is in flight by now)
             x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
@@ -532,17 +575,8 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
             }
         }
-        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
-        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
-        float dir_pre[kTilesPerWave][3];
-#pragma unroll
-        for (int ti = 0; ti < kTilesPerWave; ti++) {
-            const size_t bs = (size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15);
-            const bool valid = bs < a.M;
-#pragma unroll
-            for (int c = 0; c < 3; c++) dir_pre[ti][c] = valid ? a.dirs[3 * bs + c] : 0.f;
-        }
-        // a sample outside the box gathers the rows of cell (0, 0, 0) of every level and is zeroed afterwards (branch-free)
+        if (DMA == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // positions, directions, offsets AND the weight DMA: nothing in flight from here
+        PVD_FSTAMP(1);
 #pragma unroll
         for (uint32_t l0 = 0; l0 < L; l0 += G) {
             uint32_t v[G][4];
@@ -561,11 +595,13 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 level3_rows(lv, g.gridtype, g.align_corners, cell, xb, row);
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) v[j][k] = table[row[k]];
+                // G = 14: the levels are ISSUED coarse to fine and CONSUMED in the same order while the finer ones are still in
+                // flight (vmcnt retires in order: level j is blended behind s_waitcnt vmcnt(4 (13 - j))), so the blend arithmetic
+                // of the early levels runs under the fine levels' memory time.  The fences keep the scheduler from hoisting all
+                // 56 address computations to the top (201 VGPRs) and from interleaving the blends (one vmcnt(0) for all).
+                if (G == 14) __builtin_amdgcn_sched_barrier(0);
             }
-            if (l0 == 0 && dma_pending) {
-                dma_pending = false;
-                copy_image_dma(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x);
-            }
+            if (l0 == 0) PVD_FSTAMP(2);
 #pragma unroll
             for (uint32_t j = 0; j < G; j++) {
                 const uint32_t level = l0 + j;
@@ -574,7 +610,9 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 float fr[D];
 #pragma unroll
                 for (uint32_t d = 0; d < D; d++) {
-                    const float p = fmaf(x01[d], scale, half_or_0);
+                    float xd = x01[d];
+                    asm volatile("" : "+v"(xd));  // recompute, do not keep: the same expression as above would be CSE'd into 3 live registers per level
+                    const float p = fmaf(xd, scale, half_or_0);
                     fr[d] = p - (float)(uint32_t)floorf(p);
                 }
                 uint32_t acc = 0u;
@@ -591,9 +629,13 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                     acc = pk_add(acc, xb ? pr : other);
                 }
                 if (xb == 0) *reinterpret_cast<uint32_t *>(feat + s_local * kFeatStride + 2 * level) = inside ? acc : 0u;
+                if (G == 14) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (DMA == 1 && a.image && chunk == blockIdx.x) copy_image_dma_static<HeadLds<KIND_HASH>::halfs>(lds, a.image, threadIdx.x);
+        PVD_FSTAMP(3);
         __syncthreads();  // (also covers the weights / zero columns on the first pass)
+        PVD_FSTAMP(4);
         // ---------------- phase 2: the head on the tile, 16 samples per wave and pass
         for (uint32_t t16 = wave; t16 < kFusedTile / 16; t16 += kHeadBlock / 64) {
             const uint32_t row = t16 * 16 + (lane & 15);
@@ -617,7 +659,15 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 }
             }
         }
+        PVD_FSTAMP(5);
         __syncthreads();  // the next chunk's lookup overwrites the tile
+        PVD_FSTAMP(6);
+#ifdef PVD_FUSED_PROFILE
+        if (chunk % 97u == 0 && lane == 0) {
+            long long *dst = reinterpret_cast<long long *>(a.rgb) + ((size_t)(chunk / 97u) * 4 + wave) * 8;
+            for (int q = 0; q < 8; q++) dst[q] = stamp[q];
+        }
+#endif
     }
 }
 
@@ -1004,13 +1054,17 @@ static int launch_hash_fwd_fused(const HeadArgs &a, const FusedLookup &g, hipStr
     const size_t lds_bytes = (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + kFusedTile * kFeatStride * sizeof(half_t);
     // PVD_FUSED_VARIANT (measurement; read per launch so that one process can A/B): 0 = the round-3 kernel, 7 / 14 = levels per
     // memory round trip.  All three produce the same bits.
-    int variant = 7;
-    if (const char *e = getenv("PVD_FUSED_VARIANT")) { variant = atoi(e); if (variant != 0 && variant != 14) variant = 7; }
+    int variant = 14, dma = 0;
+    if (const char *e = getenv("PVD_FUSED_VARIANT")) { variant = atoi(e); if (variant != 0 && variant != 7) variant = 14; }
+    if (const char *e = getenv("PVD_FUSED_DMA")) dma = atoi(e) == 1 ? 1 : 0;
     FusedRes gr;
     for (uint32_t l = 0; l < 14; l++) gr.res[l] = (uint32_t)ceil((double)g.scales.scale[l]) + 1u;
+
     if (variant == 0) hipLaunchKernelGGL(k_hash_fwd_fused_r3, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g);
-    else if (variant == 14) hipLaunchKernelGGL(k_hash_fwd_fused<14>, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
-    else hipLaunchKernelGGL(k_hash_fwd_fused<7>, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else if (variant == 14 && dma == 0) hipLaunchKernelGGL((k_hash_fwd_fused<14, 0>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else if (variant == 14) hipLaunchKernelGGL((k_hash_fwd_fused<14, 1>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else if (dma == 0) hipLaunchKernelGGL((k_hash_fwd_fused<7, 0>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else hipLaunchKernelGGL((k_hash_fwd_fused<7, 1>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
     return check_launch();
 }
 

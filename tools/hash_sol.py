@@ -25,6 +25,7 @@ from pvd.workload import make_model
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pmc", default=None)
+ap.add_argument("--rows", default=None, help="only rows whose name contains this substring")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -165,6 +166,8 @@ else:
     print("samples per launch: %d   algorithmic bytes (516 B/sample): %.2f MB   PVD_FUSED_VARIANT=%s" % (M, ALG / 1e6, os.environ.get("PVD_FUSED_VARIANT", "default")))
     print("%-42s %9s %10s %8s" % ("row", "us/launch", "GB/s @516", "of 8TB/s"))
     for name, fn, nbytes in ROWS:
+        if args.rows and args.rows not in name:
+            continue
         us = timed(fn)
         if nbytes:
             print("%-42s %9.2f %10.0f %8.3f" % (name, us, nbytes / us / 1e3, nbytes / us / 1e3 / 8000.0))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycle stamps of k_hash_fwd_fused from an instrumented A/B build (PVD_HIP_LIB=libpvd_hip_prof.so: every 97th workgroup's waves
-write 7 s_memtime stamps over the rgb output): start | weights staged | level group A blended | group B blended | tile visible
-(barrier) | head done | barrier.  Prints the phases of a few workgroups in ns (s_memtime ticks at 100 MHz)."""
+write 7 s_memrealtime (100 MHz) stamps over the rgb output): start | inputs + weight DMA landed | first group's gathers issued | all levels
+blended | tile visible (barrier) | head done + outputs stored | barrier.  Build: make -C aaai2023-pvd_amd/csrc prof.  Prints the phases of a few workgroups in ns (s_memtime ticks at 100 MHz)."""
 import os
 import sys
 
@@ -29,9 +29,14 @@ torch.cuda.synchronize()
 n = (x.shape[0] // 128 // 97 + 1) * 4
 st = rgb.view(-1)[: n * 8 * 2].view(torch.int64).view(-1, 8).cpu()
 t0 = int(st[:, 0][st[:, 0] > 0].min())
-names = ["weights", "groupA", "groupB", "barrier", "head", "barrier2"]
+names = ["inputs", "issue", "blend", "barrier", "head", "barrier2"]
 print("workgroup.wave: start (ns after the first)  " + "  ".join(names))
+import numpy as np
+rows = []
 for i, r in enumerate(st.tolist()):
     if r[0] <= 0:
         continue
+    rows.append([(r[0] - t0) * 10] + [(r[k + 1] - r[k]) * 10 for k in range(6)] + [(r[6] - t0) * 10])
     print("%4d.%d  %8d   " % (i // 4 * 97, i % 4, (r[0] - t0) * 10) + "  ".join("%7d" % ((r[k + 1] - r[k]) * 10) for k in range(6)))
+a = np.array(rows, dtype=np.float64)
+print("median   %8d   " % np.median(a[:, 0]) + "  ".join("%7d" % v for v in np.median(a[:, 1:7], axis=0)) + "   end (ns after first start): median %d max %d" % (np.median(a[:, 7]), a[:, 7].max()))
