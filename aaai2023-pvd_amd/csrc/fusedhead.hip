@@ -547,6 +547,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
     const uint32_t nchunks = div_up(a.M, kFusedTile);
     const float half_or_0 = g.align_corners ? 0.0f : 0.5f;
+    constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
     uint32_t off[L + 1];
 #pragma unroll
     for (uint32_t l = 0; l <= L; l++) off[l] = (uint32_t)__builtin_amdgcn_readlane(offs_v, (int)l);
@@ -555,16 +556,18 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
         const uint32_t b = chunk * kFusedTile + s_local;
         float x01[D] = {0.f, 0.f, 0.f};
         bool inside = b < a.M;
-        // (loads are unconditional on a clamped row: a select between a loaded value and a constant is a wait at the select)
+        // Unconditional loads of a clamped row: a load under a run-time condition reaches its use through a phi and is waited for
+        // at the end of the conditional block; rows past M are computed on row M - 1 and never stored.  The directions of the
+        // (two) 16-sample tiles this wave will run the head on are requested here and used after the lookup.  (Requesting a
+        // chunk's inputs one chunk ahead -- the first chunk's in front of the wait for the offsets -- was built and measured:
+        // no change, the workgroup's first wait is ONE round trip of ~3-4 us either way: profiles/r04_fused_stamps.txt.)
         const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)min(b, a.M - 1u) * D);
-        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
-        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
         float dir_pre[kTilesPerWave][3];
 #pragma unroll
         for (int ti = 0; ti < kTilesPerWave; ti++) {
             const size_t bs = min((size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15), (size_t)a.M - 1);
 #pragma unroll
-            for (int c = 0; c < 3; c++) dir_pre[ti][c] = a.dirs[3 * bs + c];  // (rows past M: computed on row M - 1, never stored)
+            for (int c = 0; c < 3; c++) dir_pre[ti][c] = a.dirs[3 * bs + c];
         }
         // a sample outside the box gathers the rows of cell (0, 0, 0) of every level and is zeroed afterwards (branch-free)
         if (inside) {  // (first use of the position: everything above is in flight by now)
@@ -575,6 +578,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
                 inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
             }
         }
+        PVD_FSTAMP(7);  // (everything the workgroup needs before its first gather has been requested)
         if (DMA == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // positions, directions, offsets AND the weight DMA: nothing in flight from here
         PVD_FSTAMP(1);
 #pragma unroll

@@ -42,6 +42,7 @@ class PVDConfig:
     sigma_clip_max: float = 7.0
     render_stu_first: bool = True
     update_stu_extra: bool = False
+    data_type: str = "synthetic"  # which random-camera generator feeds the distillation: synthetic | llff | tank (main_distill_mutual.py:206-212)
     stage_iters: dict = field(default_factory=lambda: {"stage1": 2000, "stage2": 5000})
     global_step: int = 0
     # model zoo

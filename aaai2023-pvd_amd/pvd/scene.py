@@ -135,6 +135,66 @@ def synthetic_poses(rng, scale=0.8):
     return np.stack(poses)
 
 
+def tank_poses(rng, scale=0.8):
+    """Tanks&Temples-style epoch (utils.py:136-150, --data_type tank): elevations 5..19 only, radius ~ U(3, 4) drawn after
+    the two angles of a camera; the first camera is the synthetic generator's (phi from 8, r = 4).  88 - 1 = 87 cameras."""
+    def one(ph, rand_radius):
+        theta = -180 + rng.rand() * 360
+        lo, hi = -ph, (5 - ph if (5 - ph) <= 0 else 0)
+        phi = lo + rng.rand() * (hi - lo)
+        radius = rng.uniform(3, 4) if rand_radius else 4.0
+        return nerf_matrix_to_ngp(pose_spherical(theta, phi, radius), scale)
+    poses = [one(8, False)]
+    for a in range(5, 20):
+        poses += [one(a, True) for _ in range((90 - a) // 15 + 1)]
+    return np.stack(poses)
+
+
+def llff_poses(rng, original_poses, gen_num=30):
+    """LLFF-style epoch (utils.py:152-188, --data_type llff): `gen_num` camera centres uniform in the bounding box of the training
+    cameras' translations (x, then y, then z drawn as three vectors), every camera looking at the origin with up = -y
+    (right = f x up, up = right x f, columns [right, up, forward]) and the sign of element [0, 0] flipped afterwards."""
+    t = np.asarray(original_poses)[:, :3, 3]
+    hi, lo = t.max(axis=0) + 1e-6, t.min(axis=0) - 1e-6
+    xs = rng.uniform(low=lo[0], high=hi[0], size=gen_num)
+    ys = rng.uniform(low=lo[1], high=hi[1], size=gen_num)
+    zs = rng.uniform(low=lo[2], high=hi[2], size=gen_num)
+    centers = torch.from_numpy(np.stack([xs, ys, zs], axis=1).astype(np.float32))
+
+    def normalize(v):
+        return v / (torch.norm(v, dim=-1, keepdim=True) + 1e-10)
+
+    fwd = -normalize(centers)
+    up = torch.tensor([0.0, -1.0, 0.0]).unsqueeze(0).repeat(gen_num, 1)
+    right = normalize(torch.cross(fwd, up, dim=-1))
+    up = normalize(torch.cross(right, fwd, dim=-1))
+    poses = torch.eye(4, dtype=torch.float32).unsqueeze(0).repeat(gen_num, 1, 1)
+    poses[:, :3, :3] = torch.stack((right, up, fwd), dim=-1)
+    poses[:, :3, 3] = centers
+    poses[:, 0, 0] = -poses[:, 0, 0]
+    return poses.numpy()
+
+
+def forward_facing_train_poses(rng, n=20):
+    """Stand-in for an LLFF capture's training cameras (there is no dataset offline): n cameras on a small patch in front of the
+    scene, as get_rand_poses' llff branch only uses their translations' bounding box."""
+    poses = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    poses[:, :3, 3] = rng.uniform([-0.9, -0.5, 2.4], [0.9, 0.5, 3.0], size=(n, 3)).astype(np.float32)
+    return poses
+
+
+def rand_poses(data_type, rng, original_poses=None, scale=0.8):
+    """One epoch of random distillation cameras for --data_type synthetic | llff | tank (get_rand_poses, utils.py:100-197)."""
+    if data_type == "synthetic":
+        return synthetic_poses(rng, scale)
+    if data_type == "tank":
+        return tank_poses(rng, scale)
+    if data_type == "llff":
+        assert original_poses is not None, "the llff generator samples inside the training cameras' bounding box"
+        return llff_poses(rng, original_poses)
+    raise ValueError("illegal data_type %r" % (data_type,))
+
+
 BLENDER_INTRINSICS = (1111.1, 1111.1, 400.0, 400.0)  # fx, fy, cx, cy for 800x800, camera_angle_x ~ 0.6911
 
 

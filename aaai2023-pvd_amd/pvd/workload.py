@@ -6,7 +6,7 @@ import torch
 
 from .config import PVDConfig
 from .network import NeRFNetwork
-from .scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+from .scene import BLENDER_INTRINSICS, ChairScene, forward_facing_train_poses, get_rays, packbits_torch, rand_poses, synthetic_poses
 from .trainer import DistillTrainer, RayDP, TeacherTrainer
 
 
@@ -81,7 +81,9 @@ class DistillWorkload:
         self.dp_rank = dp.rank if dp else 0
         self.gen.manual_seed(seed + 1000 * self.dp_rank)  # different rays on every rank
         self.scene = ChairScene(thicken=thicken, scale=scene_scale)
-        self.poses = torch.from_numpy(synthetic_poses(self.rng, opt.scale)).to(self.device)
+        # one epoch of random distillation cameras, by --data_type (get_rand_poses, utils.py:100-197); "synthetic" is the chair's
+        orig = forward_facing_train_poses(self.rng) if opt.data_type == "llff" else None
+        self.poses = torch.from_numpy(rand_poses(opt.data_type, self.rng, original_poses=orig, scale=opt.scale)).to(self.device)
 
         self.tea = make_model(ops, opt, opt.teacher_type, True, self.device)
         install_occupancy(self.tea, self.scene, opt)

@@ -98,6 +98,136 @@ def cpu_baseline(workload, steps, num_rays):
                       "same weights and occupancy grid as the GPU run" % (steps, num_rays)}
 
 
+def cpu_baseline_teacher(tea_gpu, opt, topt, steps, num_rays):
+    """configs[1] on the host cores: `steps` training steps of the hash teacher (`num_rays` rays each, fp32) through the CPU
+    oracle, starting from the GPU run's weights and occupancy grid (no grid update inside the sample)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.scene import BLENDER_INTRINSICS, get_rays
+    from pvd.trainer import TeacherTrainer
+    from pvd.workload import DistillWorkload
+
+    copt = PVDConfig(**{**opt.__dict__, "fp16": False, "num_rays": num_rays})
+    cw = DistillWorkload(oracle_ops(), "cpu", copt, teacher_pretrain_steps=0, seed=0)
+    tea = cw.tea
+    tea.load_state_dict({k: v.detach().float().cpu() for k, v in tea_gpu.state_dict().items()})
+    ctopt = PVDConfig(**{**topt.__dict__, "fp16": False, "num_rays": num_rays, "update_extra_interval": 10 ** 9})
+    tea.teacher_variant = True
+    tea.requires_grad_(True).train()
+    tea.args = tea.opt = ctopt
+    tea.mean_count = int(tea_gpu.mean_count * num_rays / opt.num_rays)
+    tr = TeacherTrainer(ctopt, tea, "cpu", fp16=False)
+    batches = []
+    for it in range(4):
+        r = get_rays(cw.poses[it % len(cw.poses)][None], BLENDER_INTRINSICS, 800, 800, num_rays, generator=cw.gen)
+        bg = torch.rand(1, num_rays, 3, generator=cw.gen)
+        batches.append((r["rays_o"], r["rays_d"], cw.target(r["rays_o"], r["rays_d"], bg), bg))
+    tr.global_step = 1  # (not a multiple of the update interval)
+    tr.train_step(*batches[0])  # warm-up
+
+    def timed_steps(n):
+        t0 = time.perf_counter()
+        for i in range(n):
+            tr.train_step(*batches[i % 4])
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    best_t, best_n = None, 1
+    for n in [c for c in (4, 8, 16, 32, 64, 128) if c < ncpu] + [ncpu]:
+        torch.set_num_threads(n)
+        oracle.set_num_threads(n)
+        t = timed_steps(1)
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+        elif t > 1.3 * best_t:
+            break
+    torch.set_num_threads(best_n)
+    oracle.set_num_threads(best_n)
+    dt = timed_steps(steps)
+    return {"value": steps * num_rays / dt, "unit": "rays/s", "cores": int(best_n), "kind": "port",
+            "sample": "%d teacher training steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, same weights "
+                      "and occupancy grid as the GPU run, no grid update inside the sample" % (steps, num_rays)}
+
+
+def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=True):
+    """The metric's second half, OUTSIDE the timed region: a whole (short) distillation run through the three stages of the
+    reference schedule (main_distill_mutual.py:387-396, scaled: stage 1 feature loss only, stage 2 + sigma / colour, stage 3 + RGB)
+    from a teacher trained on the analytic scene, then PSNR on held-out views rendered with the inference path
+    (distill_mutual/utils.py:491-529 PSNRMeter, :1246-1265 evaluate_one_epoch): student vs teacher, student vs the analytic
+    ground truth, teacher vs ground truth -- and the SAME rays through the HIP path and through the CPU oracle path (fp32, same
+    weights): the render-level parity figure."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    from pvd.trainer import psnr
+    from pvd.workload import DistillWorkload
+
+    opt = PVDConfig(model_type=student, iters=steps, stage_iters={"stage1": stage1, "stage2": stage2})
+    t0 = time.perf_counter()
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=teacher_steps, start_stage="stage1")
+    torch.cuda.synchronize()
+    t_teacher = time.perf_counter() - t0
+    tr = w.trainer
+
+    def spg():  # stage 3 has no further boundary: ten steps per graph launch (a stage mark may be overshot by < 10 steps)
+        return 10 if tr._stage_of(tr.global_step + 3) == 3 else 1
+
+    t1 = time.perf_counter()
+    while tr.global_step < steps:
+        if tr._stage_of(tr.global_step) != getattr(tr, "_captured_stage", None) or not getattr(w, "_graph", False):
+            w.enable_graph(steps_per_graph=spg())
+        w.step()
+    torch.cuda.synchronize()
+    t_distill = time.perf_counter() - t1
+    held_out = torch.from_numpy(synthetic_poses(np.random.RandomState(123))[:4]).to(dev)
+    res = 200
+    k = res / 800.0
+    intr = tuple(v * k for v in BLENDER_INTRINSICS)
+    rows = []
+    for m in (w.stu, w.tea):
+        m.eval()
+    with torch.no_grad():
+        for pose in held_out:
+            r = get_rays(pose[None], intr, res, res, -1)
+            with torch.autocast("cuda", dtype=torch.float16):
+                s_img = w.stu.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, max_steps=1024)["image"]
+                t_img = w.tea.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, max_steps=1024)["image"]
+            gt = w.target(r["rays_o"], r["rays_d"], torch.ones(1, res * res, 3, device=dev))
+            rows.append((float(psnr(s_img, t_img)), float(psnr(s_img, gt)), float(psnr(t_img, gt))))
+    st, sg, tg = (float(v) for v in np.mean(np.array(rows), axis=0))
+    out = {"student_vs_teacher_heldout_db": st, "student_vs_gt_db": sg, "teacher_vs_gt_db": tg, "steps": int(tr.global_step),
+           "schedule": "teacher %d steps on the analytic scene; distillation stage 1 to %d, stage 2 to %d, stage 3 to %d (the reference "
+                       "schedule scaled); 4 held-out %dx%d views, inference path (march_rays / composite_rays / compact_rays), fp16 AMP"
+                       % (teacher_steps, stage1, stage2, int(tr.global_step), res, res),
+           "teacher_train_s": t_teacher, "distill_s": t_distill}
+    if oracle_check:
+        # the same rays through libpvd_hip.so (GPU, fp32) and through the oracle operator set (CPU, fp32), same weights
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from oracle_ops import oracle_ops
+        from pvd.workload import make_model
+        res_o = 64
+        intr_o = tuple(v * res_o / 800.0 for v in BLENDER_INTRINSICS)
+        r = get_rays(held_out[:1], intr_o, res_o, res_o, -1)
+        par = {}
+        with torch.no_grad():
+            for name, m in (("student", w.stu), ("teacher", w.tea)):
+                g_img = m.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, max_steps=1024)["image"].float().cpu()
+                cm = make_model(oracle_ops(), opt, m.model_type, name == "teacher", "cpu").eval()
+                cm.load_state_dict({kk: v.detach().float().cpu() for kk, v in m.state_dict().items()})
+                cm.mean_count = m.mean_count
+                c_img = cm.render(r["rays_o"].cpu(), r["rays_d"].cpu(), staged=True, bg_color=1, perturb=False, max_steps=1024)["image"].float()
+                par[name] = (float(psnr(g_img, c_img)), float((g_img - c_img).abs().max()))
+        out["hip_vs_oracle_same_rays_db"] = min(par["student"][0], par["teacher"][0])
+        out["hip_vs_oracle_detail"] = {"student_db": par["student"][0], "student_max_abs": par["student"][1], "teacher_db": par["teacher"][0],
+                                       "teacher_max_abs": par["teacher"][1],
+                                       "what": "one held-out %dx%d view, fp32, HIP operators on the GPU vs oracle operators on the CPU, same weights" % (res_o, res_o)}
+    for m in (w.stu, w.tea):
+        m.train()
+    return out
+
+
 def teacher_workload(args, dev):
     """BASELINE.json configs[1]: training step of the hash (INGP) teacher on the synthetic chair, 4096 rays/batch, incl. the
     occupancy-grid update every 16 steps.  Eager launches (the sample budget changes with every grid update), so the
@@ -187,6 +317,13 @@ def teacher_workload(args, dev):
                      "us_per_launch": ms * 1e3, "launches": kt.launches(name)},
         "cpu_baseline": None,
     }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_teacher(tea, opt, topt, max(2, args.cpu_steps // 2), args.rays)
+        except Exception as e:  # noqa: BLE001  (never lose the line to the baseline)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     print(json.dumps(out))
 
 
@@ -206,7 +343,14 @@ def main():
                     help="strong scaling: --rays is the GLOBAL batch, split evenly across the ranks (default: weak, --rays per GPU)")
     ap.add_argument("--bound", type=float, default=1.0, help="scene bound (> 1: more than one occupancy cascade, as for Tanks&Temples, configs[4])")
     ap.add_argument("--dt-gamma", type=float, default=0.0, help="dt_gamma of the marcher (the reference uses 1/256 for unbounded scenes)")
+    ap.add_argument("--data-type", choices=["synthetic", "llff", "tank"], default="synthetic",
+                    help="random-camera generator of the distillation (get_rand_poses, distill_mutual/utils.py:100-197): configs[3] uses llff, configs[4] tank")
+    ap.add_argument("--teacher", type=str, default="hash", help="teacher model type (configs[3]: mlp)")
     ap.add_argument("--scene-scale", type=float, default=1.0, help="scale of the synthetic scene (with --bound > 1)")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="after the timed region: this many more steps in one synchronised window (`sustained`); 0 = skip")
+    ap.add_argument("--no-psnr", action="store_true", help="skip the staged distillation run + held-out PSNR (`psnr`, ~12 s, outside the timed region)")
+    ap.add_argument("--psnr-schedule", type=str, default="3000,500,1500,6000", help="teacher steps, end of stage 1, end of stage 2, total distillation steps")
     ap.add_argument("--workload", choices=["distill", "teacher"], default="distill",
                     help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
@@ -248,7 +392,8 @@ def main():
     from pvd.trainer import RayDP, psnr
     from pvd.workload import DistillWorkload
 
-    opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type="hash", fp16=not args.fp32, bound=args.bound, dt_gamma=args.dt_gamma)
+    opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type=args.teacher, fp16=not args.fp32, bound=args.bound, dt_gamma=args.dt_gamma,
+                    data_type=args.data_type)
     dp = RayDP()
     w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp, scene_scale=args.scene_scale)
     if dp.enabled:  # replicas must start bit-identical (teacher pre-training uses float atomics)
@@ -304,6 +449,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+
+    # ---- a longer window behind the timed one (the driver's K = 20 steps are 6 ms: nothing outside this process can see them)
+    sustained = None
+    if args.sustained_steps > 0:
+        n_calls = max(1, args.sustained_steps // spc)
+        if dp.enabled:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_calls):
+            w.step()
+        if dp.enabled:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        sustained = {"steps": n_calls * spc, "ms_per_step": dt / (n_calls * spc) * 1e3, "window_s": dt,
+                     "vs_timed": (dt / (n_calls * spc)) / (elapsed / args.steps)}
 
     # ---- roofline of the hash-grid lookup (the kernel north_star names).  HIP events cannot sit inside the replayed step,
     # so right after the timed region the SAME kernel is launched on the samples of one more step: the frozen teacher's
@@ -393,7 +555,7 @@ def main():
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
     total_rays = args.steps * global_rays
     out = {
-        "metric": "train rays/s (hash->%s chair distillation step)" % opt.model_type,
+        "metric": "train rays/s (%s->%s chair distillation step)" % (opt.teacher_type, opt.model_type),
         "value": total_rays / elapsed,
         "unit": "rays/s",
         "n_gpus": world,
@@ -405,9 +567,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP, as the reference forces) / f32 marcher+compositor",
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
-        "config": {"workload": "distill hash->%s, synthetic chair, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
+        "config": {"workload": "distill %s->%s, synthetic chair, %s cameras, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
                                "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps%s" % (
-                                   args.student, args.rays, args.teacher_pretrain,
+                                   args.teacher, args.student, args.data_type, args.rays, args.teacher_pretrain,
                                    "" if (args.bound == 1.0 and args.dt_gamma == 0.0) else "; bound %g (%d cascades), dt_gamma %g, scene scale %g"
                                    % (args.bound, w.stu.cascade, args.dt_gamma, args.scene_scale)),
                    "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
@@ -418,6 +580,7 @@ def main():
                    "psnr_student_vs_teacher_db": float(psnr(pred_stu.detach(), pred_tea.detach())) if pred_stu is not None else None,
                    "loss": float(loss)},
         "roofline": roof,
+        "sustained": sustained,
     }
     if dp.enabled:  # what one step's gradient exchange moved (informational; never let it cost the line)
         try:
@@ -436,6 +599,19 @@ def main():
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
     else:
         out["cpu_baseline"] = None
+    out["psnr"] = None
+    if rank == 0 and world == 1 and not args.no_psnr and not args.eager and args.student == "vm" and args.bound == 1.0:
+        try:
+            del w  # (its graphs and pools)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            ts, s1, s2, tot = (int(v) for v in args.psnr_schedule.split(","))
+            out["psnr"] = psnr_run(dev, args.student, ts, s1, s2, tot, oracle_check=not args.no_cpu_baseline)
+        except Exception as e:  # noqa: BLE001  (never lose the throughput line to the quality run)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out["psnr"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

@@ -110,3 +110,20 @@ def test_composite_wrapper_logic_matches_reference_wrapper():
                                              torch.from_numpy(G["comp_g_image"])])
     assert np.array_equal(sig.grad.numpy(), G["comp_g_sigmas"])
     assert np.array_equal(rgb.grad.numpy(), G["comp_g_rgbs"])
+
+
+# ------------------------------------------------------------------ random distillation cameras (--data_type synthetic | tank | llff)
+def test_rand_pose_generators_reproduce_the_reference():
+    """tests/golden/reference_poses.npz: the reference's get_rand_poses (distill_mutual/utils.py:100-197) run with a seeded
+    np.random (tests/golden/make_golden_poses.py); a RandomState with the same seed draws the same stream."""
+    from pvd.scene import rand_poses
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_poses.npz"))
+    for seed in (0, 7):
+        for kind in ("synthetic", "tank", "llff"):
+            orig = ref["llff_original_seed%d" % seed] if kind == "llff" else None
+            got = rand_poses(kind, np.random.RandomState(seed), original_poses=orig)
+            want = ref["%s_seed%d" % (kind, seed)]
+            assert got.shape == want.shape and got.dtype == np.float32, (kind, got.shape, want.shape)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-6, err_msg=kind)
+    with pytest.raises(ValueError):
+        rand_poses("blender", np.random.RandomState(0))

@@ -31,11 +31,11 @@ def _line(cmd, env=None, timeout=600):
     return json.loads(lines[0])
 
 
-COMMON = ["--steps", "10", "--warmup", "5", "--rays", "1024", "--teacher-pretrain", "20"]
+COMMON = ["--steps", "10", "--warmup", "5", "--rays", "1024", "--teacher-pretrain", "20", "--sustained-steps", "40"]
 
 
 def test_single_gpu_line_carries_the_contract():
-    d = _line([sys.executable, "bench.py", *COMMON, "--cpu-steps", "1"])
+    d = _line([sys.executable, "bench.py", *COMMON, "--cpu-steps", "1", "--psnr-schedule", "300,40,80,200"])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["unit"] == "rays/s" and d["vs_baseline"] is None and d["data"].startswith("synthetic")
     assert abs(d["value"] - 10 * 1024 / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
@@ -50,6 +50,19 @@ def test_single_gpu_line_carries_the_contract():
     assert r["alone"]["us_per_launch"] > 0 and r["alone"]["launches"] >= 20
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    su = d["sustained"]  # a second, longer synchronised window behind the timed one
+    assert su["steps"] == 40 and su["ms_per_step"] > 0 and abs(su["vs_timed"] - su["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    q = d["psnr"]  # the metric's second half, outside the timed region: staged distillation run + held-out views
+    assert "error" not in q, q
+    assert q["steps"] >= 200 and all(math.isfinite(q[k]) for k in ("student_vs_teacher_heldout_db", "student_vs_gt_db", "teacher_vs_gt_db"))
+    assert q["hip_vs_oracle_same_rays_db"] > 80.0, q["hip_vs_oracle_detail"]  # render-level parity: same rays, HIP vs CPU oracle, fp32
+
+
+def test_teacher_workload_line_has_a_cpu_baseline():
+    d = _line([sys.executable, "bench.py", "--workload", "teacher", "--steps", "16", "--warmup", "32", "--rays", "1024", "--cpu-steps", "2"])
+    assert d["metric"].startswith("train rays/s (hash teacher") and d["roofline"]["bytes_per_sample"] == 516
+    c = d["cpu_baseline"]
+    assert c and "error" not in c and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
 
 
 @pytest.mark.parametrize("strong", [False, True])
@@ -63,4 +76,5 @@ def test_two_ranks_as_the_driver_launches_them(strong):
     total = 10 * (1024 if strong else 2048)  # whole-job rays over the timed steps
     assert abs(d["value"] - total / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
     assert "all-reduce" in d["config"]["exchange"] and math.isfinite(d["config"]["loss"]) and d["config"]["capture_fallback"] is False
-    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert d["cpu_baseline"] is None and d["psnr"] is None  # rank 0 at N = 1 only
+    assert d["sustained"]["steps"] == 40

@@ -6,6 +6,8 @@ identical batch, fp32:
               ~9e4 sample rows -- the step bench.py times (there under AMP; the oracle has no half arithmetic, so the
               comparison is the fp32 formulation of the same step), stage 3 and stage 1
   configs[1]  one training step of the hash teacher at 4096 rays against ground-truth pixels
+  configs[3]  distill mlp -> tensors with the 128^3 x 28 Plenoxel volume (235 MB), 4096 rays, llff random cameras
+  configs[4]  distill hash -> hash, bound 2 / two cascades / dt_gamma 1/256, 4096 rays, tank random cameras
 
 Bars (north_star / VERDICT round 2): the marcher's sample counts bit-exact, both images within 1e-4, the loss within
 2e-4 relative, every gradient within 1e-3 of its largest entry.  The toy-size versions of the same comparisons are
@@ -116,3 +118,35 @@ def test_config1_teacher_full_size_step_matches_the_oracle():
         assert scale > 0, n
         err = (gg[n] - gc[n]).abs().max().item() / scale
         assert err <= 1e-3, (n, err)
+
+
+def _one_full_size_step(gpu, cpu, grad_tol):
+    """One distillation step at the workload's full size on both sides from identical weights / batch: sample counts to the unit,
+    loss, both images, every gradient."""
+    from test_hip_workloads import _distill_steps
+    worst = _distill_steps(gpu, cpu, 1, loss_rtol=2e-4, grad_tol=grad_tol)
+    got, want = _counts(gpu.stu), _counts(cpu.stu)
+    assert got == want, (got, want)
+    return worst, want[0]
+
+
+def test_config3_mlp_to_plenoxel_full_size_step_on_llff_cameras():
+    """configs[3] at its own size: NeRF-MLP teacher -> Plenoxel student with the reference's 128^3 x 28-channel volume (235 MB,
+    network.py:184-191), 4096 rays per step, cameras from the llff branch of get_rand_poses (utils.py:152-188) -- against the
+    oracle operator set on the CPU."""
+    gpu, cpu = _pair(teacher_type="mlp", model_type="tensors", num_rays=4096, data_type="llff")
+    assert gpu.stu.model_type == "tensors" and gpu.tea.model_type == "mlp" and gpu.opt.plenoxel_res == "[128,128,128]"
+    assert tuple(gpu.stu.tensor_volume[0].shape) == (1, 28, 128, 128, 128) and len(gpu.poses) == 30
+    worst, n = _one_full_size_step(gpu, cpu, grad_tol=2e-3)
+    assert n > 20000, n
+    print("configs[3] full size (128^3 Plenoxel, 4096 rays, llff cameras): %d samples, worst gradient error / max|g| = %.2e" % (n, worst))
+
+
+def test_config4_hash_to_hash_full_size_step_on_tank_cameras():
+    """configs[4] at its own size: hash -> hash, bound 2 (two cascades), dt_gamma = 1/256, 4096 rays per step, cameras from the
+    tank branch of get_rand_poses (utils.py:136-150: elevations 5..19, radius ~ U(3, 4))."""
+    gpu, cpu = _pair(scene_scale=1.9, teacher_type="hash", model_type="hash", bound=2.0, dt_gamma=1.0 / 256, num_rays=4096, data_type="tank")
+    assert gpu.stu.cascade == 2 and len(gpu.poses) == 87
+    worst, n = _one_full_size_step(gpu, cpu, grad_tol=2e-3)
+    assert n > 20000, n
+    print("configs[4] full size (bound 2, dt_gamma 1/256, 4096 rays, tank cameras): %d samples, worst gradient error / max|g| = %.2e" % (n, worst))

@@ -126,6 +126,11 @@ ROWS = [
     ("gather G=4 pipelined, 512 wg", lambda: gather(12, blocks=512), ALG),
     ("gather G=2 pipelined, 726 wg", lambda: gather(13, blocks=726), ALG),
     ("gather G=7 pipelined 64-smp, 1024 wg", lambda: gather(14, blocks=1024), ALG),
+    ("gather G=14, nontemporal loads", lambda: gather(16), ALG),
+    ("gather G=14, nontemporal levels 7-13", lambda: gather(17), ALG),
+    ("gather G=14, sc1 loads", lambda: gather(18), ALG),
+    ("gather G=14, sc1 levels 7-13", lambda: gather(19), ALG),
+    ("gather G=14, sc1 levels 10-13", lambda: gather(20), ALG),
     ("gather G=7, Morton-sorted samples", lambda: gather(0, x=x_sorted), ALG),
     ("gather G=7, sorted + XCD-contiguous", lambda: gather(0, x=x_sorted, perm=1), ALG),
     ("gather G=7, unsorted + XCD-contiguous", lambda: gather(0, perm=1), ALG),

@@ -9,6 +9,7 @@
 //   row_mask rows & mask: shrink every level's table to a cache-resident piece (the all-hit floor: TA / L1 / L2-hit rate)
 //   TILE     samples per workgroup (product: 128)
 //   PIPE     persistent workgroups, the next (chunk, group) item's loads issued before the current item's are consumed
+//   FLAVOUR  plain / nontemporal / agent-scope (sc1, L1-bypassing) loads, for all levels or the fine ones only
 //   k_sol_stream: a coalesced read of the lookup's ALGORITHMIC byte count (516 B/sample) -- what "fraction of the HBM
 //            roofline" means for a launch of this size.
 // Measurement tool (tools/hash_sol.py); not part of libpvd_hip.so.
@@ -29,7 +30,14 @@ struct SolArgs {
     uint32_t chunk_perm;   // 1: chunk c is processed by workgroup slot (c % 8) * ceil(n / 8) + c / 8 (XCD-contiguous ranges)
 };
 
-template <uint32_t G, uint32_t L0>
+template <int FLAVOUR>
+__device__ __forceinline__ uint32_t load_row(const uint32_t *p) {
+    if (FLAVOUR == 1) return __builtin_nontemporal_load(p);
+    if (FLAVOUR == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <uint32_t G, uint32_t L0, int FLAVOUR = 0, uint32_t FINE_FROM = 0>
 __device__ __forceinline__ void issue(const SolArgs &a, uint32_t g0, uint32_t gend, const float (&x01)[3], bool inside, uint32_t xb,
                                       uint32_t (&v)[G][4]) {
 #pragma unroll
@@ -47,7 +55,8 @@ __device__ __forceinline__ void issue(const SolArgs &a, uint32_t g0, uint32_t ge
         uint32_t row[4];
         level3_rows(lv, 0u, false, cell, xb, row);
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) v[j][k] = table[row[k] & a.row_mask];
+        for (uint32_t k = 0; k < 4; k++)
+            v[j][k] = level >= FINE_FROM ? load_row<FLAVOUR>(table + (row[k] & a.row_mask)) : load_row<0>(table + (row[k] & a.row_mask));
     }
 }
 
@@ -73,7 +82,7 @@ __device__ __forceinline__ uint32_t chunk_of(const SolArgs &a, uint32_t slot, ui
 }
 
 // one workgroup pass = TILE samples x 2 lanes; levels [L0, L1) in groups of G
-template <uint32_t TILE, uint32_t G, uint32_t L0, uint32_t L1, bool PIPE>
+template <uint32_t TILE, uint32_t G, uint32_t L0, uint32_t L1, bool PIPE, int FLAVOUR = 0, uint32_t FINE_FROM = 0>
 __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
     const uint32_t nchunks = (a.M + TILE - 1) / TILE;
@@ -95,7 +104,7 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
 #pragma unroll
             for (uint32_t g = 0; g < NG; g++) {
                 uint32_t v[G][4];
-                issue<G, L0>(a, L0 + g * G, L1, x01, inside, xb, v);
+                issue<G, L0, FLAVOUR, FINE_FROM>(a, L0 + g * G, L1, x01, inside, xb, v);
                 acc = fold<G, 0>(L0 + g * G, L1, v, acc);
             }
             if (b < a.M) a.out[2 * b + xb] = acc;
@@ -119,7 +128,7 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
             }
         };
         load_pos();
-        issue<G, L0>(a, L0, L1, x01, inside, xb, vA);
+        issue<G, L0, FLAVOUR, FINE_FROM>(a, L0, L1, x01, inside, xb, vA);
         uint32_t acc = 0;
         while (slot < nslots) {
             // groups 1 .. NG-1 of this chunk, then group 0 of the next chunk, each issued one item ahead
@@ -135,10 +144,10 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
                 }
                 const uint32_t gn = last ? 0u : g + 1;
                 if (g & 1u) {
-                    issue<G, L0>(a, L0 + gn * G, L1, x01, inside, xb, vA);
+                    issue<G, L0, FLAVOUR, FINE_FROM>(a, L0 + gn * G, L1, x01, inside, xb, vA);
                     acc = fold<G, 4 * G>(L0 + g * G, L1, vB, acc);
                 } else {
-                    issue<G, L0>(a, L0 + gn * G, L1, x01, inside, xb, vB);
+                    issue<G, L0, FLAVOUR, FINE_FROM>(a, L0 + gn * G, L1, x01, inside, xb, vB);
                     acc = fold<G, 4 * G>(L0 + g * G, L1, vA, acc);
                 }
                 if (last) {
@@ -169,11 +178,11 @@ __global__ void k_sol_empty(uint32_t *out) {
     if (out == nullptr) __builtin_trap();
 }
 
-template <uint32_t TILE, uint32_t G, uint32_t L0, uint32_t L1, bool PIPE>
+template <uint32_t TILE, uint32_t G, uint32_t L0, uint32_t L1, bool PIPE, int FLAVOUR = 0, uint32_t FINE_FROM = 0>
 static int launch(const SolArgs &a, uint32_t blocks, hipStream_t s) {
     const uint32_t nchunks = (a.M + TILE - 1) / TILE;
     if (blocks == 0) blocks = a.chunk_perm ? ((nchunks + 7u) / 8u) * 8u : nchunks;
-    hipLaunchKernelGGL((k_sol_gather<TILE, G, L0, L1, PIPE>), dim3(blocks), dim3(2 * TILE), 0, s, a);
+    hipLaunchKernelGGL((k_sol_gather<TILE, G, L0, L1, PIPE, FLAVOUR, FINE_FROM>), dim3(blocks), dim3(2 * TILE), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -201,6 +210,11 @@ extern "C" int sol_gather(int variant, const float *xyz, const void *grid, const
     case 13: return launch<128, 2, 0, 14, true>(a, blocks, s);
     case 14: return launch<64, 7, 0, 14, true>(a, blocks, s);
     case 15: return launch<64, 14, 0, 14, false>(a, blocks, s);
+    case 16: return launch<128, 14, 0, 14, false, 1, 0>(a, blocks, s);   // nontemporal loads, all levels
+    case 17: return launch<128, 14, 0, 14, false, 1, 7>(a, blocks, s);   // nontemporal loads, levels 7..13
+    case 18: return launch<128, 14, 0, 14, false, 2, 0>(a, blocks, s);   // sc1 (L1-bypassing) loads, all levels
+    case 19: return launch<128, 14, 0, 14, false, 2, 7>(a, blocks, s);   // sc1 loads, levels 7..13
+    case 20: return launch<128, 14, 0, 14, false, 2, 10>(a, blocks, s);  // sc1 loads, levels 10..13
     default: return -1;
     }
 }

@@ -37,6 +37,6 @@ for i, r in enumerate(st.tolist()):
     if r[0] <= 0:
         continue
     rows.append([(r[0] - t0) * 10] + [(r[k + 1] - r[k]) * 10 for k in range(6)] + [(r[6] - t0) * 10])
-    print("%4d.%d  %8d   " % (i // 4 * 97, i % 4, (r[0] - t0) * 10) + "  ".join("%7d" % ((r[k + 1] - r[k]) * 10) for k in range(6)))
+    print("%4d.%d  %8d   " % (i // 4 * 97, i % 4, (r[0] - t0) * 10) + "  ".join("%7d" % ((r[k + 1] - r[k]) * 10) for k in range(6)) + "   requested@%d" % ((r[7] - r[0]) * 10))
 a = np.array(rows, dtype=np.float64)
 print("median   %8d   " % np.median(a[:, 0]) + "  ".join("%7d" % v for v in np.median(a[:, 1:7], axis=0)) + "   end (ns after first start): median %d max %d" % (np.median(a[:, 7]), a[:, 7].max()))
