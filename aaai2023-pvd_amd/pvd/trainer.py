@@ -437,11 +437,26 @@ class _TrainerBase:
         if self.dp.enabled:
             c = self._grad_compactor()
             ov = getattr(self, "_overlap_with_exchange", None)
+            # PVD_DP_WIRE=f16 | bf16 (opt-in, NOT the reference's arithmetic): the gradient crosses the links in 16 bits -- half the
+            # bytes of the one exchange that bounds the multi-GPU step.  f16 relies on the loss scale (AMP): an
+            # overflow on the wire is an inf in the gradient, which the scaler's check (it runs after the exchange) answers by
+            # skipping the step and halving the scale, as for any other overflow; bf16 keeps fp32's range at 8 bits of mantissa.
+            wire = {"f16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("PVD_DP_WIRE", "f32"))
             if c is None:
-                self.dp.all_reduce_sum_(self.flat.flat, overlap=ov)  # one bucket, SUM (losses are already global objectives)
+                if wire is None:
+                    self.dp.all_reduce_sum_(self.flat.flat, overlap=ov)  # one bucket, SUM (losses are already global objectives)
+                else:
+                    w16 = self.flat.flat.to(wire)
+                    self.dp.all_reduce_sum_(w16, overlap=ov)
+                    self.flat.flat.copy_(w16)
             else:
                 buf = c.gather(self.flat.flat)
-                self.dp.all_reduce_sum_(buf, overlap=ov)
+                if wire is None:
+                    self.dp.all_reduce_sum_(buf, overlap=ov)
+                else:
+                    w16 = buf.to(wire)
+                    self.dp.all_reduce_sum_(w16, overlap=ov)
+                    buf = w16.to(torch.float32)
                 c.scatter(self.flat.flat, buf)
 
     def _optimize(self):

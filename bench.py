@@ -475,33 +475,67 @@ def main():
     import fusedhead
     roof = None
     try:
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-            rays_o, rays_d, bg, *_ = w.device_batch()
-            out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
-                                   max_steps=opt.max_steps)
-            xyzs, dirs = out_stu["inherited_params"][0], out_stu["inherited_params"][1]
-            for _ in range(3):
-                fusedhead.hash_head_infer(w.tea, xyzs, dirs)
-            torch.cuda.synchronize()
-            per_graph, reps = 20, 5
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    for _ in range(per_graph):
-                        fusedhead.hash_head_infer(w.tea, xyzs, dirs)
-                g.replay()
-                ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev_a.record(side)
-                for _ in range(reps):
-                    g.replay()
-                ev_b.record(side)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+        per_graph, reps = 20, 5
         n_launch = per_graph * reps
-        us_alone = ev_a.elapsed_time(ev_b) / n_launch * 1e3
-        B = int(xyzs.shape[0])
+        side = torch.cuda.Stream()
+
+        def samples_of_pose(idx):
+            """the sample rows the step generates for camera `idx` of the epoch (the in-graph batch generator's pose counter)"""
+            st = getattr(w, "_batch_state", None)
+            if st is not None and idx is not None:
+                st[0] = int(idx) % len(w.poses)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+                rays_o, rays_d, bg, *_ = w.device_batch()
+                out_stu = w.stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False, dt_gamma=opt.dt_gamma,
+                                       max_steps=opt.max_steps)
+            return out_stu["inherited_params"][0], out_stu["inherited_params"][1]
+
+        def time_alone(xyzs, dirs):
+            with torch.no_grad():
+                for _ in range(3):
+                    fusedhead.hash_head_infer(w.tea, xyzs, dirs)
+                torch.cuda.synchronize()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        for _ in range(per_graph):
+                            fusedhead.hash_head_infer(w.tea, xyzs, dirs)
+                    g.replay()
+                    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev_a.record(side)
+                    for _ in range(reps):
+                        g.replay()
+                    ev_b.record(side)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+            return ev_a.elapsed_time(ev_b) / n_launch * 1e3
+
+        # WHICH cameras: the launch's duration depends on the batch's camera (the hash keeps x-neighbours in one cache line, so
+        # rays that run along x coalesce and rays that run along y or z do not: 21.7 us vs 32 us on the same box,
+        # tools/probe_alone_vs_history.py).  `alone` = cameras of the TIMED REGION (what "the kernel's average launch duration
+        # over the timed region" is an average over); `alone_epoch` = cameras spread over the whole epoch of 312.
+        st = getattr(w, "_batch_state", None)
+        pose_now = int(st[0].item()) if st is not None else None
+        saved = st.clone() if st is not None else None
+        P = len(w.poses)
+        if pose_now is not None:
+            span = args.steps + (args.sustained_steps // spc) * spc if args.sustained_steps > 0 else args.steps
+            first = (pose_now - span) % P  # the pose counter advanced once per step since the timed region began (+ prefix prefetch)
+            timed_cams = sorted({(first + (args.steps * i) // 4) % P for i in range(4)})
+            epoch_cams = [(P * i) // 8 for i in range(8)]
+        else:
+            timed_cams, epoch_cams = [None], []
+        per_cam = {}
+        B = None
+        for cam in list(timed_cams) + [c for c in epoch_cams if c not in timed_cams]:
+            xyzs, dirs = samples_of_pose(cam)
+            per_cam[cam] = time_alone(xyzs, dirs)
+            B = int(xyzs.shape[0])
+        if saved is not None:
+            st.copy_(saved)
+        us_alone = float(np.mean([per_cam[c] for c in timed_cams]))
+        us_epoch = float(np.mean([per_cam[c] for c in epoch_cams])) if epoch_cams else None
         fused = bool(getattr(fusedhead, "FUSED_LOOKUP", False)) and opt.fp16
         # ALGORITHMIC bytes per sample: SURVEY.md section 8(d)'s figure for the f16 lookup -- position 12 + 14 levels x 8 corners x 4 B
         # (f16 pair) = 448 gathered + 14 x 2 x 2 = 56 of features = 516 B/sample.  (The fused launch does not write the 56 B of
@@ -509,9 +543,17 @@ def main():
         # 552 B/sample -- kept as `bytes_per_sample_fused` for reference; `achieved` is priced at 516.)
         bps = grid_fwd_bytes_per_sample(3, 2, 14, 2 if opt.fp16 else 4)
         gbs = lambda us_: bps * B / (us_ * 1e-6) / 1e9  # noqa: E731
-        alone = {"us_per_launch": us_alone, "launches": n_launch, "achieved": gbs(us_alone), "frac": gbs(us_alone) / HBM_PEAK_GBS,
-                 "timing": "HIP events on the launch stream around %d back-to-back launches (HIP graphs of %d), nothing else on the chip, right "
-                           "after the timed region" % (n_launch, per_graph)}
+        alone = {"us_per_launch": us_alone, "launches": n_launch * len(timed_cams), "achieved": gbs(us_alone), "frac": gbs(us_alone) / HBM_PEAK_GBS,
+                 "cameras": [c for c in timed_cams], "us_per_camera": [per_cam[c] for c in timed_cams],
+                 "timing": "HIP events on the launch stream around %d back-to-back launches (HIP graphs of %d) per camera, nothing else on the "
+                           "chip, right after the timed region, on the sample rows of %d cameras of the timed region's range" % (n_launch, per_graph, len(timed_cams))}
+        alone_epoch = None
+        if us_epoch is not None:
+            alone_epoch = {"us_per_launch": us_epoch, "achieved": gbs(us_epoch), "frac": gbs(us_epoch) / HBM_PEAK_GBS, "cameras": epoch_cams,
+                           "us_per_camera": [per_cam[c] for c in epoch_cams], "us_min": min(per_cam[c] for c in epoch_cams),
+                           "us_max": max(per_cam[c] for c in epoch_cams),
+                           "why": "same kernel, same launch size; the camera decides how many cache lines a wave's gathers touch (x-neighbours "
+                                  "share a line, y / z neighbours do not): the mean over 8 cameras spread over the epoch of %d" % P}
         # ---- the same kernel WHERE IT RUNS: inside the replayed step it sits on the forked branch of the graph next to the student's
         # table scatter and update and is stretched by sharing the chip.  That duration cannot be taken live: this runtime has no
         # way to stamp an event inside a replayed hipGraph (torch refuses external events on ROCm, plain event-record nodes return
@@ -519,18 +561,22 @@ def main():
         # measured by rocprofv3 over the driver's command and committed (profiles/r03_kernel_populations.txt); the record is
         # QUOTED here, labelled as such, when it was taken on this build of the kernel.
         in_step = None
-        rec_path = os.path.join(REPO, "profiles", "r03_in_step.json")
-        if fused and os.path.exists(rec_path):
+        rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
+        if fused and rec_path:
             rec = json.load(open(rec_path))
             if rec.get("source_sha16") == kernel_source_sha16():
                 us_in, Bi = float(rec["median_us"]), int(rec["samples_per_launch"])
                 in_step = {"us_per_launch": us_in, "mean_us": rec.get("mean_us"), "launches": rec.get("launches"), "samples_per_launch": Bi,
                            "achieved": bps * Bi / (us_in * 1e-6) / 1e9, "frac": bps * Bi / (us_in * 1e-6) / 1e9 / HBM_PEAK_GBS,
                            "timing": "NOT live: rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5` on the builder's lease, launches that "
-                                     "overlap the student's scatter / update (profiles/r03_kernel_populations.txt), same kernel source hash"}
-        head = alone  # the headline figure is the live one
+                                     "overlap the student's backward / scatter (profiles/%s), same kernel source hash"
+                                     % os.path.basename(rec_path).replace("in_step.json", "kernel_populations.txt")}
+        # headline: the in-step figure when a rocprofv3 record of THIS build of the kernel exists (the figure where the
+        # kernel actually runs), else the live alone figure; both are always in the object
+        head = in_step if in_step is not None else alone
         traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
-        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(q)), None)
+        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
+                         if os.path.exists(q)), None)
         if pmc_path:  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
             pmc = json.load(open(pmc_path))
             if pmc.get("source_sha16") == kernel_source_sha16() and fused:
@@ -543,12 +589,14 @@ def main():
         roof = {"kernel": ("k_hash_fwd_fused (pvd_hash_head_forward_fused: hash-grid lookup f16 3x2x14 + sigma/colour head, one launch)" if fused
                            else "pvd_grid_encode_forward_affine + pvd_head_forward (two launches)"),
                 "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                "where": "alone on the chip (live HIP events); inside the replayed step: see in_step",
+                "where": ("inside the replayed step, next to the student's backward (quoted rocprofv3 record of this build, see in_step); alone on "
+                          "the chip, live: see alone / alone_epoch" if in_step is not None else
+                          "alone on the chip (live HIP events, cameras of the timed region); no rocprofv3 record of this build for the in-step figure"),
                 "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * Bh, "bytes_per_sample": bps,
                 "bytes_per_sample_fused": 552 if fused else None,
-                "samples_per_launch": Bh, "us_per_launch": head["us_per_launch"], "launches": head["launches"],
-                "alone": alone, "in_step": in_step,
-                "rederive": "python tools/roofline_from_profile.py  (profiles/r03_kernel_populations.txt + r03_bench_profiled_line.json + r03_kernel_stats.csv)"}
+                "samples_per_launch": Bh, "us_per_launch": head["us_per_launch"], "launches": head.get("launches"),
+                "alone": alone, "alone_epoch": alone_epoch, "in_step": in_step,
+                "rederive": "python tools/roofline_from_profile.py  (profiles/r04_kernel_populations.txt + r04_bench_profiled_line.json + r04_kernel_stats.csv)"}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 

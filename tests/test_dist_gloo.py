@@ -231,3 +231,19 @@ def test_ray_dp_with_the_teacher_marching_first(tmp_path):
     scale = flat.abs().max().item()
     assert scale > 0
     assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("wire", ["f16", "bf16"])
+def test_ray_dp_sixteen_bit_wire_is_an_opt_in_approximation(tmp_path, wire, monkeypatch):
+    """PVD_DP_WIRE=f16 | bf16: the (compact) gradient crosses the links in 16 bits.  Replicas still end bit-identical (every rank
+    receives the same sum) and the gradient is the fp32 exchange's to the wire format's rounding; off by default."""
+    _setup_paths()
+    out32, out16 = str(tmp_path / "w32.pt"), str(tmp_path / "w16.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out32, OPT_COMPACT, True), nprocs=2, join=True)
+    monkeypatch.setenv("PVD_DP_WIRE", wire)
+    mp.spawn(_worker, args=(2, _free_port(), out16, OPT_COMPACT, True), nprocs=2, join=True)  # (asserts identical replicas itself)
+    a, b = torch.load(out32)["flat"], torch.load(out16)["flat"]
+    scale = a.abs().max().item()
+    err = (a - b).abs().max().item() / scale
+    assert 0 < err <= (2e-3 if wire == "f16" else 1.6e-2), err  # f16: 11 bits, bf16: 8 bits of significand, two roundings
