@@ -28,6 +28,7 @@
 // forms the weight gradients dW = dY . X^T with MFMAs whose operands are 16x16 transposes of the
 // register tiles (through a 512-byte LDS scratch per wave); dW tiles live in accumulators for the whole
 // launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
+#include "dda.h"
 #include "grid_lookup.h"
 #include "head_dw_reduce.h"
 
@@ -513,6 +514,70 @@ struct FusedRes {
     uint32_t res[14];  // (uint32_t)ceil((double)scale) + 1, on the host (what the kernels compute per level on the device)
 };
 
+// The 14-level lookup of ONE sample by its lane pair (x01 in [0, 1], `xb` = which x corner this lane fetches): gathers issued coarse
+// to fine in groups of G levels, each level blended in the reference's corner order as soon as its own four loads have retired, the two
+// features of a level written to `feat_row[2 level]` by the even lane.  Shared by k_hash_fwd_fused and k_infer_hash_persistent.
+template <uint32_t G>
+__device__ __forceinline__ void fused_lookup_sample(const FusedLookup &g, const FusedRes &gr, const uint32_t (&off)[15], const float (&x01)[3],
+                                                bool inside, uint32_t xb, half_t *__restrict__ feat_row) {
+    constexpr uint32_t D = 3, L = 14;
+    const float half_or_0 = g.align_corners ? 0.0f : 0.5f;
+#pragma unroll
+    for (uint32_t l0 = 0; l0 < L; l0 += G) {
+        uint32_t v[G][4];
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const uint32_t level = l0 + j;
+            if (level >= L) break;
+            const float scale = g.scales.scale[level];
+            Level3 lv;
+            lv.init(off[level + 1] - off[level], gr.res[level], g.gridtype, g.align_corners);
+            const uint32_t *__restrict__ table = g.grid + off[level];
+            uint32_t cell[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) cell[d] = inside ? (uint32_t)floorf(fmaf(x01[d], scale, half_or_0)) : 0u;
+            uint32_t row[4];
+            level3_rows(lv, g.gridtype, g.align_corners, cell, xb, row);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[j][k] = table[row[k]];
+            // G = 14: the levels are ISSUED coarse to fine and CONSUMED in the same order while the finer ones are still in
+            // flight (vmcnt retires in order: level j is blended behind s_waitcnt vmcnt(4 (13 - j))), so the blend arithmetic
+            // of the early levels runs under the fine levels' memory time.  The fences keep the scheduler from hoisting all
+            // 56 address computations to the top (201 VGPRs) and from interleaving the blends (one vmcnt(0) for all).
+            if (G == 14) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            const uint32_t level = l0 + j;
+            if (level >= L) break;
+            const float scale = g.scales.scale[level];
+            float fr[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                float xd = x01[d];
+                asm volatile("" : "+v"(xd));  // recompute, do not keep: the same expression as above would be CSE'd into 3 live registers per level
+                const float p = fmaf(xd, scale, half_or_0);
+                fr[d] = p - (float)(uint32_t)floorf(p);
+            }
+            uint32_t acc = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t yb = k & 1u, zb = k >> 1;
+                float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
+                wi *= xb ? fr[0] : 1 - fr[0];
+                wi *= yb ? fr[1] : 1 - fr[1];
+                wi *= zb ? fr[2] : 1 - fr[2];
+                const uint32_t pr = weighted_pair(wi, v[j][k]);
+                const uint32_t other = dpp_quad<0xB1>(pr);
+                acc = pk_add(acc, xb ? other : pr);
+                acc = pk_add(acc, xb ? pr : other);
+            }
+            if (xb == 0) *reinterpret_cast<uint32_t *>(feat_row + 2 * level) = inside ? acc : 0u;
+            if (G == 14) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <uint32_t G, int DMA>
 __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, FusedLookup g, FusedRes gr) {
     extern __shared__ __align__(16) half_t lds[];
@@ -546,7 +611,6 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
         *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
     const uint32_t nchunks = div_up(a.M, kFusedTile);
-    const float half_or_0 = g.align_corners ? 0.0f : 0.5f;
     constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
     uint32_t off[L + 1];
 #pragma unroll
@@ -581,61 +645,8 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
         PVD_FSTAMP(7);  // (everything the workgroup needs before its first gather has been requested)
         if (DMA == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // positions, directions, offsets AND the weight DMA: nothing in flight from here
         PVD_FSTAMP(1);
-#pragma unroll
-        for (uint32_t l0 = 0; l0 < L; l0 += G) {
-            uint32_t v[G][4];
-#pragma unroll
-            for (uint32_t j = 0; j < G; j++) {
-                const uint32_t level = l0 + j;
-                if (level >= L) break;
-                const float scale = g.scales.scale[level];
-                Level3 lv;
-                lv.init(off[level + 1] - off[level], gr.res[level], g.gridtype, g.align_corners);
-                const uint32_t *__restrict__ table = g.grid + off[level];
-                uint32_t cell[D];
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) cell[d] = inside ? (uint32_t)floorf(fmaf(x01[d], scale, half_or_0)) : 0u;
-                uint32_t row[4];
-                level3_rows(lv, g.gridtype, g.align_corners, cell, xb, row);
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) v[j][k] = table[row[k]];
-                // G = 14: the levels are ISSUED coarse to fine and CONSUMED in the same order while the finer ones are still in
-                // flight (vmcnt retires in order: level j is blended behind s_waitcnt vmcnt(4 (13 - j))), so the blend arithmetic
-                // of the early levels runs under the fine levels' memory time.  The fences keep the scheduler from hoisting all
-                // 56 address computations to the top (201 VGPRs) and from interleaving the blends (one vmcnt(0) for all).
-                if (G == 14) __builtin_amdgcn_sched_barrier(0);
-            }
-            if (l0 == 0) PVD_FSTAMP(2);
-#pragma unroll
-            for (uint32_t j = 0; j < G; j++) {
-                const uint32_t level = l0 + j;
-                if (level >= L) break;
-                const float scale = g.scales.scale[level];
-                float fr[D];
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) {
-                    float xd = x01[d];
-                    asm volatile("" : "+v"(xd));  // recompute, do not keep: the same expression as above would be CSE'd into 3 live registers per level
-                    const float p = fmaf(xd, scale, half_or_0);
-                    fr[d] = p - (float)(uint32_t)floorf(p);
-                }
-                uint32_t acc = 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t yb = k & 1u, zb = k >> 1;
-                    float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
-                    wi *= xb ? fr[0] : 1 - fr[0];
-                    wi *= yb ? fr[1] : 1 - fr[1];
-                    wi *= zb ? fr[2] : 1 - fr[2];
-                    const uint32_t pr = weighted_pair(wi, v[j][k]);
-                    const uint32_t other = dpp_quad<0xB1>(pr);
-                    acc = pk_add(acc, xb ? other : pr);
-                    acc = pk_add(acc, xb ? pr : other);
-                }
-                if (xb == 0) *reinterpret_cast<uint32_t *>(feat + s_local * kFeatStride + 2 * level) = inside ? acc : 0u;
-                if (G == 14) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        fused_lookup_sample<G>(g, gr, off, x01, inside, xb, feat + s_local * kFeatStride);
+        PVD_FSTAMP(2);
         if (DMA == 1 && a.image && chunk == blockIdx.x) copy_image_dma_static<HeadLds<KIND_HASH>::halfs>(lds, a.image, threadIdx.x);
         PVD_FSTAMP(3);
         __syncthreads();  // (also covers the weights / zero columns on the first pass)
@@ -673,6 +684,296 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
         }
 #endif
     }
+}
+
+// ====================================================================== inference of a frozen hash model: ONE launch per image
+//
+// Replaces the round loop of run_cuda's eval branch (distill_mutual/renderer.py:450-543: march_rays -> model -> composite_rays ->
+// compact_rays, ~54 rounds x 6 launches for an 800 x 800 view, every round looking up n_alive * n_step rows of which the rays that
+// ended inside the round leave zero-filled ones) by two launches -- SURVEY section 8 f2:
+//   k_infer_first_hit       thread per ray: the marcher's walk from `near` up to the ray's FIRST occupied probe (the empty space in
+//                           front of the object: a chain of dependent bitfield loads per ray, cheap only when every ray of the image
+//                           runs it at once); rays that never meet an occupied cell are not queued at all;
+//   k_infer_hash_persistent a workgroup owns kInfRays ray SLOTS, one per thread; the ray's march position and its accumulators live
+//                           in the thread's registers.  A local round:
+//       refill   free slots take the next rays of the image from a device-side queue (one atomic per workgroup);
+//       march    every live slot walks on (k_march_rays' loop, the same Dda::probe) until it holds n_step = max(min(kInfRows / live,
+//                8), 1) samples -- the reference's rule (renderer.py:493) with the workgroup's own numbers -- or has spent its probes;
+//       shade    the samples go into an LDS tile, densely packed; 14-level lookup + sigma / colour head on the tile's rows, results
+//                left in LDS (fused_lookup_sample + head_forward_tile: the arithmetic of pvd_hash_head_forward_fused);
+//       blend    every slot composites its samples in order (k_composite_rays' loop body) and retires when the ray ended or saturated.
+// A ray's samples and its sums depend on nothing but the ray: the walk is the reference's walk paused and resumed (the running t is
+// carried, never recomputed), the sums are the reference's sums in the reference's order -- the image is the round loop's, bit for
+// bit (tests/test_hip_infer_rounds.py).  One thing the reference's loop does that this does not: it restarts a ray's march every
+// round from the t its compositing reconstructed by adding up `t - last_t`; those differences are exact for consecutive samples, so
+// the two t agree.  The reference stops ALL rays once the rounds' steps add up to max_steps; here a ray stops after max_steps samples.
+struct InferImageArgs {
+    const float *rays_o, *rays_d;  // [N][3]
+    const float *nears, *fars;     // [N]
+    const int32_t *ray_ids;        // [*n_ids] rays that meet an occupied cell, any order
+    const float *t_first;          // [N] the marcher's t at the ray's first occupied probe
+    const int32_t *n_ids;          // device count
+    int32_t *queue;                // device counter, zero at launch
+    uint32_t shuffle;              // multiplier of the queue -> ray permutation (host: PVD_INFER_SHUFFLE, default 7919; 1 = image order)
+    int32_t *stats;                // [4] zero at launch: local rounds, rows shaded, walk-only rounds, workgroups that took rays
+    const uint8_t *grid;           // density bitfield
+    float bound, dt_gamma, sigma_scale;
+    uint32_t max_steps, C, H;
+    float *weights_sum, *depth, *image;  // [N], [N], [N][3]: written for the rays in ray_ids (zero-filled by the caller)
+};
+
+constexpr uint32_t kInfRows = 256;         // sample rows per local round (LDS tile)
+constexpr uint32_t kInfSteps = 8;          // samples a slot may hold per round (the reference's cap on n_step, renderer.py:493)
+constexpr uint32_t kInfProbes = 6;         // probes per slot and round beyond the samples it is looking for
+
+// The walk in front of the object: from t = near to the first occupied probe (raymarching.cu:756-810 with nothing emitted).
+__global__ void __launch_bounds__(kHeadBlock) k_infer_first_hit(InferImageArgs q, uint32_t N, float *__restrict__ t_first,
+                                                                int32_t *__restrict__ ray_ids, int32_t *__restrict__ n_ids) {
+    __shared__ uint32_t wave_cnt[kHeadBlock / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * kHeadBlock; base < N; base += gridDim.x * kHeadBlock) {  // uniform per workgroup
+        const uint32_t n = base + threadIdx.x;
+        bool keep = false;
+        if (n < N) {
+            const float near = q.nears[n], far = q.fars[n];
+            if (near < far) {
+                Dda r;
+                r.init(q.rays_o + 3 * (size_t)n, q.rays_d + 3 * (size_t)n, q.bound, q.dt_gamma, q.max_steps, q.C, q.H, q.grid);
+                float t = near;
+                while (t < far) {
+                    float x, y, z, dt, tn;
+                    if (r.probe(t, x, y, z, dt, tn)) { keep = true; break; }
+                    t = tn;
+                }
+                t_first[n] = t;
+            }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) wave_cnt[wid] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kHeadBlock / 64; w++) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            block_base = tot ? (uint32_t)atomicAdd(n_ids, (int32_t)tot) : 0u;
+        }
+        __syncthreads();
+        if (keep) ray_ids[block_base + wave_cnt[wid] + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)n;
+        __syncthreads();
+    }
+}
+
+// RAYS = ray slots per workgroup (threads 0 .. RAYS - 1 own one each; all 256 threads shade).  Fewer slots per workgroup = more
+// workgroups per image = more waves per SIMD to hide the shading's latencies, and a queue that outlasts the first fill.
+template <uint32_t RAYS>
+__global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a, FusedLookup g, FusedRes gr, InferImageArgs q) {
+    extern __shared__ __align__(16) half_t lds[];
+    constexpr uint32_t D = 3, L = 14;
+    HeadLds<KIND_HASH> W;
+    W.carve(lds);
+    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);                         // [kInfRows][kFeatStride]
+    float *pos = reinterpret_cast<float *>(feat + kInfRows * kFeatStride);                 // [kInfRows][3]
+    float *sig = pos + 3 * kInfRows;                                                       // [kInfRows]
+    float *rgb = sig + kInfRows;                                                           // [kInfRows][3]
+    float *sdir = rgb + 3 * kInfRows;                                                      // [kHeadBlock][3]: direction of the ray in slot s
+    uint32_t *row_slot = reinterpret_cast<uint32_t *>(sdir + 3 * kHeadBlock);              // [kInfRows]
+    uint32_t *wcnt = row_slot + kInfRows;                                                  // [8] scan scratch + queue hand-off
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
+    const int32_t offs_v = lane <= L ? g.offsets[lane] : 0;
+    if (a.image) copy_image(lds, a.image, HeadLds<KIND_HASH>::halfs, tid, kHeadBlock);
+    else W.load(a, tid, kHeadBlock);
+    for (uint32_t i = tid; i < kInfRows * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
+        *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
+    uint32_t off[L + 1];
+#pragma unroll
+    for (uint32_t l = 0; l <= L; l++) off[l] = (uint32_t)__builtin_amdgcn_readlane(offs_v, (int)l);
+    const uint32_t n_ids = (uint32_t)max(*q.n_ids, 0);
+    const uint32_t xb = tid & 1u, s_local = tid >> 1;
+    // queue position -> ray: position * mul mod n_ids is a permutation only for a multiplier coprime to n_ids
+    uint32_t mul = q.shuffle % max(n_ids, 1u);
+    for (;; mul++) {
+        uint32_t x = max(mul, 1u), y = max(n_ids, 1u);
+        while (y) { const uint32_t r = x % y; x = y; y = r; }
+        if (x == 1u || n_ids <= 1u) break;
+    }
+    mul = max(mul, 1u);
+
+    // the slot's ray: t = what compositing has reached (the reference's rays_t / last_t), tt = where the walk stands, and the `cnt`
+    // samples the walk has found since the last blend (position, dt, the walk's t behind the sample)
+    int32_t index = -1;
+    uint32_t taken = 0, cnt = 0;
+    float t = 0.f, tt = 0.f, far = 0.f, ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    float sx[kInfSteps], sy[kInfSteps], sz[kInfSteps], sdt[kInfSteps], stt[kInfSteps];
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 1.f};
+    bool queue_done = n_ids == 0;
+
+    // exclusive prefix of `v` over the workgroup's threads and the total (two barriers)
+    auto scan_of = [&](uint32_t v, uint32_t &total) -> uint32_t {
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+            if ((int)lane >= d) inc += up;
+        }
+        if (lane == 63) wcnt[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kHeadBlock / 64; w++) { const uint32_t c = wcnt[w]; before += w < wave ? c : 0u; tot += c; }
+        __syncthreads();
+        total = tot;
+        return before + inc - v;
+    };
+    auto retire = [&]() {  // the ray is done: its pixel leaves the slot
+        q.weights_sum[index] = ws;
+        q.depth[index] = dep;
+        q.image[3 * (size_t)index] = cr; q.image[3 * (size_t)index + 1] = cg; q.image[3 * (size_t)index + 2] = cb;
+        index = -1; cnt = 0;
+    };
+
+    uint32_t n_rounds = 0, n_rows = 0, n_walk = 0;
+#ifdef PVD_INFER_PROFILE  // phase times of workgroup 0 (100 MHz ticks): refill+scan, march, lookup, head, blend
+    long long ph[5] = {0, 0, 0, 0, 0}, tm = (long long)__builtin_amdgcn_s_memrealtime();
+#define PVD_ISTAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); ph[k] += now_ - tm; tm = now_; } while (0)
+#else
+#define PVD_ISTAMP(k) do { } while (0)
+#endif
+    __syncthreads();  // weights, zero columns
+    for (;;) {
+        // ---------------- refill: free slots take the next rays (when enough of them are free to be worth the round trip)
+        uint32_t nfree;
+        const uint32_t frank = scan_of(tid < RAYS && index < 0 ? 1u : 0u, nfree);
+        if (!queue_done && (nfree >= RAYS / 8 || nfree == RAYS)) {
+            if (tid == 0) wcnt[4] = (uint32_t)atomicAdd(q.queue, (int32_t)nfree);
+            __syncthreads();
+            const uint32_t base = wcnt[4];
+            __syncthreads();
+            if (base + nfree >= n_ids) queue_done = true;  // (uniform) the queue has been handed out completely
+            if (tid < RAYS && index < 0 && base + frank < n_ids) {
+                // queue position -> ray: a multiplicative shuffle of the (image-ordered) list, so that a workgroup's 256 rays come
+                // from all over the image -- neighbouring pixels have similar path lengths, and a workgroup of long rays would
+                // be the launch's tail (the queue is empty after the first fill whenever the image has fewer rays than slots)
+                const int32_t id = q.ray_ids[(uint32_t)(((uint64_t)(base + frank) * mul) % n_ids)];
+                index = id; taken = 0; cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { ro[c] = q.rays_o[3 * (size_t)id + c]; rd[c] = q.rays_d[3 * (size_t)id + c]; sdir[3 * tid + c] = rd[c]; }
+                t = q.nears[id]; far = q.fars[id]; tt = q.t_first[id];
+                ws = dep = cr = cg = cb = 0.f;
+            }
+        }
+        const uint32_t nlive = nfree < RAYS ? RAYS - nfree : 0u;  // (slots filled just now included below)
+        uint32_t live_now;
+        (void)scan_of(index >= 0 ? 1u : 0u, live_now);
+        if (live_now == 0) {
+            if (queue_done) break;
+            continue;
+        }
+        (void)nlive;
+        PVD_ISTAMP(0);
+        // samples per slot this round: the reference's rule (renderer.py:493) with the workgroup's own numbers
+        const uint32_t n_step = max(min(kInfRows / live_now, kInfSteps), 1u);
+        // ---------------- march: walk on (k_march_rays' loop, raymarching.cu:756-810, perturb = 0)
+        if (index >= 0) {
+            Dda r;
+            r.init(ro, rd, q.bound, q.dt_gamma, q.max_steps, q.C, q.H, q.grid);
+            for (uint32_t pb = 0; pb < n_step + kInfProbes && cnt < n_step && tt < far; pb++) {
+                float x, y, z, dt, tn;
+                if (r.probe(tt, x, y, z, dt, tn)) {
+                    tt += dt;
+#pragma unroll
+                    for (uint32_t k = 0; k < kInfSteps; k++)  // (static register indices)
+                        if (k == cnt) { sx[k] = x; sy[k] = y; sz[k] = z; sdt[k] = dt; stt[k] = tt; }
+                    cnt++;
+                } else {
+                    tt = tn;
+                }
+            }
+            if (cnt == 0 && !(tt < far)) retire();  // the walk left the box: no further sample (the round loop's dt == 0 row)
+        }
+        PVD_ISTAMP(1);
+        uint32_t rows;
+        const uint32_t row0 = scan_of(cnt, rows);
+        n_rounds++; n_rows += rows;
+        if (rows == 0) { n_walk++; continue; }  // walkers only
+#pragma unroll
+        for (uint32_t k = 0; k < kInfSteps; k++)
+            if (k < cnt) {
+                pos[3 * (row0 + k)] = sx[k]; pos[3 * (row0 + k) + 1] = sy[k]; pos[3 * (row0 + k) + 2] = sz[k];
+                row_slot[row0 + k] = tid;
+            }
+        __syncthreads();
+        // ---------------- shade: lookup (two lanes per row, 128 rows per pass) ...
+        for (uint32_t p0 = 0; p0 < rows; p0 += kFusedTile) {  // uniform
+            const uint32_t rw = p0 + s_local;
+            bool inside = rw < rows;
+            float x01[D] = {0.f, 0.f, 0.f};
+            if (inside) {
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    x01[d] = pos[3 * rw + d];
+                    if (g.aff.on) x01[d] = (x01[d] + g.aff.add) / g.aff.div;
+                    inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
+                }
+            }
+            fused_lookup_sample<7>(g, gr, off, x01, inside, xb, feat + min(rw, kInfRows - 1u) * kFeatStride);
+        }
+        __syncthreads();
+        PVD_ISTAMP(2);
+        // ... and the head, 16 rows per wave and pass; sigma / rgb stay in LDS.  (Two tiles per pass as two independent MFMA chains, and
+        // all 14 levels of the lookup in flight: 210 VGPRs = two workgroups per CU instead of three, and no faster per round.)
+        for (uint32_t t16 = wave; t16 * 16 < rows; t16 += kHeadBlock / 64) {
+            const uint32_t rw = min(t16 * 16 + (lane & 15), kInfRows - 1u);
+            TileIn<KIND_HASH> in;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + rw * kFeatStride + 16 * s2 + 4 * hi);
+            in.sraw = 0.f;
+            const uint32_t slot = rw < rows ? row_slot[rw] : 0u;
+            in.dx = sdir[3 * slot]; in.dy = sdir[3 * slot + 1]; in.dz = sdir[3 * slot + 2];
+            TileFwd tf;
+            head_forward_tile<KIND_HASH>(a, W, in, lane, tf);
+            if (hi == 0 && t16 * 16 + (lane & 15) < rows) {
+                sig[rw] = __expf(tf.F.x);
+                rgb[3 * rw] = sigmoid_h(tf.out.x); rgb[3 * rw + 1] = sigmoid_h(tf.out.y); rgb[3 * rw + 2] = sigmoid_h(tf.out.z);
+            }
+        }
+        __syncthreads();
+        PVD_ISTAMP(3);
+        // ---------------- blend (k_composite_rays' loop, raymarching.cu:858-899; sigma scaled as renderer.py:528)
+        if (cnt > 0) {
+            bool done = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kInfSteps; k++) {
+                if (k < cnt && !done) {
+                    const uint32_t rw = row0 + k;
+                    const float alpha = 1.0f - __expf(-(q.sigma_scale * sig[rw]) * sdt[k]);
+                    const float T = 1 - ws;
+                    const float w = alpha * T;
+                    ws += w;
+                    t += stt[k] - t;  // deltas[1] = (walk's t behind the sample) - last_t, added to the ray's t (raymarching.cu:795, 877)
+                    dep += w * t;
+                    cr += w * rgb[3 * rw]; cg += w * rgb[3 * rw + 1]; cb += w * rgb[3 * rw + 2];
+                    taken++;
+                    if ((double)T < 1e-4 || taken >= q.max_steps) done = true;
+                }
+            }
+            cnt = 0;
+            if (done) retire();
+        }
+        __syncthreads();  // the next round rewrites the tile
+        PVD_ISTAMP(4);
+    }
+#ifdef PVD_INFER_PROFILE
+    if (tid == 0 && blockIdx.x == 0) for (int z = 0; z < 5; z++) q.stats[4 + z] = (int32_t)ph[z];
+#endif
+    if (tid == 0 && n_rounds > 1) {
+        atomicAdd(q.stats + 0, (int32_t)n_rounds); atomicAdd(q.stats + 1, (int32_t)n_rows); atomicAdd(q.stats + 2, (int32_t)n_walk); atomicAdd(q.stats + 3, 1);
+    }
+}
+
+static size_t infer_persistent_lds_bytes() {
+    return (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + (size_t)kInfRows * kFeatStride * sizeof(half_t) +
+           sizeof(float) * (3 * kInfRows + kInfRows + 3 * kInfRows + 3 * kHeadBlock) + sizeof(uint32_t) * (kInfRows + 8);
 }
 
 __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused_r3(HeadArgs a, FusedLookup g) {
@@ -1495,6 +1796,55 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
     g.xyz = xyz; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
     g.scales = make_scales(14, S, H); g.gridtype = gridtype; g.align_corners = align_corners != 0;
     return launch_hash_fwd_fused(a, g, (hipStream_t)stream);
+}
+
+int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N, const uint8_t *bitfield,
+                         float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, float sigma_scale, float in_add, float in_div,
+                         const void *embeddings_f16, const int32_t *offsets, float S, uint32_t H0, uint32_t gridtype, int align_corners,
+                         const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
+                         float clip_sigma_min, float clip_max, int32_t *workspace, float *weights_sum, float *depth, float *image_out,
+                         pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !bitfield || !embeddings_f16 || !offsets || !Wa1 || !Wa2 || !Wc1 || !Wc2 || !Wc3 || !workspace ||
+        !weights_sum || !depth || !image_out)
+        return PVD_ERR_INVALID;
+    if (!(in_div != 0.f) || max_steps == 0 || C == 0 || H == 0) return PVD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // workspace: [0] number of rays that meet an occupied cell, [1] the queue's head, [2 .. 2 + N) their ids, [2 + N .. 2 + 2 N) t_first (float),
+    // [2 + 2 N .. 6 + 2 N) statistics of the launch
+    if (hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    if (hipMemsetAsync(workspace + 2 + 2 * (size_t)N, 0, 10 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    uint32_t hb = div_up(N, kHeadBlock);
+    if (hb > 4096) hb = 4096;
+    HeadArgs a;
+    a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = nullptr; a.M = 0;
+    a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_sigma_min; a.clip_max = clip_max;
+    a.sigma = nullptr; a.rgb = nullptr; a.feat16 = nullptr; a.image = (const half_t *)image; a.rows_dev = nullptr;
+    FusedLookup g;
+    g.xyz = nullptr; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
+    g.scales = make_scales(14, S, H0); g.gridtype = gridtype; g.align_corners = align_corners != 0;
+    FusedRes gr;
+    for (uint32_t l = 0; l < 14; l++) gr.res[l] = (uint32_t)ceil((double)g.scales.scale[l]) + 1u;
+    InferImageArgs q;
+    q.rays_o = rays_o; q.rays_d = rays_d; q.nears = nears; q.fars = fars; q.ray_ids = workspace + 2; q.n_ids = workspace; q.queue = workspace + 1;
+    q.grid = bitfield; q.bound = bound; q.dt_gamma = dt_gamma; q.sigma_scale = sigma_scale; q.max_steps = max_steps; q.C = C; q.H = H;
+    q.weights_sum = weights_sum; q.depth = depth; q.image = image_out;
+    q.t_first = reinterpret_cast<const float *>(workspace + 2 + N);
+    q.stats = workspace + 2 + 2 * (size_t)N;
+    q.shuffle = 7919u;
+    if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
+    hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
+    const size_t lds_bytes = infer_persistent_lds_bytes();
+    // ray slots per workgroup (PVD_INFER_RAYS = 64 | 128 | 256, measurement): three workgroups of 50 KB of LDS fit a CU
+    int rays = 64;
+    if (const char *e = getenv("PVD_INFER_RAYS")) { rays = atoi(e); if (rays != 128 && rays != 256) rays = 64; }
+    uint32_t blocks = div_up(N, (uint32_t)rays);
+    if (blocks > 768u) blocks = 768u;  // persistent
+    if (rays == 128) hipLaunchKernelGGL((k_infer_hash_persistent<128>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    else if (rays == 256) hipLaunchKernelGGL((k_infer_hash_persistent<256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    else hipLaunchKernelGGL((k_infer_hash_persistent<64>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    return check_launch();
 }
 
 int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstream_f16, uint32_t n_before, uint32_t n_after, const float *dirs,

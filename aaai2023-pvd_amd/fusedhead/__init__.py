@@ -78,6 +78,36 @@ def hash_head_infer(model, x, d, rows_dev=None):
     return sigma, rgb, feat
 
 
+@torch.no_grad()
+def hash_infer_image(model, rays_o, rays_d, nears, fars, dt_gamma, max_steps):
+    """(weights_sum, depth, image) of the eval branch's round loop (renderer.py:450-543) for a frozen hash model, as ONE persistent
+    launch (pvd_infer_image_hash): rays [N,3], nears / fars [N]; the accumulators as the loop leaves them (before background compositing)."""
+    enc = model.encoder
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    emb = enc.embeddings
+    cache = getattr(model, "_emb_half_cache", None)
+    key = _cache_key([emb])
+    if cache is None or cache[0] != key:
+        cache = (key, None, emb.detach().to(torch.float16))
+        model._emb_half_cache = cache
+    assert enc.offsets.shape[0] - 1 == 14 and emb.shape[1] == 2 and enc.input_dim == 3, "fused head expects the 14-level, 2-feature hash grid"
+    a = model.args
+    ws = [_w(model.sigma_net[0]), _w(model.sigma_net[1]), _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight]
+    image = _cached_image(model, KIND_HASH, ws, ps)
+    f32 = dict(dtype=torch.float32, device=dev)
+    weights_sum, depth, img = torch.zeros(N, **f32), torch.zeros(N, **f32), torch.zeros(N, 3, **f32)
+    workspace = torch.empty(2 * N + 12, dtype=torch.int32, device=dev)
+    model._last_infer_workspace = workspace  # [0] rays queued, [2 N + 2 .. 2 N + 6): local rounds / rows shaded / walk-only rounds / workgroups (tools/bench_render.py)
+    pvd_hip.infer_image_hash(rays_o.float().contiguous(), rays_d.float().contiguous(), nears.float().contiguous(), fars.float().contiguous(),
+                             model.density_bitfield, float(model.bound), float(dt_gamma), int(max_steps), int(model.cascade), int(model.grid_size),
+                             float(model.density_scale), float(model.bound), float(2 * model.bound), cache[2], enc.offsets,
+                             float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners, *ws,
+                             a.sigma_clip_min, a.sigma_clip_max, workspace, weights_sum, depth, img, image=image)
+    return weights_sum, depth, img
+
+
 def mlp_supported(model):
     """The layer structure pvd_mlp_head_forward_fused implements: 63 -> 256, hidden 256s with one skip concatenation, -> 28."""
     mlp = getattr(model, "nerf_mlp", None)

@@ -258,6 +258,12 @@ class NeRFRenderer(nn.Module):
                     "nears_fars": (nears, fars)}
 
         # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
+        if self._persistent_render(rays_o, perturb):
+            # a frozen hash model: the whole loop as ONE persistent launch (pvd_infer_image_hash; PVD_INFER_PERSISTENT=0: the rounds)
+            weights_sum, depth, image = self.ops.fused_head.hash_infer_image(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
         if self._rounds_on_device(rays_o, perturb):
             return self._run_rounds_device(rays_o, rays_d, nears, fars, bg_color, dt_gamma, max_steps, prefix, inherited_params)
         dtype = torch.float32
@@ -291,6 +297,12 @@ class NeRFRenderer(nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
+
+    def _persistent_render(self, rays_o, perturb):
+        import os
+        fh = getattr(getattr(self, "ops", None), "fused_head", None)
+        return (self._rounds_on_device(rays_o, perturb) and getattr(self, "model_type", None) == "hash" and hasattr(fh, "hash_infer_image")
+                and os.environ.get("PVD_INFER_PERSISTENT", "1") != "0")
 
     # ------------------------------------------------------------------ inference rounds, state on the device
     def _rounds_on_device(self, rays_o, perturb):

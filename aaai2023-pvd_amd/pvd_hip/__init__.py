@@ -81,7 +81,7 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
-    "pvd_head_forward", "pvd_hash_head_forward_fused",
+    "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_composite_objective_blocks", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
@@ -656,6 +656,28 @@ def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, grid
                      _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
                      _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev), meta=(M, 3, 2, 14, PVD_F16))
     _check(status, "pvd_hash_head_forward_fused")
+
+
+def infer_image_hash(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, in_add, in_div, embeddings, offsets,
+                     S, H0, gridtype, align_corners, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_max, workspace, weights_sum, depth, image_out,
+                     image=None):
+    """pvd_infer_image_hash: the eval branch's round loop of a frozen hash model as one persistent launch; see include/pvd_hip.h."""
+    dev = _dev(rays_o, rays_d, nears, fars, bitfield, embeddings, offsets, Wa1, Wa2, Wc1, Wc2, Wc3, workspace, weights_sum, depth, image_out, image)
+    _want(embeddings, torch.float16, "embeddings"), _want(offsets, torch.int32, "offsets"), _want(workspace, torch.int32, "workspace")
+    _want(bitfield, torch.uint8, "bitfield")
+    _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, Wa1=Wa1, Wa2=Wa2, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, weights_sum=weights_sum,
+             depth=depth, image_out=image_out)
+    N = rays_o.shape[0]
+    if offsets.numel() != 15 or embeddings.dim() != 2 or embeddings.shape[1] != 2:
+        raise PvdHipError("the persistent hash render expects the 14-level, 2-feature table")
+    if rays_d.shape[0] < N or nears.numel() < N or fars.numel() < N or weights_sum.numel() < N or depth.numel() < N or image_out.numel() < 3 * N \
+            or workspace.numel() < 2 * N + 12:
+        raise PvdHipError("buffers shorter than N rays")
+    _check_image(0, image)
+    _call("pvd_infer_image_hash", dev, _p(rays_o), _p(rays_d), _p(nears), _p(fars), _u32(N), _p(bitfield), _f32(bound), _f32(dt_gamma),
+          _u32(max_steps), _u32(C), _u32(H), _f32(sigma_scale), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H0),
+          _u32(gridtype), _int(int(bool(align_corners))), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image), _f32(clip_sigma_min),
+          _f32(clip_max), _p(workspace), _p(weights_sum), _p(depth), _p(image_out))
 
 
 def mlp_head_forward_fused(pts16, wstream, n_before, n_after, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_max, sigma, rgb, feat16,

@@ -320,6 +320,24 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
                                 float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
                                 pvd_stream_t stream);
 
+/* A whole inference render of a frozen hash model in ONE persistent launch (+ a small compaction launch): what run_cuda's eval
+ * branch does in rounds -- march_rays -> model -> composite_rays -> compact_rays until every ray has ended
+ * (distill_mutual/renderer.py:450-543, raymarching.cu:704-948) -- with the rays' state in registers, the samples of a round in
+ * LDS and the alive queue in device memory; a thread-per-ray launch first walks every ray to its first
+ * occupied cell.  rays_o / rays_d [N,3], nears / fars [N] (pvd_near_far_from_aabb),
+ * bitfield / bound / dt_gamma / max_steps / C / H as for pvd_march_rays (perturb = 0); sigma_scale = density_scale
+ * (renderer.py:528); the model as for pvd_hash_head_forward_fused (H0 = the encoder's base resolution).  workspace: 2 N + 12 int32 ([2 N + 2 .. 2 N + 6): local rounds, rows shaded, walk-only rounds, workgroups used).
+ * weights_sum [N], depth [N], image [N,3]: ZERO-FILLED by the caller, written for every ray that enters the box -- the values the
+ * round loop leaves there (background compositing and depth normalisation stay with the caller, renderer.py:545-548).  A ray's
+ * result does not depend on how rays are grouped into rounds, so the image is the round loop's; the reference stops ALL rays
+ * once the rounds' steps add up to max_steps, here a ray stops after its own max_steps steps. */
+int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N,
+                         const uint8_t *bitfield, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                         float sigma_scale, float in_add, float in_div, const void *embeddings_f16, const int32_t *offsets, float S,
+                         uint32_t H0, uint32_t gridtype, int align_corners, const float *Wa1, const float *Wa2, const float *Wc1,
+                         const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_max,
+                         int32_t *workspace, float *weights_sum, float *depth, float *image_out, pvd_stream_t stream);
+
 /* The frozen `mlp` model (NeRF trunk + sigma / colour head; NeRFNetwork.forward with model_type "mlp", network.py:154-182 and
  * :413-437, under no_grad + fp16 autocast) in one launch.
  *   pts_f16 [M][64] f16: positional encoding padded to 64 columns (pvd_freq_encode(out_dtype = PVD_F16, row_stride = 64));

@@ -46,6 +46,7 @@ def test_device_rounds_match_the_host_synchronised_loop(kind, full_image, monkey
     m = _model(kind)
     o, d = _rays(3000, full_image)
     outs = []
+    monkeypatch.setenv("PVD_INFER_PERSISTENT", "0")  # (the round loops; the one-launch render of a hash model: below)
     for on_device in ("0", "1"):
         monkeypatch.setenv("PVD_INFER_DEVICE_ROUNDS", on_device)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
@@ -69,12 +70,78 @@ def test_device_rounds_respect_max_steps_and_empty_images():
     res = []
     for on_device in ("0", "1"):
         os.environ["PVD_INFER_DEVICE_ROUNDS"] = on_device
+        os.environ["PVD_INFER_PERSISTENT"] = "0"
         try:
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 a = m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=24)["image"].float()
                 b = m.render(o + 100.0, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float()
         finally:
             os.environ.pop("PVD_INFER_DEVICE_ROUNDS", None)
+            os.environ.pop("PVD_INFER_PERSISTENT", None)
         res.append((a, b))
     assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-5
     assert torch.equal(res[1][1], torch.ones_like(res[1][1])) and torch.equal(res[0][1], res[1][1])  # all background
+
+
+@pytest.mark.parametrize("full_image", [False, True])
+def test_persistent_hash_render_is_the_round_loops_image(full_image, monkeypatch):
+    """pvd_infer_image_hash (ONE persistent launch: ray slots in registers, samples in LDS, the alive queue in device memory) against
+    the round loop with the reference's per-round read-back: a ray's samples and sums depend on nothing but the ray, so every pixel,
+    every depth and every accumulated weight must be the round loop's -- bit for bit."""
+    m = _model("hash")
+    o, d = _rays(5000, full_image)
+    outs = []
+    for persistent in ("0", "1"):
+        monkeypatch.setenv("PVD_INFER_PERSISTENT", persistent)
+        monkeypatch.setenv("PVD_INFER_DEVICE_ROUNDS", "1" if persistent == "1" else "0")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+        outs.append((out["image"].float(), out["depth"].float()))
+    (img0, dep0), (img1, dep1) = outs
+    assert img0.std().item() > 0.02 and torch.isfinite(img1).all()
+    assert torch.equal(img0, img1), (img0 - img1).abs().max().item()
+    assert torch.equal(torch.isnan(dep0), torch.isnan(dep1)) and torch.equal(torch.nan_to_num(dep0), torch.nan_to_num(dep1))
+    # all background when nothing enters the box; a second call on the same model reuses its caches
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        b = m.render(o + 100.0, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float()
+        again = m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float()
+    assert torch.equal(b, torch.ones_like(b)) and torch.equal(again, img1)
+
+
+def test_persistent_hash_render_with_two_cascades_and_a_growing_step(monkeypatch):
+    """bound 2 (two cascades of the occupancy grid) and dt_gamma = 1/256 (configs[4]'s marcher) through the persistent launch"""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import ChairScene
+    from pvd.workload import install_occupancy, make_model
+    torch.manual_seed(4)
+    opt = PVDConfig(model_type="hash", bound=2.0, dt_gamma=1.0 / 256)
+    opt.stage_iters = {"stage1": -1, "stage2": -1}
+    m = make_model(hip_ops(), opt, "hash", False, torch.device(DEV))
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.4, 0.4)
+    install_occupancy(m, ChairScene(scale=1.9), opt)
+    m.eval()
+    o, d = _rays(4096)
+    o = o * 1.9
+    outs = []
+    for persistent in ("0", "1"):
+        monkeypatch.setenv("PVD_INFER_PERSISTENT", persistent)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            outs.append(m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=1.0 / 256, max_steps=1024)["image"].float())
+    assert outs[0].std().item() > 0.02 and torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
+@pytest.mark.parametrize("n_rays,shuffle", [(1, 7919), (63, 7919), (2 * 7919, 7919), (777, 1)])
+def test_persistent_hash_render_renders_every_ray_once(n_rays, shuffle, monkeypatch):
+    """The queue hands rays out through a multiplicative shuffle: it must be a permutation for ANY number of rays (also a multiple of
+    the multiplier), and workgroups with fewer rays than slots must terminate."""
+    m = _model("hash")
+    o, d = _rays(n_rays)
+    monkeypatch.setenv("PVD_INFER_SHUFFLE", str(shuffle))
+    outs = []
+    for persistent in ("0", "1"):
+        monkeypatch.setenv("PVD_INFER_PERSISTENT", persistent)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            outs.append(m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float())
+    assert torch.equal(outs[0], outs[1])
