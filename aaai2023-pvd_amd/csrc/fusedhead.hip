@@ -722,7 +722,7 @@ struct InferImageArgs {
     float *weights_sum, *depth, *image;  // [N], [N], [N][3]: written for the rays in ray_ids (zero-filled by the caller)
 };
 
-constexpr uint32_t kInfRows = 256;         // sample rows per local round (LDS tile)
+constexpr uint32_t kInfRows = 256;         // sample rows per local round (LDS tile): the most any variant uses
 constexpr uint32_t kInfSteps = 8;          // samples a slot may hold per round (the reference's cap on n_step, renderer.py:493)
 constexpr uint32_t kInfProbes = 6;         // probes per slot and round beyond the samples it is looking for
 
@@ -766,24 +766,24 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_first_hit(InferImageArgs q
 
 // RAYS = ray slots per workgroup (threads 0 .. RAYS - 1 own one each; all 256 threads shade).  Fewer slots per workgroup = more
 // workgroups per image = more waves per SIMD to hide the shading's latencies, and a queue that outlasts the first fill.
-template <uint32_t RAYS>
+template <uint32_t RAYS, uint32_t ROWS>
 __global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a, FusedLookup g, FusedRes gr, InferImageArgs q) {
     extern __shared__ __align__(16) half_t lds[];
     constexpr uint32_t D = 3, L = 14;
     HeadLds<KIND_HASH> W;
     W.carve(lds);
-    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);                         // [kInfRows][kFeatStride]
-    float *pos = reinterpret_cast<float *>(feat + kInfRows * kFeatStride);                 // [kInfRows][3]
-    float *sig = pos + 3 * kInfRows;                                                       // [kInfRows]
-    float *rgb = sig + kInfRows;                                                           // [kInfRows][3]
-    float *sdir = rgb + 3 * kInfRows;                                                      // [kHeadBlock][3]: direction of the ray in slot s
-    uint32_t *row_slot = reinterpret_cast<uint32_t *>(sdir + 3 * kHeadBlock);              // [kInfRows]
-    uint32_t *wcnt = row_slot + kInfRows;                                                  // [8] scan scratch + queue hand-off
+    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);                         // [ROWS][kFeatStride]
+    float *pos = reinterpret_cast<float *>(feat + ROWS * kFeatStride);                 // [ROWS][3]
+    float *sig = pos + 3 * ROWS;                                                       // [ROWS]
+    float *rgb = sig + ROWS;                                                           // [ROWS][3]
+    float *sdir = rgb + 3 * ROWS;                                                      // [kHeadBlock][3]: direction of the ray in slot s
+    uint32_t *row_slot = reinterpret_cast<uint32_t *>(sdir + 3 * kHeadBlock);              // [ROWS]
+    uint32_t *wcnt = row_slot + ROWS;                                                  // [8] scan scratch + queue hand-off
     const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
     const int32_t offs_v = lane <= L ? g.offsets[lane] : 0;
     if (a.image) copy_image(lds, a.image, HeadLds<KIND_HASH>::halfs, tid, kHeadBlock);
     else W.load(a, tid, kHeadBlock);
-    for (uint32_t i = tid; i < kInfRows * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
+    for (uint32_t i = tid; i < ROWS * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
         *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
     uint32_t off[L + 1];
 #pragma unroll
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a
         (void)nlive;
         PVD_ISTAMP(0);
         // samples per slot this round: the reference's rule (renderer.py:493) with the workgroup's own numbers
-        const uint32_t n_step = max(min(kInfRows / live_now, kInfSteps), 1u);
+        const uint32_t n_step = max(min(ROWS / live_now, kInfSteps), 1u);
         // ---------------- march: walk on (k_march_rays' loop, raymarching.cu:756-810, perturb = 0)
         if (index >= 0) {
             Dda r;
@@ -916,14 +916,14 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a
                     inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
                 }
             }
-            fused_lookup_sample<7>(g, gr, off, x01, inside, xb, feat + min(rw, kInfRows - 1u) * kFeatStride);
+            fused_lookup_sample<7>(g, gr, off, x01, inside, xb, feat + min(rw, ROWS - 1u) * kFeatStride);
         }
         __syncthreads();
         PVD_ISTAMP(2);
         // ... and the head, 16 rows per wave and pass; sigma / rgb stay in LDS.  (Two tiles per pass as two independent MFMA chains, and
         // all 14 levels of the lookup in flight: 210 VGPRs = two workgroups per CU instead of three, and no faster per round.)
         for (uint32_t t16 = wave; t16 * 16 < rows; t16 += kHeadBlock / 64) {
-            const uint32_t rw = min(t16 * 16 + (lane & 15), kInfRows - 1u);
+            const uint32_t rw = min(t16 * 16 + (lane & 15), ROWS - 1u);
             TileIn<KIND_HASH> in;
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + rw * kFeatStride + 16 * s2 + 4 * hi);
@@ -1841,9 +1841,12 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
     if (const char *e = getenv("PVD_INFER_RAYS")) { rays = atoi(e); if (rays != 128 && rays != 256) rays = 64; }
     uint32_t blocks = div_up(N, (uint32_t)rays);
     if (blocks > 768u) blocks = 768u;  // persistent
-    if (rays == 128) hipLaunchKernelGGL((k_infer_hash_persistent<128>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
-    else if (rays == 256) hipLaunchKernelGGL((k_infer_hash_persistent<256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
-    else hipLaunchKernelGGL((k_infer_hash_persistent<64>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    int rows_tile = 256;
+    if (const char *e = getenv("PVD_INFER_ROWS")) rows_tile = atoi(e) == 128 ? 128 : 256;
+    if (rays == 128) hipLaunchKernelGGL((k_infer_hash_persistent<128, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    else if (rays == 256) hipLaunchKernelGGL((k_infer_hash_persistent<256, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    else if (rows_tile == 128) hipLaunchKernelGGL((k_infer_hash_persistent<64, 128>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    else hipLaunchKernelGGL((k_infer_hash_persistent<64, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
     return check_launch();
 }
 
