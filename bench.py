@@ -252,10 +252,23 @@ def teacher_workload(args, dev):
     tr = TeacherTrainer(topt, tea, dev, fp16=not args.fp32)
     tea.mean_count = measure_mean_count(tea, w.poses, opt, generator=w.gen)
     batches = []
-    for it in range(16):
-        r = get_rays(w.poses[it % len(w.poses)][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
-        bg = torch.rand(1, opt.num_rays, 3, device=dev, generator=w.gen)
-        batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
+    data = "synthetic (analytic chair-like scene; no dataset offline)"
+    if args.data_root:
+        # a Blender-format scene on disk through the reference-shaped reader (pvd/provider.py <- distill_mutual/provider.py:133-326):
+        # frames + cameras from transforms_train.json, ground truth = the PNGs' pixels blended over a random background by their alpha
+        from pvd.provider import BlenderScene, training_target
+        scene = BlenderScene(args.data_root, "train", scale=opt.scale, device=dev, num_rays=opt.num_rays)
+        for it in range(16):
+            b = scene.batch([it % len(scene)], generator=w.gen)
+            gt, bg = training_target(b["images"], generator=w.gen)
+            batches.append((b["rays_o"], b["rays_d"], gt, bg))
+        data = "Blender-format scene read by pvd/provider.py from %s: %d train views of %dx%d (tools/make_blender_scene.py: the synthetic chair written to disk)" % (
+            args.data_root, len(scene), scene.W, scene.H)
+    else:
+        for it in range(16):
+            r = get_rays(w.poses[it % len(w.poses)][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
+            bg = torch.rand(1, opt.num_rays, 3, device=dev, generator=w.gen)
+            batches.append((r["rays_o"], r["rays_d"], w.target(r["rays_o"], r["rays_d"], bg), bg))
     name = "pvd_grid_encode_forward"
     block = (not args.eager) and args.steps % 16 == 0 and args.warmup % 16 == 0 and args.warmup >= 32
     launch = "eager"
@@ -305,7 +318,7 @@ def teacher_workload(args, dev):
         "metric": "train rays/s (hash teacher training step)", "value": args.steps * args.rays / elapsed, "unit": "rays/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP) / f32 marcher+compositor",
-        "data": "synthetic (analytic chair-like scene; no dataset offline)",
+        "data": data,
         "config": {"workload": "train hash teacher, synthetic chair, %d rays/step, occupancy update every %d steps"
                                % (args.rays, topt.update_extra_interval), "rays_per_gpu": args.rays, "parallelism": "single GPU",
                    "launch": launch, "mean_count": int(tea.mean_count), "psnr_vs_analytic_gt_db": float(psnr(pred.detach(), batches[(args.steps - 1) % 16][2])),
@@ -346,6 +359,8 @@ def main():
     ap.add_argument("--data-type", choices=["synthetic", "llff", "tank"], default="synthetic",
                     help="random-camera generator of the distillation (get_rand_poses, distill_mutual/utils.py:100-197): configs[3] uses llff, configs[4] tank")
     ap.add_argument("--teacher", type=str, default="hash", help="teacher model type (configs[3]: mlp)")
+    ap.add_argument("--data-root", type=str, default=None,
+                    help="--workload teacher: train from a Blender-format scene on disk (transforms_train.json + PNGs) through pvd/provider.py")
     ap.add_argument("--scene-scale", type=float, default=1.0, help="scale of the synthetic scene (with --bound > 1)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="after the timed region: this many more steps in one synchronised window (`sustained`); 0 = skip")

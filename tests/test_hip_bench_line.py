@@ -65,6 +65,20 @@ def test_teacher_workload_line_has_a_cpu_baseline():
     assert c and "error" not in c and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
 
 
+def test_teacher_workload_from_a_blender_scene_on_disk(tmp_path):
+    """configs[1] fed by pvd/provider.py (the reference's NeRFDataset, provider.py:133-326) from a scene written by
+    tools/make_blender_scene.py: transforms_train.json + RGBA PNGs -> rays, alpha-blended targets -> the same training block."""
+    root = str(tmp_path / "chair")
+    p = subprocess.run([sys.executable, "tools/make_blender_scene.py", root, "--views", "8", "--res", "64"], cwd=REPO, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    assert os.path.exists(os.path.join(root, "transforms_train.json")) and os.path.exists(os.path.join(root, "train", "r_0.png"))
+    d = _line([sys.executable, "bench.py", "--workload", "teacher", "--steps", "16", "--warmup", "32", "--rays", "1024", "--no-cpu-baseline",
+               "--data-root", root])
+    assert d["data"].startswith("Blender-format scene read by pvd/provider.py") and "8 train views of 64x64" in d["data"]
+    assert d["value"] > 0 and math.isfinite(d["config"]["loss"]) and d["config"]["psnr_vs_analytic_gt_db"] > 5.0
+
+
 @pytest.mark.parametrize("strong", [False, True])
 def test_two_ranks_as_the_driver_launches_them(strong):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r03_in_step.json: the roofline kernel's duration INSIDE the replayed step, from the launch populations of a
+"""profiles/r04_in_step.json: the roofline kernel's duration INSIDE the replayed step, from the launch populations of a
 rocprofv3 kernel trace of the driver's bench command (tools/kernel_populations.py), stamped with the hash of the kernel's
 sources so that bench.py quotes it only for the build it was taken on.
-  in_step_record.py <kernel_populations.txt> <bench_profiled_line.json> > profiles/r03_in_step.json"""
+  in_step_record.py <kernel_populations.txt> <bench_profiled_line.json> > profiles/r04_in_step.json"""
 import json
 import os
 import re
