@@ -537,13 +537,15 @@ def main():
         if pose_now is not None:
             span = args.steps + (args.sustained_steps // spc) * spc if args.sustained_steps > 0 else args.steps
             first = (pose_now - span) % P  # the pose counter advanced once per step since the timed region began (+ prefix prefetch)
-            timed_cams = sorted({(first + (args.steps * i) // 4) % P for i in range(4)})
+            n_t = min(args.steps, 10)
+            timed_cams = sorted({(first + (args.steps * i) // n_t) % P for i in range(n_t)})
             epoch_cams = [(P * i) // 8 for i in range(8)]
+            next_cam = (first + args.steps) % P  # the batch right behind the timed region: what rounds 1-3 measured on (one camera)
         else:
-            timed_cams, epoch_cams = [None], []
+            timed_cams, epoch_cams, next_cam = [None], [], None
         per_cam = {}
         B = None
-        for cam in list(timed_cams) + [c for c in epoch_cams if c not in timed_cams]:
+        for cam in list(timed_cams) + [c for c in epoch_cams + ([next_cam] if next_cam is not None else []) if c not in timed_cams]:
             xyzs, dirs = samples_of_pose(cam)
             per_cam[cam] = time_alone(xyzs, dirs)
             B = int(xyzs.shape[0])
@@ -561,7 +563,7 @@ def main():
         alone = {"us_per_launch": us_alone, "launches": n_launch * len(timed_cams), "achieved": gbs(us_alone), "frac": gbs(us_alone) / HBM_PEAK_GBS,
                  "cameras": [c for c in timed_cams], "us_per_camera": [per_cam[c] for c in timed_cams],
                  "timing": "HIP events on the launch stream around %d back-to-back launches (HIP graphs of %d) per camera, nothing else on the "
-                           "chip, right after the timed region, on the sample rows of %d cameras of the timed region's range" % (n_launch, per_graph, len(timed_cams))}
+                           "chip, right after the timed region, on the sample rows of %d cameras of the timed region" % (n_launch, per_graph, len(timed_cams))}
         alone_epoch = None
         if us_epoch is not None:
             alone_epoch = {"us_per_launch": us_epoch, "achieved": gbs(us_epoch), "frac": gbs(us_epoch) / HBM_PEAK_GBS, "cameras": epoch_cams,
@@ -610,7 +612,10 @@ def main():
                 "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * Bh, "bytes_per_sample": bps,
                 "bytes_per_sample_fused": 552 if fused else None,
                 "samples_per_launch": Bh, "us_per_launch": head["us_per_launch"], "launches": head.get("launches"),
-                "alone": alone, "alone_epoch": alone_epoch, "in_step": in_step,
+                "alone": alone, "alone_epoch": alone_epoch,
+                "alone_next_batch": (None if next_cam is None else {"camera": next_cam, "us_per_launch": per_cam[next_cam], "frac": gbs(per_cam[next_cam]) / HBM_PEAK_GBS,
+                                                                    "what": "rounds 1-3's protocol: ONE camera, the batch right behind the timed region"}),
+                "in_step": in_step,
                 "rederive": "python tools/roofline_from_profile.py  (profiles/r04_kernel_populations.txt + r04_bench_profiled_line.json + r04_kernel_stats.csv)"}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
