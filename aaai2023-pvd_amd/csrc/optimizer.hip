@@ -221,8 +221,16 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
             G = reinterpret_cast<const float4 *>(g)[i];
             if (ex.zero_g) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#ifndef PVD_ADAMW_NT
+#define PVD_ADAMW_NT 1
+#endif
+#if PVD_ADAMW_NT
         const f4v Mn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(m) + i);
         const f4v Vn = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v) + i);
+#else
+        const f4v Mn = reinterpret_cast<const f4v *>(m)[i];
+        const f4v Vn = reinterpret_cast<const f4v *>(v)[i];
+#endif
         float4 M = make_float4(Mn.x, Mn.y, Mn.z, Mn.w), V = make_float4(Vn.x, Vn.y, Vn.z, Vn.w);
         if (ex.g16 && e >= ex.g16_begin && e < ex.g16_end) {  // 4 halfs = one 8-byte load (range start is a multiple of 4)
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
@@ -245,8 +253,13 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
             l1_acc += l1 * fabsf(param);
         }
         reinterpret_cast<float4 *>(p)[i] = P;
+#if PVD_ADAMW_NT
         __builtin_nontemporal_store((f4v){M.x, M.y, M.z, M.w}, reinterpret_cast<f4v *>(m) + i);
         __builtin_nontemporal_store((f4v){V.x, V.y, V.z, V.w}, reinterpret_cast<f4v *>(v) + i);
+#else
+        reinterpret_cast<f4v *>(m)[i] = (f4v){M.x, M.y, M.z, M.w};
+        reinterpret_cast<f4v *>(v)[i] = (f4v){V.x, V.y, V.z, V.w};
+#endif
     }
     if (ex.l1_next && !skip) {
 #pragma unroll
