@@ -145,3 +145,25 @@ def test_persistent_hash_render_renders_every_ray_once(n_rays, shuffle, monkeypa
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             outs.append(m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_persistent_hash_render_of_a_whole_400x400_view():
+    """160 000 rays in one launch; the ones that meet an occupied cell are queued and rendered by several hundred workgroups"""
+    from pvd.scene import get_rays, synthetic_poses
+    import os
+    m = _model("hash")
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(2))).to(DEV)
+    r = get_rays(poses[40][None], (555.55, 555.55, 200.0, 200.0), 400, 400, -1)
+    outs = []
+    for persistent in ("0", "1"):
+        os.environ["PVD_INFER_PERSISTENT"] = persistent
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                out = m.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+        finally:
+            os.environ.pop("PVD_INFER_PERSISTENT", None)
+        outs.append((out["image"].float(), torch.nan_to_num(out["depth"].float())))
+    assert outs[0][0].std().item() > 0.02
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    st = m._last_infer_workspace[-10:-6].tolist()
+    assert st[3] >= 100 and st[1] > 100000 and int(m._last_infer_workspace[0]) > 64 * 100  # workgroups that took rays; rows shaded; rays queued
