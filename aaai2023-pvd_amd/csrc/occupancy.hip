@@ -9,7 +9,9 @@
 //   * mean of the clamped grid, threshold = min(mean, density_thresh), packbits (:752-760),
 // as five small kernels and NO host round trip (the reference -- and the torch formulation -- synchronise for nonzero(),
 // for the mean and per 64^3 block of the full sweep).  Random numbers: PCG32 keyed by (seed, cell slot); the reference uses
-// torch's generator, so only the distribution is reproduced, not the stream.
+// torch's generator, so only the distribution is reproduced, not the stream -- except through pvd_occ_sample_replay /
+// pvd_occ_update_ordered, which take the draws as input and resolve duplicate cells like a sequential assignment: a run of the
+// reference can then be replayed cell for cell (tests/test_hip_occupancy.py).
 #include "pvd_device.h"
 
 namespace pvd {
@@ -70,6 +72,61 @@ __global__ void __launch_bounds__(kOccBlock) k_occ_positions(uint32_t H, uint32_
         const float r = g.next_float();
         xyz[3 * (size_t)i + a] = u * (bound_c - hgs) + (r * 2.0f - 1.0f) * hgs;
     }
+}
+
+// The same positions from SUPPLIED draws (pvd_occ_sample_replay): what the reference's torch calls return for one cascade, in its
+// order -- cells = randint(0, H, (n_uniform, 3)); picks = randint(0, #occupied, n_occ) into the ASCENDING list of occupied Morton
+// indices (nonzero()); jitter = rand(n, 3) in [0, 1), row k of it belonging to the k-th queried point (full sweep: the meshgrid
+// point (x * H + y) * H + z, renderer.py:700-712) -- so that a run of the reference can be replayed cell for cell.
+__global__ void __launch_bounds__(kOccBlock) k_occ_positions_replay(uint32_t H, uint32_t n_uniform, uint32_t n_occ, int full, float bound_c,
+                                                                   const int32_t *__restrict__ cells, const int32_t *__restrict__ list,
+                                                                   const int32_t *__restrict__ picks, const float *__restrict__ jitter,
+                                                                   int32_t *__restrict__ indices, float *__restrict__ xyz) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n_uniform + n_occ) return;
+    uint32_t cx, cy, cz, row = i;
+    int32_t idx;
+    if (full) {
+        idx = (int32_t)i;
+        cx = gather3(i); cy = gather3(i >> 1); cz = gather3(i >> 2);
+        row = (cx * H + cy) * H + cz;
+    } else if (i < n_uniform) {
+        cx = (uint32_t)cells[3 * (size_t)i]; cy = (uint32_t)cells[3 * (size_t)i + 1]; cz = (uint32_t)cells[3 * (size_t)i + 2];
+        idx = (int32_t)morton3(cx, cy, cz);
+    } else {
+        idx = list[picks[i - n_uniform]];
+        cx = gather3((uint32_t)idx); cy = gather3((uint32_t)idx >> 1); cz = gather3((uint32_t)idx >> 2);
+    }
+    const float hgs = bound_c / (float)H;
+    const float c[3] = {(float)cx, (float)cy, (float)cz};
+    indices[i] = idx;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float u = 2.0f * c[a] / (float)(H - 1) - 1.0f;
+        const float r = jitter[3 * (size_t)row + a];
+        xyz[3 * (size_t)i + a] = u * (bound_c - hgs) + (r * 2.0f - 1.0f) * hgs;
+    }
+}
+
+// tmp_grid[cas, indices] = sigmas with duplicates resolved the way a sequential assignment resolves them (the reference on the
+// CPU): the LAST position holding a cell wins.  owner[cell] = max position (pass 1), the owner writes (pass 2).
+__global__ void __launch_bounds__(kOccBlock) k_occ_fill_i32(int32_t *__restrict__ p, uint32_t n, int32_t v) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(kOccBlock) k_occ_owner(int32_t *__restrict__ owner, const int32_t *__restrict__ indices, uint32_t n) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t idx = indices[i];
+    if (idx >= 0) atomicMax(owner + idx, (int32_t)i);
+}
+__global__ void __launch_bounds__(kOccBlock) k_occ_scatter_owned(float *__restrict__ tmp, const int32_t *__restrict__ owner,
+                                                                const int32_t *__restrict__ indices, const float *__restrict__ sigmas,
+                                                                float scale, uint32_t n) {
+    const uint32_t i = blockIdx.x * kOccBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t idx = indices[i];
+    if (idx >= 0 && owner[idx] == (int32_t)i) tmp[idx] = sigmas[i] * scale;
 }
 
 __global__ void __launch_bounds__(kOccBlock) k_occ_fill(float *__restrict__ tmp, uint32_t n4, float v) {
@@ -185,6 +242,34 @@ int pvd_occ_update(float *density_grid, float *tmp, const int32_t *indices, cons
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_occ_fill, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, tmp, H3 / 4, -1.0f);
     if (n) hipLaunchKernelGGL(k_occ_scatter, dim3(div_up(n, kOccBlock)), dim3(kOccBlock), 0, s, tmp, indices, sigmas, sigma_scale, n);
+    hipLaunchKernelGGL(k_occ_ema, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, tmp, H3 / 4, decay);
+    return check_launch();
+}
+
+int pvd_occ_sample_replay(uint32_t H, uint32_t n_uniform, uint32_t n_occupied, int full, float bound_c, const int32_t *cells,
+                          const int32_t *occ_list, const int32_t *picks, const float *jitter, int32_t *indices, float *xyz,
+                          pvd_stream_t stream) {
+    if (!jitter || !indices || !xyz || H < 2 || H > 1024) return PVD_ERR_INVALID;
+    if (full) { n_uniform = H * H * H; n_occupied = 0; }
+    if (n_uniform + n_occupied == 0) return PVD_OK;
+    if ((!full && n_uniform && !cells) || (n_occupied && (!occ_list || !picks))) return PVD_ERR_INVALID;
+    hipLaunchKernelGGL(k_occ_positions_replay, dim3(div_up(n_uniform + n_occupied, kOccBlock)), dim3(kOccBlock), 0, (hipStream_t)stream, H,
+                       n_uniform, n_occupied, full, bound_c, cells, occ_list, picks, jitter, indices, xyz);
+    return check_launch();
+}
+
+int pvd_occ_update_ordered(float *density_grid, float *tmp, int32_t *owner, const int32_t *indices, const float *sigmas, uint32_t n,
+                           uint32_t H, float sigma_scale, float decay, pvd_stream_t stream) {
+    if (!density_grid || !tmp || !owner || (n && (!indices || !sigmas)) || H < 2 || H > 1024) return PVD_ERR_INVALID;
+    const uint32_t H3 = H * H * H;
+    if (H3 & 3u) return PVD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_occ_fill, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, tmp, H3 / 4, -1.0f);
+    if (n) {
+        hipLaunchKernelGGL(k_occ_fill_i32, dim3(div_up(H3, kOccBlock)), dim3(kOccBlock), 0, s, owner, H3, -1);
+        hipLaunchKernelGGL(k_occ_owner, dim3(div_up(n, kOccBlock)), dim3(kOccBlock), 0, s, owner, indices, n);
+        hipLaunchKernelGGL(k_occ_scatter_owned, dim3(div_up(n, kOccBlock)), dim3(kOccBlock), 0, s, tmp, owner, indices, sigmas, sigma_scale, n);
+    }
     hipLaunchKernelGGL(k_occ_ema, dim3(div_up(H3 / 4, kOccBlock)), dim3(kOccBlock), 0, s, density_grid, tmp, H3 / 4, decay);
     return check_launch();
 }

@@ -490,6 +490,9 @@ class NeRFRenderer(nn.Module):
         xyz = torch.empty(n, 3, dtype=torch.float32, device=dev)
         for cas in range(C):
             st["calls"] += 1
+            if self.occ_replay:
+                self._occ_cascade_replay(occ, st, cas, full, n_u, indices, xyz, decay)
+                continue
             occ.occ_sample(self.density_grid[cas], H, n_u, n_o, full, float(min(2 ** cas, self.bound)), 0x0cc0 + 7919 * st["calls"], st["list"],
                            st["count"], indices, xyz)
             sig = self.density(xyz)["sigma"].reshape(-1).detach().float().contiguous()
@@ -503,6 +506,36 @@ class NeRFRenderer(nn.Module):
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
             self._publish_budget()
         self.local_step = 0
+
+    occ_replay = False  # True: the device path consumes torch's CPU generator exactly as the reference's update_extra_state does
+
+    def _occ_cascade_replay(self, occ, st, cas, full, n_u, indices, xyz, decay):
+        """One cascade of the device-side update with the REFERENCE's random draws: the torch calls of renderer.py:700-741 in their
+        order and shapes on the CPU generator (so torch.manual_seed(s) here = torch.manual_seed(s) before the reference's own
+        CPU run), handed to pvd_occ_sample_replay; duplicate cells resolved like the reference's sequential assignment
+        (pvd_occ_update_ordered).  Host round trips as in the reference (nonzero, the draws): a checking mode, not a fast one."""
+        dev = self.density_grid.device
+        H = self.grid_size
+        bound_c = float(min(2 ** cas, self.bound))
+        if full:
+            assert H <= 128, "the reference sweeps in 128^3 blocks: replay covers the single-block case"
+            jitter = torch.rand(H ** 3, 3).to(dev)
+            occ.occ_sample_replay(H, 0, 0, True, bound_c, None, None, None, jitter, indices, xyz)
+            n = H ** 3
+        else:
+            cells = torch.randint(0, H, (n_u, 3))
+            lst = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+            n_o = 0
+            picks = None
+            if lst.shape[0] > 0:
+                picks = torch.randint(0, lst.shape[0], [n_u], dtype=torch.long).to(torch.int32).to(dev)
+                n_o = n_u
+            n = n_u + n_o
+            jitter = torch.rand(n, 3).to(dev)
+            occ.occ_sample_replay(H, n_u, n_o, False, bound_c, cells.to(torch.int32).to(dev).contiguous(), lst.to(torch.int32).contiguous(), picks,
+                                  jitter, indices, xyz)
+        sig = self.density(xyz[:n].contiguous())["sigma"].reshape(-1).detach().float().contiguous()
+        occ.occ_update_ordered(self.density_grid[cas], st["tmp"], st["list"], indices[:n].contiguous(), sig, H, float(self.density_scale), float(decay))
 
     # ---- sample budget in device memory (captured training steps)
     sample_alloc = None  # rows the training branch allocates when set (>= the aligned mean_count); see fix_sample_alloc

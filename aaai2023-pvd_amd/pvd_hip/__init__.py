@@ -77,7 +77,7 @@ ENTRY_POINTS = (
     "pvd_abi_version", "pvd_status_string", "pvd_last_hip_error",
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
-    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish",
+    "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
@@ -580,7 +580,34 @@ def occ_finish(density_grid, density_thresh, mean_thresh, scratch, bitfield):
     _call("pvd_occ_finish", dev, _p(density_grid), _u32(density_grid.numel()), _f32(density_thresh), _p(mean_thresh), _p(scratch), _p(bitfield))
 
 
-occupancy_backend = types.SimpleNamespace(occ_sample=occ_sample, occ_update=occ_update, occ_finish=occ_finish)
+def occ_sample_replay(H, n_uniform, n_occupied, full, bound_c, cells, occ_list, picks, jitter, indices, xyz):
+    """pvd_occ_sample_replay: the positions of pvd_occ_sample from supplied draws (a replay of a run of the reference)."""
+    dev = _dev(jitter, indices, xyz, cells, occ_list, picks)
+    _f32_all(jitter=jitter, xyz=xyz)
+    _want(indices, torch.int32, "indices")
+    for name, t in (("cells", cells), ("occ_list", occ_list), ("picks", picks)):
+        if t is not None:
+            _want(t, torch.int32, name)
+    n = (H ** 3) if full else (n_uniform + n_occupied)
+    if jitter.numel() < 3 * n or indices.numel() < n or xyz.numel() < 3 * n or (not full and n_uniform and cells.numel() < 3 * n_uniform) \
+            or (n_occupied and picks.numel() < n_occupied):
+        raise PvdHipError("occ_sample_replay: a draw array is shorter than the slots it feeds")
+    _call("pvd_occ_sample_replay", dev, _u32(H), _u32(n_uniform), _u32(n_occupied), _int(int(bool(full))), _f32(bound_c), _p(cells), _p(occ_list),
+          _p(picks), _p(jitter), _p(indices), _p(xyz))
+
+
+def occ_update_ordered(density_grid, tmp, owner, indices, sigmas, H, sigma_scale, decay):
+    dev = _dev(density_grid, tmp, owner, indices, sigmas)
+    _f32_all(density_grid=density_grid, tmp=tmp, sigmas=sigmas)
+    _want(indices, torch.int32, "indices"), _want(owner, torch.int32, "owner")
+    if owner.numel() < H ** 3:
+        raise PvdHipError("occ_update_ordered: owner needs H^3 entries")
+    _call("pvd_occ_update_ordered", dev, _p(density_grid), _p(tmp), _p(owner), _p(indices), _p(sigmas), _u32(indices.numel()), _u32(H),
+          _f32(sigma_scale), _f32(decay))
+
+
+occupancy_backend = types.SimpleNamespace(occ_sample=occ_sample, occ_update=occ_update, occ_finish=occ_finish, occ_sample_replay=occ_sample_replay,
+                                         occ_update_ordered=occ_update_ordered)
 
 
 # --------------------------------------------------------------------------- Plenoxel dense-volume lookup + SH head

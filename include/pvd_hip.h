@@ -404,6 +404,18 @@ int pvd_occ_sample(const float *density_grid, uint32_t H, uint32_t n_uniform, ui
                    pvd_stream_t stream);
 int pvd_occ_update(float *density_grid, float *tmp, const int32_t *indices, const float *sigmas, uint32_t n, uint32_t H,
                    float sigma_scale, float decay, pvd_stream_t stream);
+/* Replay of a run of the reference (its random draws are torch's; pvd_occ_sample draws its own):
+ *   pvd_occ_sample_replay  : pvd_occ_sample's positions from supplied draws -- cells [n_uniform][3] int32 = randint(0, H, (n, 3));
+ *                            occ_list = the occupied cells' Morton indices ASCENDING (nonzero()), picks [n_occupied] int32 =
+ *                            randint(0, #occupied, n) into it; jitter [n][3] f32 in [0, 1) = rand(n, 3), row k for the k-th point
+ *                            the reference queries (full sweep, H <= 128: the meshgrid point (x H + y) H + z; renderer.py:700-741).
+ *   pvd_occ_update_ordered : pvd_occ_update with duplicate cells resolved as a sequential assignment resolves them (the last
+ *                            position wins; plain pvd_occ_update: whichever write lands last); owner [H^3] int32 is scratch. */
+int pvd_occ_sample_replay(uint32_t H, uint32_t n_uniform, uint32_t n_occupied, int full, float bound_c, const int32_t *cells,
+                          const int32_t *occ_list, const int32_t *picks, const float *jitter, int32_t *indices, float *xyz,
+                          pvd_stream_t stream);
+int pvd_occ_update_ordered(float *density_grid, float *tmp, int32_t *owner, const int32_t *indices, const float *sigmas, uint32_t n,
+                           uint32_t H, float sigma_scale, float decay, pvd_stream_t stream);
 int pvd_occ_finish(const float *density_grid, uint32_t n_cells, float density_thresh, float *mean_thresh, float *scratch,
                    uint8_t *bitfield, pvd_stream_t stream);
 

@@ -167,3 +167,58 @@ def test_mark_untrained_grid_on_the_device_marks_the_cells_the_cpu_run_marks():
         m.update_extra_state()
     assert torch.equal(m.density_grid[before < 0], before[before < 0])
     assert (m.density_grid[before >= 0] >= 0).all()
+
+
+@pytest.mark.parametrize("bound", [1, 2])
+def test_device_path_replays_the_reference_run_cell_for_cell(bound):
+    """The REFERENCE's own update_extra_state run (tests/golden/reference_step.npz: hash model, 16^3 grid, one and two cascades, full
+    sweeps and partial updates, CPU generator seeded per call -- the fixture tests/test_golden_occupancy.py pins the torch path with)
+    replayed through the device path: `occ_replay` makes it consume torch's CPU generator in the reference's order
+    (pvd_occ_sample_replay) and resolve duplicate cells like the reference's sequential assignment (pvd_occ_update_ordered).
+    Every cell of the grid then carries the reference's value (up to the fp32 rounding of the density network on another
+    device), the same cells are untouched, and the bitfield differs in at most a few threshold-marginal cells."""
+    import os
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import make_model
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_step.npz"), allow_pickle=False)
+    pre = "occ_b%d__" % bound
+    opt = PVDConfig(model_type="hash", teacher_type="hash", bound=float(bound), PE=6, skip=2, nerf_layer_num=5, nerf_layer_wide=32,
+                    resolution0=12, plenoxel_res="[12,12,12]", grid_size=int(G["grid_size"]), density_thresh=10.0, fp16=False)
+    torch.manual_seed(0)
+    net = make_model(hip_ops(), opt, "hash", True, dev)
+    sd = {}
+    for k in [str(k) for k in G[pre + "keys"]]:
+        if "embeddings" in k:
+            torch.manual_seed(777)
+            sd[k] = (torch.rand(net.state_dict()[k].shape) - 0.5) * 0.6
+        else:
+            sd[k] = torch.from_numpy(G[pre + "sd__" + k])
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    net.occ_replay = True
+    with torch.no_grad():
+        net.density_grid.copy_(torch.from_numpy(G[pre + "marked"]).to(dev))  # (mark_untrained_grid on the device: its own test above)
+    n_partial = 0
+    for i in G[pre + "calls"]:
+        c = pre + "u%d__" % int(i)
+        net.iter_density = int(G[c + "iter_density"])
+        n_partial += net.iter_density >= 16
+        counts = G[c + "counts"]
+        if len(counts):
+            net.step_counter.zero_()
+            net.step_counter[:len(counts)] = torch.from_numpy(counts).to(dev)
+            net.local_step = len(counts)
+        torch.manual_seed(int(G[c + "seed"]))
+        with torch.no_grad():
+            net.update_extra_state()
+        ref = G[c + "grid"]
+        got = net.density_grid.cpu().numpy()
+        np.testing.assert_array_equal(got < 0, ref < 0)
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-5)
+        assert float(net.mean_density) == pytest.approx(float(G[c + "mean_density"]), rel=1e-4)
+        flips = np.unpackbits(net.density_bitfield.cpu().numpy() ^ G[c + "bitfield"]).sum()
+        assert flips <= 4, flips
+        assert int(net.mean_count) == int(G[c + "mean_count"])
+        assert net.local_step == 0 and net.iter_density == int(G[c + "iter_density"]) + 1
+    assert n_partial >= 1  # the uniform + occupied-cell branch (duplicates, ordered scatter) was replayed too
