@@ -78,15 +78,53 @@ class FlatAdamW(torch.optim.Optimizer):
         if owed is None:
             return False
         self._part_a_owed = None
-        cold, log, count, warm_a, scaled, l1n = owed
+        self._launch_part_a(owed)
+        if self._owed_is_carried:  # a recording's last step, run here instead of by the next replay: that replay must find it done
+            self._owed_is_carried = False
+            if not torch.cuda.is_current_stream_capturing():
+                owed[6][0:1].fill_(1.0)  # (the record's "skipped" flag: the replayed launch returns at once)
+        return True
+
+    def _launch_part_a(self, owed):
+        cold, log, count, warm_a, scaled, l1n, snap = owed
         d = self.defaults
         pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
-                           d["eps"], d["weight_decay"], self.step_count, self._snapshot[2:3] if scaled else None, None,
-                           l1_ranges=getattr(self, "_l1", None), l1_next=l1n, cold_bits=cold, lazy=(log, count, warm_a), replay=self._snapshot)
+                           d["eps"], d["weight_decay"], self.step_count, snap[2:3] if scaled else None, None,
+                           l1_ranges=getattr(self, "_l1", None), l1_next=l1n, cold_bits=cold, lazy=(log, count, warm_a), replay=snap)
         if torch.cuda.is_current_stream_capturing():
             self._graph_is_two_part = True  # (note_device_steps: what a replay leaves in the L1 partial sums)
         pvd_hip.note_weights_changed(self.params)
-        return True
+
+    # A recording's LAST step has no later step of the same graph to carry its part A: with `carry_last` its record goes to a
+    # buffer of its own and the NEXT replay's first branch launches it (run_carried_part_a, recorded once per graph); between
+    # replays the host knows it as owed (note_carried_part_a), so a flush / an eager step runs it and marks the record as done.
+    carry_last = False
+    _next_step_is_last = False
+    _owed_is_carried = False
+    _snap_last = None
+
+    def _snap_buffers(self):
+        if self._snap_last is None:
+            dev, n = self.flat_p.device, 4 + len(self.segment_ends)
+            self._snapshots = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._snap_last = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._snap_last[0] = 1.0  # nothing owed yet
+            self._snapshot = self._snapshots[0]
+
+    def _part_a_record(self, scaled, snap):
+        lazy, st = self._lazy_state(), getattr(self, "_l1_track", None)
+        return (self._cold_bits, lazy[0], lazy[1], self._warm_A, bool(scaled), (st["buf"][4096:], st["scale"]) if st is not None else None, snap)
+
+    @torch.no_grad()
+    def run_carried_part_a(self, scaled):
+        """(while recording, on the branch of a graph's FIRST step) part A of the previous replay's last step."""
+        self._snap_buffers()
+        self._launch_part_a(self._part_a_record(scaled, self._snap_last))
+
+    def note_carried_part_a(self, scaled):
+        """(after a replay of a graph recorded with carry_last) its last step's part A is owed."""
+        self._part_a_owed = self._part_a_record(scaled, self._snap_last)
+        self._owed_is_carried = True
 
     def _two_part_now(self, lazy):
         return bool(self.two_part and lazy is not None and len(lazy) >= 3 and getattr(self, "_half_grad", None) is None
@@ -107,18 +145,25 @@ class FlatAdamW(torch.optim.Optimizer):
             st["buf"][0] = self.l1_value(st["scale"])
 
     def begin_two_part(self, defer):
-        """Called by the trainer BEFORE it records steps whose update is split (eagerly: may launch)."""
+        """Called by the trainer BEFORE it records steps whose update is split (eagerly: may launch).  Returns whether the recorded
+        steps WILL split: they need the warm-group lists (deferred decay of the cold groups) and rows of both kinds."""
         self.flush()
-        self.two_part, self.defer_part_a = True, bool(defer)
         if self._cold_dirty:  # the lists are built by the first step after the touched set changed; the recording needs them now
             self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
             self._cold_dirty = False
-        if getattr(self, "_warm_A", None) is not None and self._warm_A.numel() > 0 and self._cold_bits is not None:
-            self._l1_layout_is("two")
+        will = bool(self.touched is not None and self._cold_bits is not None and self._lazy_state() is not None
+                    and os.environ.get("PVD_ADAMW_WARM_LIST", "1") != "0" and getattr(self, "_warm_A", None) is not None
+                    and self._warm_A.numel() > 0 and self._warm_B.numel() > 0)
+        if not will:
+            return False
+        self._snap_buffers()  # (allocated and initialised OUTSIDE the recording)
+        self.two_part, self.defer_part_a = True, bool(defer)
+        self._l1_layout_is("two")
+        return True
 
     def end_two_part(self):
         """After the recording: eager steps go back to the single launch (the recorded graph keeps the two parts)."""
-        self.two_part = self.defer_part_a = False
+        self.two_part = self.defer_part_a = self.carry_last = self._next_step_is_last = False
 
     touched = None  # set_touched(): the only entries of flat_g anything ever writes (pvd/dp_compact.py), or None = all
     _outside_is_zero = False
@@ -151,6 +196,8 @@ class FlatAdamW(torch.optim.Optimizer):
         outside them would be added to every replayed step's L1 value.  Start the sums afresh when the shape changes."""
         if self._graph_is_two_part:
             self._l1_layout_is("two")
+        if self._owed_is_carried and self._part_a_owed is not None:  # the graph's first branch runs it
+            self._part_a_owed, self._owed_is_carried = None, False
 
     def note_device_steps(self, n):
         """n update steps ran on the device without step() being called (a graph replay): keep the host's idea of the log's
@@ -340,8 +387,14 @@ class FlatAdamW(torch.optim.Optimizer):
                           and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) >= 3)
         if two:
             # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
-            if self._snapshot is None:
-                self._snapshot = torch.zeros(4 + len(self.segment_ends), dtype=torch.float32, device=self.flat_p.device)
+            # the step's record: two buffers taken in turn (part A of step k may still be reading its own while step k + 1 writes), and
+            # one of its own for a recording's last step (carry_last)
+            self._snap_buffers()
+            if self.carry_last and self._next_step_is_last:
+                self._next_step_is_last = False
+                self._snapshot = self._snap_last
+            else:
+                self._snapshot = self._snapshots[1] if self._snapshot is self._snapshots[0] else self._snapshots[0]
             pvd_hip.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.segment_ends, self.lr_dev, d["betas"][0], d["betas"][1],
                                d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                                schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
@@ -349,7 +402,7 @@ class FlatAdamW(torch.optim.Optimizer):
                                cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B), snapshot=self._snapshot, zero_after=zero_after,
                                arrivals=self._tail_in_kernel())
             self._part_a_owed = (cold, lazy[0], lazy[1], self._warm_A, getattr(self, "grad_scale", None) is not None,
-                                 (st["buf"][4096:], st["scale"]) if st is not None else None)
+                                 (st["buf"][4096:], st["scale"]) if st is not None else None, self._snapshot)
             if not self.defer_part_a:
                 self.run_part_a()
         else:

@@ -570,6 +570,8 @@ class _TrainerBase:
             self.optimizer.before_replay()  # (stale L1 partial sums of another launch shape)
         self._cap.replay()
         if self.flat_opt:
+            if getattr(self, "_replay_owes_part_a", None) is not None:
+                self.optimizer.note_carried_part_a(self._replay_owes_part_a)
             self.optimizer.note_device_steps(self.steps_per_replay)
             if getattr(self, "_graph_zeroes", False):
                 self.optimizer._zeroed_by_step = True  # the graph's last update left the touched set clean
@@ -947,18 +949,32 @@ class DistillTrainer(_TrainerBase):
                 carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-        # Two-part AdamW (PVD_ADAMW_SPLIT=1; FlatAdamW.two_part, single GPU, fork at "start"): the update behind the table scatter
-        # covers only what the backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the
-        # update's bytes, read by nobody before the next objective -- are updated first thing on the NEXT step's forked branch, next
-        # to the student's instruction-bound forward, with the scalars the step recorded.  Bit-identical parameters
-        # (tests/test_hip_fused_misc.py, tests/test_hip_graph.py).  MEASURED SLOWER and therefore off: 0.340 vs 0.325 ms/step
-        # (profiles/r03_adamw_split_ab.txt) -- the update is a pure HBM stream (~190 MB); moved next to the forward it takes the
-        # bandwidth the forward's gathers wait on, and the second launch + the cross-branch wait cost what the shorter tail saves.
-        split = (self.flat_opt and not self.dp.enabled and fork_mode == "start" and K >= 2 and os.environ.get("PVD_ADAMW_SPLIT", "0") == "1")
+        # Two-part AdamW (FlatAdamW.two_part; single GPU, fork at "start"): the update behind the table scatter covers only what the
+        # backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the update's bytes, read by
+        # nothing but their own update -- are updated one step later on the forked branch, with the scalars the step recorded.
+        # Bit-identical parameters and moments (tests/test_hip_graph.py, tests/test_hip_fused_misc.py).  WHERE on the branch decides:
+        #   "1"    first thing, next to the student's forward; the objective waits for it (exact L1 value).  Slower than one launch:
+        #          0.340 vs 0.325 ms/step (profiles/r03_adamw_split_ab.txt) -- a 90 MB stream on top of the forward's gathers.
+        #   "late" (default) at the END of the branch, next to the head backward and the table scatter, which wait on the matrix cores
+        #          and on the memory side's atomic units, not on HBM: 0.280 vs 0.296 ms/step (profiles/r04_adamw_late_ab.txt).
+        #   "0"    one launch.
+        split_mode = os.environ.get("PVD_ADAMW_SPLIT", "late")
+        split = (self.flat_opt and not self.dp.enabled and fork_mode == "start" and K >= 2 and split_mode in ("1", "late"))
+        # "late": part A of step k - 1 is launched at the END of step k's branch (after the next prefix: next to step k's head backward
+        # and table scatter, which wait on the matrix cores and on the memory side) instead of at its start; the objective does not
+        # wait for it -- the L1 VALUE it reports then counts the L1-only rows one step late (parameters and gradients are unaffected:
+        # those rows are read by nothing but their own update)
+        late = split and split_mode == "late"
+        # ... and the LAST step's part A rides on the next replay's first branch instead of trailing the graph (FlatAdamW.carry_last)
+        carry_a = late and carried is not None and os.environ.get("PVD_ADAMW_CARRY", "1") != "0"
+        scaled = bool(getattr(self.scaler, "_enabled", False))
+        self._replay_owes_part_a = None
         fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
         pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
+        if split and not self.optimizer.begin_two_part(defer=True):
+            split = late = carry_a = False  # (no warm-group lists, or no rows of one of the two kinds: one launch)
         if split:
-            self.optimizer.begin_two_part(defer=True)
+            self.optimizer.carry_last = carry_a
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)
@@ -992,7 +1008,7 @@ class DistillTrainer(_TrainerBase):
                                     packed = torch.cuda.Event()
                                     packed.record(branch)
                                     self.model_stu._before_head = lambda: main.wait_event(packed)
-                                if split and self.optimizer.run_part_a():  # what the previous step's update still owes
+                                if split and not late and self.optimizer.run_part_a():  # what the previous step's update still owes
                                     done = torch.cuda.Event()
                                     done.record(branch)
                                     # (the objective adds up the L1 term from the partial sums this launch refreshes)
@@ -1002,6 +1018,10 @@ class DistillTrainer(_TrainerBase):
                                 nxt = self.prefetch(batch_fn)
                                 if k + 1 == K:  # for the next replay
                                     carried.store(nxt)
+                                if late:
+                                    self.optimizer.run_part_a()
+                                    if carry_a and k == 0:
+                                        self.optimizer.run_carried_part_a(scaled)
                                 return nxt
 
                         def teacher_stage(part, k=k):
@@ -1065,11 +1085,16 @@ class DistillTrainer(_TrainerBase):
                         if more and pre_next is None:  # "optimizer", or a student without the hook point
                             pre_next = fork()
                         self._exchange()
+                        if carry_a and k + 1 == K:
+                            self.optimizer._next_step_is_last = True
                         self._optimize()
                         if pre_next is not None:  # join
                             main.wait_stream(branch)
                             pre = pre_next
-                    if split:
+                    if split and carry_a:
+                        self.optimizer._part_a_owed = None  # the last step's: recorded on the next replay's first branch
+                        self._replay_owes_part_a = scaled
+                    elif split:
                         self.optimizer.run_part_a()  # the last step's: a replay leaves nothing owed
                 except Exception:
                     self.model_stu._between_backwards = None
@@ -1089,6 +1114,9 @@ class DistillTrainer(_TrainerBase):
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         self.pipelined_ingraph = True
         self.pipeline_fork = fork_mode
+        # how the recorded steps update: "0" one launch, "1" / "late" two parts (only if the optimizer did split: a student without
+        # L1-only rows keeps the single launch)
+        self.adamw_split = split_mode if (split and getattr(self.optimizer, "_graph_is_two_part", False)) else "0"
         return self._static_out
 
     def _capture_deep(self, batch_fn, K, side):

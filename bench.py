@@ -641,6 +641,10 @@ def main():
                                    "" if (args.bound == 1.0 and args.dt_gamma == 0.0) else "; bound %g (%d cascades), dt_gamma %g, scene scale %g"
                                    % (args.bound, w.stu.cascade, args.dt_gamma, args.scene_scale)),
                    "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
+                   "update": {"late": "AdamW in two launches: rows the backward can write behind the scatter; the L1-only rows one step later on the forked "
+                                      "branch (same bits; the reported loss counts their L1 value one step late)",
+                              "1": "AdamW in two launches (L1-only rows at the start of the next step's branch)"}.get(
+                       getattr(w.trainer, "adamw_split", "0"), "AdamW in one launch"),
                    "capture_fallback": (not args.eager) and not launch_mode.startswith("hipGraph replay"),  # True = the step fell back to eager launches (~5x the ms)
                    "samples_per_step_per_gpu": samples,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,

@@ -75,15 +75,19 @@ def test_several_steps_per_graph_launch_train_like_single_step_replays():
     assert float(wa.trainer.optimizer.param_groups[0]["lr"]) == pytest.approx(float(wb.trainer.optimizer.param_groups[0]["lr"]), rel=1e-6)
 
 
-def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits():
+@pytest.mark.parametrize("mode", ["1", "late"])
+def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits(mode):
     """Multi-step graph, fork at "start": AdamW runs in two parts -- behind the scatter only what the backward can have written;
     the L1-only / still-decaying rows (`_warm_A`) one step later on the forked branch, from the scalars the step recorded
     (FlatAdamW.two_part, pvd_adamw_extras.snapshot / replay).  Those rows see no atomics, so against the same run with the
     single launch (PVD_ADAMW_SPLIT=0) their parameters and both moments must agree BIT FOR BIT after several replays; the
-    other rows and the loss agree to the scatter's rounding."""
+    other rows and the loss agree to the scatter's rounding.
+    mode "late" (the default of the bench): part A of step k is launched at the END of step k + 1's branch (next to the backward),
+    the objective does not wait for it, and the part A of a graph's LAST step is carried to the next replay's first branch
+    (FlatAdamW.carry_last): after the replays it is still owed, and flush() / an eager step runs it exactly once."""
     import os
     runs = {}
-    for split in ("1", "0"):
+    for split in (mode, "0"):
         old = os.environ.get("PVD_ADAMW_SPLIT")
         os.environ["PVD_ADAMW_SPLIT"] = split
         try:
@@ -92,22 +96,26 @@ def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits():
             w.enable_graph(steps_per_graph=4)
             tr, o = w.trainer, w.trainer.optimizer
             assert getattr(tr, "pipelined_ingraph", False) and tr.pipeline_fork == "start"
-            assert o._graph_is_two_part == (split == "1") and o._part_a_owed is None and not o.two_part
+            assert o._graph_is_two_part == (split != "0") and o._part_a_owed is None and not o.two_part
             losses = [float(w.step()[0]) for _ in range(3)]
+            assert (o._part_a_owed is not None and o._owed_is_carried) == (split == "late")  # the last step's part A rides on the next replay
             a = (o._warm_A.long()[:, None] * 4 + torch.arange(4, device=o.flat_p.device)).reshape(-1)
             assert a.numel() > 10000
             o.flush()
             l1 = float(o.l1_value(1.0))
             # an eager step after the replays goes back to the single launch (and re-bases the L1 partial sums)
             le = float(tr.train_step(*w.device_batch())[0])
+            # ... and a replay after that: the part A the flush ran must not be applied again by the replay's first branch
+            losses.append(float(w.step()[0]))
+            o.flush()
             runs[split] = (o.flat_p[a].clone(), o.flat_m[a].clone(), o.flat_v[a].clone(), losses, l1, le, float(o.step_count[0]))
         finally:
             if old is None:
                 os.environ.pop("PVD_ADAMW_SPLIT", None)
             else:
                 os.environ["PVD_ADAMW_SPLIT"] = old
-    (pa, ma, va, la, l1a, lea, sa), (pb, mb, vb, lb, l1b, leb, sb) = runs["1"], runs["0"]
-    assert sa == sb and sa >= 8  # (the same steps were applied / skipped by the loss scaler in both runs)
+    (pa, ma, va, la, l1a, lea, sa), (pb, mb, vb, lb, l1b, leb, sb) = runs[mode], runs["0"]
+    assert sa == sb and sa >= 12  # (the same steps were applied / skipped by the loss scaler in both runs)
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     assert (ma != 0).any()  # (the L1 term does drive these rows)
     assert np.allclose(la, lb, rtol=2e-3) and abs(l1a - l1b) <= 1e-4 * abs(l1b) and abs(lea - leb) <= 2e-3 * abs(leb), (la, lb, l1a, l1b, lea, leb)
