@@ -479,7 +479,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         // the deferred part: the scalars of the recorded step (found_inf, step count, scale, learning rates as published), no tail
         ex.sched_kind = 0;
         uint64_t blocks_a = ((uint64_t)ex.n_warm + kOptBlock - 1) / kOptBlock;
-        if (blocks_a > 256 * 16) blocks_a = 256 * 16;
+        static int cap_a = -1;  // PVD_ADAMW_BLOCKS_A: workgroups of the deferred part (it runs NEXT TO other kernels: how many wave slots it takes)
+        if (cap_a < 0) { const char *e = getenv("PVD_ADAMW_BLOCKS_A"); cap_a = e ? atoi(e) : 0; if (cap_a < 1 || cap_a > 4096) cap_a = 512; }  // 512: 0.2803 vs 0.2830 ms/step with 4096 (profiles/r04_adamw_late_ab.txt)
+        if (blocks_a > (uint64_t)cap_a) blocks_a = (uint64_t)cap_a;
         if (blocks_a < 1) blocks_a = 1;
         hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks_a), dim3(kOptBlock), 0, s, p, const_cast<float *>(g), m, v, n, seg,
                            const_cast<float *>(replay + 4), beta1, beta2, eps, weight_decay, const_cast<float *>(replay + 1),
