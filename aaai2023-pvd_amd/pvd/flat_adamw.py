@@ -142,7 +142,20 @@ class FlatAdamW(torch.optim.Optimizer):
         st = getattr(self, "_l1_track", None)
         if st is not None:
             st["buf"].zero_()
-            st["buf"][0] = self.l1_value(st["scale"])
+            total = self.l1_value(st["scale"])
+            if layout == "two" and getattr(self, "_warm_A", None) is not None and self._warm_A.numel() > 0:
+                # the two regions start out with THEIR rows' sums: the first part B then replaces region one with its rows' new sums while
+                # region two still describes the deferred rows as they are in memory (their update comes a step later)
+                a = (self._warm_A.long()[:, None] * 4 + torch.arange(4, device=self._warm_A.device)).reshape(-1)
+                a_val = torch.zeros((), dtype=torch.float32, device=a.device)
+                for b, e, c in self._l1:
+                    sel = a[(a >= b) & (a < e)]
+                    if sel.numel():
+                        a_val = a_val + float(c * st["scale"]) * self.flat_p[sel].abs().sum()
+                st["buf"][4096] = a_val
+                st["buf"][0] = total - a_val
+            else:
+                st["buf"][0] = total
 
     def begin_two_part(self, defer):
         """Called by the trainer BEFORE it records steps whose update is split (eagerly: may launch).  Returns whether the recorded
@@ -270,6 +283,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if st is not None:  # per-workgroup partial sums: the launch shape changes with the list, start them afresh
             st["buf"].zero_()
             st["buf"][0] = self.l1_value(st["scale"])
+            self._l1_layout = "one"  # (a two-part recording re-bases the two regions: _l1_layout_is)
         return packed if self.cold_fraction > 0.05 else None
 
     def zero_grad(self, set_to_none=False):

@@ -99,6 +99,9 @@ def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits(mo
             assert o._graph_is_two_part == (split != "0") and o._part_a_owed is None and not o.two_part
             losses = [float(w.step()[0]) for _ in range(3)]
             assert (o._part_a_owed is not None and o._owed_is_carried) == (split == "late")  # the last step's part A rides on the next replay
+            st = o._l1_track  # the L1 value the next objective would add = the L1 term of the parameters as they are in memory now
+            torch.cuda.synchronize()
+            assert abs(float(st["buf"].sum()) - float(o.l1_value(st["scale"]))) <= 2e-5 * abs(float(o.l1_value(st["scale"]))), split
             a = (o._warm_A.long()[:, None] * 4 + torch.arange(4, device=o.flat_p.device)).reshape(-1)
             assert a.numel() > 10000
             o.flush()
