@@ -496,6 +496,10 @@ struct FusedLookup {
     LevelScales scales;
     uint32_t gridtype;
     bool align_corners;
+    // (measurement, pvd_hash_head_forward_fused_span) DEVICE [2] or NULL: span[0] = min over the launch's workgroups of their start,
+    // span[1] = max of their end, in s_memrealtime ticks (100 MHz) -- how long THIS launch lasted where it ran, e.g. inside a
+    // replayed graph next to other kernels, where no host-side event can be placed.  The caller initialises {~0, 0}.
+    unsigned long long *span = nullptr;
 };
 
 // Round 4.  What the round-3 kernel below (k_hash_fwd_fused_r3, kept for A/B: PVD_FUSED_VARIANT=0) really executed was
@@ -589,6 +593,10 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
 #define PVD_FSTAMP(k) do { } while (0)
 #endif
     PVD_FSTAMP(0);
+    // (measurement) the workgroup's start time, parked in LDS until the end: no register lives across the kernel for it, and no
+    // global memory operation is issued here (the gathers' graded vmcnt waits would have to drain it)
+    __shared__ unsigned long long span_t0;
+    if (g.span && threadIdx.x == 0) span_t0 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
     if (blockIdx.x * kFusedTile >= a.M) return;  // nothing for this workgroup: skip the weight staging too
     HeadLds<KIND_HASH> W;
@@ -683,6 +691,10 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
             for (int q = 0; q < 8; q++) dst[q] = stamp[q];
         }
 #endif
+    }
+    if (g.span && threadIdx.x == 0) {
+        atomicMin(g.span, span_t0);
+        atomicMax(g.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -1783,6 +1795,15 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
                                 const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
                                 float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
                                 pvd_stream_t stream) {
+    return pvd_hash_head_forward_fused_span(xyz, in_add, in_div, embeddings_f16, offsets, S, H, gridtype, align_corners, dirs, M, Wa1, Wa2, Wc1,
+                                            Wc2, Wc3, image, clip_sigma_min, clip_max, sigma, rgb, feat16, rows_dev, nullptr, stream);
+}
+
+int pvd_hash_head_forward_fused_span(const float *xyz, float in_add, float in_div, const void *embeddings_f16, const int32_t *offsets, float S,
+                                     uint32_t H, uint32_t gridtype, int align_corners, const float *dirs, uint32_t M, const float *Wa1,
+                                     const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3, const void *image,
+                                     float clip_sigma_min, float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
+                                     uint64_t *span, pvd_stream_t stream) {
     if (M == 0) return PVD_OK;
     if (!xyz || !embeddings_f16 || !offsets || !dirs || !Wa1 || !Wa2 || !Wc1 || !Wc2 || !Wc3 || !sigma || !rgb || !feat16) return PVD_ERR_INVALID;
     if (!(in_div != 0.f)) return PVD_ERR_INVALID;
@@ -1795,6 +1816,7 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
     FusedLookup g;
     g.xyz = xyz; g.aff = {true, in_add, in_div}; g.grid = (const uint32_t *)embeddings_f16; g.offsets = offsets;
     g.scales = make_scales(14, S, H); g.gridtype = gridtype; g.align_corners = align_corners != 0;
+    g.span = reinterpret_cast<unsigned long long *>(span);
     return launch_hash_fwd_fused(a, g, (hipStream_t)stream);
 }
 

@@ -67,7 +67,7 @@ def hash_head_infer(model, x, d, rows_dev=None):
     if FUSED_LOOKUP:  # lookup + head in one launch, no [L,M,C] intermediate (bit-identical outputs)
         pvd_hip.hash_head_forward_fused(xin, float(bound), float(2 * bound), cache[2], enc.offsets, S, enc.base_resolution, enc.gridtype_id,
                                         enc.align_corners, d.float().contiguous(), M, *ws, a.sigma_clip_min, a.sigma_clip_max, sigma, rgb, feat,
-                                        image=image, rows_dev=rows_dev)
+                                        image=image, rows_dev=rows_dev, span=model.__dict__.pop("_fused_span", None))
         return sigma, rgb, feat
     assert rows_dev is None, "a device-side row count needs the fused lookup + head launch"
     out = torch.empty(L, M, C, dtype=torch.float16, device=dev)

@@ -971,6 +971,12 @@ class DistillTrainer(_TrainerBase):
         self._replay_owes_part_a = None
         fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
         pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
+        # (measurement, bench.py) record_fused_spans: every recorded launch of the frozen hash teacher's lookup + head writes its own
+        # extent {first workgroup's start, last one's end} into a row of fused_spans [K, 2] (pvd_hash_head_forward_fused_span)
+        self.fused_spans = None
+        if getattr(self, "record_fused_spans", False) and getattr(self.model_tea, "model_type", "") == "hash":
+            import pvd_hip
+            self.fused_spans = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT)] * K, dtype=torch.int64, device=self.device)
         if split and not self.optimizer.begin_two_part(defer=True):
             split = late = carry_a = False  # (no warm-group lists, or no rows of one of the two kinds: one launch)
         if split:
@@ -1001,6 +1007,8 @@ class DistillTrainer(_TrainerBase):
 
                         def fork(k=k):
                             branch.wait_stream(main)
+                            if self.fused_spans is not None:  # (measurement) this step's teacher launch leaves its extent in row k
+                                self.model_tea._fused_span = self.fused_spans[k]
                             with torch.cuda.stream(branch):
                                 if fork_at == "start" and pack_ahead is not None and pack_ahead(self.model_stu):
                                     # the student's f16 weight image for THIS step's head (5 us on the main chain otherwise): the
@@ -1133,6 +1141,12 @@ class DistillTrainer(_TrainerBase):
         torch.cuda.synchronize()
         fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
         pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
+        # (measurement, bench.py) record_fused_spans: every recorded launch of the frozen hash teacher's lookup + head writes its own
+        # extent {first workgroup's start, last one's end} into a row of fused_spans [K, 2] (pvd_hash_head_forward_fused_span)
+        self.fused_spans = None
+        if getattr(self, "record_fused_spans", False) and getattr(self.model_tea, "model_type", "") == "hash":
+            import pvd_hip
+            self.fused_spans = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT)] * K, dtype=torch.int64, device=self.device)
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)

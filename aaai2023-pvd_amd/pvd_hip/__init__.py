@@ -81,7 +81,7 @@ ENTRY_POINTS = (
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_backward", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
-    "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_infer_image_hash",
+    "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_composite_objective_blocks", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
@@ -669,8 +669,10 @@ def head_forward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sig
 
 
 def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, gridtype, align_corners, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3,
-                            clip_sigma_min, clip_max, sigma, rgb, feat16, image=None, rows_dev=None):
-    """Lookup (f16 table, 14 levels x 2 features) + hash head of a frozen model in one launch; see include/pvd_hip.h."""
+                            clip_sigma_min, clip_max, sigma, rgb, feat16, image=None, rows_dev=None, span=None):
+    """Lookup (f16 table, 14 levels x 2 features) + hash head of a frozen model in one launch; see include/pvd_hip.h.
+    span: optional int64 [2] DEVICE tensor {start, end} in 100 MHz ticks that the launch fills (min / max over its workgroups:
+    initialise with FUSED_SPAN_INIT) -- the launch's own extent where it ran (pvd_hash_head_forward_fused_span)."""
     dev = _dev(xyz, embeddings, offsets, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, sigma, rgb, feat16, image)
     _want(embeddings, torch.float16, "embeddings"), _want(offsets, torch.int32, "offsets")
     _f32_all(xyz=xyz, dirs=dirs, Wa1=Wa1, Wa2=Wa2, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, sigma=sigma, rgb=rgb, feat16=feat16)
@@ -679,10 +681,34 @@ def hash_head_forward_fused(xyz, in_add, in_div, embeddings, offsets, S, H, grid
     if xyz.shape[0] < M or dirs.shape[0] < M or sigma.numel() < M or rgb.numel() < 3 * M or feat16.numel() < 16 * M:
         raise PvdHipError("buffers shorter than M rows")
     _check_image(0, image)
+    if span is not None:
+        _dev(span)
+        _want(span, torch.int64, "span")
+        if span.numel() < 2 or span.device != dev:
+            raise PvdHipError("span must be an int64 [2] tensor on the launch's device")
+        status = _invoke("pvd_hash_head_forward_fused_span", dev, _p(xyz), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H),
+                         _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
+                         _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev), _p(span),
+                         meta=(M, 3, 2, 14, PVD_F16))
+        _check(status, "pvd_hash_head_forward_fused_span")
+        return
     status = _invoke("pvd_hash_head_forward_fused", dev, _p(xyz), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H),
                      _u32(gridtype), _int(int(bool(align_corners))), _p(dirs), _u32(M), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image),
                      _f32(clip_sigma_min), _f32(clip_max), _p(sigma), _p(rgb), _p(feat16), _rows_dev(rows_dev, dev), meta=(M, 3, 2, 14, PVD_F16))
     _check(status, "pvd_hash_head_forward_fused")
+
+
+# {start, end} of an empty span record: unsigned ~0 (as int64: -1) for the min, 0 for the max
+FUSED_SPAN_INIT = (-1, 0)
+
+
+def fused_span_us(span):
+    """[..., 2] int64 span records -> microseconds per record (NaN where the launch did not write)."""
+    import numpy as _np
+    s = span.detach().cpu().numpy().astype("uint64")
+    start, end = s[..., 0], s[..., 1]
+    out = (end.astype("float64") - start.astype("float64")) * 0.01
+    return _np.where((start == _np.uint64(0xFFFFFFFFFFFFFFFF)) | (end == 0), _np.nan, out)
 
 
 def infer_image_hash(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, in_add, in_div, embeddings, offsets,

@@ -428,6 +428,8 @@ def main():
         else int(os.environ["PVD_STEPS_PER_GRAPH"])
     if not args.eager:
         try:
+            # (roofline, in_step) every recorded launch of the teacher's lookup + head leaves its own extent behind: read after the timed region
+            w.trainer.record_fused_spans = not dp.enabled
             w.enable_graph(steps_per_graph=spg)  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
             launch_mode = "hipGraph replay" + (" (%d steps per graph launch%s)" % (
                 w.steps_per_call, (", the next replay's marches + teacher forwards on ONE forked branch per graph" if getattr(w.trainer, "pipeline_fork", "") == "graph" else
@@ -481,6 +483,27 @@ def main():
         dt = time.perf_counter() - t1
         sustained = {"steps": n_calls * spc, "ms_per_step": dt / (n_calls * spc) * 1e3, "window_s": dt,
                      "vs_timed": (dt / (n_calls * spc)) / (elapsed / args.steps)}
+
+    # ---- the roofline kernel WHERE IT RUNS, live: a few more replays behind the measured windows; every launch of the teacher's
+    # lookup + head inside the replayed graph writes {first workgroup's start, last workgroup's end} (the device's 100 MHz counter)
+    # into its own record (pvd_hash_head_forward_fused_span), reset here before every replay
+    in_step_live = None
+    spans = getattr(w.trainer, "fused_spans", None)
+    if spans is not None and not args.eager:
+        try:
+            import pvd_hip
+            init = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT)] * spans.shape[0], dtype=torch.int64, device=spans.device)
+            vals = []
+            for _ in range(max(2, 100 // spc)):
+                spans.copy_(init)
+                w.step()
+                torch.cuda.synchronize()
+                vals.extend(float(v) for v in pvd_hip.fused_span_us(spans) if v == v)
+            if vals:
+                in_step_live = {"us_per_launch": float(np.median(vals)), "mean_us": float(np.mean(vals)), "min_us": float(np.min(vals)),
+                                "max_us": float(np.max(vals)), "launches": len(vals)}
+        except Exception as e:  # noqa: BLE001
+            in_step_live = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
 
     # ---- roofline of the hash-grid lookup (the kernel north_star names).  HIP events cannot sit inside the replayed step,
     # so right after the timed region the SAME kernel is launched on the samples of one more step: the frozen teacher's
@@ -572,11 +595,12 @@ def main():
                            "why": "same kernel, same launch size; the camera decides how many cache lines a wave's gathers touch (x-neighbours "
                                   "share a line, y / z neighbours do not): the mean over 8 cameras spread over the epoch of %d" % P}
         # ---- the same kernel WHERE IT RUNS: inside the replayed step it sits on the forked branch of the graph next to the student's
-        # table scatter and update and is stretched by sharing the chip.  That duration cannot be taken live: this runtime has no
-        # way to stamp an event inside a replayed hipGraph (torch refuses external events on ROCm, plain event-record nodes return
-        # hipErrorInvalidHandle from hipEventElapsedTime: tools/probe_graph_events.py, profiles/r03_graph_events_probe.txt).  It is
-        # measured by rocprofv3 over the driver's command and committed (profiles/r03_kernel_populations.txt); the record is
-        # QUOTED here, labelled as such, when it was taken on this build of the kernel.
+        # head backward and is stretched by sharing the chip.  No host-side event can be placed inside a replayed hipGraph on this
+        # runtime (torch refuses external events on ROCm, plain event-record nodes return hipErrorInvalidHandle from
+        # hipEventElapsedTime: tools/probe_graph_events.py, profiles/r03_graph_events_probe.txt) -- since round 4 the launch stamps
+        # its own extent (in_step_live above: the headline).  The rocprofv3 record of the driver's command, committed under
+        # profiles/, is kept next to it as the outside view of the same quantity when it was taken on this build of the kernel
+        # (under the profiler the graph's kernels overlap less, so that figure is the shorter one).
         in_step = None
         rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
         if fused and rec_path:
@@ -588,8 +612,17 @@ def main():
                            "timing": "NOT live: rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5` on the builder's lease, launches that "
                                      "overlap the student's backward / scatter (profiles/%s), same kernel source hash"
                                      % os.path.basename(rec_path).replace("in_step.json", "kernel_populations.txt")}
-        # headline: the in-step figure when a rocprofv3 record of THIS build of the kernel exists (the figure where the
-        # kernel actually runs), else the live alone figure; both are always in the object
+        # ... and LIVE since round 4: the launch stamps its own extent (in_step_live above); the rocprofv3 record stays in the object
+        # as the outside corroboration of the same quantity (`in_step_rocprof`)
+        in_step_rocprof = in_step
+        if fused and in_step_live is not None and "error" not in in_step_live:
+            us_in = in_step_live["us_per_launch"]
+            in_step = dict(in_step_live, samples_per_launch=B, achieved=gbs(us_in), frac=gbs(us_in) / HBM_PEAK_GBS,
+                           timing="LIVE: every launch of the kernel inside the replayed graphs writes {min start, max end} over its workgroups in "
+                                  "s_memrealtime ticks (10 ns) into its own record; %d replays behind the timed and the sustained window, "
+                                  "median over their launches" % max(2, 100 // spc))
+        # headline: the in-step figure (the figure where the kernel actually runs), else the live alone figure; both are
+        # always in the object
         head = in_step if in_step is not None else alone
         traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
         pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
@@ -606,8 +639,9 @@ def main():
         roof = {"kernel": ("k_hash_fwd_fused (pvd_hash_head_forward_fused: hash-grid lookup f16 3x2x14 + sigma/colour head, one launch)" if fused
                            else "pvd_grid_encode_forward_affine + pvd_head_forward (two launches)"),
                 "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                "where": ("inside the replayed step, next to the student's backward (quoted rocprofv3 record of this build, see in_step); alone on "
-                          "the chip, live: see alone / alone_epoch" if in_step is not None else
+                "where": ("inside the replayed step, next to the student's backward (%s, see in_step); alone on "
+                          "the chip, live: see alone / alone_epoch" % ("live: the launch's own start / end stamps" if in_step is not in_step_rocprof
+                                                                     else "quoted rocprofv3 record of this build") if in_step is not None else
                           "alone on the chip (live HIP events, cameras of the timed region); no rocprofv3 record of this build for the in-step figure"),
                 "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * Bh, "bytes_per_sample": bps,
                 "bytes_per_sample_fused": 552 if fused else None,
@@ -615,7 +649,7 @@ def main():
                 "alone": alone, "alone_epoch": alone_epoch,
                 "alone_next_batch": (None if next_cam is None else {"camera": next_cam, "us_per_launch": per_cam[next_cam], "frac": gbs(per_cam[next_cam]) / HBM_PEAK_GBS,
                                                                     "what": "rounds 1-3's protocol: ONE camera, the batch right behind the timed region"}),
-                "in_step": in_step,
+                "in_step": in_step, "in_step_rocprof": in_step_rocprof if in_step_rocprof is not in_step else None,
                 "rederive": "python tools/roofline_from_profile.py  (profiles/r04_kernel_populations.txt + r04_bench_profiled_line.json + r04_kernel_stats.csv)"}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}

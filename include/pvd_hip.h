@@ -320,6 +320,18 @@ int pvd_hash_head_forward_fused(const float *xyz, float in_add, float in_div, co
                                 float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
                                 pvd_stream_t stream);
 
+/* The same launch, leaving its own extent behind: span (DEVICE uint64 [2], initialised {~0, 0} by the caller; NULL = plain
+ * pvd_hash_head_forward_fused) receives span[0] = min over the workgroups of their start and span[1] = max of their end in ticks of
+ * the device's constant 100 MHz counter (s_memrealtime) -- (span[1] - span[0]) * 10 ns is how long the launch lasted WHERE IT
+ * RAN: recorded into a hipGraph next to other kernels, where no host event can bracket it (bench.py's `roofline.in_step`).  Only
+ * the G = 7 / 14 kernels of the default build write it (PVD_FUSED_VARIANT=0 leaves it untouched). */
+int pvd_hash_head_forward_fused_span(const float *xyz, float in_add, float in_div, const void *embeddings_f16,
+                                     const int32_t *offsets, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                     const float *dirs, uint32_t M, const float *Wa1, const float *Wa2, const float *Wc1,
+                                     const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min,
+                                     float clip_max, float *sigma, float *rgb, float *feat16, const int32_t *rows_dev,
+                                     uint64_t *span, pvd_stream_t stream);
+
 /* A whole inference render of a frozen hash model in ONE persistent launch (+ a small compaction launch): what run_cuda's eval
  * branch does in rounds -- march_rays -> model -> composite_rays -> compact_rays until every ray has ended
  * (distill_mutual/renderer.py:450-543, raymarching.cu:704-948) -- with the rays' state in registers, the samples of a round in

@@ -48,6 +48,9 @@ def test_single_gpu_line_carries_the_contract():
     assert r["bytes_per_sample"] == 516  # SURVEY section 8(d)'s algorithmic figure for the f16 lookup
     assert abs(r["achieved"] - r["bytes_per_sample"] * r["samples_per_launch"] / (r["us_per_launch"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
     assert r["alone"]["us_per_launch"] > 0 and r["alone"]["launches"] >= 20
+    # the headline figure is the kernel's duration INSIDE the replayed step, stamped by the launch itself (live, not quoted)
+    assert r["in_step"]["timing"].startswith("LIVE") and r["in_step"]["launches"] >= 20 and r["in_step"]["us_per_launch"] > 0
+    assert abs(r["us_per_launch"] - r["in_step"]["us_per_launch"]) < 1e-9 and "live" in r["where"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     su = d["sustained"]  # a second, longer synchronised window behind the timed one

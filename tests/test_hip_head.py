@@ -330,6 +330,39 @@ def test_every_variant_of_the_fused_kernel_produces_the_same_bits(variant, dma, 
         assert all(torch.equal(a, b) for a, b in zip(ref, got)), (variant, dma, M)
 
 
+def test_the_fused_launch_stamps_its_own_extent():
+    """pvd_hash_head_forward_fused_span: the same outputs bit for bit, and {min start, max end} over the launch's workgroups in the
+    device's 100 MHz counter -- bench.py reads the in-step duration of the roofline kernel from it, inside a replayed graph where no
+    host event can sit.  The span of a launch alone on the chip must agree with a HIP-event bracket of the same launch."""
+    import fusedhead
+    import pvd_hip
+    m = _model("hash").eval()
+    x, d = _inputs(92928)
+    ref = fusedhead.hash_head_infer(m, x, d)
+    span = torch.tensor(list(pvd_hip.FUSED_SPAN_INIT), dtype=torch.int64, device=x.device)
+    assert np.isnan(pvd_hip.fused_span_us(span))  # an untouched record reads as "not written"
+    m._fused_span = span
+    got = fusedhead.hash_head_infer(m, x, d)
+    assert "_fused_span" not in m.__dict__  # consumed by the launch it was meant for
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    torch.cuda.synchronize()
+    us = float(pvd_hip.fused_span_us(span))
+    assert 5.0 < us < 500.0, us
+    # against HIP events around the same launch (events add the launch's ramp and a kernel boundary: a few us more)
+    times = []
+    for _ in range(5):
+        span.copy_(torch.tensor(list(pvd_hip.FUSED_SPAN_INIT), dtype=torch.int64, device=x.device))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        m._fused_span = span
+        a.record()
+        fusedhead.hash_head_infer(m, x, d)
+        b.record()
+        torch.cuda.synchronize()
+        times.append((float(pvd_hip.fused_span_us(span)), 1e3 * a.elapsed_time(b)))
+    s_us, e_us = min(t[0] for t in times), min(t[1] for t in times)
+    assert s_us <= e_us + 1.0 and s_us >= 0.4 * e_us, times  # (the bracket also covers the launch of the output allocations' fills, if any)
+
+
 def test_vm_head_weight_gradient_reduction_riding_on_the_table_scatter():
     """The reduction of the VM head's per-workgroup weight-gradient tiles inside the table scatter's launch
     (pvd_head_backward_defer + pvd_vm_backward_rider, csrc/head_dw_reduce.h) against its own launch (PVD_HEAD_DW_RIDE=0): the same
