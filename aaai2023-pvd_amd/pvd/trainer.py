@@ -822,6 +822,10 @@ class DistillTrainer(_TrainerBase):
         # stage that gets captured is the one AFTER them, and they must not straddle a stage boundary (the warm-up and the
         # captured step would then build different losses)
         warm = 3
+        if self.flat_opt:
+            self.optimizer.flush()  # (a part of the previous recording's last update may still be owed: FlatAdamW.carry_last)
+        self._replay_owes_part_a = None  # what replay() tells the optimizer afterwards belongs to the recording made below
+        self.fused_spans = None
         stage = self._stage_of(self.global_step)
         assert self._stage_of(self.global_step + warm) == stage, \
             "capture_step: the %d warm-up steps cross a stage boundary (global_step %d); step eagerly past it first" % (warm, self.global_step)
