@@ -82,3 +82,15 @@ def test_the_binding_settles_the_hardware_queues_before_the_runtime_starts():
     assert run(GPU_MAX_HW_QUEUES="4") == ["4", "4", "caller", "False"]
     assert run(GPU_MAX_HW_QUEUES="4", PVD_FORKED_GRAPHS="1") == ["4", "4", "caller", "True"]
     assert run(PVD_FORKED_GRAPHS="0") == ["2", "2", "package", "False"]
+
+
+def test_span_records_read_as_microseconds(hip_lib_built):
+    """pvd_hip.fused_span_us: {start, end} records of pvd_hash_head_forward_fused_span in ticks of the device's 100 MHz counter ->
+    microseconds; a record nobody wrote (FUSED_SPAN_INIT: unsigned ~0 / 0) reads as NaN.  (Host-side helper: no GPU involved.)"""
+    import numpy as np
+    import torch
+    import pvd_hip
+    rec = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT), [1000, 3350], [2 ** 40, 2 ** 40 + 5]], dtype=torch.int64)
+    us = pvd_hip.fused_span_us(rec)
+    assert np.isnan(us[0]) and us[1] == 23.5 and abs(us[2] - 0.05) < 1e-12
+    assert np.isnan(pvd_hip.fused_span_us(rec[0]))  # a single record
