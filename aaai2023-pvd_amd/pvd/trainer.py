@@ -963,7 +963,11 @@ class DistillTrainer(_TrainerBase):
         #          and on the memory side's atomic units, not on HBM: 0.280 vs 0.296 ms/step (profiles/r04_adamw_late_ab.txt).
         #   "0"    one launch.
         split_mode = os.environ.get("PVD_ADAMW_SPLIT", "late")
-        split = (self.flat_opt and not self.dp.enabled and fork_mode == "start" and K >= 2 and split_mode in ("1", "late"))
+        # (ray-DP with the collectives in the graph: the deferred rows are the ones no sample reaches -- they are not part of the
+        # exchange, and their update needs nothing but the step's scalars, which are the same on every rank -- so "late" holds there
+        # too, and the deferred part then runs under the exchange)
+        split = (self.flat_opt and fork_mode == "start" and K >= 2 and split_mode in ("1", "late")
+                 and (not self.dp.enabled or (self.dp.ingraph and split_mode == "late")))
         # "late": part A of step k - 1 is launched at the END of step k's branch (after the next prefix: next to step k's head backward
         # and table scatter, which wait on the matrix cores and on the memory side) instead of at its start; the objective does not
         # wait for it -- the L1 VALUE it reports then counts the L1-only rows one step late (parameters and gradients are unaffected:

@@ -99,6 +99,8 @@ def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1")
     if ingraph:  # both collectives recorded into the one graph of the step
         assert dp.ingraph and len(cap.graphs) == 1 and len(cap.between) == 0
         assert bool(getattr(w.trainer, "pipelined_ingraph", False)) == (pipeline == "2" and steps_per_graph > 1)
+        if pipeline == "2" and steps_per_graph > 1:  # the update's deferred part rides on the branch under ray-DP as well (rank-independent rows)
+            assert w.trainer.adamw_split == "late" and w.trainer.optimizer._graph_is_two_part
     else:
         assert len(cap.graphs) == 3 and len(cap.between) == 2
         assert getattr(w.trainer, "_g_prefix", None) is not None
