@@ -24,6 +24,12 @@ def t_ar_us(n, mb, busbw_gbs):
     return 2.0 * (n - 1) / n * mb * 1e6 / (busbw_gbs * 1e9) * 1e6 + 2 * (n - 1) * a.hop_us
 
 
+def t_direct_us(n, mb, link_gbs=76.8, lat_us=6.0):
+    """two-shot all-reduce on a fully connected node: reduce-scatter then all-gather, every GPU sends B / n to each
+    of its n - 1 peers over its own link at the same time: 2 x (B / n) / link bandwidth (one direction of one xGMI link) + two latencies"""
+    return 2.0 * (mb * 1e6 / n) / (link_gbs * 1e9) * 1e6 + 2 * lat_us
+
+
 print("step_1 %.3f ms, ray-DP recording %.3f ms, %.1f MB on the wire in fp32, %.0f us per ring hop" % (a.step1, a.step_dp, a.mb, a.hop_us))
 print("%-44s %8s %8s %8s" % ("", "N = 2", "N = 4", "N = 8"))
 for label, mb, hidden in (("fp32 wire, exchange not overlapped (shipped)", a.mb, 0.0),
@@ -36,3 +42,8 @@ for label, mb, hidden in (("fp32 wire, exchange not overlapped (shipped)", a.mb,
             t = max(t_ar_us(n, mb, bw) - hidden, 0.0)
             eff.append(a.step1 * 1e3 / (a.step_dp * 1e3 + t))
         print("%-44s %8.2f %8.2f %8.2f   (bus bandwidth %3.0f GB/s: t_AR(8) = %3.0f us)" % (label, eff[0], eff[1], eff[2], bw, t_ar_us(8, mb, bw)))
+
+for label, mb, hidden in (("direct two-shot over all 7 links, fp32", a.mb, 0.0), ("direct two-shot, 16-bit wire", a.mb / 2, 0.0),
+                          ("direct two-shot, fp32, bucket overlap", a.mb, 66.0)):
+    eff = [a.step1 * 1e3 / (a.step_dp * 1e3 + max(t_direct_us(n, mb) - hidden, 0.0)) for n in (2, 4, 8)]
+    print("%-44s %8.2f %8.2f %8.2f   (76.8 GB/s per link and direction: t_AR(8) = %3.0f us)" % (label, eff[0], eff[1], eff[2], t_direct_us(8, mb)))
