@@ -178,11 +178,41 @@ class RayDP:
         self.ingraph = (self.enabled and dist.get_backend(group) == "nccl" and os.environ.get("PVD_DP_INGRAPH", "1") != "0")
 
 
+    def _two_shot_sum_(self, t):
+        """SUM over ranks as reduce-scatter + all-gather built from ALL-TO-ALL exchanges (PVD_DP_EXCHANGE=twoshot, opt-in): rank r
+        receives chunk r of every peer, adds the n chunks in rank order, and sends the sum to every peer.  On a fully connected
+        node every rank then talks to its n - 1 peers at once over its own links -- 2 (S / n) / one link's bandwidth instead of
+        a ring's 2 (n - 1) / n S / (its slowest hop) (tools/scale_model.py) -- and every
+        element is summed by exactly ONE rank, so the replicas receive identical bits by construction."""
+        n = self.world_size
+        flat = t.reshape(-1)
+        chunk = (flat.numel() + n - 1) // n
+        send = flat
+        if chunk * n != flat.numel():
+            send = torch.zeros(chunk * n, dtype=flat.dtype, device=flat.device)
+            send[:flat.numel()].copy_(flat)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)  # recv[k * chunk : (k + 1) * chunk] = rank k's chunk `rank`
+        red = recv.view(n, chunk)[0].clone()
+        for k in range(1, n):  # rank order: the same sum whichever rank forms it
+            red.add_(recv.view(n, chunk)[k])
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, red.repeat(n), group=self.group)  # out[k * chunk : ...] = the sum rank k formed
+        flat.copy_(out[:flat.numel()])
+        return t
+
     def all_reduce_sum_(self, t, overlap=None):
         """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
         next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
         if self.enabled:
-            run = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            # (verified on gloo only, tests/test_dist_gloo.py.  NOT recorded into a graph and not taken in a one-rank world: an attempt to
+            # capture RCCL's all-to-all in a forced one-rank world did not return within ten minutes on the GPU box)
+            two_shot = (os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "twoshot" and self.world_size > 1
+                        and not (self.capture is not None and self.capture.active and self.ingraph)
+                        and t.numel() >= int(os.environ.get("PVD_DP_TWOSHOT_MIN", "65536")))  # (scalars and short buffers: one latency-bound all-reduce)
+            run = (lambda: self._two_shot_sum_(t)) if two_shot else (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
+            if two_shot:
+                overlap = None  # (its exchanges are issued synchronously: the overlap callable would only follow them)
             if self.capture is not None and self.capture.active and self.ingraph:
                 run()  # recorded as a node of the graph being captured
             elif self.capture is not None and self.capture.active:
