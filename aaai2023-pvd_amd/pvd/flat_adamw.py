@@ -170,13 +170,20 @@ class FlatAdamW(torch.optim.Optimizer):
         if not will:
             return False
         self._snap_buffers()  # (allocated and initialised OUTSIDE the recording)
+        self._graph_is_two_part = False  # (set again by the first part A this recording launches)
         self.two_part, self.defer_part_a = True, bool(defer)
         self._l1_layout_is("two")
         return True
 
-    def end_two_part(self):
-        """After the recording: eager steps go back to the single launch (the recorded graph keeps the two parts)."""
+    def end_two_part(self, failed=False):
+        """After the recording: eager steps go back to the single launch (the recorded graph keeps the two parts).  failed: the
+        recording raised -- no graph with two parts exists, and whatever is recorded next (the trainer's back-to-back fall-back)
+        is a single launch whose L1 partial sums must be laid out as one region BEFORE that capture begins."""
         self.two_part = self.defer_part_a = self.carry_last = self._next_step_is_last = False
+        if failed:
+            self._graph_is_two_part = False
+            self._owed_is_carried = False
+            self._l1_layout_is("one")
 
     touched = None  # set_touched(): the only entries of flat_g anything ever writes (pvd/dp_compact.py), or None = all
     _outside_is_zero = False

@@ -582,7 +582,7 @@ class _TrainerBase:
         if self.flat_opt:
             self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
             self.optimizer._part_a_owed = None  # (a two-part update recorded half way: nothing of it ran)
-            self.optimizer.end_two_part()
+            self.optimizer.end_two_part(failed=True)
         for mdl in (getattr(self, "model_stu", None), self.model):
             if mdl is not None and getattr(mdl, "_between_backwards", None) is not None:
                 mdl._between_backwards = None

@@ -124,6 +124,32 @@ def test_two_part_update_in_the_pipelined_graph_leaves_the_single_launch_bits(mo
     assert np.allclose(la, lb, rtol=2e-3) and abs(l1a - l1b) <= 1e-4 * abs(l1b) and abs(lea - leb) <= 2e-3 * abs(leb), (la, lb, l1a, l1b, lea, leb)
 
 
+def test_a_forked_recording_that_fails_falls_back_to_back_to_back_steps_that_train(monkeypatch):
+    """with the update in two parts by default, a forked recording that raises half way left the L1 partial sums laid
+    out for two parts; the back-to-back fall-back (one launch per step, recorded without warm-up) then tripped over
+    `the form of the update must be settled before a capture begins`.  Force the failure: the fall-back must record, replay
+    and track an undisturbed run of the same seeds (a replayed step's loss includes the L1 value, which the stale layout
+    over-counted)."""
+    ref = _workload(13)
+    torch.cuda.manual_seed(41)
+    ref.enable_graph(steps_per_graph=4)
+    assert getattr(ref.trainer, "pipelined_ingraph", False) and ref.trainer.optimizer._graph_is_two_part
+    lr = [float(ref.step()[0]) for _ in range(3)]
+    monkeypatch.setenv("PVD_TEST_FAIL_IN_CAPTURE", "forked")
+    w = _workload(13)
+    torch.cuda.manual_seed(41)
+    w.enable_graph(steps_per_graph=4)
+    monkeypatch.delenv("PVD_TEST_FAIL_IN_CAPTURE")
+    tr, o = w.trainer, w.trainer.optimizer
+    assert getattr(tr, "capture_fallback", None) == "back-to-back" and not getattr(tr, "pipelined_ingraph", False)
+    assert not o._graph_is_two_part and o._l1_layout == "one" and o._part_a_owed is None and not o.two_part
+    lw = [float(w.step()[0]) for _ in range(3)]
+    assert np.all(np.isfinite(lw)) and np.allclose(lw, lr, rtol=2e-3), (lw, lr)
+    st = o._l1_track
+    torch.cuda.synchronize()
+    assert abs(float(st["buf"].sum()) - float(o.l1_value(st["scale"]))) <= 2e-5 * abs(float(o.l1_value(st["scale"])))
+
+
 def test_what_the_host_believes_about_the_gradients_after_a_replay_is_what_the_graph_did():
     """Inside a multi-step graph the update zeroes the gradients it has read (touched-set / warm-list form), so only the first
     step of the graph launches a zero_grad; after a replay the touched set IS clean and the next zero_grad has nothing to
