@@ -502,7 +502,7 @@ struct FusedLookup {
     unsigned long long *span = nullptr;
 };
 
-// Round 4.  What the round-3 kernel below (k_hash_fwd_fused_r3, kept for A/B: PVD_FUSED_VARIANT=0) really executed was
+// Round 4.  What the round-3 kernel (removed in round 5; DESIGN section 10.1, profiles/r04_fused_variants_ab.txt) really executed was
 // FOURTEEN dependent memory round trips per workgroup, not two: `g.offsets` is a pointer inside a by-value struct, so the
 // compiler cannot prove the table of level offsets invariant, fetches offsets[level + 1] with a VECTOR load in front of every
 // level and waits for it -- and vmcnt retires in order, so that wait (s_waitcnt vmcnt(1) / vmcnt(0) in the ISA) also drains
@@ -988,128 +988,6 @@ static size_t infer_persistent_lds_bytes() {
            sizeof(float) * (3 * kInfRows + kInfRows + 3 * kInfRows + 3 * kHeadBlock) + sizeof(uint32_t) * (kInfRows + 8);
 }
 
-__global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused_r3(HeadArgs a, FusedLookup g) {
-    extern __shared__ __align__(16) half_t lds[];
-    constexpr uint32_t D = 3, L = 14;
-    if (a.rows_dev) a.M = min(a.M, (uint32_t)max(*a.rows_dev, 0));
-    if (blockIdx.x * kFusedTile >= a.M) return;  // nothing for this workgroup: skip the weight staging too
-    HeadLds<KIND_HASH> W;
-    W.carve(lds);
-    half_t *feat = lds + ((HeadLds<KIND_HASH>::halfs + 7) & ~7);  // [kFusedTile][kFeatStride]
-    const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4, wave = threadIdx.x >> 6;
-    // The head's weights: with a packed image, 24 KB of L2 hits go straight into LDS (global_load_lds_dwordx4: no data
-    // registers, nothing to wait for here) while the lookup below runs; register-staged in front of the lookup they were 2.3 us
-    // of a 24 us workgroup (cycle stamps, tools/prof_fused_stamps.py).  The barrier after the lookup drains them.
-    bool dma_pending = a.image != nullptr;  // issued behind the first group of gathers (below)
-    if (!dma_pending) W.load(a, threadIdx.x, kHeadBlock);
-    for (uint32_t i = threadIdx.x; i < kFusedTile * 2; i += kHeadBlock)  // features 28..31 of every row: zero for good
-        *reinterpret_cast<uint32_t *>(feat + (i >> 1) * kFeatStride + 28 + 2 * (i & 1)) = 0u;
-    const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
-    const uint32_t nchunks = div_up(a.M, kFusedTile);
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        // ---------------- phase 1: 14-level lookup of sample b by the lane pair (b, xb)
-        const uint32_t b = chunk * kFusedTile + s_local;
-        float x01[D] = {0.f, 0.f, 0.f};
-        bool inside = b < a.M;
-        if (inside) {
-            const Pos3 p = *reinterpret_cast<const Pos3 *>(g.xyz + (size_t)b * D);
-            x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                if (g.aff.on) x01[d] = (x01[d] + g.aff.add) / g.aff.div;
-                inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
-            }
-        }
-        // directions of the (two) 16-sample tiles this wave will run the head on: loaded now, used after the lookup
-        constexpr int kTilesPerWave = kFusedTile / 16 / (kHeadBlock / 64);
-        float dir_pre[kTilesPerWave][3];
-#pragma unroll
-        for (int ti = 0; ti < kTilesPerWave; ti++) {
-            const size_t bs = (size_t)chunk * kFusedTile + (wave + ti * (kHeadBlock / 64)) * 16 + (lane & 15);
-            const bool valid = bs < a.M;
-#pragma unroll
-            for (int c = 0; c < 3; c++) dir_pre[ti][c] = valid ? a.dirs[3 * bs + c] : 0.f;
-        }
-        // The 14 levels in two groups of 7: all 28 gathers of a group are issued before the first blend, so a wave has one
-        // memory round trip per group instead of one per level (the levels are independent; with <= 3 workgroups per CU nothing
-        // else hides that latency).  Branch-free: a sample outside the box gathers row 0 of every level and is zeroed afterwards.
-        constexpr uint32_t G = 7;
-#pragma unroll
-        for (uint32_t l0 = 0; l0 < L; l0 += G) {
-            uint32_t v[G][4];
-            float fr[G][D];
-#pragma unroll
-            for (uint32_t j = 0; j < G; j++) {
-                const uint32_t level = l0 + j;
-                const uint32_t off0 = (uint32_t)g.offsets[level];
-                const float scale = g.scales.scale[level];
-                LevelIndex<D> index;
-                index.init((uint32_t)g.offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, g.gridtype, g.align_corners);
-                const uint32_t *__restrict__ table = g.grid + off0;
-                uint32_t cell[D];
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) {
-                    const float p = fmaf(x01[d], scale, g.align_corners ? 0.0f : 0.5f);
-                    const float fl = floorf(p);
-                    cell[d] = inside ? (uint32_t)fl : 0u;
-                    fr[j][d] = p - (float)(uint32_t)fl;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t pg[D] = {cell[0] + xb, cell[1] + (k & 1u), cell[2] + (k >> 1)};
-                    v[j][k] = table[inside ? index(pg) : 0u];
-                }
-            }
-            if (l0 == 0 && dma_pending) {
-                dma_pending = false;
-                copy_image_dma(lds, a.image, HeadLds<KIND_HASH>::halfs, threadIdx.x);
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < G; j++) {
-                uint32_t acc = 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t yb = k & 1u, zb = k >> 1;
-                    float wi = 1;  // the reference's product order: ((1 * wx) * wy) * wz
-                    wi *= xb ? fr[j][0] : 1 - fr[j][0];
-                    wi *= yb ? fr[j][1] : 1 - fr[j][1];
-                    wi *= zb ? fr[j][2] : 1 - fr[j][2];
-                    const uint32_t pr = weighted_pair(wi, v[j][k]);
-                    const uint32_t other = dpp_quad<0xB1>(pr);
-                    acc = pk_add(acc, xb ? other : pr);
-                    acc = pk_add(acc, xb ? pr : other);
-                }
-                if (xb == 0) *reinterpret_cast<uint32_t *>(feat + s_local * kFeatStride + 2 * (l0 + j)) = inside ? acc : 0u;
-            }
-        }
-        __syncthreads();  // (also covers the weights / zero columns on the first pass)
-        // ---------------- phase 2: the head on the tile, 16 samples per wave and pass
-        for (uint32_t t16 = wave; t16 < kFusedTile / 16; t16 += kHeadBlock / 64) {
-            const uint32_t row = t16 * 16 + (lane & 15);
-            const size_t bs = (size_t)chunk * kFusedTile + row;
-            const bool valid = bs < a.M;
-            TileIn<KIND_HASH> in;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) in.x[s2] = *reinterpret_cast<const h4 *>(feat + row * kFeatStride + 16 * s2 + 4 * hi);
-            in.sraw = 0.f;
-            const int tsel = (int)((t16 - wave) / (kHeadBlock / 64));
-            in.dx = dir_pre[tsel][0]; in.dy = dir_pre[tsel][1]; in.dz = dir_pre[tsel][2];
-            TileFwd t;
-            head_forward_tile<KIND_HASH>(a, W, in, lane, t);
-            if (valid) {
-                *reinterpret_cast<f4 *>(a.feat16 + bs * 16 + 4 * hi) = t.F;
-                if (hi == 0) {
-                    a.sigma[bs] = __expf(t.F.x);
-                    a.rgb[3 * bs] = sigmoid_h(t.out.x);
-                    a.rgb[3 * bs + 1] = sigmoid_h(t.out.y);
-                    a.rgb[3 * bs + 2] = sigmoid_h(t.out.z);
-                }
-            }
-        }
-        __syncthreads();  // the next chunk's lookup overwrites the tile
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // The frozen `mlp` model (vanilla NeRF trunk, network.py:154-182 / forward_nerf_mlp, then the same sigma / colour head) in one
 // launch: positional encoding [M][64] f16 in (pvd_freq_encode), sigma / rgb / feature_sigma_color out.  The reference runs it
@@ -1369,19 +1247,13 @@ static int launch_hash_fwd_fused(const HeadArgs &a, const FusedLookup &g, hipStr
     uint32_t blocks = nchunks;
     if (blocks > 256u * 4u) blocks = 256u * 4u;  // persistent beyond 4 workgroups per CU
     const size_t lds_bytes = (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + kFusedTile * kFeatStride * sizeof(half_t);
-    // PVD_FUSED_VARIANT (measurement; read per launch so that one process can A/B): 0 = the round-3 kernel, 7 / 14 = levels per
-    // memory round trip.  All three produce the same bits.
-    int variant = 14, dma = 0;
-    if (const char *e = getenv("PVD_FUSED_VARIANT")) { variant = atoi(e); if (variant != 0 && variant != 7) variant = 14; }
+    // PVD_FUSED_DMA (measurement; read per launch so that one process can A/B): where the weight image's LDS-DMA is issued.  Same bits.
+    int dma = 0;
     if (const char *e = getenv("PVD_FUSED_DMA")) dma = atoi(e) == 1 ? 1 : 0;
     FusedRes gr;
     for (uint32_t l = 0; l < 14; l++) gr.res[l] = (uint32_t)ceil((double)g.scales.scale[l]) + 1u;
-
-    if (variant == 0) hipLaunchKernelGGL(k_hash_fwd_fused_r3, dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g);
-    else if (variant == 14 && dma == 0) hipLaunchKernelGGL((k_hash_fwd_fused<14, 0>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
-    else if (variant == 14) hipLaunchKernelGGL((k_hash_fwd_fused<14, 1>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
-    else if (dma == 0) hipLaunchKernelGGL((k_hash_fwd_fused<7, 0>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
-    else hipLaunchKernelGGL((k_hash_fwd_fused<7, 1>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    if (dma == 0) hipLaunchKernelGGL((k_hash_fwd_fused<14, 0>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
+    else hipLaunchKernelGGL((k_hash_fwd_fused<14, 1>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr);
     return check_launch();
 }
 
@@ -1408,9 +1280,31 @@ struct HeadBwdArgs {
     float *partials;        // [blocks][DwLayout::floats]
 };
 
-// 16x16 transpose of a register tile through LDS: in = X[row 4hi+j][col l&15]  ->  out = X[row l&15][col 4hi+j]
+// 16x16 transpose of a register tile through LDS: in = X[row 4hi+j][col l&15]  ->  out = X[row l&15][col 4hi+j].
+// Lane (c, hi) parks its four values -- X[4hi .. 4hi+3][c] -- as ONE 8-byte chunk of row c of T = X^T (ds_write_b64), and
+// ds_read_b64_tr_b16 hands every 16-lane group the [4][16] block T[4hi .. 4hi+3][0 .. 15] column-major: lane n of group hi receives
+// T[4hi + j][n] = X[n][4hi + j], j = 0..3 (lane i of the group addresses the chunk (row 4hi + i/4, columns 4(i%4) ..)).  Two LDS
+// instructions per tile instead of four 2-byte stores and a read.  The four chunks of row c sit at chunk position hi ^ (c >> 2): a
+// 16-lane store group (one hi, c = 0..15) then covers all 32 store banks once, and a 32-lane read group (rows 8 hi' .. 8 hi' + 7,
+// every chunk once) all 64 read banks once -- the row-major [16][16] halfs of rounds 2-4 put lanes c and c + 4 (stores) and rows
+// r and r + 8 (reads) on one bank: SQ_LDS_BANK_CONFLICT 1.4 cycles per LDS instruction (profiles/r04_pmc_step_kernels.csv).
+#ifndef PVD_HEAD_TR
+#define PVD_HEAD_TR 1
+#endif
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ h4 transpose_tile(h4 v, half_t *__restrict__ scratch, uint32_t lane) {
     const uint32_t c = lane & 15, hi = lane >> 4;
+#if PVD_HEAD_TR
+    *reinterpret_cast<h4 *>(scratch + c * 16 + 4 * (hi ^ (c >> 2))) = v;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t row = 4 * hi + (c >> 2);
+    const fp16x4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        (__attribute__((address_space(3))) fp16x4_t *)(scratch + row * 16 + 4 * ((c & 3) ^ hi)));
+    __builtin_amdgcn_wave_barrier();
+    h4 r;
+    __builtin_memcpy(&r, &t, sizeof(r));
+    return r;
+#else
     scratch[(4 * hi + 0) * 16 + c] = v.x;
     scratch[(4 * hi + 1) * 16 + c] = v.y;
     scratch[(4 * hi + 2) * 16 + c] = v.z;
@@ -1419,6 +1313,7 @@ __device__ __forceinline__ h4 transpose_tile(h4 v, half_t *__restrict__ scratch,
     const h4 r = *reinterpret_cast<const h4 *>(scratch + c * 16 + 4 * hi);
     __builtin_amdgcn_wave_barrier();
     return r;
+#endif
 }
 
 __device__ __forceinline__ h4 mask_relu(f4 g, h4 act) {  // dPre = dAct * (act > 0), rounded to f16
@@ -1707,29 +1602,15 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
     if (w1 > w0) __hip_atomic_fetch_add(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// waves per SIMD the backward is compiled for: 1 = all accumulators in registers (> 256 VGPRs), 2 = twice the
-// workgroups with ~40-80 spilled registers.  PVD_HEAD_BWD_OCC overrides (measurement).
-static int head_bwd_occupancy(int kind) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("PVD_HEAD_BWD_OCC");
-        forced = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
-    }
-    if (forced) return forced;
-    (void)kind;
-    return 1;  // measured after the one-tile-ahead loads: 1 wins for both heads (teacher step 0.59 vs 0.73 ms at 2)
-}
-
 template <int KIND>
 static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s,
                            pvd_head_dw_rider *defer = nullptr) {
     size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 256;
     if (lds_halfs < 2 * (size_t)DwLayout<KIND>::floats) lds_halfs = 2 * (size_t)DwLayout<KIND>::floats;
     const uint32_t nblocks = nwaves / (kHeadBlock / 64);
-    if (head_bwd_occupancy(KIND) == 2)
-        hipLaunchKernelGGL((k_head_bwd<KIND, 2>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
-    else
-        hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
+    // one wave per SIMD, all accumulators in registers (> 256 VGPRs); two waves with ~40-80 spilled registers measured slower for both
+    // heads (teacher step 0.59 vs 0.73 ms) and were removed
+    hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
     if (defer) {  // the reduction rides on the caller's next launch (pvd_vm_backward_rider)
         defer->partials = a.partials; defer->nblocks = nblocks; defer->gWa1 = gWa1; defer->gWc1 = gW1; defer->gWc2 = gW2; defer->gWc3 = gW3;
         return check_launch();
@@ -1858,17 +1739,11 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
     if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
     hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
     const size_t lds_bytes = infer_persistent_lds_bytes();
-    // ray slots per workgroup (PVD_INFER_RAYS = 64 | 128 | 256, measurement): three workgroups of 50 KB of LDS fit a CU
-    int rays = 64;
-    if (const char *e = getenv("PVD_INFER_RAYS")) { rays = atoi(e); if (rays != 128 && rays != 256) rays = 64; }
-    uint32_t blocks = div_up(N, (uint32_t)rays);
+    // 64 ray slots per workgroup, 256 sample rows per local round: three workgroups of 50 KB of LDS fit a CU (128 / 256 slots and
+    // 128-row tiles measured slower, profiles/r04_render.txt, and were removed)
+    uint32_t blocks = div_up(N, 64u);
     if (blocks > 768u) blocks = 768u;  // persistent
-    int rows_tile = 256;
-    if (const char *e = getenv("PVD_INFER_ROWS")) rows_tile = atoi(e) == 128 ? 128 : 256;
-    if (rays == 128) hipLaunchKernelGGL((k_infer_hash_persistent<128, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
-    else if (rays == 256) hipLaunchKernelGGL((k_infer_hash_persistent<256, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
-    else if (rows_tile == 128) hipLaunchKernelGGL((k_infer_hash_persistent<64, 128>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
-    else hipLaunchKernelGGL((k_infer_hash_persistent<64, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    hipLaunchKernelGGL((k_infer_hash_persistent<64, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
     return check_launch();
 }
 
@@ -1892,7 +1767,8 @@ int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstr
 static uint32_t head_bwd_waves(int kind, uint32_t M) {
     const uint32_t ntiles = div_up(M, 16u);
     uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
-    if (blocks > 256u * head_bwd_occupancy(kind)) blocks = 256u * head_bwd_occupancy(kind);  // one workgroup per CU and occupancy slot
+    (void)kind;
+    if (blocks > 256u) blocks = 256u;  // one workgroup per CU (persistent)
     if (blocks < 1) blocks = 1;
     return blocks * (kHeadBlock / 64);
 }

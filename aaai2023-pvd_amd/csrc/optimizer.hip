@@ -479,9 +479,9 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         // the deferred part: the scalars of the recorded step (found_inf, step count, scale, learning rates as published), no tail
         ex.sched_kind = 0;
         uint64_t blocks_a = ((uint64_t)ex.n_warm + kOptBlock - 1) / kOptBlock;
-        static int cap_a = -1;  // PVD_ADAMW_BLOCKS_A: workgroups of the deferred part (it runs NEXT TO other kernels: how many wave slots it takes)
-        if (cap_a < 0) { const char *e = getenv("PVD_ADAMW_BLOCKS_A"); cap_a = e ? atoi(e) : 0; if (cap_a < 1 || cap_a > 4096) cap_a = 512; }  // 512: 0.2803 vs 0.2830 ms/step with 4096 (profiles/r04_adamw_late_ab.txt)
-        if (blocks_a > (uint64_t)cap_a) blocks_a = (uint64_t)cap_a;
+        // the deferred part runs NEXT TO other kernels: 512 workgroups leave them their wave slots (0.2803 vs 0.2830 ms/step with
+        // 4096, profiles/r04_adamw_late_ab.txt)
+        if (blocks_a > 512u) blocks_a = 512u;
         if (blocks_a < 1) blocks_a = 1;
         hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks_a), dim3(kOptBlock), 0, s, p, const_cast<float *>(g), m, v, n, seg,
                            const_cast<float *>(replay + 4), beta1, beta2, eps, weight_decay, const_cast<float *>(replay + 1),
@@ -489,12 +489,8 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         return check_launch();
     }
     uint64_t blocks = ((ex.warm ? (uint64_t)ex.n_warm : n / 4) + kOptBlock - 1) / kOptBlock;
-    static int cap = -1;  // PVD_ADAMW_BLOCKS: workgroups of the update launch (measurement)
-    if (cap < 0) { const char *e = getenv("PVD_ADAMW_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > 65535) cap = 256 * 16; }
-    if (blocks > (uint64_t)cap) blocks = (uint64_t)cap;
-    // every workgroup writes one partial into l1_next[blockIdx.x]; the buffer's contract is ">= 4096 floats" (pvd_hip.h), so the
-    // measurement knob above must not grow the grid past it while the L1 value is tracked
-    if (ex.l1_next && blocks > 4096) blocks = 4096;
+    // 16 workgroups per CU; every workgroup writes one partial into l1_next[blockIdx.x], whose contract is ">= 4096 floats" (pvd_hip.h)
+    if (blocks > 4096u) blocks = 4096u;
     if (blocks < 1) blocks = 1;
     const bool amp = extras_host && extras_host->amp_scale;
     if (amp && (!extras_host->amp_growth_tracker || !found_inf || extras_host->amp_interval < 1)) return PVD_ERR_INVALID;

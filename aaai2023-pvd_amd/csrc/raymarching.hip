@@ -175,27 +175,6 @@ __global__ void __launch_bounds__(kBlock) k_packbits(const float *__restrict__ g
 // them (column 2 = count after pass 1, column 1 = offset after the scan), so the ABI needs
 // no workspace.  reference: kernel_march_rays_train, raymarching.cu:313-483.
 
-__global__ void __launch_bounds__(kBlock) k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                        const uint8_t *__restrict__ grid, float bound, float dt_gamma,
-                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                                        const float *__restrict__ nears, const float *__restrict__ fars,
-                                                        int32_t *__restrict__ rays, uint32_t ray_base_unused, uint32_t perturb) {
-    (void)ray_base_unused;
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    Dda r;
-    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
-    const float far = fars[n];
-    float t = ray_t0(nears[n], r.dt_min, perturb, 42u, n);  // rng = pcg32{42} (:488), advance(n) (:352)
-    uint32_t num = 0;
-    while (t < far && num < max_steps) {
-        float x, y, z, dt, tn;
-        if (r.probe(t, x, y, z, dt, tn)) { num++; t += dt; }
-        else t = tn;
-    }
-    rays[3 * (size_t)n + 2] = (int32_t)num;
-}
-
 // Single-workgroup exclusive scan of the per-ray counts (N is 4096 in training; a
 // 640k-ray full image is 625 trips of a 1024-wide scan).  Also bumps the caller's counter
 // the way the reference's two atomics do (:408-409).
@@ -246,43 +225,6 @@ __global__ void __launch_bounds__(kScanBlock) k_march_scan(int32_t *__restrict__
 __device__ __forceinline__ uint32_t logical_budget(uint32_t M, const int32_t *__restrict__ budget) {
     return budget ? min(M, (uint32_t)max(*budget, 0)) : M;
 }
-
-__global__ void __launch_bounds__(kBlock) k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                        const uint8_t *__restrict__ grid, float bound, float dt_gamma,
-                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                                        const float *__restrict__ nears, const float *__restrict__ fars,
-                                                        float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                                                        const int32_t *__restrict__ rays, uint32_t perturb,
-                                                        const int32_t *__restrict__ budget) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t off = (uint32_t)rays[3 * (size_t)n + 1];
-    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
-    if (num == 0) return;
-    if (off + num >= logical_budget(M, budget)) return;  // strict (:419)
-    Dda r;
-    r.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
-    const float far = fars[n];
-    float t = ray_t0(nears[n], r.dt_min, perturb, 42u, n);
-    float last_t = t;
-    float *px = xyzs + 3 * (size_t)off, *pd = dirs + 3 * (size_t)off, *pl = deltas + 2 * (size_t)off;
-    uint32_t step = 0;
-    while (t < far && step < num) {
-        float x, y, z, dt, tn;
-        if (r.probe(t, x, y, z, dt, tn)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-            t += dt;
-            pl[0] = dt;
-            pl[1] = t - last_t;  // skipped gaps included (:463-465)
-            last_t = t;
-            px += 3; pd += 3; pl += 2; step++;
-        } else {
-            t = tn;
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------ wave-per-ray marcher (dt_gamma == 0)
 // With dt_gamma == 0 every advance of t -- an occupied step or one trip of the skip loop -- adds the
@@ -973,69 +915,6 @@ __global__ void __launch_bounds__(kBlock) k_composite_bwd_wave(const float *__re
     }
 }
 
-// ------------------------------------------------------------------ composite (train)
-
-// reference: kernel_composite_rays_train_forward, raymarching.cu:504-582
-__global__ void __launch_bounds__(kBlock) k_composite_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                                          const float *__restrict__ deltas, const int32_t *__restrict__ rays,
-                                                          uint32_t M, uint32_t N, float *__restrict__ weights_sum,
-                                                          float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[3 * (size_t)n];
-    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
-    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
-    float r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0, T = 1.0f;
-    if (!(num == 0 || offset + num >= M)) {
-        for (uint32_t s = 0; s < num; s++) {
-            const size_t i = (size_t)offset + s;
-            const float2 dl = reinterpret_cast<const float2 *>(deltas)[i];
-            const float alpha = 1.0f - __expf(-sigmas[i] * dl.x);
-            const float w = alpha * T;
-            r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
-            t += dl.y;
-            d += w * t;
-            ws += w;
-            T *= 1.0f - alpha;
-        }
-    }
-    weights_sum[index] = ws;
-    depth[index] = d;
-    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
-}
-
-// reference: kernel_composite_rays_train_backward, raymarching.cu:606-686
-__global__ void __launch_bounds__(kBlock) k_composite_bwd(const float *__restrict__ grad_ws, const float *__restrict__ grad_image,
-                                                          const float *__restrict__ sigmas, const float *__restrict__ rgbs,
-                                                          const float *__restrict__ deltas, const int32_t *__restrict__ rays,
-                                                          const float *__restrict__ weights_sum, const float *__restrict__ image,
-                                                          uint32_t M, uint32_t N, float *__restrict__ grad_sigmas,
-                                                          float *__restrict__ grad_rgbs) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[3 * (size_t)n];
-    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1];
-    const uint32_t num = (uint32_t)rays[3 * (size_t)n + 2];
-    if (num == 0 || offset + num >= M) return;
-    const float gws = grad_ws[index];
-    const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
-    const float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
-    const float wsF = weights_sum[index];
-    float r = 0, g = 0, b = 0, ws = 0, T = 1.0f;
-    for (uint32_t s = 0; s < num; s++) {
-        const size_t i = (size_t)offset + s;
-        const float dl0 = deltas[2 * i];
-        const float c0 = rgbs[3 * i], c1 = rgbs[3 * i + 1], c2 = rgbs[3 * i + 2];
-        const float alpha = 1.0f - __expf(-sigmas[i] * dl0);
-        const float w = alpha * T;
-        r += w * c0; g += w * c1; b += w * c2;
-        ws += w;
-        T *= 1.0f - alpha;  // post-update T enters the sigma gradient (:668-673)
-        grad_rgbs[3 * i] = g0 * w; grad_rgbs[3 * i + 1] = g1 * w; grad_rgbs[3 * i + 2] = g2 * w;
-        grad_sigmas[i] = dl0 * (g0 * (T * c0 - (rF - r)) + g1 * (T * c1 - (gF - g)) + g2 * (T * c2 - (bF - b)) + gws * (T - (wsF - ws)));
-    }
-}
-
 // ------------------------------------------------------------------ inference trio
 
 // reference: kernel_march_rays, raymarching.cu:704-811
@@ -1365,40 +1244,28 @@ int pvd_march_rays_train_ws(const float *rays_o, const float *rays_d, const uint
     PVD_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter);
     PVD_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1);
     // one wavefront per ray, for a constant step (dt_gamma = 0: all BASELINE configs with bound 1) and for a growing one alike
-    // (the lattice of dt_gamma > 0 is a recurrence instead of an arithmetic sequence; thread-per-ray left 94 % of the SIMDs idle
-    // at 4096 rays).  PVD_MARCH_THREAD_PER_RAY=1: the serial kernels for dt_gamma > 0 (A/B, tests).
-    static int serial_gamma = -1;
-    if (serial_gamma < 0) { const char *e = getenv("PVD_MARCH_THREAD_PER_RAY"); serial_gamma = (e && e[0] == '1') ? 1 : 0; }
-    const bool wave = dt_gamma == 0.0f || !serial_gamma;
-    MarchRayRecords *records = (wave && workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
+    // (the lattice of dt_gamma > 0 is a recurrence instead of an arithmetic sequence; thread-per-ray kernels left 94 % of the SIMDs
+    // idle at 4096 rays and were removed in round 5)
+    MarchRayRecords *records = (workspace && workspace_bytes >= pvd_march_workspace_bytes(N) && N <= kMarchFusedScanMaxRays)
                                    ? (MarchRayRecords *)workspace : nullptr;
     if (fresh && !records) {  // only the record path initialises what it does not write: do it up front for the others
         (void)hipMemsetAsync(xyzs, 0, 3 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(dirs, 0, 3 * (size_t)M * sizeof(float), s);
         (void)hipMemsetAsync(deltas, 0, 2 * (size_t)M * sizeof(float), s); (void)hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), s);
     }
-    if (wave) {
-        const dim3 g(div_up(N, kRaysPerBlock)), b(kBlock);
-        hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, perturb,
-                           records, counter, records && fresh ? 1u : 0u);
-        if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
-            hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs,
-                               dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u, budget_dev);
-            return check_launch();
-        }
-#ifdef PVD_MARCH_PROFILE
-        return check_launch();
-#endif
-        hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
-        hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
-                           deltas, rays, perturb, budget_dev);
+    const dim3 g(div_up(N, kRaysPerBlock)), b(kBlock);
+    hipLaunchKernelGGL(k_march_count_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, perturb,
+                       records, counter, records && fresh ? 1u : 0u);
+    if (records) {  // two launches: the write pass rebuilds the samples from the chunk records and scans the counts itself
+        hipLaunchKernelGGL(k_march_write_records, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs,
+                           dirs, deltas, rays, perturb, records, counter, fresh ? 1u : 0u, budget_dev);
         return check_launch();
     }
-    // dt grows with t: the step sequence is inherently serial per ray
-    hipLaunchKernelGGL(k_march_count, dim3(div_up(N, kBlock)), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
-                       nears, fars, rays, 0u, perturb);
+#ifdef PVD_MARCH_PROFILE
+    return check_launch();
+#endif
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(kScanBlock), 0, s, rays, N, counter);
-    hipLaunchKernelGGL(k_march_write, dim3(div_up(N, kBlock)), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
-                       nears, fars, xyzs, dirs, deltas, rays, perturb, budget_dev);
+    hipLaunchKernelGGL(k_march_write_wave, g, b, 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                       deltas, rays, perturb, budget_dev);
     return check_launch();
 }
 

@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
     }
 }
 
-// factor sets [I0, I1) of one run of samples; (0, 3) = everything in one wave, (i, i + 1) = one plane/line pair per wave
+// factor sets [I0, I1) of one run of samples: (i, i + 1) = one plane/line pair per wave (all three in one wave -- a third of the waves,
+// three times the serial work per sample -- measured slower and was removed)
 template <typename T, int I0, int I1>
 __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, const VmTables &tb,
                                             const float *__restrict__ g_sigma, const T *__restrict__ g_prod, const VmGrads &gr) {
@@ -452,12 +453,6 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
         pw[i].close(gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
         lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], Rv);
     }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kVmBlock) k_vm_bwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
-                                                     const float *__restrict__ g_sigma, const T *__restrict__ g_prod, VmGrads gr) {
-    vm_bwd_body<T, 0, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
 }
 
 // blockIdx.y = factor set: three times the waves, a third of the serial work per sample in each
@@ -594,22 +589,14 @@ static int vm_backward_impl(const float *xyz, uint32_t M, const float *aabb_host
     const uint32_t chunk = pick_chunk(M, true);
     const uint32_t waves = div_up(M, chunk);
     const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
-    static int split = -1;  // PVD_VM_BWD_SPLIT=0/1 (measurement); default: split
-    if (split < 0) { const char *e = getenv("PVD_VM_BWD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
-    const dim3 grid3(grid.x, rider ? 4 : 3);
+    const dim3 grid3(grid.x, rider ? 4 : 3);  // blockIdx.y = factor set (3 = the riding reduction)
     const pvd_head_dw_rider hd = rider ? *rider : pvd_head_dw_rider{};
-    if (rider && !split) return PVD_ERR_UNSUPPORTED;
-    if (prod_dtype == PVD_F32) {
-        if (split) hipLaunchKernelGGL((k_vm_bwd_split<float>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                      (const float *)grad_color_prod, gr, hd);
-        else hipLaunchKernelGGL((k_vm_bwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                (const float *)grad_color_prod, gr);
-    } else if (prod_dtype == PVD_F16) {
-        if (split) hipLaunchKernelGGL((k_vm_bwd_split<half_t>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                      (const half_t *)grad_color_prod, gr, hd);
-        else hipLaunchKernelGGL((k_vm_bwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
-                                (const half_t *)grad_color_prod, gr);
-    }
+    if (prod_dtype == PVD_F32)
+        hipLaunchKernelGGL((k_vm_bwd_split<float>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                           (const float *)grad_color_prod, gr, hd);
+    else if (prod_dtype == PVD_F16)
+        hipLaunchKernelGGL((k_vm_bwd_split<half_t>), grid3, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, grad_sigma_feat,
+                           (const half_t *)grad_color_prod, gr, hd);
     else
         return PVD_ERR_UNSUPPORTED;
     return check_launch();

@@ -12,7 +12,7 @@ import torch
 import pvd_hip
 
 KIND_HASH, KIND_VM = 0, 1
-FUSED_LOOKUP = os.environ.get("PVD_HASH_FUSED", "1") != "0"  # frozen hash model: lookup + head in one launch (A/B knob, tests)
+FUSED_LOOKUP = True  # frozen hash model: lookup + head in one launch (tests switch it off to compare with the two launches)
 
 
 def _outputs(M, dev):

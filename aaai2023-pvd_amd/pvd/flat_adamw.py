@@ -57,9 +57,7 @@ class FlatAdamW(torch.optim.Optimizer):
     _arrivals = None
 
     def _tail_in_kernel(self):
-        """The arrival counter of the in-kernel tail (PVD_ADAMW_TAIL_KERNEL=1 keeps the separate one-thread launch)."""
-        if os.environ.get("PVD_ADAMW_TAIL_KERNEL", "0") == "1":
-            return None
+        """The arrival counter of the in-kernel tail (the last workgroup to arrive does what a one-thread launch did)."""
         if self._arrivals is None:
             self._arrivals = torch.zeros(65 * 32, dtype=torch.int32, device=self.flat_p.device)
         return self._arrivals
@@ -162,10 +160,10 @@ class FlatAdamW(torch.optim.Optimizer):
         steps WILL split: they need the warm-group lists (deferred decay of the cold groups) and rows of both kinds."""
         self.flush()
         if self._cold_dirty:  # the lists are built by the first step after the touched set changed; the recording needs them now
-            self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
+            self._cold_bits = self._build_cold_bits()
             self._cold_dirty = False
         will = bool(self.touched is not None and self._cold_bits is not None and self._lazy_state() is not None
-                    and os.environ.get("PVD_ADAMW_WARM_LIST", "1") != "0" and getattr(self, "_warm_A", None) is not None
+                    and getattr(self, "_warm_A", None) is not None
                     and self._warm_A.numel() > 0 and self._warm_B.numel() > 0)
         if not will:
             return False
@@ -279,13 +277,6 @@ class FlatAdamW(torch.optim.Optimizer):
         in_touched[self.touched.idx >> 2] = True
         self._warm_B = ((~cold) & in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
         self._warm_A = ((~cold) & ~in_touched[:n4]).nonzero().squeeze(1).to(torch.int32).contiguous()
-        # the single launch walks B then A: the A run's gradient is structurally zero (outside the touched set the buffer holds
-        # zeros for good), so the update neither reads nor re-zeroes it there (pvd_adamw_extras.warm_zero_grad_from)
-        if os.environ.get("PVD_ADAMW_NOGRAD_RUN", "0") == "1" and self._warm_A.numel() > 0 and self._warm_B.numel() > 0:
-            self._warm_groups = torch.cat([self._warm_B, self._warm_A]).contiguous()
-            self._warm_nograd_from = int(self._warm_B.numel())
-        else:
-            self._warm_nograd_from = 0
         st = getattr(self, "_l1_track", None)
         if st is not None:  # per-workgroup partial sums: the launch shape changes with the list, start them afresh
             st["buf"].zero_()
@@ -383,15 +374,13 @@ class FlatAdamW(torch.optim.Optimizer):
         capturing = torch.cuda.is_current_stream_capturing()
         if self._cold_dirty and not capturing:
             self.flush()  # with the old bitmap
-            self._cold_bits = self._build_cold_bits() if os.environ.get("PVD_ADAMW_COLD", "1") != "0" else None
+            self._cold_bits = self._build_cold_bits()
             self._cold_dirty = False
         cold = self._cold_bits if (self.touched is not None and self._outside_is_zero and not self._cold_dirty
                                    and getattr(self, "_half_grad", None) is None) else None
         lazy = self._lazy_state() if cold is not None else None
-        if lazy is not None and os.environ.get("PVD_ADAMW_WARM_LIST", "1") != "0":
+        if lazy is not None:
             lazy = (lazy[0], lazy[1], self._warm_groups)
-            if getattr(self, "_warm_nograd_from", 0) and self._outside_is_zero:
-                lazy = lazy + (self._warm_nograd_from,)
         if lazy is None and self._lazy_logged and not capturing:
             self.flush()  # this step decays the cold groups itself: the logged decays come first
         if lazy is not None:

@@ -321,15 +321,7 @@ class NeRFNetwork(NeRFRenderer):
                 head_dw = {} if (torch.is_grad_enabled() and os.environ.get("PVD_HEAD_DW_RIDE", "1") != "0") else None
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec,
                                                 *(() if head_dw is None else (head_dw,)))
-                hook = getattr(self, "_between_backwards", None)  # (trainer: called between the head's and the lookup's backward)
-                if hook is not None and prod.requires_grad:
-                    prod.register_hook(hook)
-                    self._between_backwards = None  # taken
                 out = fh.vm_head_train(self, sraw, prod, d, head_dw=head_dw if prod.requires_grad else None)
-                hook = getattr(self, "_before_head_backward", None)  # (trainer: called when sigma's gradient arrives, i.e. after the
-                if hook is not None and out[0].requires_grad:        #  compositing backward and right before the head's backward)
-                    out[0].register_hook(hook)
-                    self._before_head_backward = None  # taken
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student
             elif (self.model_type == "mlp" and not torch.is_grad_enabled() and hasattr(fh, "features_head_infer")
@@ -345,8 +337,8 @@ class NeRFNetwork(NeRFRenderer):
                 if self._in_stage1():
                     return None, None
                 self.sigma_l = feat[..., 0]
-                # a second handle on the same values: the fused backward adds the two gradients (PVD_HEAD_RGB2=0: autograd does)
-                self.color_l = out[3] if (len(out) > 3 and os.environ.get("PVD_HEAD_RGB2", "1") != "0") else color
+                # a second handle on the same values: the fused backward adds the two gradients
+                self.color_l = out[3] if len(out) > 3 else color
                 return sigma, color
         if self.model_type == "vm":
             sigma_raw, color_raw = self.vm_features(x)

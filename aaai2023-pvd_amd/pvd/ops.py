@@ -43,18 +43,7 @@ def hip_ops():
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         rays_o, rays_d, bg, nears, fars = f(1, N, 3), f(1, N, 3), f(1, N, 3), f(N), f(N)
         fx, fy, cx, cy = intrinsics
-        order = os.environ.get("PVD_BATCH_ORDER", "")  # measurement knob: "morton" = the SAME rays, rows in image-space Z order
-        inds = torch.empty(N, dtype=torch.int64, device=dev) if order == "morton" else None
-        pvd_hip.make_ray_batch(poses, state, seed, fx, fy, cx, cy, H, W, N, aabb, min_near, inds, rays_o, rays_d, bg, nears, fars)
-        if inds is not None:
-            def spread(v):  # 10 bits -> every other bit
-                v = (v | (v << 8)) & 0x00FF00FF
-                v = (v | (v << 4)) & 0x0F0F0F0F
-                v = (v | (v << 2)) & 0x33333333
-                return (v | (v << 1)) & 0x55555555
-            perm = torch.argsort(spread(inds % W) | (spread(inds // W) << 1))
-            rays_o, rays_d, bg = rays_o[:, perm].contiguous(), rays_d[:, perm].contiguous(), bg[:, perm].contiguous()
-            nears, fars = nears[perm].contiguous(), fars[perm].contiguous()
+        pvd_hip.make_ray_batch(poses, state, seed, fx, fy, cx, cy, H, W, N, aabb, min_near, None, rays_o, rays_d, bg, nears, fars)
         return rays_o, rays_d, bg, (nears, fars)
 
     def freq_encode(x, bands, include_input=True, out_dtype=torch.float32, row_stride=None):

@@ -1,0 +1,154 @@
+"""Ray data parallelism (new work, the reference has none -- tools/details.md:24): every rank renders its own rays against
+replicated models; one flat-bucket all-reduce (SUM) of the student gradient per step over RCCL/xGMI; norm-type losses are made
+global by all-reducing the sum of squares first.  Also the flat gradient bucket the exchange moves."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class RayDP:
+    """Ray-level data parallel context.  world_size == 1 -> every collective is a no-op."""
+
+    def __init__(self, group=None):
+        # PVD_DP_FORCE=1 keeps every collective live in a world of one rank (test mode: the communication library's
+        # streams / watchdog next to graph capture, on a single-GPU box)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("PVD_DP_FORCE") == "1")
+        self.group = group
+        self.world_size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.capture = None  # a SegmentedCapture while the trainer records a step
+        # RCCL collectives can be recorded INTO the step's HIP graph (probed on MI355X / ROCm 7: tools/probe_rccl_capture.py):
+        # the whole step is then ONE graph launch instead of three graphs with two eager collectives between them (~60 us of
+        # fixed overhead per step).  gloo cannot be captured; PVD_DP_INGRAPH=0 keeps the segmented form; a capture that
+        # fails falls back to it (DistillTrainer.capture_step).
+        self.ingraph = (self.enabled and dist.get_backend(group) == "nccl" and os.environ.get("PVD_DP_INGRAPH", "1") != "0")
+
+
+    def _two_shot_sum_(self, t):
+        """SUM over ranks as reduce-scatter + all-gather built from ALL-TO-ALL exchanges (PVD_DP_EXCHANGE=twoshot, opt-in): rank r
+        receives chunk r of every peer, adds the n chunks in rank order, and sends the sum to every peer.  On a fully connected
+        node every rank then talks to its n - 1 peers at once over its own links -- 2 (S / n) / one link's bandwidth instead of
+        a ring's 2 (n - 1) / n S / (its slowest hop) (tools/scale_model.py) -- and every
+        element is summed by exactly ONE rank, so the replicas receive identical bits by construction."""
+        n = self.world_size
+        flat = t.reshape(-1)
+        chunk = (flat.numel() + n - 1) // n
+        send = flat
+        if chunk * n != flat.numel():
+            send = torch.zeros(chunk * n, dtype=flat.dtype, device=flat.device)
+            send[:flat.numel()].copy_(flat)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)  # recv[k * chunk : (k + 1) * chunk] = rank k's chunk `rank`
+        red = recv.view(n, chunk)[0].clone()
+        for k in range(1, n):  # rank order: the same sum whichever rank forms it
+            red.add_(recv.view(n, chunk)[k])
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, red.repeat(n), group=self.group)  # out[k * chunk : ...] = the sum rank k formed
+        flat.copy_(out[:flat.numel()])
+        return t
+
+    def all_reduce_sum_(self, t, overlap=None):
+        """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
+        next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
+        if self.enabled:
+            # (verified on gloo only, tests/test_dist_gloo.py.  NOT recorded into a graph and not taken in a one-rank world: an attempt to
+            # capture RCCL's all-to-all in a forced one-rank world did not return within ten minutes on the GPU box)
+            two_shot = (os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "twoshot" and self.world_size > 1
+                        and not (self.capture is not None and self.capture.active and self.ingraph)
+                        and t.numel() >= int(os.environ.get("PVD_DP_TWOSHOT_MIN", "65536")))  # (scalars and short buffers: one latency-bound all-reduce)
+            run = (lambda: self._two_shot_sum_(t)) if two_shot else (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
+            if two_shot:
+                overlap = None  # (its exchanges are issued synchronously: the overlap callable would only follow them)
+            if self.capture is not None and self.capture.active and self.ingraph:
+                run()  # recorded as a node of the graph being captured
+            elif self.capture is not None and self.capture.active:
+                replay = None
+                if overlap is not None:
+                    def replay():
+                        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        overlap()
+                        work.wait()
+                self.capture.break_for(run, replay)  # collectives stay out of the graphs: eager, between two replays
+            else:
+                run()
+        return t
+
+    def global_sum(self, local):
+        """Value = sum over ranks, gradient = gradient of the local term (d total / d local = 1)."""
+        if not self.enabled:
+            return local
+        tot = self.all_reduce_sum_(local.detach().clone())
+        return tot + (local - local.detach())
+
+    def global_norm_l2(self, diff):
+        """|| concat_r diff_r ||_2 with the right gradient on every shard (torch.norm over the whole
+        batch is not a sum of per-shard norms)."""
+        if not self.enabled:
+            return torch.norm(diff.float())  # zero-safe subgradient, as the reference's torch.norm (utils.py:947)
+        s_local = (diff.float() ** 2).sum()
+        s_tot = self.all_reduce_sum_(s_local.detach().clone())
+        n = torch.sqrt(s_tot)
+        return n + (s_local - s_local.detach()) / (2 * n.clamp_min(1e-20))
+
+    def global_norm_l1(self, diff):
+        return self.global_sum(diff.float().abs().sum())
+
+    def global_mean(self, x):
+        """mean over the global batch (equal shard sizes are not assumed)."""
+        if not self.enabled:
+            return x.float().mean()
+        cnt = self.all_reduce_sum_(torch.tensor(float(x.numel()), device=x.device))
+        return self.global_sum(x.float().sum()) / cnt
+
+
+class FlatGrads:
+    """All trainable parameters' gradients as views into ONE flat fp32 buffer, so the step's
+    gradient exchange is a single all-reduce with no packing copies (autograd accumulates in place
+    into pre-set .grad views)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            assert p.dtype == torch.float32
+            p.grad = self._view(p, off)
+            off += p.numel()
+
+    def _view(self, p, off):
+        # same strides as the parameter (VM factors are channels-last): fused AdamW requires params and
+        # grads to share one memory layout, and autograd then accumulates without a re-layout
+        return torch.as_strided(self.flat, p.size(), p.stride(), storage_offset=off)
+
+    def zero_(self):
+        self.flat.zero_()
+        # re-attach: optimizers / zero_grad(set_to_none) may have dropped the views
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + 1].data_ptr():
+                p.grad = self._view(p, off)
+            off += p.numel()
+
+
+class _FlatOptGrads:
+    """FlatGrads interface over FlatAdamW's own gradient buffer."""
+
+    def __init__(self, opt):
+        self.opt, self.flat, self.params = opt, opt.flat_g, opt.params
+
+    def zero_(self):
+        self.opt.zero_grad()
+
+
+def _make_loss(kind, dp):
+    """reference: Trainer.get_loss, utils.py:941-952 (normL2 is a Frobenius norm, NOT a mean)."""
+    if kind == "L2":
+        return lambda pred, gt: dp.global_mean((gt.float() - pred.float()) ** 2)
+    if kind == "normL2":
+        return lambda pred, gt: dp.global_norm_l2(pred - gt)
+    if kind == "normL1":
+        return lambda pred, gt: dp.global_norm_l1(pred - gt)
+    raise ValueError("error loss_type")

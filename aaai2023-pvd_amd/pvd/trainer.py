@@ -10,12 +10,13 @@ Ray data parallelism (new work, the reference has none -- tools/details.md:24): 
 its own rays against replicated models; one flat-bucket all-reduce (SUM) of the student gradient per
 step over RCCL/xGMI; norm-type losses are made global by all-reducing the sum of squares first.
 """
-import gc
-import math
 import os
 
 import torch
 import torch.distributed as dist
+
+from .capture import CarriedPrefix, SegmentedCapture
+from .ray_dp import FlatGrads, RayDP, _FlatOptGrads, _make_loss
 
 
 def pvd_forked_graphs_ok():
@@ -31,280 +32,6 @@ def psnr(pred, truth):
     """-10 log10(mean squared error) (reference: PSNRMeter.update, utils.py:500-507)."""
     mse = torch.mean((pred.float() - truth.float()) ** 2)
     return -10.0 * torch.log10(mse)
-
-
-def _tree_map(obj, fn):
-    if torch.is_tensor(obj):
-        return fn(obj)
-    if isinstance(obj, dict):
-        return {k: _tree_map(v, fn) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_tree_map(v, fn) for v in obj)
-    return obj
-
-
-def _tree_tensors(obj, out):
-    _tree_map(obj, lambda t: out.append(t) or t)
-    return out
-
-
-class CarriedPrefix:
-    """A static home for the results of DistillTrainer.prefetch across graph replays: the prefix recorded next to the LAST step
-    of a multi-step graph feeds the FIRST step of the next replay.  Storage by storage (views of one buffer stay views of one
-    buffer: sigma_l is column 0 of feature_sigma_color), same sizes / strides / offsets."""
-
-    def __init__(self, pre):
-        self._stores = {}  # data_ptr of a source storage -> flat uint8 tensor owning the static copy
-
-        def home(t):
-            st = t.untyped_storage()
-            if st.data_ptr() not in self._stores:
-                flat = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (st.nbytes(),), (1,))
-                self._stores[st.data_ptr()] = flat.clone()
-            dst = self._stores[st.data_ptr()].untyped_storage()
-            return torch.empty(0, dtype=t.dtype, device=t.device).set_(dst, t.storage_offset(), t.size(), t.stride())
-        self.pre = _tree_map(pre, home)
-        self._layout = [(t.dtype, tuple(t.size()), tuple(t.stride()), t.storage_offset()) for t in _tree_tensors(pre, [])]
-
-    def store(self, pre):
-        """Copy a new prefix (same structure and layout) into the static home: one multi-tensor copy on the current stream."""
-        new, old = _tree_tensors(pre, []), _tree_tensors(self.pre, [])
-        assert [(t.dtype, tuple(t.size()), tuple(t.stride()), t.storage_offset()) for t in new] == self._layout, \
-            "the prefix changed shape between steps of one capture"
-        srcs, dsts, seen = [], [], set()
-        for tn, to in zip(new, old):
-            sn, so = tn.untyped_storage(), to.untyped_storage()
-            if sn.data_ptr() in seen:
-                continue
-            seen.add(sn.data_ptr())
-            assert sn.nbytes() == so.nbytes()
-            srcs.append(torch.empty(0, dtype=torch.uint8, device=tn.device).set_(sn, 0, (sn.nbytes(),), (1,)))
-            dsts.append(torch.empty(0, dtype=torch.uint8, device=to.device).set_(so, 0, (so.nbytes(),), (1,)))
-        torch._foreach_copy_(dsts, srcs)
-
-
-class SegmentedCapture:
-    """A step as a chain of HIP graphs with eager host calls between them.  `break_for(fn)` ends the graph being
-    captured, runs fn() eagerly (and remembers it), and starts the next graph in the same memory pool; `replay()` replays
-    graph 0, calls fn 0, replays graph 1, ...  Used to keep collectives out of the graphs."""
-
-    def __init__(self, device):
-        self.device = device
-        self.graphs, self.between = [], []
-        self.pool = None
-        self.active = False
-        self._stream = torch.cuda.Stream(device)
-
-    def _begin(self):
-        g = torch.cuda.CUDAGraph()
-        # thread_local: a communication library's watchdog thread may touch the device while we capture
-        if self.pool is None:
-            self.pool = torch.cuda.graph_pool_handle()  # one private pool for all segments: tensors live across them
-        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
-        self.graphs.append(g)
-        self.active = True
-
-    def _end(self):
-        self.active = False
-        self.graphs[-1].capture_end()
-
-    def __enter__(self):
-        # as torch.cuda.graph.__enter__ does: collect garbage and return cached blocks BEFORE the capture begins, and keep the
-        # cyclic collector off while it is under way -- an earlier trainer's graphs (reference cycles: collected whenever the
-        # collector happens to run) would otherwise be destroyed, and their private pools released, in the middle of this
-        # capture.  PVD_CAPTURE_GC=0 restores the old behaviour (tools/flake_hunt.sh).
-        self._gc_was_enabled = None
-        torch.cuda.synchronize()
-        if os.environ.get("PVD_CAPTURE_GC", "1") != "0":
-            gc.collect()
-            torch.cuda.empty_cache()
-            self._gc_was_enabled = gc.isenabled()
-            gc.disable()
-        self._stream.wait_stream(torch.cuda.current_stream())
-        self._ctx = torch.cuda.stream(self._stream)
-        self._ctx.__enter__()
-        try:
-            self._begin()
-        except BaseException:
-            self._ctx.__exit__(None, None, None)
-            self._restore_gc()
-            raise
-        return self
-
-    def _restore_gc(self):
-        if self._gc_was_enabled:
-            gc.enable()
-        self._gc_was_enabled = None
-
-    def __exit__(self, exc_type, exc, tb):
-        try:
-            if self.active:
-                self._end()
-        finally:
-            self._ctx.__exit__(exc_type, exc, tb)
-            self._restore_gc()
-        torch.cuda.current_stream().wait_stream(self._stream)
-        return False
-
-    def break_for(self, fn, replay_fn=None):
-        """fn runs now (between two captures); replay_fn (default: fn) is what runs at that point of every replay."""
-        self._end()
-        fn()
-        self.between.append(replay_fn or fn)
-        self._begin()
-
-    def replay(self):
-        for i, g in enumerate(self.graphs):
-            g.replay()
-            if i < len(self.between):
-                self.between[i]()
-
-
-class RayDP:
-    """Ray-level data parallel context.  world_size == 1 -> every collective is a no-op."""
-
-    def __init__(self, group=None):
-        # PVD_DP_FORCE=1 keeps every collective live in a world of one rank (test mode: the communication library's
-        # streams / watchdog next to graph capture, on a single-GPU box)
-        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("PVD_DP_FORCE") == "1")
-        self.group = group
-        self.world_size = dist.get_world_size(group) if self.enabled else 1
-        self.rank = dist.get_rank(group) if self.enabled else 0
-        self.capture = None  # a SegmentedCapture while the trainer records a step
-        # RCCL collectives can be recorded INTO the step's HIP graph (probed on MI355X / ROCm 7: tools/probe_rccl_capture.py):
-        # the whole step is then ONE graph launch instead of three graphs with two eager collectives between them (~60 us of
-        # fixed overhead per step).  gloo cannot be captured; PVD_DP_INGRAPH=0 keeps the segmented form; a capture that
-        # fails falls back to it (DistillTrainer.capture_step).
-        self.ingraph = (self.enabled and dist.get_backend(group) == "nccl" and os.environ.get("PVD_DP_INGRAPH", "1") != "0")
-
-
-    def _two_shot_sum_(self, t):
-        """SUM over ranks as reduce-scatter + all-gather built from ALL-TO-ALL exchanges (PVD_DP_EXCHANGE=twoshot, opt-in): rank r
-        receives chunk r of every peer, adds the n chunks in rank order, and sends the sum to every peer.  On a fully connected
-        node every rank then talks to its n - 1 peers at once over its own links -- 2 (S / n) / one link's bandwidth instead of
-        a ring's 2 (n - 1) / n S / (its slowest hop) (tools/scale_model.py) -- and every
-        element is summed by exactly ONE rank, so the replicas receive identical bits by construction."""
-        n = self.world_size
-        flat = t.reshape(-1)
-        chunk = (flat.numel() + n - 1) // n
-        send = flat
-        if chunk * n != flat.numel():
-            send = torch.zeros(chunk * n, dtype=flat.dtype, device=flat.device)
-            send[:flat.numel()].copy_(flat)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)  # recv[k * chunk : (k + 1) * chunk] = rank k's chunk `rank`
-        red = recv.view(n, chunk)[0].clone()
-        for k in range(1, n):  # rank order: the same sum whichever rank forms it
-            red.add_(recv.view(n, chunk)[k])
-        out = torch.empty_like(send)
-        dist.all_to_all_single(out, red.repeat(n), group=self.group)  # out[k * chunk : ...] = the sum rank k formed
-        flat.copy_(out[:flat.numel()])
-        return t
-
-    def all_reduce_sum_(self, t, overlap=None):
-        """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
-        next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
-        if self.enabled:
-            # (verified on gloo only, tests/test_dist_gloo.py.  NOT recorded into a graph and not taken in a one-rank world: an attempt to
-            # capture RCCL's all-to-all in a forced one-rank world did not return within ten minutes on the GPU box)
-            two_shot = (os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "twoshot" and self.world_size > 1
-                        and not (self.capture is not None and self.capture.active and self.ingraph)
-                        and t.numel() >= int(os.environ.get("PVD_DP_TWOSHOT_MIN", "65536")))  # (scalars and short buffers: one latency-bound all-reduce)
-            run = (lambda: self._two_shot_sum_(t)) if two_shot else (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
-            if two_shot:
-                overlap = None  # (its exchanges are issued synchronously: the overlap callable would only follow them)
-            if self.capture is not None and self.capture.active and self.ingraph:
-                run()  # recorded as a node of the graph being captured
-            elif self.capture is not None and self.capture.active:
-                replay = None
-                if overlap is not None:
-                    def replay():
-                        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                        overlap()
-                        work.wait()
-                self.capture.break_for(run, replay)  # collectives stay out of the graphs: eager, between two replays
-            else:
-                run()
-        return t
-
-    def global_sum(self, local):
-        """Value = sum over ranks, gradient = gradient of the local term (d total / d local = 1)."""
-        if not self.enabled:
-            return local
-        tot = self.all_reduce_sum_(local.detach().clone())
-        return tot + (local - local.detach())
-
-    def global_norm_l2(self, diff):
-        """|| concat_r diff_r ||_2 with the right gradient on every shard (torch.norm over the whole
-        batch is not a sum of per-shard norms)."""
-        if not self.enabled:
-            return torch.norm(diff.float())  # zero-safe subgradient, as the reference's torch.norm (utils.py:947)
-        s_local = (diff.float() ** 2).sum()
-        s_tot = self.all_reduce_sum_(s_local.detach().clone())
-        n = torch.sqrt(s_tot)
-        return n + (s_local - s_local.detach()) / (2 * n.clamp_min(1e-20))
-
-    def global_norm_l1(self, diff):
-        return self.global_sum(diff.float().abs().sum())
-
-    def global_mean(self, x):
-        """mean over the global batch (equal shard sizes are not assumed)."""
-        if not self.enabled:
-            return x.float().mean()
-        cnt = self.all_reduce_sum_(torch.tensor(float(x.numel()), device=x.device))
-        return self.global_sum(x.float().sum()) / cnt
-
-
-class FlatGrads:
-    """All trainable parameters' gradients as views into ONE flat fp32 buffer, so the step's
-    gradient exchange is a single all-reduce with no packing copies (autograd accumulates in place
-    into pre-set .grad views)."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            assert p.dtype == torch.float32
-            p.grad = self._view(p, off)
-            off += p.numel()
-
-    def _view(self, p, off):
-        # same strides as the parameter (VM factors are channels-last): fused AdamW requires params and
-        # grads to share one memory layout, and autograd then accumulates without a re-layout
-        return torch.as_strided(self.flat, p.size(), p.stride(), storage_offset=off)
-
-    def zero_(self):
-        self.flat.zero_()
-        # re-attach: optimizers / zero_grad(set_to_none) may have dropped the views
-        off = 0
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + 1].data_ptr():
-                p.grad = self._view(p, off)
-            off += p.numel()
-
-
-class _FlatOptGrads:
-    """FlatGrads interface over FlatAdamW's own gradient buffer."""
-
-    def __init__(self, opt):
-        self.opt, self.flat, self.params = opt, opt.flat_g, opt.params
-
-    def zero_(self):
-        self.opt.zero_grad()
-
-
-def _make_loss(kind, dp):
-    """reference: Trainer.get_loss, utils.py:941-952 (normL2 is a Frobenius norm, NOT a mean)."""
-    if kind == "L2":
-        return lambda pred, gt: dp.global_mean((gt.float() - pred.float()) ** 2)
-    if kind == "normL2":
-        return lambda pred, gt: dp.global_norm_l2(pred - gt)
-    if kind == "normL1":
-        return lambda pred, gt: dp.global_norm_l1(pred - gt)
-    raise ValueError("error loss_type")
 
 
 class _TrainerBase:
@@ -389,9 +116,8 @@ class _TrainerBase:
     def _grad_compactor(self):
         """pvd/dp_compact.py: exchange only the table rows that occupied cells can touch (exact: the rest is zero on every
         rank).  Needs the dense L1 gradient out of the flat buffer (folded into the optimizer kernel, or off)."""
-        import os
         o, m = self.opt, self.model
-        if not self.compact_exchange or os.environ.get("PVD_DP_COMPACT", "1") == "0" or m.model_type not in ("vm", "tensors"):
+        if not self.compact_exchange or m.model_type not in ("vm", "tensors"):
             return None
         if m.model_type == "vm" and o.l1_reg_weight > 0.0 and not self.flat_opt:
             return None  # autograd writes w/n * sign(p) into every sigma-plane entry
@@ -424,46 +150,12 @@ class _TrainerBase:
         written (the same set the compact exchange moves), so after one full clear only those are cleared and
         inf-checked (FlatAdamW.set_touched); PVD_TOUCHED_SET=0 turns that off."""
         if self.flat_opt:
-            import os
             c = self._grad_compactor() if os.environ.get("PVD_TOUCHED_SET", "1") != "0" else None
             if c is not self.optimizer.touched:
                 self.optimizer.set_touched(c)
         self.flat.zero_()
 
-    def _step_prologue(self):
-        """zero_grad (+ the student's weight image) at the start of a step.  PVD_PROLOGUE_FORK=1: on a side stream, i.e. as a
-        parallel branch of the captured step that joins after the march (compute_loss) -- these launches are a few us of
-        latency each and depend on nothing the marcher does.  Measured: 0.411 vs 0.394 ms/step -- a fork / join pair inside a
-        hipGraph costs more (~17 us) than the ~11 us of launches it hides; off by default."""
-        fh = getattr(getattr(self, "model_stu", None), "ops", None)
-        fh = getattr(fh, "fused_head", None)
-        if os.environ.get("PVD_PROLOGUE_FORK", "0") != "1" or fh is None or not hasattr(fh, "prepack_train_image") or self.dp.enabled:
-            self._zero_grads()
-            return
-        main = torch.cuda.current_stream()
-        side = getattr(self, "_prologue_stream", None)
-        if side is None:
-            side = self._prologue_stream = torch.cuda.Stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._zero_grads()
-            fh.prepack_train_image(self.model_stu)
-        self._prologue_join = lambda: main.wait_stream(side)
-
-    def _fork_prefix(self, launch):
-        """Single GPU, pipelined capture: launch the NEXT step's parameter-independent prefix (its own graph) on a side
-        stream, next to this step's inf check / AdamW on the main stream; joined before the next step starts."""
-        side = self._pipe_stream
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            launch()
-        self._pipe_pending = True
-
     def _exchange(self):
-        ov = getattr(self, "_overlap_with_exchange", None)
-        if not self.dp.enabled and ov is not None and self.dp.capture is not None and self.dp.capture.active:
-            self.dp.capture.break_for(lambda: None, lambda: self._fork_prefix(ov))  # cut the graph here: fork point
-            return
         if self.dp.enabled:
             c = self._grad_compactor()
             ov = getattr(self, "_overlap_with_exchange", None)
@@ -536,7 +228,7 @@ class _TrainerBase:
         try:
             with cap:
                 for _ in range(max(1, int(steps_per_graph))):
-                    self._step_prologue()
+                    self._zero_grads()
                     self._static_out = body()
                     if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
                         raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
@@ -557,7 +249,7 @@ class _TrainerBase:
         only the first step of the graph launches a zero_grad.  What the host knows about the gradients after such a recording
         is settled by replay() (a recording runs nothing)."""
         if self.flat_opt:
-            self.optimizer.zero_in_step = bool(on) and os.environ.get("PVD_ADAMW_ZERO_IN_STEP", "1") != "0"
+            self.optimizer.zero_in_step = bool(on)
             if on:
                 self._graph_zeroes = False
                 # the first recorded step must record its zero_grad whatever the previous replay left behind: a graph that
@@ -576,16 +268,12 @@ class _TrainerBase:
         traceback.print_exc()
         torch.cuda.synchronize()
         self.dp.capture = None
-        self.__dict__.pop("_before_objective", None)
         self._fold_launches(False)
         self._graph_zeroes = False
         if self.flat_opt:
             self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
             self.optimizer._part_a_owed = None  # (a two-part update recorded half way: nothing of it ran)
             self.optimizer.end_two_part(failed=True)
-        for mdl in (getattr(self, "model_stu", None), self.model):
-            if mdl is not None and getattr(mdl, "_between_backwards", None) is not None:
-                mdl._between_backwards = None
 
     def replay(self):
         assert getattr(self, "_captured_occ_epoch", None) in (None, self._marching_model().occ_epoch), \
@@ -593,9 +281,6 @@ class _TrainerBase:
         if self.flat_opt:
             import pvd_hip
             pvd_hip.note_weights_changed(self.optimizer.params)  # the captured optimizer kernel rewrites the parameters
-        if getattr(self, "_pipe_pending", False):  # the prefix forked during the previous step feeds this one
-            torch.cuda.current_stream().wait_stream(self._pipe_stream)
-            self._pipe_pending = False
         if self.flat_opt:
             self.optimizer.before_replay()  # (stale L1 partial sums of another launch shape)
         self._cap.replay()
@@ -631,11 +316,6 @@ class DistillTrainer(_TrainerBase):
                                   dtype=torch.float32, device=self.device)
         self.fea_rate = self.rates[1:2]
         self.fused_loss = getattr(model_stu.ops, "distill_loss", None)
-        import os
-        # measured on MI355X: 0.565 ms/step with the two forwards as parallel graph branches vs 0.545 ms in sequence
-        # (both forwards already occupy every CU; the fork/join costs more than the overlap gains) -> off by default
-        self.overlap_teacher = self.device_type == "cuda" and os.environ.get("PVD_OVERLAP_TEACHER", "0") == "1"
-        self._side = torch.cuda.Stream(self.device) if self.overlap_teacher else None
 
     def render_kwargs(self):
         o = self.opt
@@ -683,57 +363,33 @@ class DistillTrainer(_TrainerBase):
             if out_tea.get("image") is not None and pre.get("replayed_ahead", False):
                 out_tea["image"] = out_tea["image"].clone()  # the prefix graph overwrites its outputs one step ahead
             # the teacher's outputs exist already: the stage-3 objective can ride on the student's compositing launches
-            # (ObjectiveRide: two launches fewer on the chain; PVD_OBJECTIVE_RIDE=0 keeps the separate launches)
+            # (ObjectiveRide: two launches fewer on the chain)
             ride = None
             if (self.fused_loss is not None and o.loss_type == "normL2" and not self.dp.enabled and torch.is_grad_enabled()
                     and self._stage_of(self.global_step) == 3 and out_tea.get("image") is not None
                     and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc * 0.995, o.loss_rate_rgb) > 0.0
                     and torch.is_tensor(getattr(tea, "feature_sigma_color", None)) and torch.is_tensor(getattr(tea, "color_l", None))
                     and tea.feature_sigma_color.dim() == 2 and tea.feature_sigma_color.shape[-1] == 16
-                    and tea.feature_sigma_color.dtype == torch.float32 and pre["rays_o"].is_cuda
-                    and os.environ.get("PVD_OBJECTIVE_RIDE", "1") != "0" and os.environ.get("PVD_LOSS_DEFER", "0") != "1"):
+                    and tea.feature_sigma_color.dtype == torch.float32 and pre["rays_o"].is_cuda):
                 from .losses import ObjectiveRide
-                # PVD_OBJECTIVE_FINISH=0: k_loss_final stays a launch of its own between the passes
-                # (and never when the L1 value is added to the loss by the host afterwards -- L1 on, VM student, non-flat
-                # optimizer: the finished loss only exists after the backward launch, as with PVD_LOSS_DEFER)
+                # the objective is finished inside the compositing backward's launch -- never when the L1 value is added to the loss
+                # by the host afterwards (L1 on, VM student, non-flat optimizer: k_loss_final then stays a launch of its own)
                 l1_on_host = o.l1_reg_weight > 0.0 and o.model_type == "vm" and not self.flat_opt
-                fin = os.environ.get("PVD_OBJECTIVE_FINISH", "1") != "0" and not l1_on_host
+                fin = not l1_on_host
                 ride = ObjectiveRide(out_tea["image"], tea.feature_sigma_color, tea.color_l, rates_decay=self.rates if fin else None, fea_decay=0.995)
             out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
                                  inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, objective=ride, **kw)
             self._ride = ride if (ride is not None and ride.S is not None) else None
-        elif self.overlap_teacher and rays_o.is_cuda and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
-            # march once, then the frozen teacher's forward runs on a side stream next to the student's forward
-            # (they share only the samples); in a captured step this becomes two parallel branches of the graph
-            inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, **kw)
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side), torch.no_grad():
-                out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                     inherited_params=inh, nears_fars=nf, premarched=True, **kw)
-            out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                 inherited_params=inh, nears_fars=nf, premarched=True, **kw)
-            main.wait_stream(self._side)
         else:
-            join = self.__dict__.pop("_prologue_join", None)
             out_tea = None
-            if join is not None and stu.cuda_ray and bool(getattr(o, "render_stu_first", True)):
-                # the step's prologue (zero_grad, weight image) was forked onto a side stream: march first, join, then the forward
-                inh, nf = stu.march(rays_o, rays_d, perturb=True, force_all_rays=False, **kw_stu)
-                join()
+            if not bool(getattr(o, "render_stu_first", True)) and stu.cuda_ray:
+                # the TEACHER marches and the student inherits its samples (utils.py:1020-1043, renderer.py:392-411)
+                with torch.no_grad():
+                    out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
                 out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                     inherited_params=inh, nears_fars=nf, premarched=True, **kw)
+                                     inherited_params=out_tea["inherited_params"], nears_fars=out_tea.get("nears_fars"), **kw)
             else:
-                if join is not None:
-                    join()
-                if not bool(getattr(o, "render_stu_first", True)) and stu.cuda_ray:
-                    # the TEACHER marches and the student inherits its samples (utils.py:1020-1043, renderer.py:392-411)
-                    with torch.no_grad():
-                        out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
-                    out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                         inherited_params=out_tea["inherited_params"], nears_fars=out_tea.get("nears_fars"), **kw)
-                else:
-                    out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
+                out_stu = stu.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False, **kw_stu)
             if out_tea is None:
                 with torch.no_grad():
                     out_tea = tea.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
@@ -778,9 +434,6 @@ class DistillTrainer(_TrainerBase):
             info.update(color=l_col.detach(), sigma=l_sig.detach())
             return loss, info, None, None
 
-        wait_l1 = self.__dict__.pop("_before_objective", None)
-        if wait_l1 is not None:
-            wait_l1()  # a deferred part of the previous step's update refreshes the L1 term's partial sums (see _capture_ingraph_pipelined)
         if fused_nofea:
             l3, norms = self.fused_loss(pred_stu, pred_tea, stu.sigma_l.float().unsqueeze(-1), tea.sigma_l.float().unsqueeze(-1),
                                         stu.color_l.float(), tea.color_l.float(), self.rates, self.dp, fea_decay=0.995)
@@ -794,15 +447,10 @@ class DistillTrainer(_TrainerBase):
                     self._l1_term(partials_only=True)
                     extra = self.optimizer.l1_partials(1.0 / self.dp.world_size)
             add_l1 = o.l1_reg_weight > 0.0 and o.model_type == "vm" and extra is None
-            # PVD_LOSS_DEFER=1: nothing looks at the value of the objective before loss.backward() in a training step, so it can be
-            # finished inside the backward launch (pvd_distill_loss_backward) instead of by a launch of its own.  Bit-identical
-            # (tests/test_hip_fused_misc.py) and measured: 0.3945 vs 0.3930 ms/step -- the single-workgroup launch it removes
-            # was hidden behind its neighbours in the replayed graph; off by default.
-            defer = not add_l1 and torch.is_grad_enabled() and os.environ.get("PVD_LOSS_DEFER", "0") == "1"
             ride = self.__dict__.pop("_ride", None)
-            rkw = {} if (ride is None or defer) else {"ride": ride}
+            rkw = {} if ride is None else {"ride": ride}
             l4, norms = self.fused_loss(pred_stu, pred_tea, stu.feature_sigma_color, tea.feature_sigma_color, stu.color_l.float(),
-                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra, defer=defer, **rkw)
+                                        tea.color_l.float(), self.rates, self.dp, fea_decay=0.995, extra=extra, **rkw)
             loss = l4  # (loss is still the python 0.0 here: no "0 + x" launch)
             if add_l1:
                 loss = loss + self._l1_term()
@@ -848,7 +496,7 @@ class DistillTrainer(_TrainerBase):
             rays_o, rays_d, bg, *rest = batch_fn()
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 return self.compute_loss(rays_o, rays_d, bg, *rest)
-        # the 3 eager warm-up steps inside capture() / _capture_pipelined() are real steps: they advance global_step, so the
+        # the 3 eager warm-up steps inside capture() / the pipelined recordings are real steps: they advance global_step, so the
         # stage that gets captured is the one AFTER them, and they must not straddle a stage boundary (the warm-up and the
         # captured step would then build different losses)
         warm = 3
@@ -882,11 +530,7 @@ class DistillTrainer(_TrainerBase):
                 self.capture_fallback = "segmented"
         elif self.dp.enabled and stu_marches and stage == 3 and os.environ.get("PVD_DP_OVERLAP", "1") != "0":
             out = self._capture_pipelined(batch_fn, body)
-        elif not self.dp.enabled and stu_marches and stage == 3 and os.environ.get("PVD_PIPELINE", "0") == "1":
-            self._pipe_stream = torch.cuda.Stream()
-            out = self._capture_pipelined(batch_fn, body)  # fork point instead of a collective (see _exchange)
-        elif (not self.dp.enabled and stage == 3 and steps_per_graph > 1 and os.environ.get("PVD_PIPELINE_INGRAPH", "1") != "0"
-              and stu_marches and pvd_forked_graphs_ok()):
+        elif not self.dp.enabled and stage == 3 and steps_per_graph > 1 and stu_marches and pvd_forked_graphs_ok():
             # single GPU, several steps per graph: the same fork -- next step's batch / march / teacher forward (ALU- and
             # latency-bound) recorded next to this step's table scatter + inf check + AdamW inside the one graph
             try:
@@ -904,12 +548,18 @@ class DistillTrainer(_TrainerBase):
     def _capture_ingraph_pipelined(self, batch_fn, body, steps_per_graph):
         """Several steps per graph (single GPU, or ray-DP with the collectives recorded into the graph): the parameter-
         independent prefix of step k + 1 (batch, march, frozen teacher's forward and compositing) is recorded on a FORKED
-        stream next to step k's table scatter, gradient exchange and update, and joined before step k + 1's student forward --
-        inside one graph: no extra graph launches, one fork / join pair per step.  The scatter waits on the memory side, the
-        update on HBM and the exchange on xGMI while the prefix is instruction- and L2-bound, so the two chains share the chip
-        (0.379 -> 0.327 ms/step on one GPU).  Same batches in the same order, same update rule as the
-        back-to-back recording (tests/test_hip_graph.py, tests/test_hip_dp_graph.py)."""
+        stream next to step k -- the fork at the START of the step, the join behind its update -- inside one graph: no extra
+        graph launches, one fork / join pair per step.  The scatter waits on the memory side, the update on HBM and the
+        exchange on xGMI while the prefix is instruction- and L2-bound, so the two chains share the chip (DESIGN section 6;
+        0.379 -> 0.327 ms/step on one GPU).  The prefix next to the LAST step of the graph feeds the FIRST step of the next
+        replay through a static home (`CarriedPrefix`), so every step has its prefix overlapped.  Same batches in the same
+        order, same update rule as the back-to-back recording (tests/test_hip_graph.py, tests/test_hip_dp_graph.py).
+        The other placements of the fork that were built and measured slower (before the backward / the update, between the
+        head's and the table's backward, one fork per graph, two steps deep, the teacher held back) are recorded with their
+        numbers in profiles/r03_fork_modes.txt, r04_fork_modes.txt, r04_fork_optimizer.txt and DESIGN sections 9.3 / 10.9."""
         assert self.device_type == "cuda" and (not self.dp.enabled or self.dp.ingraph)
+        K = int(steps_per_graph)
+        assert K >= 2, "with one step per graph the step's own scatter would still read the samples the carried prefix overwrites"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # eager warm-up steps (communicators, compactor, caches), as in capture()
@@ -924,287 +574,66 @@ class DistillTrainer(_TrainerBase):
                 del out
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        K = max(1, int(steps_per_graph))
-        # the prefix next to the LAST step of the graph feeds the FIRST step of the next replay through a static home, so that
-        # every step has its prefix overlapped, whatever the number of steps per graph (K >= 2: with one step per graph the
-        # step's own scatter would still be reading the samples the copy overwrites)
-        carried = None
-        # (default "start": 0.322 vs 0.330 ms/step at 20 steps per graph, level at 5, profiles/r03_fork_modes.txt)
-        fork_mode = os.environ.get("PVD_PIPELINE_FORK", "start")
-        per_graph = fork_mode == "graph" and K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0"
         self._graph_zeroes = False
-        if K >= 2 and not self.dp.enabled:
+        if not self.dp.enabled:
             self._fold_launches(True)
-        if per_graph:
-            # ONE fork / join pair per GRAPH instead of one per step (a pair costs the main chain ~10 us at the fork and ~9 us at
-            # the join, profiles/r03_step_timeline.txt): the branch records the prefixes of all K steps of the NEXT replay back to
-            # back, the main chain records the K steps of this replay on the prefixes carried over from the previous one; after
-            # the join the K new prefixes move into the static homes (one multi-tensor copy per prefix).
-            with torch.cuda.stream(side):
-                homes = [CarriedPrefix(self.prefetch(batch_fn)) for _ in range(K)]  # prologue: the first replay's prefixes, eagerly
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            cap = SegmentedCapture(self.device)
-            self.dp.capture = cap
-            branch = torch.cuda.Stream(self.device)
-            try:
-                with cap:
-                    main = torch.cuda.current_stream()
-                    branch.wait_stream(main)
-                    try:
-                        with torch.cuda.stream(branch):
-                            nxts = [self.prefetch(batch_fn) for _ in range(K)]
-                        for k in range(K):
-                            self._zero_grads()
-                            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                                self._static_out = self.compute_loss(None, None, None, pre=homes[k].pre)
-                            self._backward(self._static_out[0])
-                            if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
-                                raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
-                            self._exchange()
-                            self._optimize()
-                    finally:
-                        main.wait_stream(branch)  # a capture can only be ended with its forked work joined
-                    for k in range(K):
-                        homes[k].store(nxts[k])
-            finally:
-                self.dp.capture = None
-                self._fold_launches(False)
-            self._cap = cap
-            self.steps_per_replay = K
-            self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
-            self.pipelined_ingraph = True
-            self.pipeline_fork = "graph"
-            return self._static_out
-        if fork_mode == "deep" and K >= 3 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
-            return self._capture_deep(batch_fn, K, side)
-        if K >= 2 and os.environ.get("PVD_PIPELINE_CARRY", "1") != "0":
-            with torch.cuda.stream(side):
-                carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-        # Two-part AdamW (FlatAdamW.two_part; single GPU, fork at "start"): the update behind the table scatter covers only what the
-        # backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the update's bytes, read by
-        # nothing but their own update -- are updated one step later on the forked branch, with the scalars the step recorded.
-        # Bit-identical parameters and moments (tests/test_hip_graph.py, tests/test_hip_fused_misc.py).  WHERE on the branch decides:
-        #   "1"    first thing, next to the student's forward; the objective waits for it (exact L1 value).  Slower than one launch:
-        #          0.340 vs 0.325 ms/step (profiles/r03_adamw_split_ab.txt) -- a 90 MB stream on top of the forward's gathers.
-        #   "late" (default) at the END of the branch, next to the head backward and the table scatter, which wait on the matrix cores
-        #          and on the memory side's atomic units, not on HBM: 0.280 vs 0.296 ms/step (profiles/r04_adamw_late_ab.txt).
-        #   "0"    one launch.
-        split_mode = os.environ.get("PVD_ADAMW_SPLIT", "late")
-        # (ray-DP with the collectives in the graph: the deferred rows are the ones no sample reaches -- they are not part of the
-        # exchange, and their update needs nothing but the step's scalars, which are the same on every rank -- so "late" holds there
-        # too, and the deferred part then runs under the exchange)
-        split = (self.flat_opt and fork_mode == "start" and K >= 2 and split_mode in ("1", "late")
-                 and (not self.dp.enabled or (self.dp.ingraph and split_mode == "late")))
-        # "late": part A of step k - 1 is launched at the END of step k's branch (after the next prefix: next to step k's head backward
-        # and table scatter, which wait on the matrix cores and on the memory side) instead of at its start; the objective does not
-        # wait for it -- the L1 VALUE it reports then counts the L1-only rows one step late (parameters and gradients are unaffected:
-        # those rows are read by nothing but their own update)
-        late = split and split_mode == "late"
-        # ... and the LAST step's part A rides on the next replay's first branch instead of trailing the graph (FlatAdamW.carry_last)
-        carry_a = late and carried is not None and os.environ.get("PVD_ADAMW_CARRY", "1") != "0"
+        with torch.cuda.stream(side):
+            carried = CarriedPrefix(self.prefetch(batch_fn))  # prologue: the first replayed step's prefix, eagerly
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # Two-part AdamW (FlatAdamW.two_part, PVD_ADAMW_SPLIT=late, the default; =0: one launch): the update behind the table scatter
+        # covers only what the backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the
+        # update's bytes, read by nothing but their own update -- are updated ONE STEP LATER at the END of the next step's branch,
+        # next to the head backward and the table scatter, which wait on the matrix cores and on the memory side's atomic units, not
+        # on HBM: 0.280 vs 0.296 ms/step (profiles/r04_adamw_late_ab.txt; at the START of the branch it measured slower than one
+        # launch, profiles/r03_adamw_split_ab.txt).  Bit-identical parameters and moments (tests/test_hip_graph.py).  The objective
+        # does not wait for it: the L1 VALUE it reports counts those rows one step late.  Under ray-DP with the collectives in the
+        # graph the deferred rows are the ones no sample reaches -- not part of the exchange, updated from the step's scalars,
+        # which are the same on every rank -- and the deferred part then runs under the exchange.
+        late = (self.flat_opt and os.environ.get("PVD_ADAMW_SPLIT", "late") == "late" and (not self.dp.enabled or self.dp.ingraph))
         scaled = bool(getattr(self.scaler, "_enabled", False))
         self._replay_owes_part_a = None
         fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
-        pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
+        pack_ahead = getattr(fh, "prepack_train_image", None)
         # (measurement, bench.py) record_fused_spans: every recorded launch of the frozen hash teacher's lookup + head writes its own
         # extent {first workgroup's start, last one's end} into a row of fused_spans [K, 2] (pvd_hash_head_forward_fused_span)
         self.fused_spans = None
         if getattr(self, "record_fused_spans", False) and getattr(self.model_tea, "model_type", "") == "hash":
             import pvd_hip
             self.fused_spans = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT)] * K, dtype=torch.int64, device=self.device)
-        if split and not self.optimizer.begin_two_part(defer=True):
-            split = late = carry_a = False  # (no warm-group lists, or no rows of one of the two kinds: one launch)
-        if split:
-            self.optimizer.carry_last = carry_a
+        if late and not self.optimizer.begin_two_part(defer=True):
+            late = False  # (no warm-group lists, or no rows of one of the two kinds: one launch)
+        if late:
+            # ... and the LAST step's deferred part rides on the next replay's first branch instead of trailing the graph
+            self.optimizer.carry_last = True
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)
         try:
             with cap:
                 main = torch.cuda.current_stream()
-                pre = carried.pre if carried is not None else self.prefetch(batch_fn)
+                pre = carried.pre
                 try:
                     for k in range(K):
-                        more = k + 1 < K or carried is not None  # a prefix to record next to this step
-                        # where the next prefix branches off: "mid" = between the student's head backward and its table scatter
-                        # (a VM student; anything else: as "backward"), "backward" = before this step's backward, "optimizer" =
-                        # before its exchange + update.  (Not before compute_loss: it reads tea.feature_sigma_color, which the
-                        # prefix rebinds.)
-                        # "start" = before this step's forward: compute_loss re-installs the teacher outputs of ITS prefix first
-                        # thing, so the rebinding is harmless once the fork's host code has run before it.
-                        # "headbwd" = right before the student's head backward (after the objective's and the compositing backward).
-                        # "start2" = two stages: the batch and the march (instruction-bound) fork at the start, next to the student's
-                        # forward; the frozen teacher's forward (gathers) is held back until the student's head backward begins, so
-                        # that it does not sit on top of the short latency-bound launches of the objective in between.
-                        two_stage = fork_mode == "start2"
-                        fork_at = "start" if two_stage else (fork_mode if fork_mode in ("mid", "backward", "optimizer", "start", "headbwd") else "start")
-                        pre_next = None
-
-                        def fork(k=k):
-                            branch.wait_stream(main)
-                            if self.fused_spans is not None:  # (measurement) this step's teacher launch leaves its extent in row k
-                                self.model_tea._fused_span = self.fused_spans[k]
-                            with torch.cuda.stream(branch):
-                                if fork_at == "start" and pack_ahead is not None and pack_ahead(self.model_stu):
-                                    # the student's f16 weight image for THIS step's head (5 us on the main chain otherwise): the
-                                    # weights are final (the fork follows the previous update), the head waits for it
-                                    packed = torch.cuda.Event()
-                                    packed.record(branch)
-                                    self.model_stu._before_head = lambda: main.wait_event(packed)
-                                if split and not late and self.optimizer.run_part_a():  # what the previous step's update still owes
-                                    done = torch.cuda.Event()
-                                    done.record(branch)
-                                    # (the objective adds up the L1 term from the partial sums this launch refreshes)
-                                    self._before_objective = lambda: main.wait_event(done)
-                                if two_stage:
-                                    return self.prefetch_march(batch_fn)  # stage 1; stage 2 (teacher) follows from the hook below
-                                nxt = self.prefetch(batch_fn)
-                                if k + 1 == K:  # for the next replay
-                                    carried.store(nxt)
-                                if late:
-                                    self.optimizer.run_part_a()
-                                    if carry_a and k == 0:
-                                        self.optimizer.run_carried_part_a(scaled)
-                                return nxt
-
-                        def teacher_stage(part, k=k):
-                            branch.wait_stream(main)  # not before the main chain has come this far
-                            with torch.cuda.stream(branch):
-                                nxt = self.prefetch_teacher(part)
-                                if k + 1 == K:
-                                    carried.store(nxt)
-                                return nxt
-                        held = {}
-                        if more and fork_at == "mid":  # between the student's head backward and its table scatter
-
-                            def between(grad, held=held):
-                                if "pre" not in held:
-                                    held["pre"] = fork()
-                                return None
-                            self.model_stu._between_backwards = between
-                        if more and fork_at == "headbwd":
-
-                            def before_head(grad, held=held):
-                                if "pre" not in held:
-                                    held["pre"] = fork()
-                                return None
-                            self.model_stu._before_head_backward = before_head
-                        if more and two_stage:
-                            held["part"] = fork()
-
-                            def before_head2(grad, held=held):
-                                if "pre" not in held:
-                                    held["pre"] = teacher_stage(held["part"])
-                                return None
-                            self.model_stu._before_head_backward = before_head2
-                        elif more and fork_at == "start":
-                            pre_next = fork()
-                        elif split:
-                            self.optimizer.run_part_a()  # no branch to put it on
-                        self._zero_grads()
-                        try:
-                            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                                self._static_out = self.compute_loss(None, None, None, pre=pre)
-                        finally:
-                            if fork_at == "mid" and getattr(self.model_stu, "_between_backwards", None) is not None:
-                                fork_at = "backward"  # the forward did not take the hook (not a fused VM student)
-                            if fork_at == "headbwd" and getattr(self.model_stu, "_before_head_backward", None) is not None:
-                                fork_at = "backward"
-                            if two_stage and getattr(self.model_stu, "_before_head_backward", None) is not None:
-                                held["pre"] = teacher_stage(held["part"])  # hook not taken: the teacher stage before the backward
-                            self.model_stu._between_backwards = None
-                            self.model_stu._before_head_backward = None
-                        if more and fork_at == "backward":  # the next step's prefix depends on nothing this step computes
-                            pre_next = fork()
-                        self._backward(self._static_out[0])
-                        if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
-                            raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
-                        if more and two_stage:
-                            pre_next = held.get("pre")
-                            if pre_next is None:  # the forward did not take the hook (not a fused VM student): stage 2 now
-                                pre_next = teacher_stage(held["part"])
-                        if more and fork_at in ("mid", "headbwd"):
-                            pre_next = held.get("pre")
-                        if more and pre_next is None:  # "optimizer", or a student without the hook point
-                            pre_next = fork()
-                        self._exchange()
-                        if carry_a and k + 1 == K:
-                            self.optimizer._next_step_is_last = True
-                        self._optimize()
-                        if pre_next is not None:  # join
-                            main.wait_stream(branch)
-                            pre = pre_next
-                    if split and carry_a:
-                        self.optimizer._part_a_owed = None  # the last step's: recorded on the next replay's first branch
-                        self._replay_owes_part_a = scaled
-                    elif split:
-                        self.optimizer.run_part_a()  # the last step's: a replay leaves nothing owed
-                except Exception:
-                    self.model_stu._between_backwards = None
-                    self.model_stu._before_head_backward = None
-                    self.model_stu.__dict__.pop("_before_head", None)
-                    self.model_stu.__dict__.pop("_train_image_ready", None)
-                    self.__dict__.pop("_before_objective", None)
-                    main.wait_stream(branch)  # a capture can only be ended with its forked work joined
-                    raise
-        finally:
-            self.dp.capture = None
-            self._fold_launches(False)
-            if split:
-                self.optimizer.end_two_part()
-        self._cap = cap
-        self.steps_per_replay = K
-        self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
-        self.pipelined_ingraph = True
-        self.pipeline_fork = fork_mode
-        # how the recorded steps update: "0" one launch, "1" / "late" two parts (only if the optimizer did split: a student without
-        # L1-only rows keeps the single launch)
-        self.adamw_split = split_mode if (split and getattr(self.optimizer, "_graph_is_two_part", False)) else "0"
-        return self._static_out
-
-    def _capture_deep(self, batch_fn, K, side):
-        """PVD_PIPELINE_FORK=deep: the fork at the start of the step, the branch TWO steps deep -- first the frozen teacher's forward
-        on the samples of step k + 1 (marched during step k - 1's branch: the gathers then run next to the student's
-        instruction-bound forward instead of on top of its table scatter), then the batch and the march of step k + 2
-        (instruction-bound, next to the atomics-bound scatter).  No additional edge in the graph: still one fork and one join per
-        step.  Two static homes carry the state across replays (the complete prefix of the next replay's step 1, the marched
-        samples of its step 2); K >= 3 so that nobody still reads a home when the last step's branch refills it."""
-        with torch.cuda.stream(side):
-            full_home = CarriedPrefix(self.prefetch(batch_fn))
-            part_home = CarriedPrefix(self.prefetch_march(batch_fn))
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        fh = getattr(getattr(self.model_stu, "ops", None), "fused_head", None)
-        pack_ahead = getattr(fh, "prepack_train_image", None) if os.environ.get("PVD_PACK_ON_BRANCH", "1") != "0" else None
-        # (measurement, bench.py) record_fused_spans: every recorded launch of the frozen hash teacher's lookup + head writes its own
-        # extent {first workgroup's start, last one's end} into a row of fused_spans [K, 2] (pvd_hash_head_forward_fused_span)
-        self.fused_spans = None
-        if getattr(self, "record_fused_spans", False) and getattr(self.model_tea, "model_type", "") == "hash":
-            import pvd_hip
-            self.fused_spans = torch.tensor([list(pvd_hip.FUSED_SPAN_INIT)] * K, dtype=torch.int64, device=self.device)
-        cap = SegmentedCapture(self.device)
-        self.dp.capture = cap
-        branch = torch.cuda.Stream(self.device)
-        try:
-            with cap:
-                main = torch.cuda.current_stream()
-                pre, part = full_home.pre, part_home.pre
-                try:
-                    for k in range(K):
+                        # the fork, first thing in the step: compute_loss below re-installs the teacher outputs of ITS prefix before
+                        # it reads them, so the rebinding the next prefix does on the host is harmless
                         branch.wait_stream(main)
+                        if self.fused_spans is not None:  # (measurement) this step's teacher launch leaves its extent in row k
+                            self.model_tea._fused_span = self.fused_spans[k]
                         with torch.cuda.stream(branch):
                             if pack_ahead is not None and pack_ahead(self.model_stu):
+                                # the student's f16 weight image for THIS step's head (5 us on the main chain otherwise): the
+                                # weights are final (the fork follows the previous update), the head waits for it
                                 packed = torch.cuda.Event()
                                 packed.record(branch)
                                 self.model_stu._before_head = lambda packed=packed: main.wait_event(packed)
-                            nxt_full = self.prefetch_teacher(part)
-                            nxt_part = self.prefetch_march(batch_fn)
+                            pre_next = self.prefetch(batch_fn)
                             if k + 1 == K:  # for the next replay
-                                full_home.store(nxt_full)
-                                part_home.store(nxt_part)
+                                carried.store(pre_next)
+                            if late:
+                                self.optimizer.run_part_a()  # what the previous step's update still owes
+                                if k == 0:
+                                    self.optimizer.run_carried_part_a(scaled)  # ... and the previous replay's last step
                         self._zero_grads()
                         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                             self._static_out = self.compute_loss(None, None, None, pre=pre)
@@ -1212,9 +641,14 @@ class DistillTrainer(_TrainerBase):
                         if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") in ("1", "forked") and k == 1:  # exercises the fall-backs
                             raise RuntimeError("forced failure inside the forked capture (PVD_TEST_FAIL_IN_CAPTURE)")
                         self._exchange()
+                        if late and k + 1 == K:
+                            self.optimizer._next_step_is_last = True
                         self._optimize()
-                        main.wait_stream(branch)
-                        pre, part = nxt_full, nxt_part
+                        main.wait_stream(branch)  # join
+                        pre = pre_next
+                    if late:
+                        self.optimizer._part_a_owed = None  # the last step's: recorded on the next replay's first branch
+                        self._replay_owes_part_a = scaled
                 except Exception:
                     self.model_stu.__dict__.pop("_before_head", None)
                     self.model_stu.__dict__.pop("_train_image_ready", None)
@@ -1223,11 +657,16 @@ class DistillTrainer(_TrainerBase):
         finally:
             self.dp.capture = None
             self._fold_launches(False)
+            if late:
+                self.optimizer.end_two_part()
         self._cap = cap
         self.steps_per_replay = K
         self._captured_occ_epoch = self._marching_model().occ_epoch if (self.flat_opt and self.optimizer.touched is not None) else None
         self.pipelined_ingraph = True
-        self.pipeline_fork = "deep"
+        self.pipeline_fork = "start"
+        # how the recorded steps update: "0" one launch, "late" two parts (only if the optimizer did split: a student without L1-only
+        # rows keeps the single launch)
+        self.adamw_split = "late" if (late and getattr(self.optimizer, "_graph_is_two_part", False)) else "0"
         return self._static_out
 
     def _capture_pipelined(self, batch_fn, body):
@@ -1387,7 +826,7 @@ class TeacherTrainer(_TrainerBase):
         m.fix_sample_alloc()
         self._block_batches = batches
         self.pipelined_block = False
-        if not self.dp.enabled and os.environ.get("PVD_TEACHER_PIPELINE", "1") != "0" and pvd_forked_graphs_ok():
+        if not self.dp.enabled and pvd_forked_graphs_ok():
             step0, local0 = self.global_step, m.local_step
             try:
                 self._capture_block_pipelined(batches)

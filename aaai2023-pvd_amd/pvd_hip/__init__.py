@@ -448,8 +448,8 @@ def grid_set_fwd_kernel(lanes_per_sample=2, persistent_blocks=4096):
     return rc
 
 
-if os.environ.get("PVD_GRID_LPS"):  # A/B knob: PVD_GRID_LPS=2 [PVD_GRID_PERSIST=4096] [PVD_GRID_AFFINE=1]
-    grid_set_fwd_kernel(int(os.environ["PVD_GRID_LPS"]), int(os.environ.get("PVD_GRID_PERSIST", "0")) | ((1 << 30) if os.environ.get("PVD_GRID_AFFINE") == "1" else 0))
+if os.environ.get("PVD_GRID_LPS"):  # A/B knob: PVD_GRID_LPS=2 [PVD_GRID_PERSIST=4096]
+    grid_set_fwd_kernel(int(os.environ["PVD_GRID_LPS"]), int(os.environ.get("PVD_GRID_PERSIST", "0")))
 
 
 # --------------------------------------------------------------------------- _shencoder

@@ -886,3 +886,73 @@ int pvdo_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* The sigma / colour head under torch.autocast(float16) -- distill_mutual/network.py:413-437 (hash / mlp: sigma_net,
+ * clamp, trunc_exp, color_net, sigmoid) and :344-381 (vm: basis_mat inside get_color_feat :290-309, the clamps, the
+ * same colour head).  What autocast does to that code on the device the reference trains on:
+ *   - every nn.Linear (all of them bias-free, network.py:111-152) takes its input and its fp32 master weight rounded to
+ *     f16, accumulates in fp32 and stores f16; F.relu and torch.clamp act on those f16 values;
+ *   - trunc_exp (tools/activation.py: custom_fwd(cast_inputs=torch.float32)) and the SH direction encoding
+ *     (shencoder/sphere_harmonics.py: custom_fwd(cast_inputs=torch.float32)) run in fp32;
+ *   - torch.cat([enc_d (f32), geo_feat (f16)]) promotes to f32 and the next Linear rounds it to f16 again;
+ *   - torch.sigmoid on the last Linear's f16 output: evaluated in fp32, stored f16;
+ *   - vm: sigma_feat comes out of grid_sample in fp32 (an autocast-to-fp32 op) and is clamped in fp32; basis_mat's
+ *     input (the plane x line products) is rounded to f16 by the Linear.
+ * This is the arithmetic of the timed configuration's fused MFMA head (fusedhead.hip: head_forward_tile), restated
+ * with a plain ascending-k fp32 sum per output -- the matrix cores add the same exact products in another order, so
+ * the two agree up to the rounding of an fp32 sum, i.e. up to one f16 ulp on the rare entry that lands on a tie.
+ *   kind 0 (hash / mlp trunk): x0 = encoder output [M][28] f16; Wa1 = sigma_net.0 [64][28], Wa2 = sigma_net.1 [16][64]
+ *   kind 1 (vm)              : x0 = products [M][144] f16, sigma_raw [M] f32; Wa1 = basis_mat [15][144]
+ *   Wc1 [64][31], Wc2 [64][64], Wc3 [3][64]; dirs [M][3] unit vectors.
+ * Outputs: sigma [M] f32 = exp(feature 0), rgb [M][3] (f16 values widened), feat16 [M][16] = feature_sigma_color. */
+static inline float h_round(float v) { return pvdo_f16_to_f32(pvdo_f32_to_f16(v)); }
+
+static void linear_f16(const float *W, int rows, int cols, const float *x_h /* f16 values */, float *y_h, int relu) {
+    for (int o = 0; o < rows; o++) {
+        float acc = 0.0f;
+        for (int k = 0; k < cols; k++) acc += h_round(W[(size_t)o * cols + k]) * x_h[k]; /* exact products, fp32 sum */
+        float r = h_round(acc);
+        if (relu && !(r > 0.0f)) r = 0.0f;
+        y_h[o] = r;
+    }
+}
+
+int pvdo_head_forward_amp(int kind, const uint16_t *x0, const float *sigma_raw, const float *dirs, uint32_t M,
+                          const float *Wa1, const float *Wa2, const float *Wc1, const float *Wc2, const float *Wc3,
+                          float clip_sigma_min, float clip_feat_min, float clip_max,
+                          float *sigma, float *rgb, float *feat16) {
+    if (kind != 0 && kind != 1) return -1;
+    float *sh = (float *)malloc((size_t)M * 16 * sizeof(float));
+    if (!sh) return -2;
+    if (pvdo_sh_encode_forward(dirs, sh, M, 3, 4, 0, 0) != 0) { free(sh); return -1; } /* network.py:104 (degree 4), fp32 */
+#pragma omp parallel for schedule(static)
+    for (uint32_t b = 0; b < M; b++) {
+        float F[16]; /* feature_sigma_color */
+        if (kind == 0) {
+            float x[28], h1[64], h[16];
+            for (int k = 0; k < 28; k++) x[k] = pvdo_f16_to_f32(x0[(size_t)b * 28 + k]);
+            linear_f16(Wa1, 64, 28, x, h1, 1);  /* network.py:414-417 */
+            linear_f16(Wa2, 16, 64, h1, h, 0);
+            h[0] = h_round(fminf(clip_max, fmaxf(clip_sigma_min, h[0]))); /* :418-420, on the f16 tensor */
+            for (int k = 0; k < 16; k++) F[k] = h[k];
+        } else {
+            float x[144], cf[15];
+            for (int k = 0; k < 144; k++) x[k] = pvdo_f16_to_f32(x0[(size_t)b * 144 + k]);
+            linear_f16(Wa1, 15, 144, x, cf, 0); /* basis_mat, network.py:308 */
+            F[0] = fminf(clip_max, fmaxf(clip_sigma_min, sigma_raw[b]));             /* :357-360 (fp32) */
+            for (int k = 0; k < 15; k++) F[1 + k] = fminf(clip_max, fmaxf(clip_feat_min, cf[k])); /* :361-363 */
+        }
+        for (int k = 0; k < 16; k++) feat16[(size_t)b * 16 + k] = F[k];
+        sigma[b] = expf(F[0]); /* trunc_exp forward, fp32 (:425 / :372) */
+        float in[31], c1[64], c2[64], c3[3];
+        for (int k = 0; k < 16; k++) in[k] = h_round(sh[(size_t)b * 16 + k]);  /* torch.cat -> f32 -> the Linear's f16 cast */
+        for (int k = 0; k < 15; k++) in[16 + k] = h_round(F[1 + k]);
+        linear_f16(Wc1, 64, 31, in, c1, 1); /* :429-434 */
+        linear_f16(Wc2, 64, 64, c1, c2, 1);
+        linear_f16(Wc3, 3, 64, c2, c3, 0);
+        for (int k = 0; k < 3; k++) rgb[(size_t)b * 3 + k] = h_round(1.0f / (1.0f + expf(-c3[k]))); /* :435 */
+    }
+    free(sh);
+    return 0;
+}

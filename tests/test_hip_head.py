@@ -309,11 +309,11 @@ def test_fused_lookup_and_head_is_bit_identical_to_the_two_launches(M, bound, mo
     assert torch.isfinite(s1).all() and f1.abs().max().item() > 0
 
 
-@pytest.mark.parametrize("variant,dma", [("0", "0"), ("7", "0"), ("7", "1"), ("14", "0"), ("14", "1")])
-def test_every_variant_of_the_fused_kernel_produces_the_same_bits(variant, dma, monkeypatch):
-    """PVD_FUSED_VARIANT = 0 (the round-3 kernel: offsets re-read per level, LevelIndex per corner), 7 / 14 (levels per memory round
-    trip; offsets in SGPRs, Level3 index shapes, blended as the loads retire) x PVD_FUSED_DMA (where the weight image's LDS-DMA is
-    issued): all against lookup + head as two launches, incl. a second cascade, out-of-box samples and a multi-chunk workgroup."""
+@pytest.mark.parametrize("dma", ["0", "1"])
+def test_every_variant_of_the_fused_kernel_produces_the_same_bits(dma, monkeypatch):
+    """k_hash_fwd_fused (14 levels per memory round trip; offsets in SGPRs, Level3 index shapes, blended as the loads retire) x
+    PVD_FUSED_DMA (where the weight image's LDS-DMA is issued): against lookup + head as two launches, incl. a second cascade,
+    out-of-box samples and a multi-chunk workgroup.  (The round-3 kernel and the 7-levels-per-round-trip form were removed in round 5.)"""
     import fusedhead
     m = _model("hash").eval()
     for M, bound in ((4099, 1), (20000, 2), (140001, 1)):
@@ -324,10 +324,9 @@ def test_every_variant_of_the_fused_kernel_produces_the_same_bits(variant, dma, 
         monkeypatch.setattr(fusedhead, "FUSED_LOOKUP", False)
         ref = fusedhead.hash_head_infer(m, x, d)
         monkeypatch.setattr(fusedhead, "FUSED_LOOKUP", True)
-        monkeypatch.setenv("PVD_FUSED_VARIANT", variant)
         monkeypatch.setenv("PVD_FUSED_DMA", dma)
         got = fusedhead.hash_head_infer(m, x, d)
-        assert all(torch.equal(a, b) for a, b in zip(ref, got)), (variant, dma, M)
+        assert all(torch.equal(a, b) for a, b in zip(ref, got)), (dma, M)
 
 
 def test_the_fused_launch_stamps_its_own_extent():

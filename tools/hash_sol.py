@@ -89,11 +89,8 @@ xin = (x01 * 2 - 1).contiguous()
 xin_sorted = (x_sorted * 2 - 1).contiguous()
 
 
-def product(x=None, variant=None):
-    if variant is not None:
-        os.environ["PVD_FUSED_VARIANT"] = str(variant)  # read by the launch wrapper on every call
+def product(x=None):
     fusedhead.hash_head_infer(m, xin if x is None else x, d)
-    os.environ.pop("PVD_FUSED_VARIANT", None)
 
 
 ALL_HIT = 0x3FFF  # 16 k rows = 64 KB per level: every level resident in every L2 (and mostly in L1)
@@ -103,9 +100,7 @@ ROWS = [
     ("stream 516 B/sample, 2048 wg", lambda: stream(2048), ALG),
     ("stream 516 B/sample, 8192 wg", lambda: stream(8192), ALG),
     ("product: lookup + head (fused), default", product, ALG),
-    ("product, round-3 kernel (variant 0)", lambda: product(variant=0), ALG),
-    ("product, G=7 (variant 7)", lambda: product(variant=7), ALG),
-    ("product, G=14 (variant 14)", lambda: product(variant=14), ALG),
+    ("product (k_hash_fwd_fused<14>)", lambda: product(), ALG),
     ("gather G=7 (product's structure)", lambda: gather(0), ALG),
     ("gather G=14 (one round trip)", lambda: gather(1), ALG),
     ("gather G=4", lambda: gather(2), ALG),
@@ -168,7 +163,7 @@ if args.pmc:
     torch.cuda.synchronize()
     print("samples_per_launch", M)
 else:
-    print("samples per launch: %d   algorithmic bytes (516 B/sample): %.2f MB   PVD_FUSED_VARIANT=%s" % (M, ALG / 1e6, os.environ.get("PVD_FUSED_VARIANT", "default")))
+    print("samples per launch: %d   algorithmic bytes (516 B/sample): %.2f MB" % (M, ALG / 1e6))
     print("%-42s %9s %10s %8s" % ("row", "us/launch", "GB/s @516", "of 8TB/s"))
     for name, fn, nbytes in ROWS:
         if args.rows and args.rows not in name:

@@ -29,9 +29,12 @@ __global__ void __launch_bounds__(256) k_rate(float *__restrict__ buf, uint32_t 
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (uint32_t i = 0; i < iters; i++) {
         r = r * 1664525u + 1013904223u;
-        const uint32_t row = ((r >> 8) % distinct) * (rows / distinct);
+        uint32_t row = ((r >> 8) % distinct) * (rows / distinct);
+        if (MODE == 8) row = (wave * iters + i) % rows;                                   // every wave streams its own consecutive rows
+        if (MODE == 9) row = ((wave * 64u) % (rows - 64u)) + ((r >> 8) & 63u);              // random inside the wave's own 16 KB window
+        if (MODE == 10) row = (((r >> 8) % (rows / 16u)) * 16u) + (i & 15u);               // runs of 16 consecutive rows (4 KB), random runs
         float *p = base + (size_t)row * 64 + lane;
-        if (MODE == 0) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 0 || MODE >= 8) { if (MODE != 11 || lane < 16) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else if (MODE == 1 || MODE == 2) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (MODE == 3) __builtin_nontemporal_store(v, p);
         else if (MODE == 4) { *p = v; }
@@ -86,6 +89,13 @@ int main() {
             run<3>("nt-store", buf, rows, waves, iters, distinct, ticks);
             run<4>("store", buf, rows, waves, iters, distinct, ticks);
         }
+    }
+    for (uint32_t waves : {8192u}) {
+        const uint32_t iters = 1400000u / waves * 4;
+        run<8>("seq-rows", buf, rows, waves, iters, 270000u, ticks);
+        run<9>("16KB-win", buf, rows, waves, iters, 270000u, ticks);
+        run<10>("4KB-runs", buf, rows, waves, iters, 270000u, ticks);
+        run<11>("16-lanes", buf, rows, waves, iters, 270000u, ticks);  // one 64-byte request per instruction (the line printed counts 4)
     }
     for (uint32_t waves : {256u, 1024u, 4096u}) {
         run<5>("agent+wait", buf, rows, waves, 200, 270000u, ticks);
