@@ -349,76 +349,129 @@ __device__ __forceinline__ TileIn<KIND> load_tile_in(const HeadArgs &a, size_t b
     return in;
 }
 
-template <int KIND>
-__device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, const TileIn<KIND> &in, uint32_t lane, TileFwd &t) {
+// NT tiles at once: every weight fragment is read from LDS once and feeds NT independent MFMAs (the backward runs one wave per
+// SIMD: nothing else hides an LDS round trip or a matrix-core result).  Per tile the operations and their order are those of a
+// single tile: bit-identical outputs whatever NT.
+template <int KIND, int NT>
+__device__ __forceinline__ void head_forward_tiles(const HeadArgs &a, const HeadLds<KIND> &W, const TileIn<KIND> *__restrict__ in, uint32_t lane,
+                                                   TileFwd *__restrict__ t) {
     const uint32_t hi = lane >> 4;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     // ---- stage A: features -> 16-row feature tile
     if (KIND == KIND_HASH) {
-        const h4 X[2] = {in.x[0], in.x[1]};
-        h4 Ha[4];
+        h4 Ha[NT][4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            f4 acc = zero;
+            f4 acc[NT];
 #pragma unroll
-            for (int s = 0; s < 2; s++) acc = mfma(W.Wa1.afrag(n, s, lane), X[s], acc);
-            Ha[n] = relu_h4(to_h4(acc));
+            for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const h4 A = W.Wa1.afrag(n, s, lane);
+#pragma unroll
+                for (int u = 0; u < NT; u++) acc[u] = mfma(A, in[u].x[s], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NT; u++) Ha[u][n] = relu_h4(to_h4(acc[u]));
         }
-        f4 acc = zero;
+        f4 acc[NT];
 #pragma unroll
-        for (int s = 0; s < 4; s++) acc = mfma(W.Wa2.afrag(0, s, lane), Ha[s], acc);
-        h4 Fh = to_h4(acc);  // Linear output is f16
-        t.raw = zero;
-        t.sig_raw = (float)Fh.x;  // pre-clamp h0 (for the clamp's backward mask)
-        if (hi == 0) {
-            const float c = fminf(a.clip_max, fmaxf(a.clip_sigma_min, (float)Fh.x));
-            Fh.x = (half_t)c;
+        for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const h4 A = W.Wa2.afrag(0, s, lane);
+#pragma unroll
+            for (int u = 0; u < NT; u++) acc[u] = mfma(A, Ha[u][s], acc[u]);
         }
-        t.Fh = Fh;
-        t.F = (f4){(float)Fh.x, (float)Fh.y, (float)Fh.z, (float)Fh.w};
 #pragma unroll
-        for (int s = 0; s < 2; s++) t.X[s] = X[s];
+        for (int u = 0; u < NT; u++) {
+            h4 Fh = to_h4(acc[u]);  // Linear output is f16
+            t[u].raw = zero;
+            t[u].sig_raw = (float)Fh.x;  // pre-clamp h0 (for the clamp's backward mask)
+            if (hi == 0) {
+                const float c = fminf(a.clip_max, fmaxf(a.clip_sigma_min, (float)Fh.x));
+                Fh.x = (half_t)c;
+            }
+            t[u].Fh = Fh;
+            t[u].F = (f4){(float)Fh.x, (float)Fh.y, (float)Fh.z, (float)Fh.w};
 #pragma unroll
-        for (int n = 0; n < 4; n++) t.Ha[n] = Ha[n];
+            for (int s = 0; s < 2; s++) t[u].X[s] = in[u].x[s];
+#pragma unroll
+            for (int n = 0; n < 4; n++) t[u].Ha[n] = Ha[u][n];
+        }
     } else {
-        f4 acc = zero;
+        f4 acc[NT];
 #pragma unroll
-        for (int s = 0; s < 9; s++) acc = mfma(W.Wa1.afrag(0, s, lane), in.x[s], acc);
-        const h4 rawh = to_h4(acc);  // basis_mat output, f16
-        t.raw = (f4){(float)rawh.x, (float)rawh.y, (float)rawh.z, (float)rawh.w};
-        f4 F;
-        F.x = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.x));
-        F.y = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.y));
-        F.z = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.z));
-        F.w = fminf(a.clip_max, fmaxf(a.clip_feat_min, t.raw.w));
-        t.sig_raw = 0.f;
-        if (hi == 0) {
-            t.sig_raw = in.sraw;
-            F.x = fminf(a.clip_max, fmaxf(a.clip_sigma_min, t.sig_raw));  // row 0 := clamped sigma feature (fp32)
+        for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            const h4 A = W.Wa1.afrag(0, s, lane);
+#pragma unroll
+            for (int u = 0; u < NT; u++) acc[u] = mfma(A, in[u].x[s < (KIND == KIND_VM ? 9 : 2) ? s : 0], acc[u]);
         }
-        t.F = F;
-        t.Fh = to_h4(F);
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            const h4 rawh = to_h4(acc[u]);  // basis_mat output, f16
+            t[u].raw = (f4){(float)rawh.x, (float)rawh.y, (float)rawh.z, (float)rawh.w};
+            f4 F;
+            F.x = fminf(a.clip_max, fmaxf(a.clip_feat_min, t[u].raw.x));
+            F.y = fminf(a.clip_max, fmaxf(a.clip_feat_min, t[u].raw.y));
+            F.z = fminf(a.clip_max, fmaxf(a.clip_feat_min, t[u].raw.z));
+            F.w = fminf(a.clip_max, fmaxf(a.clip_feat_min, t[u].raw.w));
+            t[u].sig_raw = 0.f;
+            if (hi == 0) {
+                t[u].sig_raw = in[u].sraw;
+                F.x = fminf(a.clip_max, fmaxf(a.clip_sigma_min, t[u].sig_raw));  // row 0 := clamped sigma feature (fp32)
+            }
+            t[u].F = F;
+            t[u].Fh = to_h4(F);
+        }
     }
     // ---- stage B: colour head
-    t.sh = sh_frag(in.dx, in.dy, in.dz, hi);
+#pragma unroll
+    for (int u = 0; u < NT; u++) t[u].sh = sh_frag(in[u].dx, in[u].dy, in[u].dz, hi);
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        f4 acc = zero;
-        acc = mfma(W.Wc1.afrag(n, 0, lane), t.sh, acc);
-        acc = mfma(W.Wc1.afrag(n, 1, lane), t.Fh, acc);  // column 16 (log-sigma) has zero weight
-        t.H1[n] = relu_h4(to_h4(acc));
+        const h4 A0 = W.Wc1.afrag(n, 0, lane), A1 = W.Wc1.afrag(n, 1, lane);
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            f4 acc = zero;
+            acc = mfma(A0, t[u].sh, acc);
+            acc = mfma(A1, t[u].Fh, acc);  // column 16 (log-sigma) has zero weight
+            t[u].H1[n] = relu_h4(to_h4(acc));
+        }
     }
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        f4 acc = zero;
+        f4 acc[NT];
 #pragma unroll
-        for (int s = 0; s < 4; s++) acc = mfma(W.Wc2.afrag(n, s, lane), t.H1[s], acc);
-        t.H2[n] = relu_h4(to_h4(acc));
+        for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const h4 A = W.Wc2.afrag(n, s, lane);
+#pragma unroll
+            for (int u = 0; u < NT; u++) acc[u] = mfma(A, t[u].H1[s], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NT; u++) t[u].H2[n] = relu_h4(to_h4(acc[u]));
     }
-    f4 acc = zero;
+    {
+        f4 acc[NT];
 #pragma unroll
-    for (int s = 0; s < 4; s++) acc = mfma(W.Wc3.afrag(0, s, lane), t.H2[s], acc);
-    t.out = acc;
+        for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const h4 A = W.Wc3.afrag(0, s, lane);
+#pragma unroll
+            for (int u = 0; u < NT; u++) acc[u] = mfma(A, t[u].H2[s], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NT; u++) t[u].out = acc[u];
+    }
+}
+template <int KIND>
+__device__ __forceinline__ void head_forward_tile(const HeadArgs &a, const HeadLds<KIND> &W, const TileIn<KIND> &in, uint32_t lane, TileFwd &t) {
+    head_forward_tiles<KIND, 1>(a, W, &in, lane, &t);
 }
 
 __device__ __forceinline__ float sigmoid_h(float pre) {
@@ -434,14 +487,18 @@ __global__ void __launch_bounds__(kHeadBlock) k_head_fwd(HeadArgs a) {
     if (blockIdx.x * (kHeadBlock / 64) * 16u >= a.M) return;  // nothing for this workgroup: skip the weight staging too
     HeadLds<KIND> W;
     W.carve(lds);
-    if (a.image) copy_image(lds, a.image, HeadLds<KIND>::halfs, threadIdx.x, kHeadBlock);
-    else W.load(a, threadIdx.x, kHeadBlock);
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
     const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
     const uint32_t nwaves = gridDim.x * (kHeadBlock / 64);
     const uint32_t ntiles = div_up(a.M, 16u);
+    // A cold launch is a chain of memory round trips of 1.5-2 us each (kernel arguments -> weight image -> first tile's inputs -> ...):
+    // the launch costs 10 us whatever M (tools/bench_head.py, M = 64).  The packed image goes by LDS-DMA, every piece in flight at
+    // once, and the first tile's inputs are requested BEHIND it in the same round trip (one wait for both).
+    if (a.image) copy_image_dma_static<HeadLds<KIND>::halfs>(lds, a.image, threadIdx.x);
     TileIn<KIND> nxt = load_tile_in<KIND>(a, (size_t)wave * 16 + (lane & 15), (size_t)wave * 16 + (lane & 15) < a.M, lane);
+    if (a.image) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the DMA has landed before the barrier releases the readers
+    else W.load(a, threadIdx.x, kHeadBlock);
+    __syncthreads();
     for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
         const size_t b = (size_t)tile * 16 + (lane & 15);
         const bool valid = b < a.M;
@@ -1324,6 +1381,24 @@ __device__ __forceinline__ h4 mask_relu(f4 g, h4 act) {  // dPre = dAct * (act >
     return r;
 }
 
+#ifndef PVD_HEAD_NT
+#define PVD_HEAD_NT 1
+#endif
+typedef half_t h8 __attribute__((ext_vector_type(8)));
+struct TrFrag { h4 v[PVD_HEAD_NT]; };    // the transposed register tiles of the NT tiles of a trip
+struct TrFragIn { h4 v[PVD_HEAD_NT]; };
+// dW tile += sum over the samples of all NT tiles: one K = 32 MFMA for two tiles, a chain of K = 16 ones otherwise
+__device__ __forceinline__ f4 mfma_nt(const TrFrag &A, const TrFrag &B, f4 c) {
+#if PVD_HEAD_NT == 2
+    const h8 a8 = __builtin_shufflevector(A.v[0], A.v[1], 0, 1, 2, 3, 4, 5, 6, 7), b8 = __builtin_shufflevector(B.v[0], B.v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+#else
+#pragma unroll
+    for (int u = 0; u < PVD_HEAD_NT; u++) c = mfma(A.v[u], B.v[u], c);
+    return c;
+#endif
+}
+
 template <int KIND, int OCC>
 __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
     extern __shared__ __align__(16) half_t lds[];
@@ -1332,7 +1407,7 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
     HeadLdsT<KIND> T;
     T.carve(lds + HeadLds<KIND>::halfs);
     const LdsMat Wa1T = T.Wa1T, Wa2T = T.Wa2T, Wc1T = T.Wc1T, Wc2T = T.Wc2T, Wc3T = T.Wc3T;
-    half_t *scratch = lds + HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (threadIdx.x >> 6) * 256;  // 512 B per wave
+    half_t *scratch = lds + HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (threadIdx.x >> 6) * 512;  // two 512-byte transpose pieces per wave
 #ifdef PVD_HEAD_PROFILE
     long long *stamps = reinterpret_cast<long long *>(a.partials + (size_t)gridDim.x * DwLayout<KIND>::floats);
     int n_stamp = 0;
@@ -1341,22 +1416,13 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
 #define PVD_STAMP() do { } while (0)
 #endif
     PVD_STAMP();
-    if (a.f.image) {
-        copy_image(lds, a.f.image, HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs, threadIdx.x, kHeadBlock);
-    } else {
-        W.load(a.f, threadIdx.x, kHeadBlock);
-        T.load(a.f, threadIdx.x, kHeadBlock);
-    }
-    PVD_STAMP();
-    __syncthreads();
-    PVD_STAMP();
-
     const uint32_t lane = threadIdx.x & 63u, hi = lane >> 4;
     const uint32_t wave = (blockIdx.x * kHeadBlock + threadIdx.x) >> 6;
     const uint32_t nwaves = gridDim.x * (kHeadBlock / 64);
     const uint32_t ntiles = div_up(a.f.M, 16u);
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     const h4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+    if (a.f.image) copy_image_dma_static<HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs>(lds, a.f.image, threadIdx.x);  // (see k_head_fwd)
 
     using LY = DwLayout<KIND>;
     f4 dWa[LY::a], dW1[8], dW2[16], dW3[4];
@@ -1381,158 +1447,251 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
         }
         return q;
     };
-    const size_t b_first = (size_t)wave * 16 + (lane & 15);
-    TileIn<KIND> nxt = load_tile_in<KIND>(a.f, b_first, b_first < a.f.M, lane);
-    TileGrad nxt_g = load_grad(b_first, b_first < a.f.M);
-    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
-        const size_t b = (size_t)tile * 16 + (lane & 15);
-        const bool valid = b < a.f.M;
-        const TileIn<KIND> in = nxt;
-        const TileGrad gin = nxt_g;
-        if (tile + nwaves < ntiles) {  // next tile's inputs: in flight while this tile computes
-            const size_t bn = (size_t)(tile + nwaves) * 16 + (lane & 15);
-            nxt = load_tile_in<KIND>(a.f, bn, bn < a.f.M, lane);
-            nxt_g = load_grad(bn, bn < a.f.M);
+    // NT = 2 tiles (32 consecutive samples) per trip: every weight fragment read from LDS feeds two independent MFMAs, the two
+    // tiles' dependent chains (MFMA -> f16 -> mask -> MFMA ...) interleave, and a weight-gradient tile takes both tiles' samples in
+    // ONE v_mfma_f32_16x16x32_f16 (k = 8 hi + 4 u + j  <->  sample 4 hi + j of tile u, the same for both operands).  One wave per
+    // SIMD has nothing else to fill those latencies with: 9.2 k cycles per tile at NT = 1 (profiles/r05_head_bwd_stamps_tr.txt).
+    constexpr int NT = PVD_HEAD_NT;
+    const uint32_t ntrips = div_up(ntiles, (uint32_t)NT);
+    TileIn<KIND> nxt[NT];
+    TileGrad nxt_g[NT];
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+        const size_t bf = ((size_t)wave * NT + u) * 16 + (lane & 15);
+        nxt[u] = load_tile_in<KIND>(a.f, bf, bf < a.f.M, lane);
+        nxt_g[u] = load_grad(bf, bf < a.f.M);
+    }
+    // (the first trip's inputs were requested behind the image's DMA: one round trip for both)
+    if (a.f.image) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the DMA has landed before the barrier releases the readers
+    } else {
+        W.load(a.f, threadIdx.x, kHeadBlock);
+        T.load(a.f, threadIdx.x, kHeadBlock);
+    }
+    PVD_STAMP();
+    __syncthreads();
+    PVD_STAMP();
+    for (uint32_t trip = wave; trip < ntrips; trip += nwaves) {
+        size_t b[NT];
+        bool valid[NT];
+        TileIn<KIND> in[NT];
+        TileGrad gin[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            b[u] = ((size_t)trip * NT + u) * 16 + (lane & 15);
+            valid[u] = b[u] < a.f.M;
+            in[u] = nxt[u];
+            gin[u] = nxt_g[u];
         }
-        TileFwd t;
+        if (trip + nwaves < ntrips) {  // next trip's inputs: in flight while this one computes
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const size_t bn = ((size_t)(trip + nwaves) * NT + u) * 16 + (lane & 15);
+                nxt[u] = load_tile_in<KIND>(a.f, bn, bn < a.f.M, lane);
+                nxt_g[u] = load_grad(bn, bn < a.f.M);
+            }
+        }
+        TileFwd t[NT];
         PVD_STAMP();
-        head_forward_tile<KIND>(a.f, W, in, lane, t);
+        head_forward_tiles<KIND, NT>(a.f, W, in, lane, t);
         PVD_STAMP();
 
         // ---- d loss / d (colour layer 3 pre-activation): rows 0..2 live in the hi == 0 lanes
-        h4 D3 = hzero;
-        if (valid && hi == 0) {
-            const float s0 = sigmoid_h(t.out.x), s1 = sigmoid_h(t.out.y), s2 = sigmoid_h(t.out.z);
-            D3.x = (half_t)(gin.r * s0 * (1.0f - s0));
-            D3.y = (half_t)(gin.g * s1 * (1.0f - s1));
-            D3.z = (half_t)(gin.bl * s2 * (1.0f - s2));
-        }
-        h4 D2[4], D1[4];
+        h4 D3[NT];
 #pragma unroll
-        for (int n = 0; n < 4; n++) D2[n] = mask_relu(mfma(Wc3T.afrag(n, 0, lane), D3, zero), t.H2[n]);
+        for (int u = 0; u < NT; u++) {
+            D3[u] = hzero;
+            if (valid[u] && hi == 0) {
+                const float s0 = sigmoid_h(t[u].out.x), s1 = sigmoid_h(t[u].out.y), s2 = sigmoid_h(t[u].out.z);
+                D3[u].x = (half_t)(gin[u].r * s0 * (1.0f - s0));
+                D3[u].y = (half_t)(gin[u].g * s1 * (1.0f - s1));
+                D3[u].z = (half_t)(gin[u].bl * s2 * (1.0f - s2));
+            }
+        }
+        h4 D2[NT][4], D1[NT][4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            f4 acc = zero;
+            const h4 A = Wc3T.afrag(n, 0, lane);
 #pragma unroll
-            for (int s = 0; s < 4; s++) acc = mfma(Wc2T.afrag(n, s, lane), D2[s], acc);
-            D1[n] = mask_relu(acc, t.H1[n]);
+            for (int u = 0; u < NT; u++) D2[u][n] = mask_relu(mfma(A, D3[u], zero), t[u].H2[n]);
         }
-        f4 dF = zero;  // rows 16..31 of the colour layer's input = the feature tile (row 16 has zero weights)
 #pragma unroll
-        for (int s = 0; s < 4; s++) dF = mfma(Wc1T.afrag(1, s, lane), D1[s], dF);
-        if (valid) { dF.x += gin.feat.x; dF.y += gin.feat.y; dF.z += gin.feat.z; dF.w += gin.feat.w; }
-        // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
-        // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
-        float g0 = 0.f;
-        if (hi == 0 && valid) {
-            g0 = dF.x + gin.sig * __expf(fminf(12.f, fmaxf(-12.f, t.F.x)));
-            g0 = (t.sig_raw >= a.f.clip_sigma_min && t.sig_raw <= a.f.clip_max) ? g0 : 0.f;
-        }
-        h4 Da;  // gradient of stage A's output tile
-        if (KIND == KIND_VM) {
-            // clamp backward on the colour features; row 0 leaves through g_sigma_raw
-            const float lo = a.f.clip_feat_min, hi_c = a.f.clip_max;
-            f4 dcf;
-            dcf.x = (t.raw.x >= lo && t.raw.x <= hi_c) ? dF.x : 0.f;
-            dcf.y = (t.raw.y >= lo && t.raw.y <= hi_c) ? dF.y : 0.f;
-            dcf.z = (t.raw.z >= lo && t.raw.z <= hi_c) ? dF.z : 0.f;
-            dcf.w = (t.raw.w >= lo && t.raw.w <= hi_c) ? dF.w : 0.f;
-            if (hi == 0) {
-                if (valid) a.g_sigma_raw[b] = g0;
-                dcf.x = 0.f;
+        for (int n = 0; n < 4; n++) {
+            f4 acc[NT];
+#pragma unroll
+            for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const h4 A = Wc2T.afrag(n, s, lane);
+#pragma unroll
+                for (int u = 0; u < NT; u++) acc[u] = mfma(A, D2[u][s], acc[u]);
             }
-            Da = to_h4(dcf);
+#pragma unroll
+            for (int u = 0; u < NT; u++) D1[u][n] = mask_relu(acc[u], t[u].H1[n]);
+        }
+        f4 dF[NT];  // rows 16..31 of the colour layer's input = the feature tile (row 16 has zero weights)
+#pragma unroll
+        for (int u = 0; u < NT; u++) dF[u] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const h4 A = Wc1T.afrag(1, s, lane);
+#pragma unroll
+            for (int u = 0; u < NT; u++) dF[u] = mfma(A, D1[u][s], dF[u]);
+        }
+        h4 Da[NT];  // gradient of stage A's output tile
+        f4 dh[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            if (valid[u]) { dF[u].x += gin[u].feat.x; dF[u].y += gin[u].feat.y; dF[u].z += gin[u].feat.z; dF[u].w += gin[u].feat.w; }
+            // row 0 = log-sigma: sigma = trunc_exp(F0) -> g * exp(clamp(F0, -12, 12)) (tools/activation.py:18), plus
+            // whatever arrived through feature_sigma_color[:, 0]; then the sigma clamp's mask
+            float g0 = 0.f;
+            if (hi == 0 && valid[u]) {
+                g0 = dF[u].x + gin[u].sig * __expf(fminf(12.f, fmaxf(-12.f, t[u].F.x)));
+                g0 = (t[u].sig_raw >= a.f.clip_sigma_min && t[u].sig_raw <= a.f.clip_max) ? g0 : 0.f;
+            }
+            if (KIND == KIND_VM) {
+                // clamp backward on the colour features; row 0 leaves through g_sigma_raw
+                const float lo = a.f.clip_feat_min, hi_c = a.f.clip_max;
+                f4 dcf;
+                dcf.x = (t[u].raw.x >= lo && t[u].raw.x <= hi_c) ? dF[u].x : 0.f;
+                dcf.y = (t[u].raw.y >= lo && t[u].raw.y <= hi_c) ? dF[u].y : 0.f;
+                dcf.z = (t[u].raw.z >= lo && t[u].raw.z <= hi_c) ? dF[u].z : 0.f;
+                dcf.w = (t[u].raw.w >= lo && t[u].raw.w <= hi_c) ? dF[u].w : 0.f;
+                if (hi == 0) {
+                    if (valid[u]) a.g_sigma_raw[b[u]] = g0;
+                    dcf.x = 0.f;
+                }
+                Da[u] = to_h4(dcf);
+            } else {
+                // hash: only h0 is clamped (network.py:418-420); the tile is sigma_net.1's output
+                dh[u] = dF[u];
+                if (hi == 0) dh[u].x = g0;
+                Da[u] = to_h4(dh[u]);
+            }
+        }
+        if (KIND == KIND_VM) {
             // d loss / d products = Wb'^T . Da, written as the f16 [M][144] the VM backward reads
 #pragma unroll
             for (int tk = 0; tk < 9; tk++) {
-                const h4 g = to_h4(mfma(Wa1T.afrag(tk, 0, lane), Da, zero));
-                if (valid) *reinterpret_cast<h4 *>(a.g_x0 + b * 144 + 16 * tk + 4 * hi) = g;
+                const h4 A = Wa1T.afrag(tk, 0, lane);
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const h4 g = to_h4(mfma(A, Da[u], zero));
+                    if (valid[u]) *reinterpret_cast<h4 *>(a.g_x0 + b[u] * 144 + 16 * tk + 4 * hi) = g;
+                }
             }
-        } else {
-            // hash: only h0 is clamped (network.py:418-420); the tile is sigma_net.1's output
-            f4 dh = dF;
-            if (hi == 0) dh.x = g0;
-            Da = to_h4(dh);
         }
-        h4 Dh[4];  // hash: gradient of sigma_net's hidden layer (pre-relu)
+        h4 Dh[NT][4];  // hash: gradient of sigma_net's hidden layer (pre-relu)
         if (KIND == KIND_HASH) {
 #pragma unroll
-            for (int n = 0; n < 4; n++) Dh[n] = mask_relu(mfma(Wa2T.afrag(n, 0, lane), Da, zero), t.Ha[n]);
+            for (int n = 0; n < 4; n++) {
+                const h4 A = Wa2T.afrag(n, 0, lane);
+#pragma unroll
+                for (int u = 0; u < NT; u++) Dh[u][n] = mask_relu(mfma(A, Da[u], zero), t[u].Ha[n]);
+            }
             // d loss / d encoder features = W_s0^T . Dh, stored level-major [14][M][2] (what pvd_grid_encode_backward reads)
 #pragma unroll
             for (int tk = 0; tk < 2; tk++) {
-                f4 acc = zero;
+                f4 acc[NT];
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = mfma(Wa1T.afrag(tk, s, lane), Dh[s], acc);
-                const h4 g = to_h4(acc);
-                const int k0 = 16 * tk + 4 * hi;
-                if (valid && k0 < 28) {
-                    uint32_t w2[2];
-                    __builtin_memcpy(w2, &g, 8);
-                    const uint32_t lv = k0 >> 1;
-                    *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)lv * a.f.M + b) * 2) = w2[0];
-                    *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)(lv + 1) * a.f.M + b) * 2) = w2[1];
+                for (int u = 0; u < NT; u++) acc[u] = zero;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const h4 A = Wa1T.afrag(tk, s, lane);
+#pragma unroll
+                    for (int u = 0; u < NT; u++) acc[u] = mfma(A, Dh[u][s], acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const h4 g = to_h4(acc[u]);
+                    const int k0 = 16 * tk + 4 * hi;
+                    if (valid[u] && k0 < 28) {
+                        uint32_t w2[2];
+                        __builtin_memcpy(w2, &g, 8);
+                        const uint32_t lv = k0 >> 1;
+                        *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)lv * a.f.M + b[u]) * 2) = w2[0];
+                        *reinterpret_cast<uint32_t *>(a.g_x0 + ((size_t)(lv + 1) * a.f.M + b[u]) * 2) = w2[1];
+                    }
                 }
             }
         }
         PVD_STAMP();
-        // ---- weight gradients: dW[n][k] += sum_samples dY[n][s] X[k][s]  (both operands transposed tiles)
-        {
-            const h4 TD3 = transpose_tile(D3, scratch, lane);
+        // ---- weight gradients: dW[n][k] += sum_samples dY[n][s] X[k][s]  (both operands transposed tiles; the NT tiles' samples
+        // side by side along the contracted index)
+        auto tr = [&](const h4 (&v)[NT]) __attribute__((always_inline)) {
+            TrFrag r;
 #pragma unroll
-            for (int tk = 0; tk < 4; tk++) dW3[tk] = mfma(TD3, transpose_tile(t.H2[tk], scratch, lane), dW3[tk]);
+            for (int u = 0; u < NT; u++) r.v[u] = transpose_tile(v[u], scratch + (u & 1) * 256, lane);
+            return r;
+        };
+        auto pick = [&](auto member) __attribute__((always_inline)) {  // the same member of every tile, as an array
+            TrFragIn q;
+#pragma unroll
+            for (int u = 0; u < NT; u++) q.v[u] = member(u);
+            return q;
+        };
+#define PVD_TR(expr) tr(pick([&](int u) __attribute__((always_inline)) { return (expr); }).v)
+        {
+            const TrFrag TD3 = PVD_TR(D3[u]);
+#pragma unroll
+            for (int tk = 0; tk < 4; tk++) dW3[tk] = mfma_nt(TD3, PVD_TR(t[u].H2[tk]), dW3[tk]);
         }
         {
-            h4 TH1[4];
+            TrFrag TH1[4];
 #pragma unroll
-            for (int tk = 0; tk < 4; tk++) TH1[tk] = transpose_tile(t.H1[tk], scratch, lane);
+            for (int tk = 0; tk < 4; tk++) TH1[tk] = PVD_TR(t[u].H1[tk]);
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
-                const h4 TD = transpose_tile(D2[tn], scratch, lane);
+                const TrFrag TD = PVD_TR(D2[u][tn]);
 #pragma unroll
-                for (int tk = 0; tk < 4; tk++) dW2[tn * 4 + tk] = mfma(TD, TH1[tk], dW2[tn * 4 + tk]);
+                for (int tk = 0; tk < 4; tk++) dW2[tn * 4 + tk] = mfma_nt(TD, TH1[tk], dW2[tn * 4 + tk]);
             }
         }
         {
-            const h4 TSH = transpose_tile(t.sh, scratch, lane), TF = transpose_tile(t.Fh, scratch, lane);
+            const TrFrag TSH = PVD_TR(t[u].sh), TF = PVD_TR(t[u].Fh);
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
-                const h4 TD = transpose_tile(D1[tn], scratch, lane);
-                dW1[tn * 2] = mfma(TD, TSH, dW1[tn * 2]);
-                dW1[tn * 2 + 1] = mfma(TD, TF, dW1[tn * 2 + 1]);
+                const TrFrag TD = PVD_TR(D1[u][tn]);
+                dW1[tn * 2] = mfma_nt(TD, TSH, dW1[tn * 2]);
+                dW1[tn * 2 + 1] = mfma_nt(TD, TF, dW1[tn * 2 + 1]);
             }
         }
         if (KIND == KIND_VM) {
-            const h4 TD = transpose_tile(Da, scratch, lane);
+            const TrFrag TD = PVD_TR(Da[u]);
 #pragma unroll
-            for (int tk = 0; tk < 9; tk++) dWa[tk] = mfma(TD, transpose_tile(in.x[tk < (KIND == KIND_VM ? 9 : 2) ? tk : 0], scratch, lane), dWa[tk]);
+            for (int tk = 0; tk < 9; tk++) dWa[tk] = mfma_nt(TD, PVD_TR(in[u].x[tk < (KIND == KIND_VM ? 9 : 2) ? tk : 0]), dWa[tk]);
         } else {
             // sigma_net.0 [64][32]: tiles tn*2+tk;  sigma_net.1 [16][64]: tiles 8+tk
-            const h4 TX0 = transpose_tile(t.X[0], scratch, lane), TX1 = transpose_tile(t.X[1], scratch, lane);
+            const TrFrag TX0 = PVD_TR(t[u].X[0]), TX1 = PVD_TR(t[u].X[1]);
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
-                const h4 TD = transpose_tile(Dh[tn], scratch, lane);
-                dWa[tn * 2] = mfma(TD, TX0, dWa[tn * 2]);
-                dWa[tn * 2 + 1] = mfma(TD, TX1, dWa[tn * 2 + 1]);
+                const TrFrag TD = PVD_TR(Dh[u][tn]);
+                dWa[tn * 2] = mfma_nt(TD, TX0, dWa[tn * 2]);
+                dWa[tn * 2 + 1] = mfma_nt(TD, TX1, dWa[tn * 2 + 1]);
             }
-            const h4 TDa = transpose_tile(Da, scratch, lane);
+            const TrFrag TDa = PVD_TR(Da[u]);
 #pragma unroll
-            for (int tk = 0; tk < 4; tk++) dWa[8 + tk] = mfma(TDa, transpose_tile(t.Ha[tk], scratch, lane), dWa[8 + tk]);
+            for (int tk = 0; tk < 4; tk++) dWa[8 + tk] = mfma_nt(TDa, PVD_TR(t[u].Ha[tk]), dWa[8 + tk]);
         }
+#undef PVD_TR
     }
 
     PVD_STAMP();
-    // ---- one partial per WORKGROUP: the four waves add their accumulator tiles in LDS one after the other (the
-    // weights are dead by now; plain 16-byte read-modify-writes -- LDS float atomics measured 118k cycles here),
-    // then the block writes [tile][reg j][lane] coalesced.
+    // ---- one partial per WORKGROUP: the four waves' accumulator tiles are summed in LDS in two rounds over TWO regions (waves 0 / 1
+    // store, waves 2 / 3 add: two waves busy per round instead of one wave in each of four turns; the weights are dead by now; plain
+    // 16-byte read-modify-writes -- LDS float atomics measured 118k cycles here), then the block writes region 0 + region 1 as
+    // [tile][reg j][lane], coalesced.
     __syncthreads();
     float *__restrict__ red = reinterpret_cast<float *>(lds);
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    for (uint32_t turn = 0; turn < kHeadBlock / 64; turn++) {
-        if (wave_in_block == turn) {
+    static_assert(kHeadBlock == 256, "the epilogue pairs waves (0, 2) and (1, 3)");
+    for (uint32_t round = 0; round < 2; round++) {
+        if ((wave_in_block >> 1) == round) {
+            float *__restrict__ reg = red + (wave_in_block & 1u) * LY::floats;
             auto put = [&](int tile, f4 v) {
-                float *q = red + tile * 256 + lane;
-                if (turn != 0) { v.x += q[0]; v.y += q[64]; v.z += q[128]; v.w += q[192]; }
+                float *q = reg + tile * 256 + lane;
+                if (round != 0) { v.x += q[0]; v.y += q[64]; v.z += q[128]; v.w += q[192]; }
                 q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
             };
 #pragma unroll
@@ -1547,7 +1706,7 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
         __syncthreads();
     }
     float *__restrict__ out = a.partials + (size_t)blockIdx.x * LY::floats;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)LY::floats; i += kHeadBlock) out[i] = red[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)LY::floats; i += kHeadBlock) out[i] = red[i] + red[LY::floats + i];
     PVD_STAMP();
 #undef PVD_STAMP
 }
@@ -1605,9 +1764,16 @@ __global__ void __launch_bounds__(256) k_head_reduce_dw(const float *__restrict_
 template <int KIND>
 static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, float *gWa2, float *gW1, float *gW2, float *gW3, hipStream_t s,
                            pvd_head_dw_rider *defer = nullptr) {
-    size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 256;
-    if (lds_halfs < 2 * (size_t)DwLayout<KIND>::floats) lds_halfs = 2 * (size_t)DwLayout<KIND>::floats;
+    size_t lds_halfs = HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs + (kHeadBlock / 64) * 512;
+    if (lds_halfs < 4 * (size_t)DwLayout<KIND>::floats) lds_halfs = 4 * (size_t)DwLayout<KIND>::floats;  // the epilogue's two fp32 regions
     const uint32_t nblocks = nwaves / (kHeadBlock / 64);
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in (one workgroup per CU either way)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd<KIND, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(lds_halfs * sizeof(half_t))) != hipSuccess)
+            return PVD_ERR_LAUNCH;
+        attr_set = true;
+    }
     // one wave per SIMD, all accumulators in registers (> 256 VGPRs); two waves with ~40-80 spilled registers measured slower for both
     // heads (teacher step 0.59 vs 0.73 ms) and were removed
     hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
@@ -1765,8 +1931,8 @@ int pvd_mlp_head_forward_fused(const void *pts_f16, uint32_t M, const void *wstr
 }
 
 static uint32_t head_bwd_waves(int kind, uint32_t M) {
-    const uint32_t ntiles = div_up(M, 16u);
-    uint32_t blocks = div_up(ntiles, kHeadBlock / 64);
+    const uint32_t ntrips = div_up(div_up(M, 16u), (uint32_t)PVD_HEAD_NT);  // a wave takes PVD_HEAD_NT tiles per trip
+    uint32_t blocks = div_up(ntrips, kHeadBlock / 64);
     (void)kind;
     if (blocks > 256u) blocks = 256u;  // one workgroup per CU (persistent)
     if (blocks < 1) blocks = 1;

@@ -26,15 +26,24 @@ def hip_ops():
     import vmencoder
     import plenoxel
 
-    def get_rays_fused(pose, intrinsics, H, W, N):
-        """reference: get_rays (utils.py:324-404) for one pose: randint pixel ids + one HIP kernel."""
+    def get_rays_fused(pose, intrinsics, H, W, N, error_map=None, generator=None):
+        """reference: get_rays (utils.py:324-404) for one pose: randint pixel ids (or the error-map draw, :357-381) + one HIP kernel."""
         dev = pose.device
-        inds = torch.randint(0, H * W, size=[N], device=dev)  # may duplicate, like the reference
+        coarse = None
+        if error_map is not None:
+            from .scene import sample_pixels_by_error
+            inds2, coarse = sample_pixels_by_error(error_map.reshape(1, -1).to(dev), N, H, W, generator)
+            inds = inds2[0].contiguous()
+        else:
+            inds = torch.randint(0, H * W, size=[N], device=dev, generator=generator)  # may duplicate, like the reference
         rays_o = torch.empty(1, N, 3, device=dev)
         rays_d = torch.empty(1, N, 3, device=dev)
         fx, fy, cx, cy = intrinsics
         pvd_hip.get_rays(pose.reshape(4, 4).contiguous(), fx, fy, cx, cy, inds, W, N, rays_o, rays_d)
-        return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
+        out = {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None]}
+        if coarse is not None:
+            out["inds_coarse"] = coarse
+        return out
 
     def make_batch(poses, state, seed, intrinsics, H, W, N, aabb, min_near):
         """One training batch in one launch (pvd_make_ray_batch): rays of N random pixels of poses[state[0]], a random

@@ -27,7 +27,7 @@ def _read_image(path):
 
 
 class BlenderScene:
-    def __init__(self, root_path, split="train", downscale=1, scale=0.8, device="cpu", num_rays=4096, preload=True, fp16=False):
+    def __init__(self, root_path, split="train", downscale=1, scale=0.8, device="cpu", num_rays=4096, preload=True, fp16=False, error_map=False):
         """split: train / val / test, or `trainval` (both files), or `all` (every *.json in the directory)."""
         self.root_path, self.split, self.downscale, self.scale = root_path, split, downscale, scale
         self.device = torch.device(device)
@@ -59,6 +59,8 @@ class BlenderScene:
         self.H, self.W = H, W
         self.poses = torch.from_numpy(np.stack(poses))             # [N, 4, 4]
         self.images = torch.from_numpy(np.stack(images))           # [N, H, W, 3|4]
+        # --error_map (provider.py:232-237): per-image sampling weights on a fixed 128 x 128 grid, all ones to begin with
+        self.error_map = torch.ones([self.images.shape[0], 128 * 128], dtype=torch.float) if (self.training and error_map) else None
         self.radius = self.poses[:, :3, 3].norm(dim=-1).mean(0).item()
 
         # intrinsics (provider.py:244-276)
@@ -80,6 +82,8 @@ class BlenderScene:
         if preload:
             self.poses = self.poses.to(self.device)
             self.images = self.images.to(torch.half if fp16 else torch.float).to(self.device)
+            if self.error_map is not None:
+                self.error_map = self.error_map.to(self.device)
 
     @staticmethod
     def _read_transforms(root, split):
@@ -111,8 +115,11 @@ class BlenderScene:
         idx = torch.as_tensor(index, dtype=torch.long, device=self.poses.device)
         poses = self.poses[idx].to(self.device)
         n = self.num_rays if num_rays is None else num_rays
-        rays = get_rays(poses, tuple(float(v) for v in self.intrinsics), self.H, self.W, n, generator=generator)
+        emap = None if self.error_map is None else self.error_map[idx.to(self.error_map.device)]  # provider.py:289
+        rays = get_rays(poses, tuple(float(v) for v in self.intrinsics), self.H, self.W, n, generator=generator, error_map=emap)
         out = {"H": self.H, "W": self.W, "rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "inds": rays["inds"]}
+        if emap is not None:  # what the trainer needs to update the map (provider.py:309-312)
+            out["index"], out["inds_coarse"] = index, rays["inds_coarse"]
         images = self.images[idx].to(self.device)
         if self.training:
             B, C = images.shape[0], images.shape[-1]

@@ -199,15 +199,41 @@ BLENDER_INTRINSICS = (1111.1, 1111.1, 400.0, 400.0)  # fx, fy, cx, cy for 800x80
 
 
 @torch.no_grad()
-def get_rays(poses, intrinsics, H, W, N=-1, generator=None, inds=None):
-    """reference: get_rays, distill_mutual/utils.py:324-404 (error-map sampling omitted).
-    poses [B,4,4] cam2world -> rays_o, rays_d [B,N,3], inds [B,N]."""
+def sample_pixels_by_error(error_map, N, H, W, generator=None):
+    """reference: the `error_map` branch of get_rays, distill_mutual/utils.py:357-381 (--error_map, main_distill_mutual.py:155).
+    error_map [B, 128*128]: per-image sampling weights on a fixed 128 x 128 grid.  N cells drawn without replacement by weight, each
+    mapped to a pixel of the H x W image with a uniform jitter inside the cell.  Returns (inds [B,N], inds_coarse [B,N]); the draws
+    are the reference's, in its order (multinomial, rand for x, rand for y), so a seeded generator reproduces its choice."""
+    device = error_map.device
+    B = error_map.shape[0]
+    inds_coarse = torch.multinomial(error_map, N, replacement=False, generator=generator)  # [B, N] in [0, 128*128)
+    inds_x, inds_y = torch.div(inds_coarse, 128, rounding_mode="floor"), inds_coarse % 128
+    sx, sy = H / 128, W / 128
+    inds_x = (inds_x * sx + torch.rand(B, N, device=device, generator=generator) * sx).long().clamp(max=H - 1)
+    inds_y = (inds_y * sy + torch.rand(B, N, device=device, generator=generator) * sy).long().clamp(max=W - 1)
+    return inds_x * W + inds_y, inds_coarse
+
+
+def update_error_map(error_map, inds_coarse, error):
+    """reference: train_step's EMA of the per-ray error into the sampled cells, utils.py:1120-1129 (loss_type L2 only):
+    error_map[b, inds_coarse] = 0.1 * old + 0.9 * error, in place.  error [B,N] in [0, 1]."""
+    ema = 0.1 * error_map.gather(1, inds_coarse) + 0.9 * error.detach().to(error_map.device)
+    error_map.scatter_(1, inds_coarse, ema)
+    return error_map
+
+
+def get_rays(poses, intrinsics, H, W, N=-1, generator=None, inds=None, error_map=None):
+    """reference: get_rays, distill_mutual/utils.py:324-404.
+    poses [B,4,4] cam2world -> rays_o, rays_d [B,N,3], inds [B,N] (+ inds_coarse [B,N] when sampling by error_map [B, 128*128])."""
     device = poses.device
     B = poses.shape[0]
     fx, fy, cx, cy = intrinsics
+    inds_coarse = None
     if N > 0:
         N = min(N, H * W)
-        if inds is None:
+        if inds is None and error_map is not None:
+            inds, inds_coarse = sample_pixels_by_error(error_map.to(device), N, H, W, generator)
+        elif inds is None:
             inds = torch.randint(0, H * W, size=[N], device=device, generator=generator)  # may duplicate
         inds = inds.expand([B, N])
     else:
@@ -220,4 +246,7 @@ def get_rays(poses, intrinsics, H, W, N=-1, generator=None, inds=None):
     dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
     rays_d = dirs @ poses[:, :3, :3].transpose(-1, -2)
     rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
-    return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds}
+    out = {"rays_o": rays_o, "rays_d": rays_d, "inds": inds}
+    if inds_coarse is not None:
+        out["inds_coarse"] = inds_coarse  # needed when the error map is updated
+    return out

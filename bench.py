@@ -56,6 +56,80 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def _host_cpu():
+    """(model string, physical cores, logical cpus) of the box (/proc/cpuinfo)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    ncpu = os.cpu_count() or 1
+    return model, (len(cores) or ncpu), ncpu
+
+
+def _cpu_protocol(step, num_rays, steps, what):
+    """SURVEY section 8(d)'s protocol on a bounded sample: 5 warm-up steps, `steps` (>= 20) steps timed one by one, median rays/s;
+    thread count = the best of a climb up to all physical cores (a job this small loses to oversubscription on a many-core host:
+    256 threads measured 34 s/step where 8 take < 1 s -- so the climb's times are reported, and the all-cores figure whenever
+    the climb reaches it), a 1-thread figure, the CPU's model string.  step(i) runs training step i."""
+    import oracle
+    model, physical, ncpu = _host_cpu()
+    sweep, best_t, best_n, k = {}, None, 1, 0
+    for n in sorted({c for c in (4, 8, 16, 32, 64, 128) if c < physical} | {physical}):
+        torch.set_num_threads(n)
+        oracle.set_num_threads(n)
+        t0 = time.perf_counter()
+        step(k)
+        t = time.perf_counter() - t0
+        k += 1
+        sweep[n] = num_rays / t
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+        elif t > 1.3 * best_t:
+            break
+    torch.set_num_threads(best_n)
+    oracle.set_num_threads(best_n)
+    for _ in range(max(0, 5 - k)):  # (the climb's steps count as warm-up)
+        step(k)
+        k += 1
+    times = []
+    for _ in range(max(int(steps), 1)):
+        t0 = time.perf_counter()
+        step(k)
+        times.append(time.perf_counter() - t0)
+        k += 1
+    torch.set_num_threads(1)
+    oracle.set_num_threads(1)
+    one = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step(k)
+        one.append(time.perf_counter() - t0)
+        k += 1
+    torch.set_num_threads(best_n)
+    oracle.set_num_threads(best_n)
+    med = sorted(times)[len(times) // 2]
+    return {"value": num_rays / med, "unit": "rays/s", "cores": int(best_n), "kind": "port",
+            "protocol": "5 warm-up + %d steps timed one by one, median" % len(times),
+            "cpu_model": model, "physical_cores": int(physical), "logical_cpus": int(ncpu),
+            "one_thread_rays_per_s": num_rays / min(one),
+            "all_physical_cores_rays_per_s": sweep.get(physical),  # null: the climb stopped below (each step there > 1.3 x the best)
+            "thread_climb_rays_per_s": {str(n): v for n, v in sweep.items()},
+            "sample": what % (len(times), num_rays)}
+
+
 def cpu_baseline(workload, steps, num_rays):
     """The same distillation step on the host cores through the CPU oracle (fp32), on a bounded
     sample: `steps` steps of `num_rays` rays with the GPU run's weights and occupancy grid."""
@@ -70,32 +144,9 @@ def cpu_baseline(workload, steps, num_rays):
     cw.tea.load_state_dict({k: v.detach().float().cpu() for k, v in workload.tea.state_dict().items()})
     cw.stu.load_state_dict({k: v.detach().float().cpu() for k, v in workload.stu.state_dict().items()})
     cw.tea.mean_count = cw.stu.mean_count = int(workload.stu.mean_count * num_rays / workload.opt.num_rays)
-    cw.step()  # warm-up
-
-    def timed_steps(n):
-        t0 = time.perf_counter()
-        for _ in range(n):
-            cw.step()
-        return time.perf_counter() - t0
-
-    # many-core hosts lose badly to oversubscription on a job this small (256 threads: 34 s/step vs
-    # <1 s/step on 8): climb the thread count while it still helps and report the best one.
-    ncpu = os.cpu_count() or 1
-    best_t, best_n = None, 1
-    for n in [c for c in (4, 8, 16, 32, 64, 128) if c < ncpu] + [ncpu]:
-        torch.set_num_threads(n)
-        oracle.set_num_threads(n)
-        t = timed_steps(1)
-        if best_t is None or t < best_t:
-            best_t, best_n = t, n
-        elif t > 1.3 * best_t:
-            break
-    torch.set_num_threads(best_n)
-    oracle.set_num_threads(best_n)
-    dt = timed_steps(steps)
-    return {"value": steps * num_rays / dt, "unit": "rays/s", "cores": int(best_n), "kind": "port",
-            "sample": "%d distillation steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, "
-                      "same weights and occupancy grid as the GPU run" % (steps, num_rays)}
+    return _cpu_protocol(lambda i: cw.step(), num_rays, steps,
+                         "%d distillation steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, "
+                         "same weights and occupancy grid as the GPU run")
 
 
 def cpu_baseline_teacher(tea_gpu, opt, topt, steps, num_rays):
@@ -125,30 +176,9 @@ def cpu_baseline_teacher(tea_gpu, opt, topt, steps, num_rays):
         bg = torch.rand(1, num_rays, 3, generator=cw.gen)
         batches.append((r["rays_o"], r["rays_d"], cw.target(r["rays_o"], r["rays_d"], bg), bg))
     tr.global_step = 1  # (not a multiple of the update interval)
-    tr.train_step(*batches[0])  # warm-up
-
-    def timed_steps(n):
-        t0 = time.perf_counter()
-        for i in range(n):
-            tr.train_step(*batches[i % 4])
-        return time.perf_counter() - t0
-
-    ncpu = os.cpu_count() or 1
-    best_t, best_n = None, 1
-    for n in [c for c in (4, 8, 16, 32, 64, 128) if c < ncpu] + [ncpu]:
-        torch.set_num_threads(n)
-        oracle.set_num_threads(n)
-        t = timed_steps(1)
-        if best_t is None or t < best_t:
-            best_t, best_n = t, n
-        elif t > 1.3 * best_t:
-            break
-    torch.set_num_threads(best_n)
-    oracle.set_num_threads(best_n)
-    dt = timed_steps(steps)
-    return {"value": steps * num_rays / dt, "unit": "rays/s", "cores": int(best_n), "kind": "port",
-            "sample": "%d teacher training steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, same weights "
-                      "and occupancy grid as the GPU run, no grid update inside the sample" % (steps, num_rays)}
+    return _cpu_protocol(lambda i: tr.train_step(*batches[i % 4]), num_rays, steps,
+                         "%d teacher training steps x %d rays, fp32, oracle C kernels (OpenMP) + PyTorch-CPU MLP/autograd/AdamW, same weights "
+                         "and occupancy grid as the GPU run, no grid update inside the sample")
 
 
 def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=True):
@@ -349,7 +379,7 @@ def main():
     ap.add_argument("--student", type=str, default="vm")
     ap.add_argument("--teacher-pretrain", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (after 5 warm-up steps; SURVEY 8d)")
     ap.add_argument("--fp32", action="store_true", help="disable AMP (the reference forces fp16 on)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
     ap.add_argument("--strong", action="store_true",

@@ -276,3 +276,25 @@ def f32_to_f16_bits(x):
 
 def f16_bits_to_f32(h):
     return float(lib().pvdo_f16_to_f32(int(h)))
+
+
+# ----------------------------------------------------------------- the head under autocast (network.py:413-437, 344-381)
+def head_forward_amp(kind, x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min=-2.0, clip_feat_min=-2.0, clip_max=7.0):
+    """kind 0: x0 [M,28] float16 (encoder / trunk output), Wa1 [64,28], Wa2 [16,64];  kind 1 (vm): x0 [M,144] float16 products,
+    sigma_raw [M], Wa1 [15,144].  Returns sigma [M], rgb [M,3], feature_sigma_color [M,16] (float32 holding the f16 values)."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float16)
+    M = x0.shape[0]
+    assert x0.shape == (M, 28 if kind == 0 else 144)
+    dirs = _c(dirs, np.float32).reshape(M, 3)
+    f = lambda a: None if a is None else _c(a, np.float32)
+    Wa1, Wa2, Wc1, Wc2, Wc3, sigma_raw = f(Wa1), f(Wa2), f(Wc1), f(Wc2), f(Wc3), f(sigma_raw)
+    assert Wa1.shape == ((64, 28) if kind == 0 else (15, 144)) and Wc1.shape == (64, 31) and Wc2.shape == (64, 64) and Wc3.shape == (3, 64)
+    assert (Wa2.shape == (16, 64)) if kind == 0 else (sigma_raw is not None and sigma_raw.shape == (M,))
+    sigma, rgb, feat = np.empty(M, np.float32), np.empty((M, 3), np.float32), np.empty((M, 16), np.float32)
+    L = lib()
+    L.pvdo_head_forward_amp.restype = ctypes.c_int
+    rc = L.pvdo_head_forward_amp(ctypes.c_int(kind), _ptr(x0.view(np.uint16)), _ptr(sigma_raw), _ptr(dirs), _u32(M), _ptr(Wa1), _ptr(Wa2),
+                                 _ptr(Wc1), _ptr(Wc2), _ptr(Wc3), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max),
+                                 _ptr(sigma), _ptr(rgb), _ptr(feat))
+    assert rc == 0, rc
+    return sigma, rgb, feat

@@ -232,5 +232,63 @@ for mt in ("vm", "mlp", "hash"):
         else:
             out[pre + "grad__" + n] = p.grad.detach().numpy()
 
+# ---- get_rays with an error map (utils.py:357-381, --error_map): weighted draw of 128 x 128 cells + jitter inside the cell
+torch.manual_seed(11)
+emap = torch.rand(2, 128 * 128) ** 4  # uneven weights
+emap[0, :4000] = 0.0                   # cells that can never be drawn
+r = ref_utils.get_rays(poses[:2], np.array([1111.1, 1111.1, 400.0, 400.0]), 800, 800, 96, emap)
+out.update(rays_e_map=emap.numpy(), rays_e_inds=r["inds"].numpy(), rays_e_inds_coarse=r["inds_coarse"].numpy(),
+           rays_e_o=r["rays_o"].numpy(), rays_e_d=r["rays_d"].numpy())
+
 np.savez_compressed(os.path.join(HERE, "reference_python.npz"), **out)
 print("wrote", os.path.join(HERE, "reference_python.npz"), "with", len(out), "arrays")
+
+# ---- the reference's head under autocast (network.py:413-437 hash, :344-381 vm): NeRFNetwork.forward run HERE under
+# torch.autocast("cpu", dtype=torch.float16).  CPU autocast applies the same policy to the head's operations as CUDA autocast does
+# (nn.Linear in f16 with fp32 accumulation and an f16 result; relu / clamp / sigmoid / cat by type promotion; grid_sample in fp32),
+# so what the sigma_net / basis_mat / color_net chain produces for given f16 inputs is the reference's own code and arithmetic.
+# Two things differ from the device the reference trains on and are therefore recorded as INPUTS of the head, not as its results:
+# the encoders run through the oracle stand-ins in fp32 (their custom_fwd is a CUDA-autocast construct), and trunc_exp is not
+# cast to fp32 on the CPU (same reason) -- the fixture's `sigma` is exp evaluated on the f16 feature, stored f16.
+amp = {}
+rs = np.random.RandomState(33)
+xq = rs.uniform(-1, 1, size=(517, 3)).astype(np.float32)
+dq = rs.standard_normal((517, 3)).astype(np.float32)
+dq /= np.linalg.norm(dq, axis=1, keepdims=True)
+amp.update(x=xq, d=dq)
+for mt in ("vm", "hash"):
+    torch.manual_seed(200 + len(mt))
+    a = small_args()
+    net = RefNet(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                 grid_size=16, model_type=mt, args=a, is_teacher=False)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "embeddings" in n:
+                torch.manual_seed(778)
+                p.copy_((torch.rand(p.shape) - 0.5) * 0.6)
+            elif p.dim() >= 2:  # features that reach both clamps, a colour head away from sigmoid(0)
+                p.mul_(6.0 if mt == "vm" and p.dim() == 4 else 4.0)
+    net.train()
+    seen = {}
+    if mt == "hash":
+        net.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("x0", o.detach().clone()))
+    else:
+        net.basis_mat.register_forward_pre_hook(lambda m, i: seen.__setitem__("x0", i[0].detach().clone()))
+        inner = net.get_sigma_feat
+        net.get_sigma_feat = lambda xn: seen.setdefault("sigma_raw", inner(xn))
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        sigma, color = net(torch.from_numpy(xq), torch.from_numpy(dq))
+    pre = "amp_%s__" % mt
+    assert color.dtype == torch.float16 and seen["x0"].dtype == torch.float32
+    amp[pre + "x0"] = seen["x0"].numpy()                       # fp32, as it reaches the first Linear (which rounds it to f16)
+    if mt == "vm":
+        amp[pre + "sigma_raw"] = seen["sigma_raw"].detach().float().numpy()
+    amp[pre + "sigma"] = sigma.float().numpy()
+    amp[pre + "color"] = color.float().numpy()
+    amp[pre + "feature_sigma_color"] = net.feature_sigma_color.float().numpy()
+    amp[pre + "feature_dtype"] = np.array(str(net.feature_sigma_color.dtype))
+    for k, v in net.state_dict().items():
+        if "embeddings" not in k and ("sigma_net" in k or "color_net" in k or "basis_mat" in k):
+            amp[pre + "sd__" + k] = v.detach().numpy()
+np.savez_compressed(os.path.join(HERE, "reference_head_amp.npz"), **amp)
+print("wrote", os.path.join(HERE, "reference_head_amp.npz"), "with", len(amp), "arrays")

@@ -95,6 +95,33 @@ def test_cameras_and_rays():
     assert np.array_equal(r2["inds"].numpy(), G["rays_n_inds"])
 
 
+def test_get_rays_error_map_sampling_is_the_references_draw():
+    """--error_map (utils.py:357-381): the reference's own get_rays with a [2, 128*128] error map, seeded; the same seed here must
+    give the same cells, the same pixels and the same rays, and no draw may land in a zero-weight cell."""
+    from pvd.scene import get_rays, update_error_map
+    poses = torch.from_numpy(G["pose_ngp"])[:2]
+    emap = torch.from_numpy(G["rays_e_map"])
+    torch.manual_seed(11)
+    assert torch.equal(torch.rand(2, 128 * 128) ** 4 * (emap > 0), emap)  # (the fixture's map, and the generator state behind it)
+    r = get_rays(poses, (1111.1, 1111.1, 400.0, 400.0), 800, 800, 96, error_map=emap)
+    assert np.array_equal(r["inds_coarse"].numpy(), G["rays_e_inds_coarse"]) and np.array_equal(r["inds"].numpy(), G["rays_e_inds"])
+    np.testing.assert_allclose(r["rays_d"].numpy(), G["rays_e_d"], atol=1e-7)
+    assert np.array_equal(r["rays_o"].numpy(), G["rays_e_o"])
+    assert (G["rays_e_inds_coarse"][0] >= 4000).all()  # cells 0..3999 of image 0 carry weight 0
+    # a drawn pixel lies inside its cell (800 / 128 = 6.25 pixels per cell side)
+    px, py = r["inds"] // 800, r["inds"] % 800
+    cx, cy = r["inds_coarse"] // 128, r["inds_coarse"] % 128
+    assert ((px >= (cx * 6.25).long()) & (px <= ((cx + 1) * 6.25).long())).all() and ((py >= (cy * 6.25).long()) & (py <= ((cy + 1) * 6.25).long())).all()
+    # the EMA update of the sampled cells (utils.py:1120-1129)
+    err = torch.rand(2, 96)
+    before = emap.clone()
+    update_error_map(emap, r["inds_coarse"], err)
+    want = 0.1 * before.gather(1, r["inds_coarse"]) + 0.9 * err
+    assert torch.equal(emap.gather(1, r["inds_coarse"]), want)
+    mask = torch.ones_like(emap, dtype=torch.bool).scatter_(1, r["inds_coarse"], False)
+    assert torch.equal(emap[mask], before[mask])
+
+
 def test_composite_wrapper_logic_matches_reference_wrapper():
     """comp_*: the reference's composite_rays_train autograd wrapper (raymarching/raymarching.py:292-357) run on the
     oracle backend vs this repo's wrapper on the same backend: allocation, saved tensors, ignored depth gradient."""
