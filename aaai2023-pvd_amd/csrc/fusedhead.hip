@@ -31,6 +31,7 @@
 #include "dda.h"
 #include "grid_lookup.h"
 #include "head_dw_reduce.h"
+#include "vm_lookup.h"
 
 #include <stdlib.h>
 
@@ -1040,6 +1041,238 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a
     }
 }
 
+// ---- the same persistent render for a frozen VM (TensoRF plane x line) model -- the student whose PSNR the metric reports
+// (pvd_infer_image_vm).  Refill / march / blend are k_infer_hash_persistent's; the shading of a round's LDS tile differs:
+//   lookup   wave w takes the rows w, w + 4, ...: lane j of the wave works out row j's sampling state once (normalised position ->
+//            three axes x {clamped taps, weights, in-range bits}), then the wave goes through its rows with lane = channel (16 sigma +
+//            48 colour), every texel of a row's three 2 x 2 + 2 footprints requested unconditionally and the next row's 18 loads in
+//            flight while this row's products are formed (vm_lookup.h: rows of one round belong to up to 64 different rays -- there
+//            is no run for k_vm_fwd's register windows to follow); products rounded to f16 into the tile's row [144], the sigma
+//            feature summed over the 16 sigma lanes in k_vm_fwd's order;
+//   head     k_head_fwd<VM>'s tile code on the LDS rows (basis_mat, clamps, colour head).
+// Arithmetic per row = pvd_vm_forward + pvd_head_forward (bit for bit); per ray = the round loop's (tests/test_hip_infer_rounds.py).
+#ifndef PVD_INFER_VM_DEPTH
+#define PVD_INFER_VM_DEPTH 2
+#endif
+constexpr uint32_t kVmInfStride = 144 + 8;  // halfs per tile row: 76 dwords = 4 x odd -- the 16 rows of an 8-byte fragment read start on distinct bank quads
+template <uint32_t RAYS, uint32_t ROWS>
+__global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, VmTables tb, InferImageArgs q) {
+    extern __shared__ __align__(16) half_t lds[];
+    HeadLds<KIND_VM> W;
+    W.carve(lds);
+    half_t *feat = lds + ((HeadLds<KIND_VM>::halfs + 7) & ~7);                          // [ROWS][kVmInfStride] plane x line products
+    float *pos = reinterpret_cast<float *>(feat + ROWS * kVmInfStride);                // [ROWS][3]
+    float *sraw = pos + 3 * ROWS;                                                      // [ROWS] raw sigma feature
+    float *sig = sraw + ROWS;                                                          // [ROWS]
+    float *rgb = sig + ROWS;                                                           // [ROWS][3]
+    float *sdir = rgb + 3 * ROWS;                                                      // [kHeadBlock][3]: direction of the ray in slot s
+    uint32_t *row_slot = reinterpret_cast<uint32_t *>(sdir + 3 * kHeadBlock);          // [ROWS]
+    uint32_t *wcnt = row_slot + ROWS;                                                  // [8] scan scratch + queue hand-off
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
+    if (a.image) { copy_image_dma_static<HeadLds<KIND_VM>::halfs>(lds, a.image, tid); __builtin_amdgcn_s_waitcnt(0x0f70); }
+    else W.load(a, tid, kHeadBlock);
+    for (uint32_t i = tid; i < ROWS * 4; i += kHeadBlock)  // the row padding (halfs 144..151) is never read; keep it defined
+        *reinterpret_cast<uint32_t *>(feat + (i >> 2) * kVmInfStride + 144 + 2 * (i & 3)) = 0u;
+    const uint32_t n_ids = (uint32_t)max(*q.n_ids, 0);
+    // the lane's channel of the twelve tables
+    const uint32_t kind = lane < kRs ? 0u : 1u, ch = kind ? lane - kRs : lane;
+    const uint32_t R = tb.ms[kind], Rv = tb.vs[kind];
+    const float *mat0 = tb.mat[kind][0] + ch, *mat1 = tb.mat[kind][1] + ch, *mat2 = tb.mat[kind][2] + ch;
+    const float *vec0 = tb.vec[kind][0] + ch, *vec1 = tb.vec[kind][1] + ch, *vec2 = tb.vec[kind][2] + ch;
+    // queue position -> ray: position * mul mod n_ids is a permutation only for a multiplier coprime to n_ids
+    uint32_t mul = q.shuffle % max(n_ids, 1u);
+    for (;; mul++) {
+        uint32_t x = max(mul, 1u), y = max(n_ids, 1u);
+        while (y) { const uint32_t r = x % y; x = y; y = r; }
+        if (x == 1u || n_ids <= 1u) break;
+    }
+    mul = max(mul, 1u);
+
+    int32_t index = -1;
+    uint32_t taken = 0, cnt = 0;
+    float t = 0.f, tt = 0.f, far = 0.f, ws = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    float sx[kInfSteps], sy[kInfSteps], sz[kInfSteps], sdt[kInfSteps], stt[kInfSteps];
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 1.f};
+    bool queue_done = n_ids == 0;
+
+    auto scan_of = [&](uint32_t v, uint32_t &total) -> uint32_t {  // exclusive prefix over the workgroup's threads and the total
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+            if ((int)lane >= d) inc += up;
+        }
+        if (lane == 63) wcnt[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kHeadBlock / 64; w++) { const uint32_t c = wcnt[w]; before += w < wave ? c : 0u; tot += c; }
+        __syncthreads();
+        total = tot;
+        return before + inc - v;
+    };
+    auto retire = [&]() {
+        q.weights_sum[index] = ws;
+        q.depth[index] = dep;
+        q.image[3 * (size_t)index] = cr; q.image[3 * (size_t)index + 1] = cg; q.image[3 * (size_t)index + 2] = cb;
+        index = -1; cnt = 0;
+    };
+
+    uint32_t n_rounds = 0, n_rows = 0, n_walk = 0;
+    __syncthreads();  // weights
+    for (;;) {
+        // ---------------- refill
+        uint32_t nfree;
+        const uint32_t frank = scan_of(tid < RAYS && index < 0 ? 1u : 0u, nfree);
+        if (!queue_done && (nfree >= RAYS / 8 || nfree == RAYS)) {
+            if (tid == 0) wcnt[4] = (uint32_t)atomicAdd(q.queue, (int32_t)nfree);
+            __syncthreads();
+            const uint32_t base = wcnt[4];
+            __syncthreads();
+            if (base + nfree >= n_ids) queue_done = true;
+            if (tid < RAYS && index < 0 && base + frank < n_ids) {
+                const int32_t id = q.ray_ids[(uint32_t)(((uint64_t)(base + frank) * mul) % n_ids)];
+                index = id; taken = 0; cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { ro[c] = q.rays_o[3 * (size_t)id + c]; rd[c] = q.rays_d[3 * (size_t)id + c]; sdir[3 * tid + c] = rd[c]; }
+                t = q.nears[id]; far = q.fars[id]; tt = q.t_first[id];
+                ws = dep = cr = cg = cb = 0.f;
+            }
+        }
+        uint32_t live_now;
+        (void)scan_of(index >= 0 ? 1u : 0u, live_now);
+        if (live_now == 0) {
+            if (queue_done) break;
+            continue;
+        }
+        const uint32_t n_step = max(min(ROWS / live_now, kInfSteps), 1u);  // the reference's rule (renderer.py:493), the workgroup's numbers
+        // ---------------- march (k_march_rays' loop, raymarching.cu:756-810, perturb = 0)
+        if (index >= 0) {
+            Dda r;
+            r.init(ro, rd, q.bound, q.dt_gamma, q.max_steps, q.C, q.H, q.grid);
+            for (uint32_t pb = 0; pb < n_step + kInfProbes && cnt < n_step && tt < far; pb++) {
+                float x, y, z, dt, tn;
+                if (r.probe(tt, x, y, z, dt, tn)) {
+                    tt += dt;
+#pragma unroll
+                    for (uint32_t k = 0; k < kInfSteps; k++)
+                        if (k == cnt) { sx[k] = x; sy[k] = y; sz[k] = z; sdt[k] = dt; stt[k] = tt; }
+                    cnt++;
+                } else {
+                    tt = tn;
+                }
+            }
+            if (cnt == 0 && !(tt < far)) retire();
+        }
+        uint32_t rows;
+        const uint32_t row0 = scan_of(cnt, rows);
+        n_rounds++; n_rows += rows;
+        if (rows == 0) { n_walk++; continue; }
+#pragma unroll
+        for (uint32_t k = 0; k < kInfSteps; k++)
+            if (k < cnt) {
+                pos[3 * (row0 + k)] = sx[k]; pos[3 * (row0 + k) + 1] = sy[k]; pos[3 * (row0 + k) + 2] = sz[k];
+                row_slot[row0 + k] = tid;
+            }
+        __syncthreads();
+        // ---------------- shade: the VM lookup of the tile's rows, wave w: rows w, w + 4, ... (lane j holds the state of its j-th row)
+        {
+            const uint32_t mine = rows > wave ? (rows - wave + 3u) / 4u : 0u;  // (uniform per wave; <= ROWS / 4 <= 64)
+            float xn[3] = {0.f, 0.f, 0.f};
+            if (lane < mine) normalise(pos, (size_t)(wave + 4u * lane), tb, xn);
+            const SampleCtl ctl = sample_ctl(xn, tb);
+            constexpr int kDepth = PVD_INFER_VM_DEPTH;  // register slots of 18 loads: depth - 1 rows' loads in flight while one row is formed
+            Taps6 tp[kDepth][3];
+            auto issue = [&](Taps6(&dst)[3], uint32_t j) __attribute__((always_inline)) {
+                j = min(j, mine - 1u);  // (a row past the wave's last repeats it: same loads, same bytes written again)
+                issue6<0>(ctl, j, mat0, vec0, R, Rv, (int)tb.W[0], dst[0]);
+                issue6<1>(ctl, j, mat1, vec1, R, Rv, (int)tb.W[1], dst[1]);
+                issue6<2>(ctl, j, mat2, vec2, R, Rv, (int)tb.W[2], dst[2]);
+            };
+            auto finish = [&](const Taps6(&src)[3], uint32_t j) __attribute__((always_inline)) {
+                j = min(j, mine - 1u);
+                const uint32_t rw = wave + 4u * j;
+                const float p0 = finish6<0>(ctl, j, src[0]), p1 = finish6<1>(ctl, j, src[1]), p2 = finish6<2>(ctl, j, src[2]);
+                float s = 0.f;
+                if (kind) {
+                    half_t *row = feat + rw * kVmInfStride + ch;
+                    row[0] = (half_t)p0; row[kRc] = (half_t)p1; row[2 * kRc] = (half_t)p2;
+                } else {
+                    s += p0; s += p1; s += p2;
+                }
+                // k_vm_fwd's xor butterfly over the 16 sigma lanes, as row rotations (same operands, same sums)
+                s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x128, 0xf, 0xf, false));
+                s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x124, 0xf, 0xf, false));
+                s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x122, 0xf, 0xf, false));
+                s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x121, 0xf, 0xf, false));
+                if (lane == 0) sraw[rw] = s;
+            };
+            if (mine > 0) {
+#pragma unroll
+                for (int dd = 0; dd < kDepth; dd++) issue(tp[dd], (uint32_t)dd);
+                for (uint32_t j = 0; j < mine; j += kDepth) {
+#pragma unroll
+                    for (int dd = 0; dd < kDepth; dd++) {
+                        finish(tp[dd], j + dd);
+                        issue(tp[dd], j + dd + kDepth);  // this slot's registers are requested again at once
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- ... and the head, 16 rows per wave and pass; sigma / rgb stay in LDS
+        for (uint32_t t16 = wave; t16 * 16 < rows; t16 += kHeadBlock / 64) {
+            const uint32_t rw = min(t16 * 16 + (lane & 15), ROWS - 1u);
+            const bool live = t16 * 16 + (lane & 15) < rows;
+            TileIn<KIND_VM> in;
+            const h4 hz = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+#pragma unroll
+            for (int s2 = 0; s2 < 9; s2++) in.x[s2] = live ? *reinterpret_cast<const h4 *>(feat + rw * kVmInfStride + 16 * s2 + 4 * hi) : hz;
+            in.sraw = (live && hi == 0) ? sraw[rw] : 0.f;
+            const uint32_t slot = live ? row_slot[rw] : 0u;
+            in.dx = live ? sdir[3 * slot] : 0.f; in.dy = live ? sdir[3 * slot + 1] : 0.f; in.dz = live ? sdir[3 * slot + 2] : 0.f;
+            TileFwd tf;
+            head_forward_tile<KIND_VM>(a, W, in, lane, tf);
+            if (hi == 0 && live) {
+                sig[rw] = __expf(tf.F.x);
+                rgb[3 * rw] = sigmoid_h(tf.out.x); rgb[3 * rw + 1] = sigmoid_h(tf.out.y); rgb[3 * rw + 2] = sigmoid_h(tf.out.z);
+            }
+        }
+        __syncthreads();
+        // ---------------- blend (k_composite_rays' loop, raymarching.cu:858-899; sigma scaled as renderer.py:528)
+        if (cnt > 0) {
+            bool done = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kInfSteps; k++) {
+                if (k < cnt && !done) {
+                    const uint32_t rw = row0 + k;
+                    const float alpha = 1.0f - __expf(-(q.sigma_scale * sig[rw]) * sdt[k]);
+                    const float T = 1 - ws;
+                    const float w = alpha * T;
+                    ws += w;
+                    t += stt[k] - t;
+                    dep += w * t;
+                    cr += w * rgb[3 * rw]; cg += w * rgb[3 * rw + 1]; cb += w * rgb[3 * rw + 2];
+                    taken++;
+                    if ((double)T < 1e-4 || taken >= q.max_steps) done = true;
+                }
+            }
+            cnt = 0;
+            if (done) retire();
+        }
+        __syncthreads();  // the next round rewrites the tile
+    }
+    if (tid == 0 && n_rounds > 1) {
+        atomicAdd(q.stats + 0, (int32_t)n_rounds); atomicAdd(q.stats + 1, (int32_t)n_rows); atomicAdd(q.stats + 2, (int32_t)n_walk); atomicAdd(q.stats + 3, 1);
+    }
+}
+
+template <uint32_t ROWS>
+static size_t infer_vm_persistent_lds_bytes() {
+    return (((size_t)HeadLds<KIND_VM>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + (size_t)ROWS * kVmInfStride * sizeof(half_t) +
+           sizeof(float) * (3 * ROWS + ROWS + ROWS + 3 * ROWS + 3 * kHeadBlock) + sizeof(uint32_t) * (ROWS + 8);
+}
+
 static size_t infer_persistent_lds_bytes() {
     return (((size_t)HeadLds<KIND_HASH>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + (size_t)kInfRows * kFeatStride * sizeof(half_t) +
            sizeof(float) * (3 * kInfRows + kInfRows + 3 * kInfRows + 3 * kHeadBlock) + sizeof(uint32_t) * (kInfRows + 8);
@@ -1910,6 +2143,60 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
     uint32_t blocks = div_up(N, 64u);
     if (blocks > 768u) blocks = 768u;  // persistent
     hipLaunchKernelGGL((k_infer_hash_persistent<64, 256>), dim3(blocks), dim3(kHeadBlock), lds_bytes, s, a, g, gr, q);
+    return check_launch();
+}
+
+int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N, const uint8_t *bitfield,
+                       float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, float sigma_scale, const float *aabb_host,
+                       const void *const *tables_host, const uint32_t *res_host, const uint32_t *texel_stride_host, const float *Wb,
+                       const float *Wc1, const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_feat_min,
+                       float clip_max, int32_t *workspace, float *weights_sum, float *depth, float *image_out, pvd_stream_t stream) {
+    if (N == 0) return PVD_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !bitfield || !aabb_host || !tables_host || !res_host || !Wb || !Wc1 || !Wc2 || !Wc3 ||
+        !workspace || !weights_sum || !depth || !image_out)
+        return PVD_ERR_INVALID;
+    if (max_steps == 0 || C == 0 || H == 0) return PVD_ERR_INVALID;
+    VmTables tb;
+    const int rc = fill_tables(tb, tables_host, res_host, aabb_host, texel_stride_host);
+    if (rc != PVD_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // workspace: as pvd_infer_image_hash
+    if (hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    if (hipMemsetAsync(workspace + 2 + 2 * (size_t)N, 0, 10 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    uint32_t hb = div_up(N, kHeadBlock);
+    if (hb > 4096) hb = 4096;
+    HeadArgs a;
+    a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = nullptr; a.M = 0;
+    a.Wa1 = Wb; a.Wa2 = nullptr; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
+    a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_feat_min; a.clip_max = clip_max;
+    a.sigma = nullptr; a.rgb = nullptr; a.feat16 = nullptr; a.image = (const half_t *)image; a.rows_dev = nullptr;
+    InferImageArgs q;
+    q.rays_o = rays_o; q.rays_d = rays_d; q.nears = nears; q.fars = fars; q.ray_ids = workspace + 2; q.n_ids = workspace; q.queue = workspace + 1;
+    q.grid = bitfield; q.bound = bound; q.dt_gamma = dt_gamma; q.sigma_scale = sigma_scale; q.max_steps = max_steps; q.C = C; q.H = H;
+    q.weights_sum = weights_sum; q.depth = depth; q.image = image_out;
+    q.t_first = reinterpret_cast<const float *>(workspace + 2 + N);
+    q.stats = workspace + 2 + 2 * (size_t)N;
+    q.shuffle = 7919u;
+    if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
+    hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
+    // PVD_INFER_VM_ROWS (measurement): sample rows per local round -- 128 (67 KB of LDS: two workgroups per CU) or 64 (48 KB: three)
+    static int rows = -1;
+    if (rows < 0) { const char *e = getenv("PVD_INFER_VM_ROWS"); rows = (e && atoi(e) == 64) ? 64 : 128; }
+    uint32_t blocks = div_up(N, 64u);
+    const uint32_t cap = rows == 64 ? 768u : 512u;
+    if (blocks > cap) blocks = cap;  // persistent
+    if (rows == 64) {
+        hipLaunchKernelGGL((k_infer_vm_persistent<64, 64>), dim3(blocks), dim3(kHeadBlock), infer_vm_persistent_lds_bytes<64>(), s, a, tb, q);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_infer_vm_persistent<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)infer_vm_persistent_lds_bytes<128>()) != hipSuccess)
+                return PVD_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128>), dim3(blocks), dim3(kHeadBlock), infer_vm_persistent_lds_bytes<128>(), s, a, tb, q);
+    }
     return check_launch();
 }
 

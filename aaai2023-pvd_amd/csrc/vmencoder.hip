@@ -19,57 +19,13 @@
 // consecutive samples that hit the same texel are merged in registers before touching memory.
 #include "pvd_device.h"
 #include "head_dw_reduce.h"
+#include "vm_lookup.h"
 
 #include <stdlib.h>
 
 namespace pvd {
 
 constexpr uint32_t kVmBlock = 256;
-constexpr uint32_t kRs = 16;  // sigma_rank (network.py:79)
-constexpr uint32_t kRc = 48;  // color_rank (network.py:80)
-
-struct VmTables {
-    const float *mat[2][3];  // [0] = sigma, [1] = colour; channels-last [H][W][R]
-    const float *vec[2][3];  // channels-last [L][R]
-    uint32_t ms[2], vs[2];   // elements between consecutive texels of a plane / taps of a line (>= R: tables may interleave)
-    uint32_t W[3], H[3], L[3];
-    float lo[3], inv_extent2[3];  // x_n = 2*(x-lo)/(hi-lo) - 1, kept as (2*(x-lo)) / (hi-lo) - 1
-    float extent[3];
-};
-
-struct VmGrads {
-    float *mat[2][3];
-    float *vec[2][3];
-};
-
-typedef _Float16 half_t;
-
-// per-axis sampling state, identical in every lane (grid_sampler_unnormalize, align_corners=True)
-struct Tap1 {
-    int i0;       // floor(pos); taps at i0 and i0+1
-    float w0, w1; // (i0+1 - pos), (pos - i0)
-    bool in0, in1;
-};
-
-__device__ __forceinline__ Tap1 tap1(float coord, uint32_t size) {
-    const float pos = ((coord + 1.0f) / 2.0f) * (float)(size - 1);
-    const float fl = floorf(pos);
-    Tap1 t;
-    t.i0 = (int)fl;
-    t.w1 = pos - fl;
-    t.w0 = (fl + 1.0f) - pos;
-    t.in0 = t.i0 >= 0 && t.i0 < (int)size;
-    t.in1 = t.i0 + 1 >= 0 && t.i0 + 1 < (int)size;
-    return t;
-}
-
-__device__ __forceinline__ void normalise(const float *__restrict__ xyz, size_t m, const VmTables &tb, float (&xn)[3]) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) xn[a] = (2.0f * (xyz[3 * m + a] - tb.lo[a])) / tb.extent[a] - 1.0f;  // network.py:345-350
-}
-
-constexpr int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
-
 // Register windows.  Consecutive samples of a ray move by about half a texel, so the 2x2 plane footprint (and the
 // 2-tap line footprint) of sample k+1 usually equals or overlaps that of sample k.  Each wave keeps the current
 // footprint in registers -- the texel VALUES (both passes: 18 coalesced 256-byte gathers per sample otherwise, which
@@ -79,11 +35,6 @@ constexpr int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
 // move reloads / flushes everything.  Every texel a ray crosses is thus read about once and receives about one
 // atomic per contiguous visit instead of one per sample and tap.  Control flow is wave-uniform: every lane shares
 // the sample's texel coordinates.
-// element offset of texel t at texel stride R: a 24-bit multiply (one full-rate instruction; the 64-bit product the plain
-// expression asks for is a quarter-rate v_mad_u64_u32 per access -- 212 of them in the forward's code).  pvd_vm_* refuse tables
-// whose texel count or byte size does not fit (fill_tables).
-__device__ __forceinline__ uint32_t toff(int t, uint32_t R) { return __umul24((uint32_t)t, R); }
-
 __device__ __forceinline__ void atom(float *__restrict__ p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool GRAD>
@@ -492,37 +443,6 @@ static uint32_t pick_chunk(uint32_t M, bool backward) {
     uint32_t chunk = 16;
     while (chunk < 64 && (uint64_t)M / chunk > 256u * 32u) chunk <<= 1;
     return chunk;
-}
-
-static int fill_tables(VmTables &tb, const void *const *tables, const uint32_t *res, const float *aabb, const uint32_t *stride) {
-    // reference shapes (network.py:199-212): mat_i [1,R,res[m1],res[m0]], vec_i [1,R,res[vec_id],1]
-    for (int i = 0; i < 3; i++) {
-        tb.W[i] = res[kM0[i]];
-        tb.H[i] = res[kM1[i]];
-        tb.L[i] = res[kV[i]];
-        if (tb.W[i] < 1 || tb.H[i] < 1 || tb.L[i] < 1) return PVD_ERR_INVALID;
-        if ((uint64_t)tb.W[i] * tb.H[i] >= (1ull << 24) || tb.L[i] >= (1u << 24)) return PVD_ERR_UNSUPPORTED;  // toff(): 24-bit texel indices
-        for (int k = 0; k < 2; k++) {
-            tb.mat[k][i] = (const float *)tables[k * 6 + i];
-            tb.vec[k][i] = (const float *)tables[k * 6 + 3 + i];
-            if (!tb.mat[k][i] || !tb.vec[k][i]) return PVD_ERR_INVALID;
-        }
-        tb.lo[i] = aabb[i];
-        tb.extent[i] = aabb[i + 3] - aabb[i];
-        tb.inv_extent2[i] = 0.f;
-    }
-    // texel strides: {sigma planes, sigma lines, colour planes, colour lines}; NULL = densely packed channels-last tables
-    const uint32_t dense[4] = {kRs, kRs, kRc, kRc};
-    if (!stride) stride = dense;
-    for (int k = 0; k < 2; k++) {
-        tb.ms[k] = stride[2 * k];
-        tb.vs[k] = stride[2 * k + 1];
-        if (tb.ms[k] < dense[2 * k] || tb.vs[k] < dense[2 * k] || tb.ms[k] > 4096u || tb.vs[k] > 4096u) return PVD_ERR_INVALID;
-        // toff() returns a 32-bit ELEMENT offset: texels x stride of every plane and line must fit
-        for (int i = 0; i < 3; i++)
-            if ((uint64_t)tb.W[i] * tb.H[i] * tb.ms[k] >= (1ull << 32) || (uint64_t)tb.L[i] * tb.vs[k] >= (1ull << 32)) return PVD_ERR_UNSUPPORTED;
-    }
-    return PVD_OK;
 }
 
 }  // namespace pvd

@@ -108,6 +108,30 @@ def hash_infer_image(model, rays_o, rays_d, nears, fars, dt_gamma, max_steps):
     return weights_sum, depth, img
 
 
+def vm_infer_image(model, rays_o, rays_d, nears, fars, dt_gamma, max_steps):
+    """(weights_sum, depth, image) of the eval branch's round loop (renderer.py:450-543) for a frozen VM model, as ONE persistent launch
+    (pvd_infer_image_vm): rays [N,3], nears / fars [N]; the accumulators as the loop leaves them (before background compositing)."""
+    from vmencoder.vm import is_channels_last
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    tables = [*model.sigma_mat, *model.sigma_vec, *model.color_mat, *model.color_vec]
+    assert all(is_channels_last(t) for t in tables), "VM factors must be stored channels-last"
+    res = [tables[0].shape[3], tables[0].shape[2], tables[1].shape[2]]  # mat_0 is [1,R,res[1],res[0]], mat_1 [1,R,res[2],res[0]]
+    a = model.args
+    smin = -100.0 if a.enable_edit_plenoxel else a.sigma_clip_min
+    ws = [_w(model.basis_mat), None, _w(model.color_net[0]), _w(model.color_net[1]), _w(model.color_net[2])]
+    image = _cached_image(model, KIND_VM, ws, [model.basis_mat.weight, model.color_net[0].weight, model.color_net[1].weight, model.color_net[2].weight])
+    f32 = dict(dtype=torch.float32, device=dev)
+    weights_sum, depth, img = torch.zeros(N, **f32), torch.zeros(N, **f32), torch.zeros(N, 3, **f32)
+    workspace = torch.empty(2 * N + 12, dtype=torch.int32, device=dev)
+    model._last_infer_workspace = workspace
+    pvd_hip.infer_image_vm(rays_o.float().contiguous(), rays_d.float().contiguous(), nears.float().contiguous(), fars.float().contiguous(),
+                           model.density_bitfield, float(model.bound), float(dt_gamma), int(max_steps), int(model.cascade), int(model.grid_size),
+                           float(model.density_scale), model._aabb(), [t.detach() for t in tables], res, ws[0], ws[2], ws[3], ws[4],
+                           smin, a.sigma_clip_min, a.sigma_clip_max, workspace, weights_sum, depth, img, image=image)
+    return weights_sum, depth, img
+
+
 def mlp_supported(model):
     """The layer structure pvd_mlp_head_forward_fused implements: 63 -> 256, hidden 256s with one skip concatenation, -> 28."""
     mlp = getattr(model, "nerf_mlp", None)

@@ -259,8 +259,10 @@ class NeRFRenderer(nn.Module):
 
         # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
         if self._persistent_render(rays_o, perturb):
-            # a frozen hash model: the whole loop as ONE persistent launch (pvd_infer_image_hash; PVD_INFER_PERSISTENT=0: the rounds)
-            weights_sum, depth, image = self.ops.fused_head.hash_infer_image(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps)
+            # a frozen hash or VM model: the whole loop as ONE persistent launch (pvd_infer_image_hash / _vm; PVD_INFER_PERSISTENT=0: the rounds)
+            fh = self.ops.fused_head
+            run = fh.hash_infer_image if self.model_type == "hash" else fh.vm_infer_image
+            weights_sum, depth, image = run(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
             return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "inherited_params": inherited_params}
@@ -301,7 +303,9 @@ class NeRFRenderer(nn.Module):
     def _persistent_render(self, rays_o, perturb):
         import os
         fh = getattr(getattr(self, "ops", None), "fused_head", None)
-        return (self._rounds_on_device(rays_o, perturb) and getattr(self, "model_type", None) == "hash" and hasattr(fh, "hash_infer_image")
+        mt = getattr(self, "model_type", None)
+        return (self._rounds_on_device(rays_o, perturb) and ((mt == "hash" and hasattr(fh, "hash_infer_image")) or
+                                                             (mt == "vm" and hasattr(fh, "vm_infer_image")))
                 and os.environ.get("PVD_INFER_PERSISTENT", "1") != "0")
 
     # ------------------------------------------------------------------ inference rounds, state on the device

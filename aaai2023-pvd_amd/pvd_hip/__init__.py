@@ -80,7 +80,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
@@ -731,6 +731,32 @@ def infer_image_hash(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max
           _u32(max_steps), _u32(C), _u32(H), _f32(sigma_scale), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _f32(S), _u32(H0),
           _u32(gridtype), _int(int(bool(align_corners))), _p(Wa1), _p(Wa2), _p(Wc1), _p(Wc2), _p(Wc3), _p(image), _f32(clip_sigma_min),
           _f32(clip_max), _p(workspace), _p(weights_sum), _p(depth), _p(image_out))
+
+
+def infer_image_vm(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, aabb_host, tables, res, Wb, Wc1, Wc2,
+                   Wc3, clip_sigma_min, clip_feat_min, clip_max, workspace, weights_sum, depth, image_out, image=None):
+    """pvd_infer_image_vm: the eval branch's round loop of a frozen VM model as one persistent launch; see include/pvd_hip.h."""
+    dev = _dev(rays_o, rays_d, nears, fars, bitfield, Wb, Wc1, Wc2, Wc3, workspace, weights_sum, depth, image_out, image)
+    for t in tables:  # (channels-last views: validated by _vm_texel_strides below, not by torch's notion of contiguity)
+        if not t.is_cuda or t.device != dev or t.dtype != torch.float32:
+            raise PvdHipError("VM factors must be float32 tensors on the same HIP device")
+    _want(workspace, torch.int32, "workspace"), _want(bitfield, torch.uint8, "bitfield")
+    _f32_all(rays_o=rays_o, rays_d=rays_d, nears=nears, fars=fars, Wb=Wb, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, weights_sum=weights_sum, depth=depth,
+             image_out=image_out)
+    N = rays_o.shape[0]
+    if rays_d.shape[0] < N or nears.numel() < N or fars.numel() < N or weights_sum.numel() < N or depth.numel() < N or image_out.numel() < 3 * N \
+            or workspace.numel() < 2 * N + 12:
+        raise PvdHipError("buffers shorter than N rays")
+    _check_image(1, image)
+    aabb = (ctypes.c_float * 6)(*[float(v) for v in aabb_host])
+    resa = (ctypes.c_uint32 * 3)(*[int(r) for r in res])
+    if len(tables) != 12:
+        raise PvdHipError("12 VM factor tables expected")
+    strides, _ = _vm_texel_strides(tables)
+    _call("pvd_infer_image_vm", dev, _p(rays_o), _p(rays_d), _p(nears), _p(fars), _u32(N), _p(bitfield), _f32(bound), _f32(dt_gamma),
+          _u32(max_steps), _u32(C), _u32(H), _f32(sigma_scale), aabb, _host_ptr_array(tables), resa, strides, _p(Wb), _p(Wc1), _p(Wc2),
+          _p(Wc3), _p(image), _f32(clip_sigma_min), _f32(clip_feat_min), _f32(clip_max), _p(workspace), _p(weights_sum), _p(depth),
+          _p(image_out))
 
 
 def mlp_head_forward_fused(pts16, wstream, n_before, n_after, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_sigma_min, clip_max, sigma, rgb, feat16,

@@ -350,6 +350,19 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
                          const float *Wc2, const float *Wc3, const void *image, float clip_sigma_min, float clip_max,
                          int32_t *workspace, float *weights_sum, float *depth, float *image_out, pvd_stream_t stream);
 
+/* The same persistent render for a frozen VM (TensoRF plane x line) model -- run_cuda's eval branch (renderer.py:450-543) over
+ * NeRFNetwork.forward's vm branch (network.py:344-381): rays / bitfield / workspace / outputs as for pvd_infer_image_hash; the tables
+ * (aabb_host, tables_host[12], res_host[3], texel_stride_host) as for pvd_vm_forward; Wb = basis_mat [15][144], Wc1..3 = color_net;
+ * image: NULL or the PVD_HEAD_VM weight image of pvd_head_pack_weights; clip_sigma_min bounds the sigma feature (-100 when
+ * enable_edit_plenoxel, network.py:355-360), clip_feat_min the colour features.  Per ray the arithmetic of pvd_vm_forward (f16
+ * products) + pvd_head_forward(PVD_HEAD_VM) + pvd_composite_rays: the image is the round loop's, bit for bit. */
+int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N,
+                       const uint8_t *bitfield, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                       float sigma_scale, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                       const uint32_t *texel_stride_host, const float *Wb, const float *Wc1, const float *Wc2, const float *Wc3,
+                       const void *image, float clip_sigma_min, float clip_feat_min, float clip_max, int32_t *workspace,
+                       float *weights_sum, float *depth, float *image_out, pvd_stream_t stream);
+
 /* The frozen `mlp` model (NeRF trunk + sigma / colour head; NeRFNetwork.forward with model_type "mlp", network.py:154-182 and
  * :413-437, under no_grad + fp16 autocast) in one launch.
  *   pts_f16 [M][64] f16: positional encoding padded to 64 columns (pvd_freq_encode(out_dtype = PVD_F16, row_stride = 64));

