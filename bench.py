@@ -181,7 +181,7 @@ def cpu_baseline_teacher(tea_gpu, opt, topt, steps, num_rays):
                          "and occupancy grid as the GPU run, no grid update inside the sample")
 
 
-def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=True):
+def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=True, dp=None, num_rays=None):
     """The metric's second half, OUTSIDE the timed region: a whole (short) distillation run through the three stages of the
     reference schedule (main_distill_mutual.py:387-396, scaled: stage 1 feature loss only, stage 2 + sigma / colour, stage 3 + RGB)
     from a teacher trained on the analytic scene, then PSNR on held-out views rendered with the inference path
@@ -194,9 +194,18 @@ def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=Tr
     from pvd.trainer import psnr
     from pvd.workload import DistillWorkload
 
-    opt = PVDConfig(model_type=student, iters=steps, stage_iters={"stage1": stage1, "stage2": stage2})
+    opt = PVDConfig(model_type=student, iters=steps, stage_iters={"stage1": stage1, "stage2": stage2}, **({"num_rays": num_rays} if num_rays else {}))
     t0 = time.perf_counter()
-    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=teacher_steps, start_stage="stage1")
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=teacher_steps, start_stage="stage1", dp=dp)
+    if dp is not None and dp.enabled:  # (tools/dp_wire_psnr.py) replicas start bit-identical, as in main()
+        import pvd_hip
+        for m in (w.tea, w.stu):
+            for t in list(m.parameters()) + list(m.buffers()):
+                d = t.data
+                if not d.is_contiguous():
+                    d = d.permute(0, 2, 3, 1) if d.dim() == 4 else d.permute(0, 2, 3, 4, 1)
+                dist.broadcast(d, src=0)
+            pvd_hip.note_weights_changed(list(m.parameters()))
     torch.cuda.synchronize()
     t_teacher = time.perf_counter() - t0
     tr = w.trainer

@@ -76,6 +76,12 @@ def gather(variant, x=None, row_mask=0xFFFFFFFF, perm=0, blocks=0):
     assert rc == 0, rc
 
 
+def split(blocks, row_mask=0xFFFFFFFF):
+    rc = lib.sol_split(p(x01), p(emb16), offs.ctypes.data_as(ctypes.c_void_p), scales.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(M), p(out),
+                       ctypes.c_uint32(row_mask), ctypes.c_uint32(blocks), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+
+
 def stream(blocks):
     rc = lib.sol_stream(p(stream_src), ctypes.c_size_t(ALG), p(out), ctypes.c_uint32(blocks), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
@@ -111,6 +117,10 @@ ROWS = [
     ("gather levels 0-9 only", lambda: gather(5), None),
     ("gather levels 10-13 only", lambda: gather(6), None),
     ("gather levels 10-13 only, all-hit", lambda: gather(6, row_mask=ALL_HIT), None),
+    ("split map: levels 10-13, pair-owned rows, 2904 wg", lambda: split(2904), None),
+    ("split map: levels 10-13, pair-owned rows, 1456 wg", lambda: split(1456), None),
+    ("split map: levels 10-13, pair-owned rows, 728 wg", lambda: split(728), None),
+    ("split map, all-hit tables, 2904 wg", lambda: split(2904, row_mask=ALL_HIT), None),
     ("gather levels 0-6 only", lambda: gather(7), None),
     ("gather levels 7-13 only", lambda: gather(8), None),
     ("gather G=7, 64-sample workgroups", lambda: gather(9), ALG),

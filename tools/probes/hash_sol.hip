@@ -165,6 +165,66 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
     }
 }
 
+// The split map (VERDICT r4 "next" 4): the four finest levels (2 MB each: 8 MB against an XCD's 4 MB of L2, every L2 pulling its own
+// copy through the fabric) served by XCD PAIRS -- pair p gathers only the rows with ((row >> 10) & 3) == p, for ALL samples (workgroup
+// b runs on XCD b % 8: pair (b % 8) >> 1; the pair's two XCDs take alternate chunks).  An L2 then holds a quarter of every fine
+// level (2 MB in all).  Four passes over the samples' index arithmetic, a quarter of the loads each; what a product kernel would
+// still have to add: the corner values written to a staging buffer and read back by the blending pass.
+template <uint32_t TILE>
+__global__ void __launch_bounds__(2 * TILE) k_sol_split(SolArgs a) {
+    const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
+    const uint32_t nchunks = (a.M + TILE - 1) / TILE;
+    const uint32_t xcd = blockIdx.x & 7u, pair = xcd >> 1, half = xcd & 1u;
+    // the pair's workgroups: blockIdx.x >> 3 enumerates the workgroups of this XCD; chunks c with c % 2 == half belong to this XCD
+    for (uint32_t c = (blockIdx.x >> 3) * 2u + half; c < nchunks; c += (gridDim.x >> 3) * 2u) {
+        const uint32_t b = c * TILE + s_local;
+        float x01[3] = {0.f, 0.f, 0.f};
+        bool inside = b < a.M;
+        if (inside) {
+            const Pos3 p = *reinterpret_cast<const Pos3 *>(a.xyz + (size_t)b * 3);
+            x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
+            for (uint32_t d = 0; d < 3; d++) inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
+        }
+        uint32_t acc = 0;
+        uint32_t v[4][4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t level = 10u + j;
+            const uint32_t off0 = (uint32_t)a.offs[level];
+            const float scale = a.scale[level];
+            Level3 lv;
+            lv.init((uint32_t)a.offs[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, 0u, false);
+            const uint32_t *__restrict__ table = a.grid + off0;
+            uint32_t cell[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) cell[d] = inside ? (uint32_t)floorf(fmaf(x01[d], scale, 0.5f)) : 0u;
+            uint32_t row[4];
+            level3_rows(lv, 0u, false, cell, xb, row);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t r = row[k] & a.row_mask;
+                v[j][k] = (((r >> 10) & 3u) == pair) ? table[r] : 0u;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) acc += v[j][k];
+        if (b < a.M && acc == 0x12345678u) a.out[2 * b + xb] = acc;  // (keeps the loads; the staging write is not part of this probe)
+    }
+}
+
+extern "C" int sol_split(const float *xyz, const void *grid, const int32_t *offs_host, const float *scale_host, uint32_t M, uint32_t *out,
+                         uint32_t row_mask, uint32_t blocks, void *stream) {
+    SolArgs a;
+    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = 0;
+    for (int i = 0; i < 15; i++) a.offs[i] = offs_host[i];
+    for (int i = 0; i < 14; i++) a.scale[i] = scale_host[i];
+    hipLaunchKernelGGL((k_sol_split<128>), dim3(blocks & ~7u), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_sol_stream(const uint4 *__restrict__ src, size_t n16, uint32_t *out) {
     uint4 acc = {0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
