@@ -552,6 +552,8 @@ def main():
     import fusedhead
     roof = None
     try:
+        if getattr(w.tea, "model_type", None) != "hash":  # (configs[3]: an mlp teacher has no hash-grid lookup)
+            raise LookupError("the roofline kernel (hash-grid lookup) does not run in this configuration: teacher is %r" % getattr(w.tea, "model_type", None))
         per_graph, reps = 20, 5
         n_launch = per_graph * reps
         side = torch.cuda.Stream()
@@ -641,7 +643,7 @@ def main():
         # profiles/, is kept next to it as the outside view of the same quantity when it was taken on this build of the kernel
         # (under the profiler the graph's kernels overlap less, so that figure is the shorter one).
         in_step = None
-        rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
+        rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r05_in_step.json", "r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
         if fused and rec_path:
             rec = json.load(open(rec_path))
             if rec.get("source_sha16") == kernel_source_sha16():
@@ -664,7 +666,7 @@ def main():
         # always in the object
         head = in_step if in_step is not None else alone
         traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
-        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
+        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
                          if os.path.exists(q)), None)
         if pmc_path:  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
             pmc = json.load(open(pmc_path))
@@ -689,7 +691,9 @@ def main():
                 "alone_next_batch": (None if next_cam is None else {"camera": next_cam, "us_per_launch": per_cam[next_cam], "frac": gbs(per_cam[next_cam]) / HBM_PEAK_GBS,
                                                                     "what": "rounds 1-3's protocol: ONE camera, the batch right behind the timed region"}),
                 "in_step": in_step, "in_step_rocprof": in_step_rocprof if in_step_rocprof is not in_step else None,
-                "rederive": "python tools/roofline_from_profile.py  (profiles/r04_kernel_populations.txt + r04_bench_profiled_line.json + r04_kernel_stats.csv)"}
+                "rederive": "python tools/roofline_from_profile.py  (profiles/r05_kernel_populations.txt + r05_bench_profiled_line.json + r05_kernel_stats.csv)"}
+    except LookupError as e:
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "note": str(e)}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
