@@ -32,6 +32,7 @@ class RayDP:
         a ring's 2 (n - 1) / n S / (its slowest hop) (tools/scale_model.py) -- and every
         element is summed by exactly ONE rank, so the replicas receive identical bits by construction."""
         n = self.world_size
+        assert t.is_contiguous(), "the two-shot exchange writes its result through a flat view: a non-contiguous tensor would lose it"
         flat = t.reshape(-1)
         chunk = (flat.numel() + n - 1) // n
         send = flat
