@@ -99,6 +99,26 @@ def test_fused_get_rays_matches_torch_formulation():
     assert torch.allclose(r["rays_d"].norm(dim=-1), torch.ones(1, 4096, device=dev), atol=1e-6)
 
 
+def test_fused_get_rays_with_an_error_map_draws_inside_the_weighted_cells():
+    """--error_map on the HIP operator set (utils.py:357-381): cells by weight without replacement, a pixel inside each cell, the
+    rays of exactly those pixels (the draw itself is pinned against the reference on the CPU: tests/test_golden.py)."""
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    dev = torch.device("cuda:0")
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(dev)
+    emap = torch.zeros(128 * 128, device=dev)
+    emap[5000:9000] = torch.rand(4000, device=dev) + 0.1  # only these cells may be drawn
+    g = torch.Generator(device=dev).manual_seed(4)
+    r = hip_ops().get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, 2048, error_map=emap, generator=g)
+    coarse, inds = r["inds_coarse"][0], r["inds"][0]
+    assert coarse.min().item() >= 5000 and coarse.max().item() < 9000 and coarse.unique().numel() == 2048
+    px, py = inds // 800, inds % 800
+    cx, cy = coarse // 128, coarse % 128
+    assert ((px >= (cx * 6.25).long()) & (px <= ((cx + 1) * 6.25).long()) & (py >= (cy * 6.25).long()) & (py <= ((cy + 1) * 6.25).long())).all()
+    ref = get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, 2048, inds=inds)
+    assert torch.equal(r["rays_o"], ref["rays_o"].contiguous()) and (r["rays_d"] - ref["rays_d"]).abs().max().item() < 3e-7
+
+
 def test_vm_non_cubic_tables_and_incoherent_order():
     """The kernel's per-axis sampling state assumes axis a is always sampled at res[a] (planes and lines agree by
     construction, network.py:199-212); check it with three different resolutions, points outside the box (zero padding,
