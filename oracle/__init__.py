@@ -298,3 +298,29 @@ def head_forward_amp(kind, x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
                                  _ptr(sigma), _ptr(rgb), _ptr(feat))
     assert rc == 0, rc
     return sigma, rgb, feat
+
+
+# ----------------------------------------------------------------- the VM plane x line lookup (network.py:216-309)
+def vm_forward(xyz, aabb, tables, res):
+    """tables: 12 arrays in the reference's layout -- sigma_mat[3] [16,H,W], sigma_vec[3] [16,L], color_mat[3] [48,H,W], color_vec[3] [48,L]
+    (leading 1 and trailing 1 dimensions of the reference's [1,R,H,W] / [1,R,L,1] parameters are accepted); res = (res_x, res_y, res_z).
+    Returns sigma_feat [M] and color_prod [M,144] (float32)."""
+    xyz = _c(xyz, np.float32).reshape(-1, 3)
+    M = xyz.shape[0]
+    aabb = _c(aabb, np.float32).reshape(6)
+    mat_ids, vec_ids = ((0, 1), (0, 2), (1, 2)), (2, 1, 0)
+    keep = []
+    for k, R in ((0, 16), (1, 48)):
+        for i in range(3):
+            t = _c(tables[6 * k + i], np.float32).reshape(R, int(res[mat_ids[i][1]]), int(res[mat_ids[i][0]]))
+            keep.append(t)
+        for i in range(3):
+            keep.append(_c(tables[6 * k + 3 + i], np.float32).reshape(R, int(res[vec_ids[i]])))
+    ptrs = (ctypes.c_void_p * 12)(*[t.ctypes.data for t in keep])
+    resa = (ctypes.c_uint32 * 3)(*[int(r) for r in res])
+    sig, prod = np.empty(M, np.float32), np.empty((M, 144), np.float32)
+    L = lib()
+    L.pvdo_vm_forward.restype = ctypes.c_int
+    rc = L.pvdo_vm_forward(_ptr(xyz), _u32(M), _ptr(aabb), ptrs, resa, _ptr(sig), _ptr(prod))
+    assert rc == 0
+    return sig, prod

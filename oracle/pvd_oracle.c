@@ -956,3 +956,59 @@ int pvdo_head_forward_amp(int kind, const uint16_t *x0, const float *sigma_raw, 
     free(sh);
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* The TensoRF "VM" plane x line lookup -- distill_mutual/network.py:216-309 (get_sigma_feat / get_color_feat over the tables of
+ * init_one_vm :193-214) with x normalised as :345-350.  F.grid_sample(align_corners=True, zero padding, bilinear) restated as
+ * PyTorch evaluates it: ix = ((x + 1) / 2) (W - 1); the four taps nw, ne, sw, se with weights (ix_se - ix)(iy_se - iy), ... ,
+ * out = nw_val * nw + ne_val * ne + sw_val * sw + se_val * se accumulated in that order, a tap outside the image contributing
+ * nothing.  The line factor is a [L, 1] image sampled at x = 0: two taps, weights 1 * w0 and 1 * w1.
+ * Tables in the REFERENCE's layout: mat_i [R][H_i][W_i] with W_i = res[mat_ids[i][0]], H_i = res[mat_ids[i][1]]; vec_i [R][L_i].
+ * color_prod [M][144] = (plane x line) per channel: no sum is formed, so it is the value the HIP lookup must produce bit for bit.
+ * sigma_feat [M] = sum over the 3 x 16 products: torch.sum's association is an implementation detail (and the HIP kernel's is a
+ * butterfly over lanes), so the oracle forms it in double and rounds once; compare within fp32 summation noise. */
+static inline float bilinear_tap(const float *img, int W, int H, int x, int y) {
+    return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
+}
+static float grid_sample_2d(const float *img, int W, int H, float gx, float gy) {
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    float out = 0.0f;
+    int any = 0;
+    /* (a tap outside contributes nothing; the first tap inside starts the sum -- 0 + v*w == v*w exactly either way) */
+    const int inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W, iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
+    if (inx0 && iny0) { out = bilinear_tap(img, W, H, x0, y0) * (wx0 * wy0); any = 1; }
+    if (inx1 && iny0) { const float t = bilinear_tap(img, W, H, x0 + 1, y0) * (wx1 * wy0); out = any ? out + t : t; any = 1; }
+    if (inx0 && iny1) { const float t = bilinear_tap(img, W, H, x0, y0 + 1) * (wx0 * wy1); out = any ? out + t : t; any = 1; }
+    if (inx1 && iny1) { const float t = bilinear_tap(img, W, H, x0 + 1, y0 + 1) * (wx1 * wy1); out = any ? out + t : t; any = 1; }
+    return out;
+}
+
+int pvdo_vm_forward(const float *xyz, uint32_t M, const float *aabb, const float *const *tables /* [12]: sigma_mat[3], sigma_vec[3],
+                    color_mat[3], color_vec[3] */, const uint32_t *res, float *sigma_feat, float *color_prod) {
+    static const int mat_ids[3][2] = {{0, 1}, {0, 2}, {1, 2}}, vec_ids[3] = {2, 1, 0};
+    const int R[2] = {16, 48};
+#pragma omp parallel for schedule(static)
+    for (uint32_t m = 0; m < M; m++) {
+        float xn[3];
+        for (int a = 0; a < 3; a++) xn[a] = (2.0f * (xyz[3 * (size_t)m + a] - aabb[a])) / (aabb[a + 3] - aabb[a]) - 1.0f; /* :345-350 */
+        double sig = 0.0;
+        for (int k = 0; k < 2; k++) {
+            for (int i = 0; i < 3; i++) {
+                const int W = (int)res[mat_ids[i][0]], H = (int)res[mat_ids[i][1]], L = (int)res[vec_ids[i]];
+                const float *mat = tables[6 * k + i], *vec = tables[6 * k + 3 + i];
+                for (int r = 0; r < R[k]; r++) {
+                    const float pv = grid_sample_2d(mat + (size_t)r * W * H, W, H, xn[mat_ids[i][0]], xn[mat_ids[i][1]]);
+                    const float lv = grid_sample_2d(vec + (size_t)r * L, 1, L, 0.0f, xn[vec_ids[i]]); /* [L, 1] image at x = 0 */
+                    const float prod = pv * lv;
+                    if (k == 0) sig += (double)prod;
+                    else color_prod[(size_t)m * 144 + i * 48 + r] = prod;
+                }
+            }
+        }
+        sigma_feat[m] = (float)sig;
+    }
+    return 0;
+}

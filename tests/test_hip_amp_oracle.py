@@ -83,6 +83,77 @@ def test_vm_head_matches_the_amp_oracle_on_the_kernels_own_products():
     _check("VM head, M = 92928", sig, rgb, feat, sig_o, rgb_o, feat_o, 0.97)
 
 
+def _vm_tables_reference_layout(m):
+    return [t.detach().float().contiguous().cpu().numpy() for t in (*m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)]
+
+
+def test_vm_lookup_is_bit_exact_against_the_oracles_c_restatement():
+    """k_vm_fwd against oracle/pvd_oracle.c: pvdo_vm_forward (network.py:216-309 restated tap by tap in grid_sample's order; pinned by
+    the reference's own vm forward, tests/test_oracle_vm.py): the 144 plane x line products are the same floats -- in fp32 and, rounded
+    once, in the f16 the AMP head reads -- and the sigma feature (a sum of 48 products whose association is the kernel's butterfly)
+    agrees to fp32 summation noise.  300^2 tables (the bench's), 92 928 samples incl. the marcher's padding rows and points outside the box."""
+    m = _model("vm").eval()
+    x, d = _inputs(92928)
+    x[100:200] *= 1.7  # outside [-1, 1]: zero padding
+    res = (m.sigma_mat[0].shape[3], m.sigma_mat[0].shape[2], m.sigma_mat[1].shape[2])
+    sig_o, prod_o = oracle.vm_forward(_np(x), m._aabb(), _vm_tables_reference_layout(m), res)
+    with torch.no_grad():
+        sraw32, prod32 = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sraw16, prod16 = m.ops.vm_encode(x, m._aabb(), *m.sigma_mat, *m.sigma_vec, *m.color_mat, *m.color_vec)
+    assert prod32.dtype == torch.float32 and prod16.dtype == torch.float16
+    assert np.array_equal(_np(prod32), prod_o), float(np.abs(_np(prod32) - prod_o).max())
+    assert np.array_equal(prod16.cpu().numpy(), prod_o.astype(np.float16))
+    assert torch.equal(sraw32, sraw16)
+    assert np.abs(_np(sraw32) - sig_o).max() <= 4e-6 * max(1.0, float(np.abs(sig_o).max())) and np.abs(prod_o).max() > 0.01
+
+
+def test_config2_amp_student_forward_matches_the_amp_oracle_end_to_end():
+    """The VM student of the timed step under AMP, no HIP value on the oracle side: oracle VM lookup (fp32) -> products rounded to
+    f16 (basis_mat's autocast cast) -> oracle AMP head -> oracle compositor, against k_vm_fwd + k_head_fwd<VM> + the HIP compositor on
+    the bench's 4096-ray batch.  The products are bit-identical (above); the sigma feature differs by fp32 summation noise, which the
+    clamp / exp / compositing carry through: features within 4e-3 (1 + |f|), image within 1e-4 max / 1e-6 mean (measured 5.3e-6 / 1.9e-8, 99.91 % of the colour features bit-identical)."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    torch.manual_seed(0)
+    w = DistillWorkload(hip_ops(), torch.device("cuda:0"), PVDConfig(num_rays=4096), teacher_pretrain_steps=0, seed=0)
+    stu = w.stu
+    with torch.no_grad():  # a student away from its initialisation (after init the colour head sees ~0.01-sized features)
+        for n, p in stu.named_parameters():
+            if p.dim() == 4:
+                p.mul_(2.5)
+            elif p.dim() == 2:
+                p.mul_(2.0)
+    import pvd_hip
+    pvd_hip.note_weights_changed(list(stu.parameters()))
+    rays_o, rays_d, bg = w.next_batch()
+    w.opt.global_step = w.trainer.global_step
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        out = stu.render(rays_o, rays_d, staged=False, bg_color=bg, perturb=True, force_all_rays=False)
+    xyzs, dirs, deltas, rays = out["inherited_params"]
+    n = int((rays[:, 1] + rays[:, 2]).max())
+    assert n > 60000, n
+    res = (stu.sigma_mat[0].shape[3], stu.sigma_mat[0].shape[2], stu.sigma_mat[1].shape[2])
+    sig_raw, prod = oracle.vm_forward(_np(xyzs[:n]), stu._aabb(), _vm_tables_reference_layout(stu), res)
+    a = stu.args
+    W = [_np(t) for t in (stu.basis_mat.weight, stu.color_net[0].weight, stu.color_net[1].weight, stu.color_net[2].weight)]
+    sig_o, rgb_o, feat_o = oracle.head_forward_amp(1, prod.astype(np.float16), sig_raw, _np(dirs[:n]), W[0], None, W[1], W[2], W[3],
+                                                   clip_sigma_min=a.sigma_clip_min, clip_feat_min=a.sigma_clip_min, clip_max=a.sigma_clip_max)
+    feat = _np(stu.feature_sigma_color[:n])
+    fd = np.abs(feat - feat_o)
+    assert (fd <= 4e-3 * (1 + np.abs(feat_o))).all() and float((feat[:, 1:] == feat_o[:, 1:]).mean()) >= 0.97, float(fd.max())
+    M = xyzs.shape[0]
+    sig_full, rgb_full = np.zeros(M, np.float32), np.zeros((M, 3), np.float32)
+    sig_full[:n], rgb_full[:n] = sig_o * stu.density_scale, rgb_o
+    ws, depth, img = oracle.composite_rays_train_forward(sig_full, rgb_full, _np(deltas), rays.cpu().numpy(), N=rays.shape[0])
+    img = img + (1 - ws[:, None]) * _np(bg).reshape(-1, 3)
+    err = np.abs(_np(out["image"]).reshape(-1, 3) - img)
+    print("configs[2] AMP student render, %d samples: colour features %.2f %% bit-identical, image max |d| %.2e, mean %.2e"
+          % (n, 100 * float((feat[:, 1:] == feat_o[:, 1:]).mean()), err.max(), err.mean()))
+    assert err.max() <= 1e-4 and err.mean() <= 1e-6 and img.std() > 0.02, (float(err.max()), float(err.mean()))
+
+
 def test_config2_amp_render_of_the_timed_step_matches_the_amp_oracle():
     """configs[2] at full size under AMP: the bench's 4096-ray batch marched by the HIP marcher (bit-exact with the oracle's), the
     frozen hash teacher's samples through k_hash_fwd_fused and the teacher image through the HIP compositor -- against oracle
