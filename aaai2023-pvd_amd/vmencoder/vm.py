@@ -80,7 +80,8 @@ def make_vm_encode(backend, device_type="cuda"):
                 backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(),
                                     [p.grad for p in ctx.leaves], **hkw)
                 return (None, None) + (None,) * len(tabs) + tail
-            grads = [torch.zeros_like(t) for t in tabs]  # preserves the channels-last strides
+            # (the factors' own strides; zeros_like would densify an interleaved view)
+            grads = [torch.empty_strided(t.shape, t.stride(), dtype=torch.float32, device=t.device).zero_() for t in tabs]
             backend.vm_backward(xyz, ctx.aabb_host, tabs, ctx.res, g_sigma.contiguous().float(), g_prod.contiguous(), grads, **hkw)
             return (None, None, *grads) + tail
 
