@@ -1120,6 +1120,9 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
     };
 
     uint32_t n_rounds = 0, n_rows = 0, n_walk = 0;
+#ifdef PVD_INFER_PROFILE
+    long long ph[5] = {0, 0, 0, 0, 0}, tm = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();  // weights
     for (;;) {
         // ---------------- refill
@@ -1147,6 +1150,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
             continue;
         }
         const uint32_t n_step = max(min(ROWS / live_now, kInfSteps), 1u);  // the reference's rule (renderer.py:493), the workgroup's numbers
+        PVD_ISTAMP(0);
         // ---------------- march (k_march_rays' loop, raymarching.cu:756-810, perturb = 0)
         if (index >= 0) {
             Dda r;
@@ -1176,6 +1180,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
                 row_slot[row0 + k] = tid;
             }
         __syncthreads();
+        PVD_ISTAMP(1);
         // ---------------- shade: the VM lookup of the tile's rows, wave w: rows w, w + 4, ... (lane j holds the state of its j-th row)
         {
             const uint32_t mine = rows > wave ? (rows - wave + 3u) / 4u : 0u;  // (uniform per wave; <= ROWS / 4 <= 64)
@@ -1221,6 +1226,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
             }
         }
         __syncthreads();
+        PVD_ISTAMP(2);
         // ---------------- ... and the head, 16 rows per wave and pass; sigma / rgb stay in LDS
         for (uint32_t t16 = wave; t16 * 16 < rows; t16 += kHeadBlock / 64) {
             const uint32_t rw = min(t16 * 16 + (lane & 15), ROWS - 1u);
@@ -1240,6 +1246,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
             }
         }
         __syncthreads();
+        PVD_ISTAMP(3);
         // ---------------- blend (k_composite_rays' loop, raymarching.cu:858-899; sigma scaled as renderer.py:528)
         if (cnt > 0) {
             bool done = false;
@@ -1262,7 +1269,11 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
             if (done) retire();
         }
         __syncthreads();  // the next round rewrites the tile
+        PVD_ISTAMP(4);
     }
+#ifdef PVD_INFER_PROFILE
+    if (tid == 0 && blockIdx.x == 0) for (int z = 0; z < 5; z++) q.stats[4 + z] = (int32_t)ph[z];
+#endif
     if (tid == 0 && n_rounds > 1) {
         atomicAdd(q.stats + 0, (int32_t)n_rounds); atomicAdd(q.stats + 1, (int32_t)n_rows); atomicAdd(q.stats + 2, (int32_t)n_walk); atomicAdd(q.stats + 3, 1);
     }
