@@ -29,6 +29,7 @@
 // register tiles (through a 512-byte LDS scratch per wave); dW tiles live in accumulators for the whole
 // launch and leave as one partial per wave, summed by a second tiny kernel straight into the gradients.
 #include "dda.h"
+#include "infer_persistent.h"
 #include "grid_lookup.h"
 #include "head_dw_reduce.h"
 #include "vm_lookup.h"
@@ -778,24 +779,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_hash_fwd_fused(HeadArgs a, Fused
 // bit (tests/test_hip_infer_rounds.py).  One thing the reference's loop does that this does not: it restarts a ray's march every
 // round from the t its compositing reconstructed by adding up `t - last_t`; those differences are exact for consecutive samples, so
 // the two t agree.  The reference stops ALL rays once the rounds' steps add up to max_steps; here a ray stops after max_steps samples.
-struct InferImageArgs {
-    const float *rays_o, *rays_d;  // [N][3]
-    const float *nears, *fars;     // [N]
-    const int32_t *ray_ids;        // [*n_ids] rays that meet an occupied cell, any order
-    const float *t_first;          // [N] the marcher's t at the ray's first occupied probe
-    const int32_t *n_ids;          // device count
-    int32_t *queue;                // device counter, zero at launch
-    uint32_t shuffle;              // multiplier of the queue -> ray permutation (host: PVD_INFER_SHUFFLE, default 7919; 1 = image order)
-    int32_t *stats;                // [4] zero at launch: local rounds, rows shaded, walk-only rounds, workgroups that took rays
-    const uint8_t *grid;           // density bitfield
-    float bound, dt_gamma, sigma_scale;
-    uint32_t max_steps, C, H;
-    float *weights_sum, *depth, *image;  // [N], [N], [N][3]: written for the rays in ray_ids (zero-filled by the caller)
-};
-
-constexpr uint32_t kInfRows = 256;         // sample rows per local round (LDS tile): the most any variant uses
-constexpr uint32_t kInfSteps = 8;          // samples a slot may hold per round (the reference's cap on n_step, renderer.py:493)
-constexpr uint32_t kInfProbes = 6;         // probes per slot and round beyond the samples it is looking for
+// (InferImageArgs, kInfRows / kInfSteps / kInfProbes: infer_persistent.h -- shared with plenoxel.hip's k_infer_px_persistent)
 
 // The walk in front of the object: from t = near to the first occupied probe (raymarching.cu:756-810 with nothing emitted).
 __global__ void __launch_bounds__(kHeadBlock) k_infer_first_hit(InferImageArgs q, uint32_t N, float *__restrict__ t_first,
@@ -1277,6 +1261,24 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
     if (tid == 0 && n_rounds > 1) {
         atomicAdd(q.stats + 0, (int32_t)n_rounds); atomicAdd(q.stats + 1, (int32_t)n_rows); atomicAdd(q.stats + 2, (int32_t)n_walk); atomicAdd(q.stats + 3, 1);
     }
+}
+
+int infer_prepare(InferImageArgs &q, const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N,
+                  const uint8_t *bitfield, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, float sigma_scale,
+                  int32_t *workspace, float *weights_sum, float *depth, float *image_out, hipStream_t s) {
+    if (hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    if (hipMemsetAsync(workspace + 2 + 2 * (size_t)N, 0, 10 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
+    uint32_t hb = div_up(N, kHeadBlock);
+    if (hb > 4096) hb = 4096;
+    q.rays_o = rays_o; q.rays_d = rays_d; q.nears = nears; q.fars = fars; q.ray_ids = workspace + 2; q.n_ids = workspace; q.queue = workspace + 1;
+    q.grid = bitfield; q.bound = bound; q.dt_gamma = dt_gamma; q.sigma_scale = sigma_scale; q.max_steps = max_steps; q.C = C; q.H = H;
+    q.weights_sum = weights_sum; q.depth = depth; q.image = image_out;
+    q.t_first = reinterpret_cast<const float *>(workspace + 2 + N);
+    q.stats = workspace + 2 + 2 * (size_t)N;
+    q.shuffle = 7919u;
+    if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
+    hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
+    return PVD_OK;
 }
 
 template <uint32_t ROWS>
@@ -2124,12 +2126,6 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
         return PVD_ERR_INVALID;
     if (!(in_div != 0.f) || max_steps == 0 || C == 0 || H == 0) return PVD_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    // workspace: [0] number of rays that meet an occupied cell, [1] the queue's head, [2 .. 2 + N) their ids, [2 + N .. 2 + 2 N) t_first (float),
-    // [2 + 2 N .. 6 + 2 N) statistics of the launch
-    if (hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
-    if (hipMemsetAsync(workspace + 2 + 2 * (size_t)N, 0, 10 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
-    uint32_t hb = div_up(N, kHeadBlock);
-    if (hb > 4096) hb = 4096;
     HeadArgs a;
     a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = nullptr; a.M = 0;
     a.Wa1 = Wa1; a.Wa2 = Wa2; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
@@ -2141,14 +2137,9 @@ int pvd_infer_image_hash(const float *rays_o, const float *rays_d, const float *
     FusedRes gr;
     for (uint32_t l = 0; l < 14; l++) gr.res[l] = (uint32_t)ceil((double)g.scales.scale[l]) + 1u;
     InferImageArgs q;
-    q.rays_o = rays_o; q.rays_d = rays_d; q.nears = nears; q.fars = fars; q.ray_ids = workspace + 2; q.n_ids = workspace; q.queue = workspace + 1;
-    q.grid = bitfield; q.bound = bound; q.dt_gamma = dt_gamma; q.sigma_scale = sigma_scale; q.max_steps = max_steps; q.C = C; q.H = H;
-    q.weights_sum = weights_sum; q.depth = depth; q.image = image_out;
-    q.t_first = reinterpret_cast<const float *>(workspace + 2 + N);
-    q.stats = workspace + 2 + 2 * (size_t)N;
-    q.shuffle = 7919u;
-    if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
-    hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
+    const int prc = infer_prepare(q, rays_o, rays_d, nears, fars, N, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, workspace, weights_sum,
+                                  depth, image_out, s);
+    if (prc != PVD_OK) return prc;
     const size_t lds_bytes = infer_persistent_lds_bytes();
     // 64 ray slots per workgroup, 256 sample rows per local round: three workgroups of 50 KB of LDS fit a CU (128 / 256 slots and
     // 128-row tiles measured slower, profiles/r04_render.txt, and were removed)
@@ -2172,25 +2163,15 @@ int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *ne
     const int rc = fill_tables(tb, tables_host, res_host, aabb_host, texel_stride_host);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // workspace: as pvd_infer_image_hash
-    if (hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
-    if (hipMemsetAsync(workspace + 2 + 2 * (size_t)N, 0, 10 * sizeof(int32_t), s) != hipSuccess) return PVD_ERR_LAUNCH;
-    uint32_t hb = div_up(N, kHeadBlock);
-    if (hb > 4096) hb = 4096;
     HeadArgs a;
     a.x0 = nullptr; a.sigma_raw = nullptr; a.dirs = nullptr; a.M = 0;
     a.Wa1 = Wb; a.Wa2 = nullptr; a.Wc1 = Wc1; a.Wc2 = Wc2; a.Wc3 = Wc3;
     a.clip_sigma_min = clip_sigma_min; a.clip_feat_min = clip_feat_min; a.clip_max = clip_max;
     a.sigma = nullptr; a.rgb = nullptr; a.feat16 = nullptr; a.image = (const half_t *)image; a.rows_dev = nullptr;
     InferImageArgs q;
-    q.rays_o = rays_o; q.rays_d = rays_d; q.nears = nears; q.fars = fars; q.ray_ids = workspace + 2; q.n_ids = workspace; q.queue = workspace + 1;
-    q.grid = bitfield; q.bound = bound; q.dt_gamma = dt_gamma; q.sigma_scale = sigma_scale; q.max_steps = max_steps; q.C = C; q.H = H;
-    q.weights_sum = weights_sum; q.depth = depth; q.image = image_out;
-    q.t_first = reinterpret_cast<const float *>(workspace + 2 + N);
-    q.stats = workspace + 2 + 2 * (size_t)N;
-    q.shuffle = 7919u;
-    if (const char *e = getenv("PVD_INFER_SHUFFLE")) q.shuffle = (uint32_t)max(atoi(e), 1);
-    hipLaunchKernelGGL(k_infer_first_hit, dim3(hb), dim3(kHeadBlock), 0, s, q, N, reinterpret_cast<float *>(workspace + 2 + N), workspace + 2, workspace);
+    const int prc = infer_prepare(q, rays_o, rays_d, nears, fars, N, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, workspace, weights_sum,
+                                  depth, image_out, s);
+    if (prc != PVD_OK) return prc;
     // PVD_INFER_VM_ROWS (measurement): sample rows per local round -- 128 (67 KB of LDS: two workgroups per CU) or 64 (48 KB: three)
     static int rows = -1;
     if (rows < 0) { const char *e = getenv("PVD_INFER_VM_ROWS"); rows = (e && atoi(e) == 64) ? 64 : 128; }

@@ -17,6 +17,7 @@
 // loaded / the leaving face flushed (4 taps, each one contiguous <=128 B access or atomic); any other
 // move reloads / flushes all 8.  The backward is bound by the memory-side atomic rate, which is why the
 // merging matters (cf. vmencoder.hip).
+#include "infer_persistent.h"
 #include "pvd_device.h"
 
 namespace pvd {
@@ -150,14 +151,17 @@ __device__ __forceinline__ void px_close(PxWindow &w, const PxVolume &v, float *
 
 // SH_k(d) for the lane's own k (k = (channel - 1) mod DEG^2), bands l < DEG
 template <int DEG>
-__device__ __forceinline__ float px_sh_of_lane(const float *__restrict__ dirs, size_t m, int k) {
+__device__ __forceinline__ float px_sh_k(float dx, float dy, float dz, int k) {
     float o[DEG * DEG];
-    pvd_sh_basis<DEG, false>(dirs[3 * m], dirs[3 * m + 1], dirs[3 * m + 2], [&](int i, float val) { o[i] = val; },
-                             [&](int, float, float, float) {});
+    pvd_sh_basis<DEG, false>(dx, dy, dz, [&](int i, float val) { o[i] = val; }, [&](int, float, float, float) {});
     float r = o[0];
 #pragma unroll
     for (int i = 1; i < DEG * DEG; i++) r = (k == i) ? o[i] : r;
     return r;
+}
+template <int DEG>
+__device__ __forceinline__ float px_sh_of_lane(const float *__restrict__ dirs, size_t m, int k) {
+    return px_sh_k<DEG>(dirs[3 * m], dirs[3 * m + 1], dirs[3 * m + 2], k);
 }
 
 __device__ __forceinline__ float px_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -257,6 +261,75 @@ __global__ void __launch_bounds__(kPxBlock) k_plenoxel_bwd(const float *__restri
     px_close(w, v, p);
 }
 
+// ---- the eval branch's round loop of a frozen Plenoxel model as ONE persistent launch (pvd_infer_image_plenoxel).
+// The slot machinery is infer_persistent_loop's; the shading of a round's rows: a half-wave (lane = channel, C <= 32) per row, the
+// eight corners of the row's cell requested unconditionally (clamped address, zero selected for corners outside the volume: the
+// rows of a round are 1-3 samples of each of ~60 rays, there is no run for k_plenoxel_fwd's register window to follow), then
+// k_plenoxel_fwd's own expressions in its order -- h = sum_t a_t w_t, the SH products summed over a colour's lanes by the same
+// shuffle tree, clamp / exp / sigmoid -- so per row the values are pvd_plenoxel_forward's and per ray the round loop's, bit for bit
+// (tests/test_hip_infer_rounds.py).  No weights, 7 KB of LDS, 163 VGPRs: three workgroups per CU.
+#ifndef PVD_INFER_PX_UNROLL
+#define PVD_INFER_PX_UNROLL 2  // 163 VGPRs, three workgroups per CU: 6.65 ms per 800 x 800 view (1: 9.12, 4: 8.8 at two per CU)
+#endif
+constexpr uint32_t kPxInfRays = 64, kPxInfRows = 128;
+template <int DEG>
+__global__ void __launch_bounds__(kPxBlock) k_infer_px_persistent(PxVolume v, InferImageArgs q) {
+    constexpr int K2 = DEG * DEG;
+    __shared__ float tile_mem[InferTile::floats<kPxInfRows, kPxBlock>()];
+    InferTile T;
+    T.carve<kPxInfRows, kPxBlock>(tile_mem);
+    const uint32_t lane = threadIdx.x & 63u, ch = lane & 31u, hw = threadIdx.x >> 5;  // 8 half-waves per workgroup
+    const bool lane_on = ch < v.C;
+    const int k = ch == 0 ? 0 : (int)(ch - 1) % K2;
+    const float *__restrict__ p = v.vol + (lane_on ? ch : 0u);
+    __syncthreads();
+    infer_persistent_loop<kPxInfRays, kPxInfRows, kPxBlock>(q, T, [&](uint32_t rows) {
+        // U rows per half-wave and pass: the 8 U corner loads are all requested before the first row is formed (one memory round
+        // trip per pass instead of one per row; the trip count is uniform -- the shuffles are executed by whole waves)
+        constexpr uint32_t U = PVD_INFER_PX_UNROLL, kHalves = kPxBlock / 32;
+        for (uint32_t r0 = 0; r0 < rows; r0 += U * kHalves) {
+            PxAxis ax[U][3];
+            float a[U][8];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t rw = min(r0 + u * kHalves + hw, rows - 1u);  // (a row past the last repeats it: nothing of it is stored)
+                const PxSample s = px_locate(T.pos, rw, v);
+#pragma unroll
+                for (int c = 0; c < 3; c++) ax[u][c] = s.ax[c];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int x = s.ax[0].i0 + (t & 1), y = s.ax[1].i0 + ((t >> 1) & 1), z = s.ax[2].i0 + (t >> 2);
+                    a[u][t] = p[px_offset(v, min(max(x, 0), (int)v.W - 1), min(max(y, 0), (int)v.H - 1), min(max(z, 0), (int)v.D - 1))];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const bool live = r0 + u * kHalves + hw < rows;
+                const uint32_t rw = min(r0 + u * kHalves + hw, rows - 1u);
+                float h = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int x = ax[u][0].i0 + (t & 1), y = ax[u][1].i0 + ((t >> 1) & 1), z = ax[u][2].i0 + (t >> 2);
+                    // px_locate's weights, k_plenoxel_fwd's sum: h += a_t * w_t in tap order, corners outside the volume count as zero
+                    const float w = (((t & 1) ? ax[u][0].w1 : ax[u][0].w0) * ((t & 2) ? ax[u][1].w1 : ax[u][1].w0)) * ((t & 4) ? ax[u][2].w1 : ax[u][2].w0);
+                    h += (px_inside(v, x, y, z) ? a[u][t] : 0.f) * w;
+                }
+                const uint32_t slot = T.row_slot[rw];
+                float part = ch == 0 ? 0.f : h * px_sh_k<DEG>(T.sdir[3 * slot], T.sdir[3 * slot + 1], T.sdir[3 * slot + 2], k);
+#pragma unroll
+                for (int off = 1; off < K2; off <<= 1) {
+                    const float up = __shfl_down(part, off, 64);
+                    if (k + off < K2) part += up;
+                }
+                if (live && lane_on) {
+                    if (ch == 0) T.sig[rw] = expf(fminf(v.clip_max, fmaxf(v.clip_min, h)));
+                    else if (k == 0) T.rgb[3 * rw + (ch - 1) / K2] = px_sigmoid(part);
+                }
+            }
+        }
+    });
+}
+
 static uint32_t px_chunk(uint32_t M) {
     uint32_t chunk = 16;
     while (chunk < 64 && (uint64_t)M / chunk > 2u * 256u * 16u) chunk <<= 1;
@@ -318,6 +391,32 @@ int pvd_plenoxel_backward(const float *xyz, const float *dirs, uint32_t M, const
         case 1: hipLaunchKernelGGL((k_plenoxel_bwd<1>), grid, block, 0, s, xyz, dirs, M, chunk, v, h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb, grad_volume); break;
         case 2: hipLaunchKernelGGL((k_plenoxel_bwd<2>), grid, block, 0, s, xyz, dirs, M, chunk, v, h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb, grad_volume); break;
         default: hipLaunchKernelGGL((k_plenoxel_bwd<3>), grid, block, 0, s, xyz, dirs, M, chunk, v, h0_raw, rgb, g_feat, g_sigma, g_sigma_l, g_rgb, grad_volume); break;
+    }
+    return check_launch();
+}
+
+int pvd_infer_image_plenoxel(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N, const uint8_t *bitfield,
+                             float bound, float dt_gamma, uint32_t max_steps, uint32_t cascade, uint32_t grid_size, float sigma_scale,
+                             const float *aabb_host, const float *volume, const uint32_t *dims_host, uint32_t C, uint32_t degree, float clip_min,
+                             float clip_max, int32_t *workspace, float *weights_sum, float *depth, float *image_out, pvd_stream_t stream) {
+    if (degree < 1 || degree > 3 || C != 3 * degree * degree + 1) return PVD_ERR_UNSUPPORTED;
+    if (N == 0) return PVD_OK;
+    if (!rays_o || !rays_d || !nears || !fars || !bitfield || !workspace || !weights_sum || !depth || !image_out) return PVD_ERR_INVALID;
+    if (max_steps == 0 || cascade == 0 || grid_size == 0) return PVD_ERR_INVALID;
+    PxVolume v;
+    const int rc = px_fill(v, volume, dims_host, C, aabb_host, clip_min, clip_max);
+    if (rc != PVD_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    InferImageArgs q;
+    const int prc = infer_prepare(q, rays_o, rays_d, nears, fars, N, bitfield, bound, dt_gamma, max_steps, cascade, grid_size, sigma_scale, workspace,
+                                  weights_sum, depth, image_out, s);
+    if (prc != PVD_OK) return prc;
+    uint32_t blocks = div_up(N, kPxInfRays);
+    if (blocks > 768u) blocks = 768u;  // persistent: 163 VGPRs = three workgroups per CU
+    switch (degree) {
+        case 1: hipLaunchKernelGGL((k_infer_px_persistent<1>), dim3(blocks), dim3(kPxBlock), 0, s, v, q); break;
+        case 2: hipLaunchKernelGGL((k_infer_px_persistent<2>), dim3(blocks), dim3(kPxBlock), 0, s, v, q); break;
+        default: hipLaunchKernelGGL((k_infer_px_persistent<3>), dim3(blocks), dim3(kPxBlock), 0, s, v, q); break;
     }
     return check_launch();
 }

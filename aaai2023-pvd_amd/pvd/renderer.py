@@ -259,9 +259,13 @@ class NeRFRenderer(nn.Module):
 
         # ---- inference: march / shade / composite in rounds with ray compaction (renderer.py:450-543)
         if self._persistent_render(rays_o, perturb):
-            # a frozen hash or VM model: the whole loop as ONE persistent launch (pvd_infer_image_hash / _vm; PVD_INFER_PERSISTENT=0: the rounds)
-            fh = self.ops.fused_head
-            run = fh.hash_infer_image if self.model_type == "hash" else fh.vm_infer_image
+            # a frozen hash, VM or Plenoxel model: the whole loop as ONE persistent launch (pvd_infer_image_hash / _vm / _plenoxel;
+            # PVD_INFER_PERSISTENT=0: the rounds)
+            if self.model_type == "tensors":
+                run = self.ops.plenoxel.infer_image
+            else:
+                fh = self.ops.fused_head
+                run = fh.hash_infer_image if self.model_type == "hash" else fh.vm_infer_image
             weights_sum, depth, image = run(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
@@ -304,9 +308,14 @@ class NeRFRenderer(nn.Module):
         import os
         fh = getattr(getattr(self, "ops", None), "fused_head", None)
         mt = getattr(self, "model_type", None)
-        return (self._rounds_on_device(rays_o, perturb) and ((mt == "hash" and hasattr(fh, "hash_infer_image")) or
-                                                             (mt == "vm" and hasattr(fh, "vm_infer_image")))
-                and os.environ.get("PVD_INFER_PERSISTENT", "1") != "0")
+        if os.environ.get("PVD_INFER_PERSISTENT", "1") == "0":
+            return False
+        if mt == "tensors":  # fp32 with or without autocast; the editing demo rewrites the volume per call (network.py:313-316): rounds
+            px = getattr(getattr(self, "ops", None), "plenoxel", None)
+            return (rays_o.is_cuda and not perturb and hasattr(px, "infer_image") and getattr(self, "bg_net", None) is None
+                    and not self.args.enable_edit_plenoxel)
+        return self._rounds_on_device(rays_o, perturb) and ((mt == "hash" and hasattr(fh, "hash_infer_image")) or
+                                                            (mt == "vm" and hasattr(fh, "vm_infer_image")))
 
     # ------------------------------------------------------------------ inference rounds, state on the device
     def _rounds_on_device(self, rays_o, perturb):

@@ -80,7 +80,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
+    "pvd_vm_forward", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_infer_image_plenoxel", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
@@ -654,7 +654,24 @@ def plenoxel_backward(xyz, dirs, aabb_host, degree, clip_min, clip_max, h0_raw, 
            "pvd_plenoxel_backward")
 
 
-plenoxel_backend = types.SimpleNamespace(plenoxel_forward=plenoxel_forward, plenoxel_backward=plenoxel_backward)
+def infer_image_plenoxel(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, cascade, grid_size, sigma_scale, aabb_host, volume,
+                         degree, clip_min, clip_max, workspace, weights_sum, depth, image_out):
+    """pvd_infer_image_plenoxel: the eval branch's round loop of a frozen Plenoxel model as one persistent launch; see include/pvd_hip.h."""
+    dev, aabb, dims, C = _px_common(rays_o, rays_d, aabb_host, volume, "volume")
+    _dev(nears, fars, bitfield, workspace, weights_sum, depth, image_out)
+    _want(workspace, torch.int32, "workspace"), _want(bitfield, torch.uint8, "bitfield")
+    _f32_all(nears=nears, fars=fars, weights_sum=weights_sum, depth=depth, image_out=image_out)
+    N = rays_o.shape[0]
+    if rays_d.shape[0] < N or nears.numel() < N or fars.numel() < N or weights_sum.numel() < N or depth.numel() < N or image_out.numel() < 3 * N \
+            or workspace.numel() < 2 * N + 12:
+        raise PvdHipError("buffers shorter than N rays")
+    _call("pvd_infer_image_plenoxel", dev, _p(rays_o), _p(rays_d), _p(nears), _p(fars), _u32(N), _p(bitfield), _f32(bound), _f32(dt_gamma),
+          _u32(max_steps), _u32(cascade), _u32(grid_size), _f32(sigma_scale), aabb, _p(volume), dims, _u32(C), _u32(degree), _f32(clip_min),
+          _f32(clip_max), _p(workspace), _p(weights_sum), _p(depth), _p(image_out))
+
+
+plenoxel_backend = types.SimpleNamespace(plenoxel_forward=plenoxel_forward, plenoxel_backward=plenoxel_backward,
+                                         infer_image_plenoxel=infer_image_plenoxel)
 
 
 # --------------------------------------------------------------------------- fused sigma / colour head

@@ -363,6 +363,16 @@ int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *ne
                        const void *image, float clip_sigma_min, float clip_feat_min, float clip_max, int32_t *workspace,
                        float *weights_sum, float *depth, float *image_out, pvd_stream_t stream);
 
+/* ... and for a frozen Plenoxel ("tensors") model -- run_cuda's eval branch over NeRFNetwork.forward's tensors branch
+ * (network.py:383-409): rays / bitfield / workspace / outputs as for pvd_infer_image_hash (cascade, grid_size: the occupancy grid's);
+ * volume / dims_host / C / degree / clip_min / clip_max / aabb_host as for pvd_plenoxel_forward.  Per row the values of
+ * pvd_plenoxel_forward, per ray pvd_composite_rays' sums: the image is the round loop's, bit for bit. */
+int pvd_infer_image_plenoxel(const float *rays_o, const float *rays_d, const float *nears, const float *fars, uint32_t N,
+                             const uint8_t *bitfield, float bound, float dt_gamma, uint32_t max_steps, uint32_t cascade,
+                             uint32_t grid_size, float sigma_scale, const float *aabb_host, const float *volume,
+                             const uint32_t *dims_host, uint32_t C, uint32_t degree, float clip_min, float clip_max,
+                             int32_t *workspace, float *weights_sum, float *depth, float *image_out, pvd_stream_t stream);
+
 /* The frozen `mlp` model (NeRF trunk + sigma / colour head; NeRFNetwork.forward with model_type "mlp", network.py:154-182 and
  * :413-437, under no_grad + fp16 autocast) in one launch.
  *   pts_f16 [M][64] f16: positional encoding padded to 64 columns (pvd_freq_encode(out_dtype = PVD_F16, row_stride = 64));

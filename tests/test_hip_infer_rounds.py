@@ -26,6 +26,8 @@ def _model(kind):
                 p.mul_(2.0)
             elif p.dim() == 4:
                 p.mul_(2.5)
+            elif p.dim() == 5:  # the Plenoxel volume starts at 0.02 randn: densities worth compositing
+                p.mul_(150.0)
     install_occupancy(m, ChairScene(), opt)
     return m.eval()
 
@@ -83,10 +85,10 @@ def test_device_rounds_respect_max_steps_and_empty_images():
     assert torch.equal(res[1][1], torch.ones_like(res[1][1])) and torch.equal(res[0][1], res[1][1])  # all background
 
 
-@pytest.mark.parametrize("kind", ["hash", "vm"])
+@pytest.mark.parametrize("kind", ["hash", "vm", "tensors"])
 @pytest.mark.parametrize("full_image", [False, True])
 def test_persistent_hash_render_is_the_round_loops_image(kind, full_image, monkeypatch):
-    """pvd_infer_image_hash / pvd_infer_image_vm (ONE persistent launch: ray slots in registers, samples in LDS, the alive queue in
+    """pvd_infer_image_hash / pvd_infer_image_vm / pvd_infer_image_plenoxel (ONE persistent launch: ray slots in registers, samples in LDS, the alive queue in
     device memory) against the round loop with the reference's per-round read-back: a ray's samples and sums depend on nothing but the
     ray, so every pixel, every depth and every accumulated weight must be the round loop's -- bit for bit."""
     m = _model(kind)
@@ -134,7 +136,8 @@ def test_persistent_hash_render_with_two_cascades_and_a_growing_step(monkeypatch
 
 
 @pytest.mark.parametrize("kind,n_rays,shuffle", [("hash", 1, 7919), ("hash", 63, 7919), ("hash", 2 * 7919, 7919), ("hash", 777, 1),
-                                                 ("vm", 1, 7919), ("vm", 63, 7919), ("vm", 2 * 7919, 7919), ("vm", 777, 1)])
+                                                 ("vm", 1, 7919), ("vm", 63, 7919), ("vm", 2 * 7919, 7919), ("vm", 777, 1),
+                                                 ("tensors", 1, 7919), ("tensors", 63, 7919), ("tensors", 2 * 7919, 7919), ("tensors", 777, 1)])
 def test_persistent_hash_render_renders_every_ray_once(kind, n_rays, shuffle, monkeypatch):
     """The queue hands rays out through a multiplicative shuffle: it must be a permutation for ANY number of rays (also a multiple of
     the multiplier), and workgroups with fewer rays than slots must terminate."""
@@ -149,7 +152,7 @@ def test_persistent_hash_render_renders_every_ray_once(kind, n_rays, shuffle, mo
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("kind", ["hash", "vm"])
+@pytest.mark.parametrize("kind", ["hash", "vm", "tensors"])
 def test_persistent_hash_render_of_a_whole_400x400_view(kind):
     """160 000 rays in one launch; the ones that meet an occupied cell are queued and rendered by several hundred workgroups"""
     from pvd.scene import get_rays, synthetic_poses
@@ -172,7 +175,7 @@ def test_persistent_hash_render_of_a_whole_400x400_view(kind):
     assert st[3] >= 100 and st[1] > 100000 and int(m._last_infer_workspace[0]) > 64 * 100  # workgroups that took rays; rows shaded; rays queued
 
 
-@pytest.mark.parametrize("kind", ["hash", "vm"])
+@pytest.mark.parametrize("kind", ["hash", "vm", "tensors"])
 def test_persistent_render_with_a_small_step_budget_differs_from_the_rounds_only_as_documented(kind, monkeypatch):
     """with max_steps small enough for rays to hit it the two loops stop differently BY DESIGN (include/pvd_hip.h): the
     reference's round loop stops ALL rays once the rounds' n_step add up to max_steps (and overshoots by up to n_step - 1), the
@@ -196,3 +199,29 @@ def test_persistent_render_with_a_small_step_budget_differs_from_the_rounds_only
     for cap in (cap_r, cap_p):
         assert ((cap - full_r)[~done_early].abs().max().item()) > 0
     assert torch.isfinite(cap_p).all()
+
+
+def test_persistent_plenoxel_render_without_autocast_and_with_degree_2(monkeypatch):
+    """The Plenoxel model is fp32 with or without autocast (network.py:383-409), so its persistent render does not depend on it; SH degree 2
+    (C = 13 channels: the half-wave's idle lanes) through the same launch."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import ChairScene
+    from pvd.workload import install_occupancy, make_model
+    o, d = _rays(3000)
+    for degree in (3, 2):
+        torch.manual_seed(5)
+        opt = PVDConfig(model_type="tensors", plenoxel_degree=degree, plenoxel_res="[48,64,80]")
+        opt.stage_iters = {"stage1": -1, "stage2": -1}
+        m = make_model(hip_ops(), opt, "tensors", False, torch.device(DEV))
+        with torch.no_grad():
+            m.tensor_volume[0].mul_(150.0)
+        install_occupancy(m, ChairScene(), opt)
+        m.eval()
+        assert m.tensor_volume[0].shape[1] == 3 * degree * degree + 1
+        outs = []
+        for persistent in ("0", "1"):
+            monkeypatch.setenv("PVD_INFER_PERSISTENT", persistent)
+            with torch.no_grad():
+                outs.append(m.render(o, d, staged=False, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)["image"].float())
+        assert outs[0].std().item() > 0.02 and torch.equal(outs[0], outs[1]), (degree, (outs[0] - outs[1]).abs().max().item())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Time of one 800 x 800 inference render (640 000 rays) of the hash teacher and the VM student: the reference-shaped loop
+"""Time of one 800 x 800 inference render (640 000 rays) of the hash teacher, the VM student and the Plenoxel student: the reference-shaped loop
 (one device-to-host read-back per round) vs the rounds whose state stays on the device (pvd_infer_*) vs -- hash model -- the
-whole loop as one persistent launch (pvd_infer_image_hash / pvd_infer_image_vm; PVD_INFER_VM_ROWS=64|128)."""
+whole loop as one persistent launch (pvd_infer_image_hash / pvd_infer_image_vm / pvd_infer_image_plenoxel; PVD_INFER_VM_ROWS=64|128)."""
 import os
 import sys
 import time
@@ -18,12 +18,12 @@ dev = torch.device("cuda:0")
 poses = torch.from_numpy(synthetic_poses(np.random.RandomState(2))).to(dev)
 r = get_rays(poses[9][None], BLENDER_INTRINSICS, 800, 800, -1)
 ONLY = os.environ.get("PVD_RENDER_ONLY")  # "p": the persistent renders alone (profiling); PVD_RENDER_KIND=hash|vm: one model
-for kind in ("hash", "vm"):
+for kind in ("hash", "vm", "tensors"):
     if os.environ.get("PVD_RENDER_KIND", kind) != kind:
         continue
     m = _model(kind)
     for mode in ("0", "1", "p"):
-        if ONLY and mode != ONLY:
+        if (ONLY and mode != ONLY) or (kind == "tensors" and mode == "1"):  # (no device-side round state for the Plenoxel model)
             continue
         os.environ["PVD_INFER_DEVICE_ROUNDS"] = "0" if mode == "0" else "1"
         os.environ["PVD_INFER_PERSISTENT"] = "1" if mode == "p" else "0"
