@@ -1040,13 +1040,17 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_hash_persistent(HeadArgs a
 #define PVD_INFER_VM_DEPTH 2
 #endif
 constexpr uint32_t kVmInfStride = 144 + 8;  // halfs per tile row: 76 dwords = 4 x odd -- the 16 rows of an 8-byte fragment read start on distinct bank quads
-template <uint32_t RAYS, uint32_t ROWS>
-__global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, VmTables tb, InferImageArgs q) {
+// ROWS sample rows per local round, shaded FT at a time (the feature tile is the big LDS consumer); OCC: waves per SIMD the register
+// budget must allow.  <64, 128, 64, 3> -- 47 KB of LDS, 168 VGPRs, three workgroups per CU -- renders the 800 x 800 view in 7.6 ms where
+// <64, 128, 128, 1> (67 KB, 192 VGPRs, two per CU) takes 8.8 and 64-row rounds at three per CU 8.4: the launch is a chain of barrier-
+// separated phases with 64 of 256 threads marching, and lives on the workgroups a CU can switch between (four per CU: no further gain).
+template <uint32_t RAYS, uint32_t ROWS, uint32_t FT, int OCC>
+__global__ void __launch_bounds__(kHeadBlock, OCC) k_infer_vm_persistent(HeadArgs a, VmTables tb, InferImageArgs q) {
     extern __shared__ __align__(16) half_t lds[];
     HeadLds<KIND_VM> W;
     W.carve(lds);
-    half_t *feat = lds + ((HeadLds<KIND_VM>::halfs + 7) & ~7);                          // [ROWS][kVmInfStride] plane x line products
-    float *pos = reinterpret_cast<float *>(feat + ROWS * kVmInfStride);                // [ROWS][3]
+    half_t *feat = lds + ((HeadLds<KIND_VM>::halfs + 7) & ~7);                          // [FT][kVmInfStride] plane x line products
+    float *pos = reinterpret_cast<float *>(feat + FT * kVmInfStride);                  // [ROWS][3]
     float *sraw = pos + 3 * ROWS;                                                      // [ROWS] raw sigma feature
     float *sig = sraw + ROWS;                                                          // [ROWS]
     float *rgb = sig + ROWS;                                                           // [ROWS][3]
@@ -1056,7 +1060,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, hi = lane >> 4, wave = tid >> 6;
     if (a.image) { copy_image_dma_static<HeadLds<KIND_VM>::halfs>(lds, a.image, tid); __builtin_amdgcn_s_waitcnt(0x0f70); }
     else W.load(a, tid, kHeadBlock);
-    for (uint32_t i = tid; i < ROWS * 4; i += kHeadBlock)  // the row padding (halfs 144..151) is never read; keep it defined
+    for (uint32_t i = tid; i < FT * 4; i += kHeadBlock)  // the row padding (halfs 144..151) is never read; keep it defined
         *reinterpret_cast<uint32_t *>(feat + (i >> 2) * kVmInfStride + 144 + 2 * (i & 3)) = 0u;
     const uint32_t n_ids = (uint32_t)max(*q.n_ids, 0);
     // the lane's channel of the twelve tables
@@ -1165,11 +1169,14 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
             }
         __syncthreads();
         PVD_ISTAMP(1);
-        // ---------------- shade: the VM lookup of the tile's rows, wave w: rows w, w + 4, ... (lane j holds the state of its j-th row)
+        // ---------------- shade, FT rows of the round at a time (the feature tile holds FT rows; positions / results all ROWS):
+        // the VM lookup of the pass's rows, wave w: rows w, w + 4, ... (lane j holds the state of its j-th row)
+        for (uint32_t base = 0; base < rows; base += FT) {
+        const uint32_t sub = min(FT, rows - base);
         {
-            const uint32_t mine = rows > wave ? (rows - wave + 3u) / 4u : 0u;  // (uniform per wave; <= ROWS / 4 <= 64)
+            const uint32_t mine = sub > wave ? (sub - wave + 3u) / 4u : 0u;  // (uniform per wave; <= FT / 4 <= 64)
             float xn[3] = {0.f, 0.f, 0.f};
-            if (lane < mine) normalise(pos, (size_t)(wave + 4u * lane), tb, xn);
+            if (lane < mine) normalise(pos, (size_t)(base + wave + 4u * lane), tb, xn);
             const SampleCtl ctl = sample_ctl(xn, tb);
             constexpr int kDepth = PVD_INFER_VM_DEPTH;  // register slots of 18 loads: depth - 1 rows' loads in flight while one row is formed
             Taps6 tp[kDepth][3];
@@ -1195,7 +1202,7 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
                 s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x124, 0xf, 0xf, false));
                 s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x122, 0xf, 0xf, false));
                 s += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x121, 0xf, 0xf, false));
-                if (lane == 0) sraw[rw] = s;
+                if (lane == 0) sraw[base + rw] = s;
             };
             if (mine > 0) {
 #pragma unroll
@@ -1212,13 +1219,13 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
         __syncthreads();
         PVD_ISTAMP(2);
         // ---------------- ... and the head, 16 rows per wave and pass; sigma / rgb stay in LDS
-        for (uint32_t t16 = wave; t16 * 16 < rows; t16 += kHeadBlock / 64) {
-            const uint32_t rw = min(t16 * 16 + (lane & 15), ROWS - 1u);
-            const bool live = t16 * 16 + (lane & 15) < rows;
+        for (uint32_t t16 = wave; t16 * 16 < sub; t16 += kHeadBlock / 64) {
+            const uint32_t fr = min(t16 * 16 + (lane & 15), FT - 1u), rw = base + fr;  // row of the feature tile / of the round
+            const bool live = t16 * 16 + (lane & 15) < sub;
             TileIn<KIND_VM> in;
             const h4 hz = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
 #pragma unroll
-            for (int s2 = 0; s2 < 9; s2++) in.x[s2] = live ? *reinterpret_cast<const h4 *>(feat + rw * kVmInfStride + 16 * s2 + 4 * hi) : hz;
+            for (int s2 = 0; s2 < 9; s2++) in.x[s2] = live ? *reinterpret_cast<const h4 *>(feat + fr * kVmInfStride + 16 * s2 + 4 * hi) : hz;
             in.sraw = (live && hi == 0) ? sraw[rw] : 0.f;
             const uint32_t slot = live ? row_slot[rw] : 0u;
             in.dx = live ? sdir[3 * slot] : 0.f; in.dy = live ? sdir[3 * slot + 1] : 0.f; in.dz = live ? sdir[3 * slot + 2] : 0.f;
@@ -1229,8 +1236,9 @@ __global__ void __launch_bounds__(kHeadBlock) k_infer_vm_persistent(HeadArgs a, 
                 rgb[3 * rw] = sigmoid_h(tf.out.x); rgb[3 * rw + 1] = sigmoid_h(tf.out.y); rgb[3 * rw + 2] = sigmoid_h(tf.out.z);
             }
         }
-        __syncthreads();
+        __syncthreads();  // (the next pass rewrites the feature tile)
         PVD_ISTAMP(3);
+        }
         // ---------------- blend (k_composite_rays' loop, raymarching.cu:858-899; sigma scaled as renderer.py:528)
         if (cnt > 0) {
             bool done = false;
@@ -1281,9 +1289,9 @@ int infer_prepare(InferImageArgs &q, const float *rays_o, const float *rays_d, c
     return PVD_OK;
 }
 
-template <uint32_t ROWS>
+template <uint32_t ROWS, uint32_t FT>
 static size_t infer_vm_persistent_lds_bytes() {
-    return (((size_t)HeadLds<KIND_VM>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + (size_t)ROWS * kVmInfStride * sizeof(half_t) +
+    return (((size_t)HeadLds<KIND_VM>::halfs + 7) & ~(size_t)7) * sizeof(half_t) + (size_t)FT * kVmInfStride * sizeof(half_t) +
            sizeof(float) * (3 * ROWS + ROWS + ROWS + 3 * ROWS + 3 * kHeadBlock) + sizeof(uint32_t) * (ROWS + 8);
 }
 
@@ -2172,23 +2180,27 @@ int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *ne
     const int prc = infer_prepare(q, rays_o, rays_d, nears, fars, N, bitfield, bound, dt_gamma, max_steps, C, H, sigma_scale, workspace, weights_sum,
                                   depth, image_out, s);
     if (prc != PVD_OK) return prc;
-    // PVD_INFER_VM_ROWS (measurement): sample rows per local round -- 128 (67 KB of LDS: two workgroups per CU) or 64 (48 KB: three)
+    // 128 sample rows per local round, shaded through a 64-row feature tile in two passes: 47 KB of LDS and (by launch bounds) 168
+    // VGPRs = THREE workgroups per CU.  PVD_INFER_VM_ROWS (measurement): 128 = the feature tile holds all 128 rows (67 KB, ~190 VGPRs:
+    // two per CU), 64 = 64-row rounds (three per CU)
     static int rows = -1;
-    if (rows < 0) { const char *e = getenv("PVD_INFER_VM_ROWS"); rows = (e && atoi(e) == 64) ? 64 : 128; }
+    if (rows < 0) { const char *e = getenv("PVD_INFER_VM_ROWS"); rows = e ? atoi(e) : 0; }
     uint32_t blocks = div_up(N, 64u);
-    const uint32_t cap = rows == 64 ? 768u : 512u;
+    const uint32_t cap = rows == 128 ? 512u : 768u;
     if (blocks > cap) blocks = cap;  // persistent
     if (rows == 64) {
-        hipLaunchKernelGGL((k_infer_vm_persistent<64, 64>), dim3(blocks), dim3(kHeadBlock), infer_vm_persistent_lds_bytes<64>(), s, a, tb, q);
-    } else {
+        hipLaunchKernelGGL((k_infer_vm_persistent<64, 64, 64, 3>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<64, 64>()), s, a, tb, q);
+    } else if (rows == 128) {
         static bool attr_set = false;
         if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_infer_vm_persistent<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)infer_vm_persistent_lds_bytes<128>()) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_infer_vm_persistent<64, 128, 128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)infer_vm_persistent_lds_bytes<128, 128>()) != hipSuccess)
                 return PVD_ERR_LAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128>), dim3(blocks), dim3(kHeadBlock), infer_vm_persistent_lds_bytes<128>(), s, a, tb, q);
+        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128, 128, 1>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<128, 128>()), s, a, tb, q);
+    } else {
+        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128, 64, 3>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<128, 64>()), s, a, tb, q);
     }
     return check_launch();
 }
