@@ -82,8 +82,8 @@ def _host_cpu():
 def _cpu_protocol(step, num_rays, steps, what):
     """SURVEY section 8(d)'s protocol on a bounded sample: 5 warm-up steps, `steps` (>= 20) steps timed one by one, median rays/s;
     thread count = the best of a climb up to all physical cores (a job this small loses to oversubscription on a many-core host:
-    256 threads measured 34 s/step where 8 take < 1 s -- so the climb's times are reported, and the all-cores figure whenever
-    the climb reaches it), a 1-thread figure, the CPU's model string.  step(i) runs training step i."""
+    256 threads measured 34 s/step where 8 take < 1 s -- so the climb's times are reported, and the all-physical-cores figure
+    always, from one step if the climb stopped below), a 1-thread figure, the CPU's model string.  step(i) runs training step i."""
     import oracle
     model, physical, ncpu = _host_cpu()
     sweep, best_t, best_n, k = {}, None, 1, 0
@@ -99,6 +99,13 @@ def _cpu_protocol(step, num_rays, steps, what):
             best_t, best_n = t, n
         elif t > 1.3 * best_t:
             break
+    if physical not in sweep:  # the climb stopped below all physical cores: that figure is part of the protocol, one step of it
+        torch.set_num_threads(physical)
+        oracle.set_num_threads(physical)
+        t0 = time.perf_counter()
+        step(k)
+        sweep[physical] = num_rays / (time.perf_counter() - t0)
+        k += 1
     torch.set_num_threads(best_n)
     oracle.set_num_threads(best_n)
     for _ in range(max(0, 5 - k)):  # (the climb's steps count as warm-up)
@@ -125,7 +132,7 @@ def _cpu_protocol(step, num_rays, steps, what):
             "protocol": "5 warm-up + %d steps timed one by one, median" % len(times),
             "cpu_model": model, "physical_cores": int(physical), "logical_cpus": int(ncpu),
             "one_thread_rays_per_s": num_rays / min(one),
-            "all_physical_cores_rays_per_s": sweep.get(physical),  # null: the climb stopped below (each step there > 1.3 x the best)
+            "all_physical_cores_rays_per_s": sweep.get(physical),  # (one step; the climb's own figure when it got there)
             "thread_climb_rays_per_s": {str(n): v for n, v in sweep.items()},
             "sample": what % (len(times), num_rays)}
 
