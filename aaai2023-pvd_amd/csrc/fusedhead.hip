@@ -2034,6 +2034,7 @@ static int launch_head_bwd(const HeadBwdArgs &a, uint32_t nwaves, float *gWa1, f
     hipLaunchKernelGGL((k_head_bwd<KIND, 1>), dim3(nblocks), dim3(kHeadBlock), lds_halfs * sizeof(half_t), s, a);
     if (defer) {  // the reduction rides on the caller's next launch (pvd_vm_backward_rider)
         defer->partials = a.partials; defer->nblocks = nblocks; defer->gWa1 = gWa1; defer->gWc1 = gW1; defer->gWc2 = gW2; defer->gWc3 = gW3;
+        defer->found_inf = nullptr;  // (the caller's to fill in: pvd_head_dw_rider)
         return check_launch();
     }
     const uint32_t nreal = (KIND == KIND_VM ? 15 * 144 : 64 * 28 + 16 * 64) + 64 * 31 + 64 * 64 + 3 * 64;

@@ -17,7 +17,7 @@ constexpr uint32_t kVmHeadReduceBlocks = (kVmHeadReal + 255u) / 256u;  // x kRed
 // one 256-thread workgroup: elements [256 bx, 256 bx + 256) of the concatenated gradients, waves of slice `slice`
 __device__ __forceinline__ void head_vm_reduce_dw(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ gWa1,
                                                   float *__restrict__ gW1, float *__restrict__ gW2, float *__restrict__ gW3, uint32_t bx,
-                                                  uint32_t slice) {
+                                                  uint32_t slice, float *__restrict__ found_inf = nullptr) {
     constexpr uint32_t nA1 = 15 * 144, n1 = 64 * 31, n2 = 64 * 64, n3 = 3 * 64;
     constexpr uint32_t c1 = 9, c2 = 17, c3 = 33;
     uint32_t i = bx * 256 + threadIdx.x;
@@ -45,6 +45,8 @@ __device__ __forceinline__ void head_vm_reduce_dw(const float *__restrict__ part
 #pragma unroll 4
     for (uint32_t w = w0; w < w1; w++) acc += partials[(size_t)w * kVmHeadTileFloats + off];
     if (w1 > w0) __hip_atomic_fetch_add(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (pvd_head_dw_rider.found_inf) a slice's sum that is inf / nan makes the weight gradient inf / nan
+    if (found_inf && (__float_as_uint(acc) & 0x7f800000u) == 0x7f800000u) found_inf[0] = 1.0f;
 }
 
 }  // namespace pvd

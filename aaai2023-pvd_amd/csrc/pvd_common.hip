@@ -8,7 +8,7 @@ void set_last_error(hipError_t e) { g_last_error = e; }
 
 extern "C" {
 
-int pvd_abi_version(void) { return 3; }  // 2: pvd_adamw_extras gained snapshot / replay; 3: + warm_zero_grad_from, zero_grad_after, arrivals
+int pvd_abi_version(void) { return 4; }  // 2: pvd_adamw_extras gained snapshot / replay; 3: + warm_zero_grad_from, zero_grad_after, arrivals; 4: pvd_head_dw_rider.found_inf
 
 const char *pvd_status_string(int status) {
     switch (status) {

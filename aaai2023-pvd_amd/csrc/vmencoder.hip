@@ -351,7 +351,8 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ x
 // three times the serial work per sample -- measured slower and was removed)
 template <typename T, int I0, int I1>
 __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, const VmTables &tb,
-                                            const float *__restrict__ g_sigma, const T *__restrict__ g_prod, const VmGrads &gr) {
+                                            const float *__restrict__ g_sigma, const T *__restrict__ g_prod, const VmGrads &gr,
+                                            float *__restrict__ found_inf) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kVmBlock + threadIdx.x) >> 6;
     const uint32_t s0 = wave * chunk;
@@ -360,6 +361,9 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
     const uint32_t kind = lane < kRs ? 0u : 1u;
     const uint32_t R = tb.ms[kind], Rv = tb.vs[kind];
     const uint32_t ch = kind ? lane - kRs : lane;
+    // (pvd_head_dw_rider.found_inf) every incoming gradient value this wave reads is looked at once: exponent all ones = inf / nan
+    uint32_t bad = 0u;
+    auto look = [&](float v) { bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; };
 
     PlaneWin<true> pw[3];
     LineWin<true> lw[3];
@@ -368,6 +372,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
 
     const WalkCtl pre = precompute_ctl(xyz, s0, s1, lane, tb);  // chunk <= 64
     const float gs_lane = (s0 + lane < s1) ? g_sigma[s0 + lane] : 0.f;
+    look(gs_lane);
     // the colour lanes' incoming gradients, one sample ahead of their use (a wave has few companions on its SIMD:
     // a load issued where it is needed costs its full latency on every sample)
     T g_next[3];
@@ -378,7 +383,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
         const float gs = bcast_f(gs_lane, m - s0);
         T g_cur[3];
 #pragma unroll
-        for (int i = I0; i < I1; i++) g_cur[i] = g_next[i];
+        for (int i = I0; i < I1; i++) { g_cur[i] = g_next[i]; look((float)g_cur[i]); }
         if (m + 1 < s1) {
 #pragma unroll
             for (int i = I0; i < I1; i++) g_next[i] = kind ? g_prod[(size_t)(m + 1) * (3 * kRc) + i * kRc + ch] : (T)0;
@@ -404,6 +409,7 @@ __device__ __forceinline__ void vm_bwd_body(const float *__restrict__ xyz, uint3
         pw[i].close(gr.mat[kind][i] + ch, (int)tb.W[i], (int)tb.H[i], R);
         lw[i].close(gr.vec[kind][i] + ch, (int)tb.L[i], Rv);
     }
+    if (found_inf && __ballot(bad != 0u) != 0ull && lane == 0) found_inf[0] = 1.0f;
 }
 
 // blockIdx.y = factor set: three times the waves, a third of the serial work per sample in each
@@ -414,12 +420,13 @@ __global__ void __launch_bounds__(kVmBlock) k_vm_bwd_split(const float *__restri
     if (blockIdx.y == 3) {  // (gridDim.y == 4) the VM head's weight-gradient reduction riding on this launch: head_dw_reduce.h
         static_assert(kVmBlock == 256, "head_vm_reduce_dw is written for 256 threads");
         for (uint32_t rb = blockIdx.x; rb < kVmHeadReduceBlocks * kReduceSlices; rb += gridDim.x)
-            head_vm_reduce_dw(hd.partials, hd.nblocks, hd.gWa1, hd.gWc1, hd.gWc2, hd.gWc3, rb % kVmHeadReduceBlocks, rb / kVmHeadReduceBlocks);
+            head_vm_reduce_dw(hd.partials, hd.nblocks, hd.gWa1, hd.gWc1, hd.gWc2, hd.gWc3, rb % kVmHeadReduceBlocks, rb / kVmHeadReduceBlocks,
+                              hd.found_inf);
         return;
     }
-    if (blockIdx.y == 0) vm_bwd_body<T, 0, 1>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
-    else if (blockIdx.y == 1) vm_bwd_body<T, 1, 2>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
-    else vm_bwd_body<T, 2, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr);
+    if (blockIdx.y == 0) vm_bwd_body<T, 0, 1>(xyz, M, chunk, tb, g_sigma, g_prod, gr, hd.found_inf);
+    else if (blockIdx.y == 1) vm_bwd_body<T, 1, 2>(xyz, M, chunk, tb, g_sigma, g_prod, gr, hd.found_inf);
+    else vm_bwd_body<T, 2, 3>(xyz, M, chunk, tb, g_sigma, g_prod, gr, hd.found_inf);
 }
 
 static uint32_t pick_chunk(uint32_t M, bool backward) {

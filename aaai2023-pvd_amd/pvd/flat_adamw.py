@@ -284,7 +284,22 @@ class FlatAdamW(torch.optim.Optimizer):
             self._l1_layout = "one"  # (a two-part recording re-bases the two regions: _l1_layout_is)
         return packed if self.cold_fraction > 0.05 else None
 
+    # ---- the inf check done by the backward itself (pvd_head_dw_rider.found_inf: the VM student's table scatter + weight-gradient
+    # reduction look at everything they complete).  inf_flag() is the scaler's flag, handed to that launch; the launch's caller reports
+    # back through note_checked_by_backward(); FlatGradScaler.step then launches no check of its own for THIS step.
+    _checked_by_backward = False
+
+    def inf_flag(self):
+        flag = getattr(self, "_found_inf_flag", None)
+        if flag is None:
+            flag = self._found_inf_flag = torch.zeros(1, dtype=torch.float32, device=self.flat_g.device)
+        return flag
+
+    def note_checked_by_backward(self):
+        self._checked_by_backward = True
+
     def zero_grad(self, set_to_none=False):
+        self._checked_by_backward = False  # (a backward before this zero_grad says nothing about the gradients to come)
         self._half_grad = None
         if self._zeroed_by_step and self.touched is not None and self._outside_is_zero:
             self._zeroed_by_step = False  # the previous step's update zeroed every group it read: the touched set is clean
@@ -459,10 +474,11 @@ class FlatGradScaler(torch.amp.GradScaler):
             raise RuntimeError("step() has already been called since the last update().")
         if state["stage"] is OptState.UNSCALED:
             return super().step(optimizer, *args, **kwargs)  # unscale_() was called explicitly: generic path
-        flag = getattr(optimizer, "_found_inf_flag", None)
-        if flag is None:
-            flag = optimizer._found_inf_flag = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_g.device)
-        optimizer.check_finite(flag)
+        flag = optimizer.inf_flag()
+        if optimizer._checked_by_backward:
+            optimizer._checked_by_backward = False  # the backward's own launches looked at every gradient they completed
+        else:
+            optimizer.check_finite(flag)
         optimizer.grad_scale, optimizer.found_inf = self._scale, flag
         optimizer.amp_update = (self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval)
         try:

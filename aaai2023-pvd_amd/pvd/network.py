@@ -319,6 +319,9 @@ class NeRFNetwork(NeRFRenderer):
                 # a dict shared by the two autograd nodes: the head's weight-gradient reduction rides on the lookup's backward
                 # launch (PVD_HEAD_DW_RIDE=0: a launch of its own)
                 head_dw = {} if (torch.is_grad_enabled() and os.environ.get("PVD_HEAD_DW_RIDE", "1") != "0") else None
+                if head_dw is not None and getattr(self, "_inf_check_in_backward", None) is not None:
+                    # (trainer) the scaler's inf check of this model's gradients rides on the same launch: (flag, note)
+                    head_dw["found_inf"] = self._inf_check_in_backward
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec,
                                                 *(() if head_dw is None else (head_dw,)))
                 out = fh.vm_head_train(self, sraw, prod, d, head_dw=head_dw if prod.requires_grad else None)

@@ -68,6 +68,11 @@ class _TrainerBase:
                 self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=opt.iters, eta_min=eta_min or 5e-5)
             self.scaler = torch.amp.GradScaler(self.device_type, enabled=amp)
         self._l1_folded = False
+        if self.flat_opt and amp and not self.dp.enabled and model.model_type == "vm" and os.environ.get("PVD_INF_CHECK_RIDE", "1") != "0":
+            # the scaler's inf check of the VM model's gradients rides on the launch that completes them (the table scatter + the head's
+            # weight-gradient reduction, pvd_head_dw_rider.found_inf): no check kernel between the scatter and the update on the step's
+            # chain.  Under ray-DP the check has to follow the exchange (an overflow on one rank skips the step on all): it stays.
+            model._inf_check_in_backward = (self.optimizer.inf_flag(), self.optimizer.note_checked_by_backward)
         if self.flat_opt and not self.dp.enabled and model.model_type == "hash":
             # the hash table's f16 scatter-add result goes straight into the update kernel (under ray-DP it is widened into
             # the fp32 buffer first, so that the exchange sees it)

@@ -540,10 +540,20 @@ def vm_backward(xyz, aabb_host, tables, res, grad_sigma_feat, grad_color_prod, g
         raise PvdHipError("VM gradient buffers must have the factors' own strides")
     if head_dw is not None and head_dw.get("rider") is not None:
         rider = head_dw.pop("rider")
+        # "found_inf": (flag [1] f32, note) -- the launch also does the GradScaler's inf check of everything it completes
+        # (pvd_head_dw_rider.found_inf); note() tells the flag's owner that this backward has looked
+        checked = head_dw.pop("found_inf", None)
+        if checked is not None:
+            flag = checked[0]
+            _dev(xyz, flag)
+            _want(flag, torch.float32, "found_inf")
+            rider.found_inf = flag.data_ptr()
         _check(_invoke("pvd_vm_backward_rider", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
                        _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), strides, ctypes.byref(rider), meta=(xyz.shape[0], dt)),
                "pvd_vm_backward_rider")
         head_dw.pop("keep", None)
+        if checked is not None:
+            checked[1]()
         return
     _check(_invoke("pvd_vm_backward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(grad_sigma_feat),
                    _p(grad_color_prod), _int(dt), _host_ptr_array(grad_tables), strides, meta=(xyz.shape[0], dt)), "pvd_vm_backward")
@@ -869,7 +879,7 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
 
 class _HeadDwRider(ctypes.Structure):  # pvd_head_dw_rider, include/pvd_hip.h
     _fields_ = [("partials", ctypes.c_void_p), ("nblocks", ctypes.c_uint32), ("gWa1", ctypes.c_void_p), ("gWc1", ctypes.c_void_p),
-                ("gWc2", ctypes.c_void_p), ("gWc3", ctypes.c_void_p)]
+                ("gWc2", ctypes.c_void_p), ("gWc3", ctypes.c_void_p), ("found_inf", ctypes.c_void_p)]
 
 
 def freq_encode(x, freq_bands, include_input=True, out_dtype=torch.float32, row_stride=None):

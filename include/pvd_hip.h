@@ -269,6 +269,12 @@ typedef struct pvd_head_dw_rider {
     const float *partials;  /* DEVICE: the head backward's workspace */
     uint32_t nblocks;
     float *gWa1, *gWc1, *gWc2, *gWc3;
+    /* (ABI 4; pvd_head_backward_defer sets it to NULL, the caller may fill it in) found_inf != NULL (DEVICE float scalar, never cleared
+     * here): pvd_vm_backward_rider's launch stores 1 into it when an incoming gradient value it reads (grad_sigma_feat,
+     * grad_color_prod) or a sum it adds into gW* is inf / nan -- GradScaler's inf check of everything this launch completes (the
+     * twelve table gradients are sums of those values times finite interpolation weights and table entries; the four weight
+     * gradients), folded into the launch, so that the step's chain has no separate check between the scatter and the update. */
+    float *found_inf;
 } pvd_head_dw_rider;
 int pvd_vm_backward_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
                           const uint32_t *res_host, const float *grad_sigma_feat, const void *grad_color_prod, int prod_dtype,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib_built):
     for s in declared_symbols():
         assert hasattr(lib, s), "libpvd_hip.so does not export %s" % s
     lib.pvd_abi_version.restype = ctypes.c_int
-    assert lib.pvd_abi_version() == 3
+    assert lib.pvd_abi_version() == 4
     lib.pvd_status_string.restype = ctypes.c_char_p
     assert lib.pvd_status_string(-2) and lib.pvd_status_string(0) == b"ok"
 

@@ -325,6 +325,74 @@ def test_gradient_outside_the_footprint_mask_is_zero(kind):
     assert int(touched.sum()) > 0.2 * c.idx.numel()  # the mask is not vacuously large
 
 
+def test_inf_check_rides_on_the_vm_scatter_launch(monkeypatch):
+    """pvd_head_dw_rider.found_inf: the scaler's inf check of the VM student's gradients is done by the launch that completes them (the
+    table scatter looks at every incoming gradient value it reads, the riding weight-gradient reduction at every sum it adds), and
+    FlatGradScaler.step launches no check of its own.  Same protocol as the separate check (PVD_INF_CHECK_RIDE=0): a clean step
+    leaves the flag alone, an overflowing one raises it in the backward, is skipped, halves the scale and clears the flag; a single
+    nan in the upstream gradient of one sample is seen; eager and replayed steps train alike."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    finals = {}
+    for ride in ("1", "0"):
+        monkeypatch.setenv("PVD_INF_CHECK_RIDE", ride)
+        opt = PVDConfig(num_rays=1024, resolution0=64, iters=200)
+        opt.stage_iters = {"stage1": -1, "stage2": -1}
+        w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=0, seed=0)
+        tr, o = w.trainer, w.trainer.optimizer
+        assert (getattr(w.stu, "_inf_check_in_backward", None) is not None) == (ride == "1")
+        calls = []
+        orig = o.check_finite
+        o.check_finite = lambda flag, orig=orig, calls=calls: (calls.append(1), orig(flag))[1]
+        for _ in range(3):
+            w.step()
+        flag = o.inf_flag()
+        assert (len(calls) == 0) == (ride == "1") and float(flag) == 0.0 and float(o.step_count) == 3.0
+
+        def backward_only(scale=None, poison=None):
+            if scale is not None:
+                tr.scaler._scale.fill_(scale)
+            tr._zero_grads()
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, *_ = tr.compute_loss(*w.next_batch())
+            if poison is not None:  # one nan in the gradient flowing back into ONE sample's colour products
+                h = w.stu.feature_sigma_color.register_hook(lambda g: g.index_put((torch.tensor([poison], device=dev), torch.tensor([3], device=dev)),
+                                                                                   torch.tensor([float("nan")], device=dev, dtype=g.dtype)))
+            tr._backward(loss)
+            if poison is not None:
+                h.remove()
+
+        # an overflowing backward (every f16 gradient value inf / nan)
+        p0, s0 = o.flat_p.clone(), float(tr.scaler._scale)
+        backward_only(scale=2.0 ** 40)
+        if ride == "1":
+            assert float(flag) == 1.0 and o._checked_by_backward  # raised by the backward's own launch
+        tr._exchange(); tr._optimize(); tr.scheduler.step(); tr.global_step += 1
+        assert torch.equal(o.flat_p, p0) and float(tr.scaler._scale) == 2.0 ** 39 and float(flag) == 0.0 and float(o.step_count) == 3.0
+        tr.scaler._scale.fill_(s0)
+        # one poisoned value
+        backward_only(poison=517)
+        tr._exchange(); tr._optimize(); tr.scheduler.step(); tr.global_step += 1
+        assert torch.equal(o.flat_p, p0) and float(tr.scaler._scale) == s0 / 2 and float(flag) == 0.0
+        tr.scaler._scale.fill_(s0)
+        # a gradient poisoned AFTER the backward, before the next zero_grad, is somebody else's to find: the separate check still exists
+        tr._zero_grads()
+        o.flat_g[o.touched.idx[10] if o.touched is not None else 10] = float("inf")
+        tr._optimize()
+        assert torch.equal(o.flat_p, p0) and len(calls) >= 1
+        tr.scaler._scale.fill_(s0)
+        # ... and training goes on, eagerly and replayed
+        w.step()
+        w.enable_graph(steps_per_graph=2)
+        losses = [float(w.step()[0]) for _ in range(6)]
+        assert all(l == l for l in losses) and float(flag) == 0.0 and not torch.equal(o.flat_p, p0)
+        finals[ride] = (losses, float(tr.scaler._scale))
+    assert finals["1"][1] == finals["0"][1]
+    assert all(abs(a - b) <= 3e-2 * abs(b) for a, b in zip(finals["1"][0], finals["0"][0])), finals
+
+
 def test_flat_adamw_half_gradient_equals_widen_and_add():
     """FlatAdamW.accept_half_grad: an f16 gradient added inside the update kernel == adding it into the fp32 gradient
     first (what autograd does for the hash table under autocast, grid.py:105-136), incl. the inf check of a scaled step."""
