@@ -333,6 +333,28 @@ __global__ void __launch_bounds__(kOptBlock) k_check_finite(const float *__restr
     if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
 }
 
+// both of the above in ONE launch, for a flat fp32 gradient one of whose ranges lives in a half-precision buffer instead (the hash
+// table's scatter-add result, pvd_adamw_extras.g16): the fp32 groups outside [skip_b4, skip_e4), then the half groups
+__global__ void __launch_bounds__(kOptBlock) k_check_finite_mixed(const float *__restrict__ g, uint64_t n4, uint64_t skip_b4, uint64_t skip_e4,
+                                                                 const _Float16 *__restrict__ g16, uint64_t n8, float *__restrict__ found_inf) {
+    const uint64_t gap = skip_e4 - skip_b4, n4_eff = n4 - gap;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kOptBlock + threadIdx.x; i < n4_eff + n8; i += (uint64_t)gridDim.x * kOptBlock) {
+        if (i < n4_eff) {
+            const float4 G = reinterpret_cast<const float4 *>(g)[i < skip_b4 ? i : i + gap];
+            const uint32_t a = __float_as_uint(G.x), b = __float_as_uint(G.y), c = __float_as_uint(G.z), d = __float_as_uint(G.w);
+            bad |= ((a & 0x7f800000u) == 0x7f800000u) | ((b & 0x7f800000u) == 0x7f800000u) | ((c & 0x7f800000u) == 0x7f800000u) |
+                   ((d & 0x7f800000u) == 0x7f800000u);
+        } else {
+            const uint4 w = reinterpret_cast<const uint4 *>(g16)[i - n4_eff];
+            const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) bad |= ((q[k] & 0x7c00u) == 0x7c00u) | ((q[k] & 0x7c000000u) == 0x7c000000u);
+        }
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+}
+
 // ---- segment-table operations over the flat gradient buffer.  The rows of a VM plane / Plenoxel volume that can receive a
 // gradient at all are known from the occupancy grid (harness: pvd/dp_compact.py); zeroing, the inf check and the ray-DP
 // gather/scatter then only touch those rows.  segs[s] = {start (flat), dst (compact), len}, one workgroup per segment.
@@ -548,6 +570,19 @@ int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_check_finite_f16, dim3((uint32_t)blocks), dim3(kOptBlock), 0, (hipStream_t)stream, (const _Float16 *)g, n >> 3,
                        found_inf);
+    return check_launch();
+}
+
+int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint64_t skip_end, const void *g16, uint64_t n16, float *found_inf,
+                           pvd_stream_t stream) {
+    if (!g || !g16 || !found_inf) return PVD_ERR_INVALID;
+    if ((n & 3u) || (skip_begin & 3u) || (skip_end & 3u) || (n16 & 7u) || skip_begin > skip_end || skip_end > n) return PVD_ERR_UNSUPPORTED;
+    const uint64_t items = (n - (skip_end - skip_begin)) / 4 + n16 / 8;
+    if (items == 0) return PVD_OK;
+    uint64_t blocks = (items + kOptBlock - 1) / kOptBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_check_finite_mixed, dim3((uint32_t)blocks), dim3(kOptBlock), 0, (hipStream_t)stream, g, n >> 2, skip_begin >> 2,
+                       skip_end >> 2, (const _Float16 *)g16, n16 >> 3, found_inf);
     return check_launch();
 }
 

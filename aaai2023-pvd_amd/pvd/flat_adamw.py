@@ -314,11 +314,16 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def check_finite(self, flag):
         """flag[0] = 1 if a gradient is inf / nan (read-only; never cleared here)."""
+        hg = getattr(self, "_half_grad", None)
         if self.touched is not None and self._outside_is_zero:
             self.touched.check_finite(self.flat_g, flag)
+        elif hg is not None and hg[2].numel() % 8 == 0 and hg[0] % 4 == 0 and hg[1] % 4 == 0 and self.flat_g.numel() % 4 == 0:
+            # the fp32 range of the parameter whose gradient came in half precision holds the zeros of zero_grad (accept_half_grad:
+            # nothing adds into it): one launch over the rest of the fp32 buffer and the half buffer
+            pvd_hip.check_finite_mixed(self.flat_g, hg[0], hg[1], hg[2], flag)
+            return
         else:
             pvd_hip.check_finite(self.flat_g, flag)
-        hg = getattr(self, "_half_grad", None)
         if hg is not None:
             pvd_hip.check_finite_f16(hg[2], flag)
 

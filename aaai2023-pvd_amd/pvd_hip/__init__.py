@@ -86,7 +86,7 @@ ENTRY_POINTS = (
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
     "pvd_composite_objective_blocks", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_l1_ranges", "pvd_segments_op",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_check_finite_mixed", "pvd_l1_ranges", "pvd_segments_op",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
@@ -1165,6 +1165,15 @@ def check_finite_f16(g, found_inf):
     dev = _dev(g, found_inf)
     _want(g, torch.float16, "g"), _want(found_inf, torch.float32, "found_inf")
     _call("pvd_check_finite_f16", dev, _p(g), ctypes.c_uint64(g.numel()), _p(found_inf))
+
+
+def check_finite_mixed(g, skip_begin, skip_end, g16, found_inf):
+    """pvd_check_finite_mixed: g (f32) outside [skip_begin, skip_end) and g16 (f16) in one launch."""
+    dev = _dev(g, g16, found_inf)
+    _f32_all(g=g, found_inf=found_inf)
+    _want(g16, torch.float16, "g16")
+    _call("pvd_check_finite_mixed", dev, _p(g), ctypes.c_uint64(g.numel()), ctypes.c_uint64(int(skip_begin)), ctypes.c_uint64(int(skip_end)), _p(g16),
+          ctypes.c_uint64(g16.numel()), _p(found_inf))
 
 
 SEG_ZERO, SEG_GATHER, SEG_SCATTER, SEG_CHECK = 0, 1, 2, 3

@@ -668,6 +668,11 @@ int pvd_adamw_lazy_flush(float *p, uint64_t n, const uint64_t *segment_ends_host
  * for an optimizer that unscales inside its own kernel (n multiple of 4). */
 int pvd_check_finite(const float *g, uint64_t n, float *found_inf, pvd_stream_t stream);
 int pvd_check_finite_f16(const void *g, uint64_t n, float *found_inf, pvd_stream_t stream); /* n multiple of 8 */
+/* Both in one launch, for a flat fp32 gradient one of whose ranges lives in a half-precision buffer instead (pvd_adamw_extras.g16: the
+ * fp32 elements [skip_begin, skip_end) are written by nobody and not read here): g[0, n) outside the range, then g16[0, n16).
+ * n, skip_begin, skip_end multiples of 4; n16 a multiple of 8. */
+int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint64_t skip_end, const void *g16, uint64_t n16,
+                           float *found_inf, pvd_stream_t stream);
 
 /* Segment-table operations over a flat f32 buffer.  segs = n_segs x {start, dst, len} (uint32, in elements): `start`
  * indexes `flat`, `dst` indexes the compact buffer `buf`.  Only the table rows the occupancy grid lets a sample touch can

@@ -325,6 +325,40 @@ def test_gradient_outside_the_footprint_mask_is_zero(kind):
     assert int(touched.sum()) > 0.2 * c.idx.numel()  # the mask is not vacuously large
 
 
+def test_mixed_inf_check_covers_exactly_the_fp32_buffer_minus_the_range_plus_the_half_buffer():
+    """pvd_check_finite_mixed (FlatAdamW.check_finite when a parameter's gradient came in half precision): one launch over the fp32
+    gradient outside that parameter's range and over the half buffer.  Every position of both is seen; the skipped range is not."""
+    import pvd_hip
+    dev = torch.device("cuda:0")
+    n, b, e = 40000, 12000, 12000 + 20480
+    g = torch.randn(n, device=dev)
+    g16 = torch.randn(20480, device=dev).half()
+    flag = torch.zeros(1, device=dev)
+    pvd_hip.check_finite_mixed(g, b, e, g16, flag)
+    assert float(flag) == 0.0
+    for pos in (b, b + 7777, e - 1):  # inside the skipped range: somebody else's (the half buffer stands for it)
+        g2 = g.clone(); g2[pos] = float("nan")
+        pvd_hip.check_finite_mixed(g2, b, e, g16, flag)
+        assert float(flag) == 0.0, pos
+    for pos in (0, 3, b - 1, e, e + 5, n - 1):
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            g2 = g.clone(); g2[pos] = bad
+            flag.zero_()
+            pvd_hip.check_finite_mixed(g2, b, e, g16, flag)
+            assert float(flag) == 1.0, (pos, bad)
+    for pos in (0, 1, 4095, 20479):
+        h2 = g16.clone(); h2[pos] = float("inf")
+        flag.zero_()
+        pvd_hip.check_finite_mixed(g, b, e, h2, flag)
+        assert float(flag) == 1.0, pos
+    flag.zero_()
+    pvd_hip.check_finite_mixed(g, 0, 0, g16, flag)      # empty range
+    pvd_hip.check_finite_mixed(g, 0, n, g16, flag)      # the whole fp32 buffer skipped
+    assert float(flag) == 0.0
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.check_finite_mixed(g, 2, 8, g16, flag)  # ranges are whole groups of four
+
+
 def test_inf_check_rides_on_the_vm_scatter_launch(monkeypatch):
     """pvd_head_dw_rider.found_inf: the scaler's inf check of the VM student's gradients is done by the launch that completes them (the
     table scatter looks at every incoming gradient value it reads, the riding weight-gradient reduction at every sum it adds), and
