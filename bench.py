@@ -469,15 +469,17 @@ def main():
 
     torch.cuda.manual_seed(1234 + rank)  # in-graph ray / background sampling: different rays on every rank
     launch_mode = "eager"
-    # steps per graph launch: the largest of 20, 10, 5, 4, 2 that divides both the timed and the warm-up step count (exactly K timed steps)
-    spg = next((k for k in (20, 10, 5, 4, 2) if args.steps % k == 0 and args.warmup % k == 0), 1) if os.environ.get("PVD_STEPS_PER_GRAPH", "") == "" \
-        else int(os.environ["PVD_STEPS_PER_GRAPH"])
-    if not args.eager:
+
+    def pick(n):
+        return next((k for k in (20, 10, 5, 4, 2) if n % k == 0), 1)
+
+    def record(spg):
+        """The step as HIP graph(s) of spg steps each (launch-bound eagerly: ~200 kernels of a few us); returns how it is launched."""
         try:
             # (roofline, in_step) every recorded launch of the teacher's lookup + head leaves its own extent behind: read after the timed region
             w.trainer.record_fused_spans = not dp.enabled
-            w.enable_graph(steps_per_graph=spg)  # the step is launch-bound eagerly (~200 kernels of a few us): replay it as HIP graph(s)
-            launch_mode = "hipGraph replay" + (" (%d steps per graph launch%s)" % (
+            w.enable_graph(steps_per_graph=spg)
+            return "hipGraph replay" + (" (%d steps per graph launch%s)" % (
                 w.steps_per_call, (", the next replay's marches + teacher forwards on ONE forked branch per graph" if getattr(w.trainer, "pipeline_fork", "") == "graph" else
                                            ", next step's march + teacher forward on a forked branch (fork at %s)" % getattr(w.trainer, "pipeline_fork", "mid"))
                 if getattr(w.trainer, "pipelined_ingraph", False) else "")
@@ -492,11 +494,41 @@ def main():
                 pass
             w._graph = False
             w._eager_device_batches = True  # keep using the one-kernel batch generator (no torch generator involved)
-            launch_mode = "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:120])
+            return "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:120])
+
+    # steps per graph launch: the largest of 20, 10, 5, 4, 2 that divides the timed step count (exactly K timed steps).  A warm-up count it
+    # does not divide (the driver's 5 before 20) is replayed from a recording of its own first -- single GPU only: under ray-DP one
+    # recording serves both, sized to divide both
+    forced = os.environ.get("PVD_STEPS_PER_GRAPH", "")
+    untimed_extra = 0  # steps run before the timed window beyond --warmup and beyond the three eager steps every recording starts with
+    spg = int(forced) if forced else pick(args.steps)
+    two_recordings = not args.eager and not forced and not dp.enabled and args.warmup > 0 and args.warmup % spg != 0
+    if not forced and not two_recordings and args.warmup % spg != 0:
+        spg = next((k for k in (20, 10, 5, 4, 2) if args.steps % k == 0 and args.warmup % k == 0), 1)
+    if two_recordings:
+        launch_mode = record(pick(args.warmup))
+        if launch_mode.startswith("hipGraph"):
+            assert args.warmup % w.steps_per_call == 0
+            for _ in range(args.warmup // w.steps_per_call):
+                w.step()
+            launch_mode = record(spg)
+            if launch_mode.startswith("hipGraph"):
+                # the timed recording's FIRST launch uploads the graph (measured: 0.2785 ms/step in the window against 0.270-0.271 on later
+                # launches): one untimed replay takes that out of the window, as the warm-up replays do for a single recording
+                w.step()
+                untimed_extra = w.steps_per_call
+            launch_mode += "; the %d warm-up steps replayed from a recording of %d steps, then one untimed replay of the timed recording" % (
+                args.warmup, pick(args.warmup))
+        else:  # (eager fall-back: the warm-up steps run below)
+            two_recordings = False
+    elif not args.eager:
+        launch_mode = record(spg)
     spc = w.steps_per_call
-    assert args.warmup % spc == 0 and args.steps % spc == 0
-    for _ in range(args.warmup // spc):
-        w.step()
+    assert args.steps % spc == 0
+    if not two_recordings:
+        assert args.warmup % spc == 0
+        for _ in range(args.warmup // spc):
+            w.step()
 
     if dp.enabled:
         dist.barrier()
@@ -729,6 +761,9 @@ def main():
                                       "branch (same bits; the reported loss counts their L1 value one step late)",
                               "1": "AdamW in two launches (L1-only rows at the start of the next step's branch)"}.get(
                        getattr(w.trainer, "adamw_split", "0"), "AdamW in one launch"),
+                   # steps that ran before the timed window beyond --warmup (each is a real optimisation step): the three eager steps every
+                   # recording starts with, and the untimed first replay of a timed recording that the warm-up count does not divide
+                   "untimed_steps_beyond_warmup": (0 if args.eager else 3 * (2 if two_recordings else 1)) + untimed_extra,
                    "capture_fallback": (not args.eager) and not launch_mode.startswith("hipGraph replay"),  # True = the step fell back to eager launches (~5x the ms)
                    "samples_per_step_per_gpu": samples,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
