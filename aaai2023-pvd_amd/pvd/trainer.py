@@ -73,6 +73,8 @@ class _TrainerBase:
             # weight-gradient reduction, pvd_head_dw_rider.found_inf): no check kernel between the scatter and the update on the step's
             # chain.  Under ray-DP the check has to follow the exchange (an overflow on one rank skips the step on all): it stays.
             model._inf_check_in_backward = (self.optimizer.inf_flag(), self.optimizer.note_checked_by_backward)
+        else:
+            model.__dict__.pop("_inf_check_in_backward", None)  # (an earlier trainer's: its flag is not this one's)
         if self.flat_opt and not self.dp.enabled and model.model_type == "hash":
             # the hash table's f16 scatter-add result goes straight into the update kernel (under ray-DP it is widened into
             # the fp32 buffer first, so that the exchange sees it)
