@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(kOptBlock) k_check_finite_mixed(const float *_
 // ---- segment-table operations over the flat gradient buffer.  The rows of a VM plane / Plenoxel volume that can receive a
 // gradient at all are known from the occupancy grid (harness: pvd/dp_compact.py); zeroing, the inf check and the ray-DP
 // gather/scatter then only touch those rows.  segs[s] = {start (flat), dst (compact), len}, one workgroup per segment.
-enum { kSegZero = 0, kSegGather = 1, kSegScatter = 2, kSegCheck = 3 };
+enum { kSegZero = 0, kSegGather = 1, kSegScatter = 2, kSegCheck = 3, kSegScatterCheck = 4 };  // 4: scatter, looking at what it moves
 template <int OP>
 __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat, float *__restrict__ buf, const uint32_t *__restrict__ segs,
                                                         uint32_t n_segs, float *__restrict__ found_inf) {
@@ -372,8 +372,9 @@ __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat
                 if (OP == kSegZero) f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (OP == kSegGather) b4[i] = f4[i];
                 if (OP == kSegScatter) f4[i] = b4[i];
-                if (OP == kSegCheck) {
-                    const float4 G = f4[i];
+                if (OP == kSegCheck || OP == kSegScatterCheck) {
+                    const float4 G = OP == kSegCheck ? f4[i] : b4[i];
+                    if (OP == kSegScatterCheck) f4[i] = G;
                     const uint32_t a = __float_as_uint(G.x), b = __float_as_uint(G.y), c = __float_as_uint(G.z), d = __float_as_uint(G.w);
                     bad |= ((a & 0x7f800000u) == 0x7f800000u) | ((b & 0x7f800000u) == 0x7f800000u) | ((c & 0x7f800000u) == 0x7f800000u) |
                            ((d & 0x7f800000u) == 0x7f800000u);
@@ -385,10 +386,15 @@ __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat
                 if (OP == kSegGather) buf[dst + i] = flat[start + i];
                 if (OP == kSegScatter) flat[start + i] = buf[dst + i];
                 if (OP == kSegCheck) bad |= (__float_as_uint(flat[start + i]) & 0x7f800000u) == 0x7f800000u;
+                if (OP == kSegScatterCheck) {
+                    const float v = buf[dst + i];
+                    flat[start + i] = v;
+                    bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+                }
             }
         }
     }
-    if (OP == kSegCheck && __ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+    if ((OP == kSegCheck || OP == kSegScatterCheck) && __ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
 }
 
 // partials[block] = sum over the block's elements of coef[range] * |p|
@@ -587,17 +593,18 @@ int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint
 }
 
 int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf, pvd_stream_t stream) {
-    if (op < kSegZero || op > kSegCheck) return PVD_ERR_INVALID;
+    if (op < kSegZero || op > kSegScatterCheck) return PVD_ERR_INVALID;
     if (n_segs == 0) return PVD_OK;
     if (!flat || !segs) return PVD_ERR_INVALID;
-    if ((op == kSegGather || op == kSegScatter) && !buf) return PVD_ERR_INVALID;
-    if (op == kSegCheck && !found_inf) return PVD_ERR_INVALID;
+    if ((op == kSegGather || op == kSegScatter || op == kSegScatterCheck) && !buf) return PVD_ERR_INVALID;
+    if ((op == kSegCheck || op == kSegScatterCheck) && !found_inf) return PVD_ERR_INVALID;
     const dim3 grid(n_segs < 65535u * 16u ? n_segs : 65535u * 16u), block(kOptBlock);
     hipStream_t s = (hipStream_t)stream;
     switch (op) {
         case kSegZero: hipLaunchKernelGGL(k_segments<kSegZero>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
         case kSegGather: hipLaunchKernelGGL(k_segments<kSegGather>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
         case kSegScatter: hipLaunchKernelGGL(k_segments<kSegScatter>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+        case kSegScatterCheck: hipLaunchKernelGGL(k_segments<kSegScatterCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
         default: hipLaunchKernelGGL(k_segments<kSegCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
     }
     return check_launch();

@@ -114,12 +114,19 @@ class GradCompactor:
             return buf
         return flat.index_select(0, self.idx)
 
-    def scatter(self, flat, buf):
+    def scatter(self, flat, buf, found_inf=None):
+        """flat[idx] = buf; found_inf (float [1], optional): set to 1 if buf holds an inf / nan -- the inf check of exactly the rows
+        check_finite() would look at, in the same pass."""
         if flat.is_cuda:
             import pvd_hip
-            pvd_hip.segments_op(pvd_hip.SEG_SCATTER, flat, self.segs, buf=buf)
+            if found_inf is not None:
+                pvd_hip.segments_op(pvd_hip.SEG_SCATTER_CHECK, flat, self.segs, buf=buf, found_inf=found_inf)
+            else:
+                pvd_hip.segments_op(pvd_hip.SEG_SCATTER, flat, self.segs, buf=buf)
         else:
             flat.index_copy_(0, self.idx, buf)
+            if found_inf is not None:
+                found_inf.masked_fill_(~torch.isfinite(buf).all(), 1.0)
 
     def zero(self, flat):
         """flat[idx] = 0: all a zero_grad has to do once the rest of the buffer is known to be zero."""

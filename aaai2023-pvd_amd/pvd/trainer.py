@@ -186,7 +186,13 @@ class _TrainerBase:
                     w16 = buf.to(wire)
                     self.dp.all_reduce_sum_(w16, overlap=ov)
                     buf = w16.to(torch.float32)
-                c.scatter(self.flat.flat, buf)
+                # the exchanged rows are exactly what the scaler's check would look at (the optimizer's touched set IS this compactor):
+                # they are looked at while they are put back, and the step has one dependent launch fewer
+                checked = (self.flat_opt and c is self.optimizer.touched and self.optimizer._outside_is_zero
+                           and bool(getattr(self.scaler, "_enabled", False)) and os.environ.get("PVD_INF_CHECK_RIDE", "1") != "0")
+                c.scatter(self.flat.flat, buf, found_inf=self.optimizer.inf_flag() if checked else None)
+                if checked:
+                    self.optimizer.note_checked_by_backward()
 
     def _optimize(self):
         self.scaler.step(self.optimizer)

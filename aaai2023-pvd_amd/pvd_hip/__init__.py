@@ -1176,7 +1176,7 @@ def check_finite_mixed(g, skip_begin, skip_end, g16, found_inf):
           ctypes.c_uint64(g16.numel()), _p(found_inf))
 
 
-SEG_ZERO, SEG_GATHER, SEG_SCATTER, SEG_CHECK = 0, 1, 2, 3
+SEG_ZERO, SEG_GATHER, SEG_SCATTER, SEG_CHECK, SEG_SCATTER_CHECK = 0, 1, 2, 3, 4
 
 
 def segments_op(op, flat, segs, buf=None, found_inf=None):
@@ -1187,11 +1187,11 @@ def segments_op(op, flat, segs, buf=None, found_inf=None):
     _want(segs, torch.int32, "segs")
     if segs.dim() != 2 or segs.shape[1] != 3 or not segs.is_contiguous():
         raise PvdHipError("segs must be a contiguous [n, 3] int32 tensor")
-    if op in (SEG_GATHER, SEG_SCATTER):
+    if op in (SEG_GATHER, SEG_SCATTER, SEG_SCATTER_CHECK):
         if buf is None:
             raise PvdHipError("gather / scatter need the compact buffer")
         _f32_all(buf=buf)
-    if op == SEG_CHECK:
+    if op in (SEG_CHECK, SEG_SCATTER_CHECK):
         if found_inf is None:
             raise PvdHipError("the inf check needs found_inf")
         _f32_all(found_inf=found_inf)

@@ -680,6 +680,7 @@ int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint
  * (utils.py:1016 `scaler.step`) and the ray-DP gradient exchange only need those rows.
  *   op 0: flat[start+i] = 0            op 1: buf[dst+i] = flat[start+i]   (gather)
  *   op 2: flat[start+i] = buf[dst+i]   op 3: found_inf[0] = 1 if any flat[start+i] is inf/nan (never cleared)
+ *   op 4: op 2 and op 3 in one pass (the exchanged gradient is checked while it is put back: ray-DP's step has one launch fewer)
  * Segments whose start, dst and len are multiples of 4 move as float4. */
 int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf,
                     pvd_stream_t stream);

@@ -325,6 +325,31 @@ def test_gradient_outside_the_footprint_mask_is_zero(kind):
     assert int(touched.sum()) > 0.2 * c.idx.numel()  # the mask is not vacuously large
 
 
+def test_segments_scatter_and_check_in_one_pass():
+    """pvd_segments_op(4): the exchanged rows are put back AND looked at (ray-DP: the scaler's check rides on the scatter of the
+    summed gradient).  Same result in `flat` as op 2; the flag as op 3 on the rows moved -- float4 and scalar segments."""
+    import pvd_hip
+    from pvd.dp_compact import segments_of
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(2)
+    idx = torch.cat([torch.arange(8, 8 + 4096 * 3), torch.arange(20001, 20001 + 37), torch.arange(30000, 30000 + 5000, 1)]).to(dev)
+    segs = segments_of(idx)
+    buf = torch.randn(idx.numel(), generator=g).to(dev)
+    flat_a, flat_b = torch.zeros(40000, device=dev), torch.zeros(40000, device=dev)
+    flag = torch.zeros(1, device=dev)
+    pvd_hip.segments_op(pvd_hip.SEG_SCATTER, flat_a, segs, buf=buf)
+    pvd_hip.segments_op(pvd_hip.SEG_SCATTER_CHECK, flat_b, segs, buf=buf, found_inf=flag)
+    assert torch.equal(flat_a, flat_b) and torch.equal(flat_b[idx], buf) and float(flag) == 0.0
+    for pos in (0, 4095, 4096 * 3, 4096 * 3 + 36, idx.numel() - 1):
+        for bad in (float("inf"), float("nan")):
+            b2 = buf.clone(); b2[pos] = bad
+            flag.zero_()
+            pvd_hip.segments_op(pvd_hip.SEG_SCATTER_CHECK, flat_b, segs, buf=b2, found_inf=flag)
+            assert float(flag) == 1.0, (pos, bad)
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.segments_op(pvd_hip.SEG_SCATTER_CHECK, flat_b, segs, buf=buf)
+
+
 def test_mixed_inf_check_covers_exactly_the_fp32_buffer_minus_the_range_plus_the_half_buffer():
     """pvd_check_finite_mixed (FlatAdamW.check_finite when a parameter's gradient came in half precision): one launch over the fp32
     gradient outside that parameter's range and over the half buffer.  Every position of both is seen; the skipped range is not."""

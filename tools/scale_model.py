@@ -9,12 +9,12 @@ quantities and an ASSUMED ring all-reduce bus bandwidth -- nothing here is a mea
   ring all-reduce of B bytes over N ranks: 2 (N - 1) / N * B / busbw + 2 (N - 1) * hop latency
   efficiency    step_1 / (step_dp + t_AR - hidden), hidden = what of the exchange an overlap could cover
 
-  python tools/scale_model.py [--step1 0.275] [--step-dp 0.318] [--mb 13.3] [--hop-us 4]"""
+  python tools/scale_model.py [--step1 0.272] [--step-dp 0.316] [--mb 13.3] [--hop-us 4]"""
 import argparse
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--step1", type=float, default=0.275)
-ap.add_argument("--step-dp", type=float, default=0.318)
+ap.add_argument("--step1", type=float, default=0.272)
+ap.add_argument("--step-dp", type=float, default=0.316)
 ap.add_argument("--mb", type=float, default=13.3)
 ap.add_argument("--hop-us", type=float, default=4.0)
 a = ap.parse_args()
