@@ -218,6 +218,27 @@ def test_dp_compact_footprint_mask_covers_every_sample_footprint(bound, cascade)
     assert m3.shape == (24, 20, 16) and m3.any() and not m3.all()
 
 
+def test_dp_compact_scatter_can_look_at_what_it_puts_back():
+    """GradCompactor.scatter(found_inf=...): the CPU twin of pvd_segments_op(4) -- the exchanged rows go back into the flat buffer and
+    an inf / nan among them raises the flag (left alone otherwise: the caller's flag is sticky)."""
+    from pvd.dp_compact import GradCompactor
+    c = GradCompactor.__new__(GradCompactor)
+    c.idx = torch.tensor([3, 4, 5, 9, 20, 21], dtype=torch.int64)
+    flat = torch.zeros(32)
+    buf = torch.arange(1.0, 7.0)
+    flag = torch.zeros(1)
+    c.scatter(flat, buf, found_inf=flag)
+    assert torch.equal(flat[c.idx], buf) and float(flat.sum()) == float(buf.sum()) and float(flag) == 0.0
+    bad = buf.clone()
+    bad[4] = float("nan")
+    c.scatter(flat, bad, found_inf=flag)
+    assert float(flag) == 1.0 and torch.isnan(flat[20])
+    c.scatter(flat, buf, found_inf=flag)  # a clean exchange does not clear it
+    assert float(flag) == 1.0 and torch.equal(flat[c.idx], buf)
+    c.scatter(flat, bad)  # no flag: plain scatter
+    assert torch.isnan(flat[20])
+
+
 def test_dp_compact_run_table_covers_the_index_set_exactly():
     """segments_of(): the run table the HIP kernels walk lists exactly the index set, in compact order, in pieces of at most
     seg_max elements."""
