@@ -301,6 +301,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self._checked_by_backward = False  # (a backward before this zero_grad says nothing about the gradients to come)
         self._half_grad = None
+        self._half_range_dirty = False
         if self._zeroed_by_step and self.touched is not None and self._outside_is_zero:
             self._zeroed_by_step = False  # the previous step's update zeroed every group it read: the touched set is clean
         elif self.touched is not None and self._outside_is_zero:
@@ -317,7 +318,7 @@ class FlatAdamW(torch.optim.Optimizer):
         hg = getattr(self, "_half_grad", None)
         if self.touched is not None and self._outside_is_zero:
             self.touched.check_finite(self.flat_g, flag)
-        elif hg is not None and hg[2].numel() % 8 == 0 and hg[0] % 4 == 0 and hg[1] % 4 == 0 and self.flat_g.numel() % 4 == 0:
+        elif hg is not None and not self._half_range_dirty and hg[2].numel() % 8 == 0 and hg[0] % 4 == 0 and hg[1] % 4 == 0 and self.flat_g.numel() % 4 == 0:
             # the fp32 range of the parameter whose gradient came in half precision holds the zeros of zero_grad (accept_half_grad:
             # nothing adds into it): one launch over the rest of the fp32 buffer and the half buffer
             pvd_hip.check_finite_mixed(self.flat_g, hg[0], hg[1], hg[2], flag)
@@ -341,6 +342,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._schedule = ({"cosine": 1, "exp": 2}[kind], float(T), float(param), self.base_lr, self.sched_step)
 
     _cold_bits, _cold_dirty = None, False
+    _half_range_dirty = False  # the fp32 gradient range of the parameter whose gradient came in half precision has been written since zero_grad
 
     def set_l1(self, tensors, weight):
         self._cold_dirty = self.touched is not None  # the regularised ranges are never cold
@@ -365,7 +367,13 @@ class FlatAdamW(torch.optim.Optimizer):
         """A half-precision gradient of `param` (the hash table's scatter-add result) for the coming step: added inside the
         update kernel instead of a widen-and-add pass over the fp32 gradient.  Returns False if it cannot be taken (then
         the caller adds it into .grad itself)."""
-        if not getattr(self, "half_grad_ok", True) or getattr(self, "_half_grad", None) is not None:
+        if not getattr(self, "half_grad_ok", True):
+            return False
+        hg = getattr(self, "_half_grad", None)
+        if hg is not None:
+            # a second backward before the step: the caller adds this gradient into the fp32 range the mixed inf check skips
+            # (check_finite), so that range is no longer zeros -- the full check runs for this step (ADVICE r5)
+            self._half_range_dirty = True
             return False
         for p, o in zip(self.params, self.offsets):
             if p is param:
@@ -444,6 +452,7 @@ class FlatAdamW(torch.optim.Optimizer):
                                arrivals=self._tail_in_kernel())
         self._zeroed_by_step = zero_after
         self._half_grad = None
+        self._half_range_dirty = False
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions
         # (GradScaler sets grad_scale / found_inf right before step() and deletes them afterwards)
 

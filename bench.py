@@ -386,6 +386,25 @@ def teacher_workload(args, dev):
     print(json.dumps(out))
 
 
+def _spawn_ranks(n):
+    """Re-execute this command line as n ranks of one node (what the driver's `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` does).  The children inherit stdout / stderr; the exit
+    code is theirs."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # (torch.distributed.run sets it anyway and says so on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,6 +435,11 @@ def main():
                     help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started the way the driver starts `--gpus 1`: spawn the N ranks here (one process per GPU through
+        # torch.distributed.run on a free local port) and hand their output through -- rank 0 prints the ONE JSON line
+        return _spawn_ranks(args.gpus)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -423,6 +447,8 @@ def main():
     # PVD_DIST_BACKEND=gloo + fewer GPUs than ranks: the N > 1 code path (two-graph capture, compact exchange) can be
     # exercised on a single-GPU box; the driver's runs use one GPU per rank over RCCL
     backend = os.environ.get("PVD_DIST_BACKEND", "nccl")
+    assert backend != "nccl" or world <= torch.cuda.device_count(), \
+        "--gpus %d over RCCL needs one GPU per rank (%d visible); PVD_DIST_BACKEND=gloo lets the ranks share a GPU" % (world, torch.cuda.device_count())
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

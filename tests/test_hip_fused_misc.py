@@ -492,6 +492,24 @@ def test_flat_adamw_half_gradient_equals_widen_and_add():
     assert ob.accept_half_grad(pb[1], h[: 4096 * 2 // 2].repeat(2).reshape(4096, 2).contiguous())
     scaler.step(ob); scaler.update()
     assert torch.equal(before, pb[1].detach()) and float(scaler.get_scale()) == 8.0
+    # a SECOND backward before the step: the optimizer already holds a half gradient, refuses the new one, and the caller
+    # adds it into the fp32 range the mixed check skips -- an inf in there must still skip the step (full check for this step)
+    ob.zero_grad()
+    fin = (torch.randn(4096, 2, device=dev) * 0.1).half()
+    assert ob.accept_half_grad(pb[1], fin) and not ob._half_range_dirty
+    bad = fin.clone()
+    bad[77, 1] = float("inf")
+    assert not ob.accept_half_grad(pb[1], bad) and ob._half_range_dirty
+    pb[1].grad.add_(bad)  # (what fusedhead's backward does when the taker refuses)
+    before = pb[1].detach().clone()
+    scaler.step(ob); scaler.update()
+    assert torch.equal(before, pb[1].detach()) and float(scaler.get_scale()) == 4.0 and not ob._half_range_dirty
+    # ... and with two finite gradients the step goes through and applies both
+    ob.zero_grad()
+    assert ob.accept_half_grad(pb[1], fin) and not ob.accept_half_grad(pb[1], fin)
+    pb[1].grad.add_(fin)
+    scaler.step(ob); scaler.update()
+    assert not torch.equal(before, pb[1].detach()) and float(scaler.get_scale()) == 4.0
 
 
 def test_segments_op_matches_index_ops():
