@@ -65,6 +65,13 @@ struct AdamExtras {
     double tail_growth, tail_backoff;
     int32_t tail_interval;
     uint32_t tail_segments;
+    // ray data parallelism (include/pvd_hip.h: compact_grad / compact_param_out / tail_clear): the gradient of warm-list entry j is
+    // gc[4 j .. 4 j + 4) (the exchanged compact buffer) instead of g[4 i ..]; the updated parameters of entry j are also written to
+    // pc[4 j ..] (what a sharded update all-gathers); the tail zeroes tail_clear[k * tail_clear_stride], k < tail_clear_n
+    const float *gc;
+    float *pc;
+    float *tail_clear;
+    uint32_t tail_clear_stride, tail_clear_n;
 };
 
 // The schedule, evaluated where it is needed (every workgroup of k_adamw, then once more by the tail that publishes it):
@@ -117,7 +124,10 @@ __device__ __forceinline__ void adamw_tail_body(float *__restrict__ step, float 
         }
     }
     if (ex.sched_kind != 0) ex.sched_step[0] += 1.0f;
-    if (!scale) return;
+    if (!scale) {
+        for (uint32_t k = 0; k < ex.tail_clear_n; k++) ex.tail_clear[(size_t)k * ex.tail_clear_stride] = 0.f;
+        return;
+    }
     if (inf) {
         scale[0] = (float)((double)scale[0] * backoff);
         tracker[0] = 0;
@@ -132,6 +142,7 @@ __device__ __forceinline__ void adamw_tail_body(float *__restrict__ step, float 
         }
     }
     found_inf[0] = 0.f;
+    for (uint32_t k = 0; k < ex.tail_clear_n; k++) ex.tail_clear[(size_t)k * ex.tail_clear_stride] = 0.f;
 }
 
 // The tail inside the update (ex.arrivals): a workgroup announces itself when it is DONE (all of them read the step's scalars
@@ -175,7 +186,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         bc_sh[1] = sqrt(1.0 - pow((double)beta2, t));
     }
     __syncthreads();  // (every scalar of the step has been READ by this workgroup beyond this point)
-    if (skip && !ex.zero_g) { adamw_announce(ex, step, found_inf, lr); return; }
+    if (skip && !ex.zero_g && !ex.pc) { adamw_announce(ex, step, found_inf, lr); return; }
     float l1_acc = 0.f;
     const double bc1 = bc_sh[0];
     const double bc2_sqrt = bc_sh[1];
@@ -192,7 +203,8 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         const uint64_t e = i << 2;
         const bool no_grad = ex.warm_nograd_from && j >= (uint64_t)ex.warm_nograd_from;  // the buffer holds zeros there, for good
         if (skip) {  // (zero_g) the skipped step's gradients must not reach the next step
-            if (!no_grad && !(test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ex.zero_g && !no_grad && !(test_cold && ((ex.cold[i >> 5] >> (uint32_t)(i & 31u)) & 1u))) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ex.pc) reinterpret_cast<float4 *>(ex.pc)[j] = reinterpret_cast<const float4 *>(p)[i];  // (the all-gather moves the unchanged values)
             continue;
         }
         uint32_t k = 0;
@@ -218,7 +230,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
         typedef float f4v __attribute__((ext_vector_type(4)));
         float4 P = reinterpret_cast<float4 *>(p)[i], G = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!no_grad) {
-            G = reinterpret_cast<const float4 *>(g)[i];
+            G = ex.gc ? reinterpret_cast<const float4 *>(ex.gc)[j] : reinterpret_cast<const float4 *>(g)[i];
             if (ex.zero_g) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #ifndef PVD_ADAMW_NT
@@ -253,6 +265,7 @@ __global__ void __launch_bounds__(kOptBlock) k_adamw(float *__restrict__ p, floa
             l1_acc += l1 * fabsf(param);
         }
         reinterpret_cast<float4 *>(p)[i] = P;
+        if (ex.pc) reinterpret_cast<float4 *>(ex.pc)[j] = P;
 #if PVD_ADAMW_NT
         __builtin_nontemporal_store((f4v){M.x, M.y, M.z, M.w}, reinterpret_cast<f4v *>(m) + i);
         __builtin_nontemporal_store((f4v){V.x, V.y, V.z, V.w}, reinterpret_cast<f4v *>(v) + i);
@@ -358,10 +371,13 @@ __global__ void __launch_bounds__(kOptBlock) k_check_finite_mixed(const float *_
 // ---- segment-table operations over the flat gradient buffer.  The rows of a VM plane / Plenoxel volume that can receive a
 // gradient at all are known from the occupancy grid (harness: pvd/dp_compact.py); zeroing, the inf check and the ray-DP
 // gather/scatter then only touch those rows.  segs[s] = {start (flat), dst (compact), len}, one workgroup per segment.
-enum { kSegZero = 0, kSegGather = 1, kSegScatter = 2, kSegCheck = 3, kSegScatterCheck = 4 };  // 4: scatter, looking at what it moves
+// 5 (ray-DP, what goes on the wire): gather, ZERO the source behind it (the next step's zero_grad), and look at what it moves -- a
+//    workgroup that sees an inf / nan stores 1 into found_inf[k * slot_stride], k < n_slots (one flag word per chunk of the exchange
+//    buffer: summed over the ranks by the collective itself, they are the step's global found_inf on every rank)
+enum { kSegZero = 0, kSegGather = 1, kSegScatter = 2, kSegCheck = 3, kSegScatterCheck = 4, kSegGatherZeroCheck = 5 };  // 4: scatter, looking at what it moves
 template <int OP>
 __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat, float *__restrict__ buf, const uint32_t *__restrict__ segs,
-                                                        uint32_t n_segs, float *__restrict__ found_inf) {
+                                                        uint32_t n_segs, float *__restrict__ found_inf, uint32_t slot_stride = 0, uint32_t n_slots = 1) {
     bool bad = false;
     for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
         const uint32_t start = segs[3 * s], dst = segs[3 * s + 1], len = segs[3 * s + 2];
@@ -372,6 +388,14 @@ __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat
                 if (OP == kSegZero) f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (OP == kSegGather) b4[i] = f4[i];
                 if (OP == kSegScatter) f4[i] = b4[i];
+                if (OP == kSegGatherZeroCheck) {
+                    const float4 G = f4[i];
+                    b4[i] = G;
+                    f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const uint32_t a = __float_as_uint(G.x), b = __float_as_uint(G.y), c = __float_as_uint(G.z), d = __float_as_uint(G.w);
+                    bad |= ((a & 0x7f800000u) == 0x7f800000u) | ((b & 0x7f800000u) == 0x7f800000u) | ((c & 0x7f800000u) == 0x7f800000u) |
+                           ((d & 0x7f800000u) == 0x7f800000u);
+                }
                 if (OP == kSegCheck || OP == kSegScatterCheck) {
                     const float4 G = OP == kSegCheck ? f4[i] : b4[i];
                     if (OP == kSegScatterCheck) f4[i] = G;
@@ -391,10 +415,18 @@ __global__ void __launch_bounds__(kOptBlock) k_segments(float *__restrict__ flat
                     flat[start + i] = v;
                     bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
                 }
+                if (OP == kSegGatherZeroCheck) {
+                    const float v = flat[start + i];
+                    buf[dst + i] = v;
+                    flat[start + i] = 0.f;
+                    bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+                }
             }
         }
     }
     if ((OP == kSegCheck || OP == kSegScatterCheck) && __ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) found_inf[0] = 1.0f;
+    if (OP == kSegGatherZeroCheck && __ballot(bad) != 0ull && (threadIdx.x & 63u) == 0)
+        for (uint32_t k = 0; k < n_slots; k++) found_inf[(size_t)k * slot_stride] = 1.0f;
 }
 
 // partials[block] = sum over the block's elements of coef[range] * |p|
@@ -471,6 +503,7 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
     ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.warm_nograd_from = 0; ex.snapshot = nullptr;
     ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
     ex.tail_interval = 1; ex.tail_segments = n_segments;
+    ex.gc = nullptr; ex.pc = nullptr; ex.tail_clear = nullptr; ex.tail_clear_stride = 0; ex.tail_clear_n = 0;
     const float *replay = nullptr;
     if (extras_host) {
         const pvd_adamw_extras &h = *extras_host;
@@ -501,6 +534,15 @@ int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, 
         if (replay && (!ex.warm || h.snapshot || h.g16 || h.arrivals)) return PVD_ERR_INVALID;  // the deferred part walks a list and records nothing
         ex.zero_g = h.zero_grad_after ? 1u : 0u;
         ex.arrivals = h.arrivals;
+        if (h.compact_grad || h.compact_param_out) {
+            // list entry j <-> compact group j: only a walk of a warm list can use them, and not the deferred part (it has no gradient)
+            if (!ex.warm || replay || ex.warm_nograd_from || h.g16) return PVD_ERR_INVALID;
+            ex.gc = h.compact_grad; ex.pc = h.compact_param_out;
+        }
+        if (h.tail_clear_n) {
+            if (!h.tail_clear || replay) return PVD_ERR_INVALID;
+            ex.tail_clear = h.tail_clear; ex.tail_clear_stride = h.tail_clear_stride; ex.tail_clear_n = h.tail_clear_n;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     if (replay) {
@@ -592,6 +634,15 @@ int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint
     return check_launch();
 }
 
+int pvd_segments_gather_zero_check(float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *slots, uint32_t slot_stride,
+                                   uint32_t n_slots, pvd_stream_t stream) {
+    if (n_segs == 0) return PVD_OK;
+    if (!flat || !buf || !segs || !slots || n_slots < 1 || n_slots > 64) return PVD_ERR_INVALID;
+    const dim3 grid(n_segs < 65535u * 16u ? n_segs : 65535u * 16u), block(kOptBlock);
+    hipLaunchKernelGGL(k_segments<kSegGatherZeroCheck>, grid, block, 0, (hipStream_t)stream, flat, buf, segs, n_segs, slots, slot_stride, n_slots);
+    return check_launch();
+}
+
 int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf, pvd_stream_t stream) {
     if (op < kSegZero || op > kSegScatterCheck) return PVD_ERR_INVALID;
     if (n_segs == 0) return PVD_OK;
@@ -601,11 +652,11 @@ int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint3
     const dim3 grid(n_segs < 65535u * 16u ? n_segs : 65535u * 16u), block(kOptBlock);
     hipStream_t s = (hipStream_t)stream;
     switch (op) {
-        case kSegZero: hipLaunchKernelGGL(k_segments<kSegZero>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
-        case kSegGather: hipLaunchKernelGGL(k_segments<kSegGather>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
-        case kSegScatter: hipLaunchKernelGGL(k_segments<kSegScatter>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
-        case kSegScatterCheck: hipLaunchKernelGGL(k_segments<kSegScatterCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
-        default: hipLaunchKernelGGL(k_segments<kSegCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf); break;
+        case kSegZero: hipLaunchKernelGGL(k_segments<kSegZero>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf, 0u, 1u); break;
+        case kSegGather: hipLaunchKernelGGL(k_segments<kSegGather>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf, 0u, 1u); break;
+        case kSegScatter: hipLaunchKernelGGL(k_segments<kSegScatter>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf, 0u, 1u); break;
+        case kSegScatterCheck: hipLaunchKernelGGL(k_segments<kSegScatterCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf, 0u, 1u); break;
+        default: hipLaunchKernelGGL(k_segments<kSegCheck>, grid, block, 0, s, flat, buf, segs, n_segs, found_inf, 0u, 1u); break;
     }
     return check_launch();
 }
@@ -619,6 +670,7 @@ int pvd_l1_ranges(const float *p, const uint64_t *begin_host, const uint64_t *en
     ex.lazy_log = nullptr; ex.lazy_count = nullptr; ex.lazy_capacity = 0; ex.warm = nullptr; ex.n_warm = 0; ex.warm_nograd_from = 0; ex.snapshot = nullptr;
     ex.zero_g = 0; ex.arrivals = nullptr; ex.tail_scale = nullptr; ex.tail_tracker = nullptr; ex.tail_growth = ex.tail_backoff = 0.0;
     ex.tail_interval = 1; ex.tail_segments = 0;
+    ex.gc = nullptr; ex.pc = nullptr; ex.tail_clear = nullptr; ex.tail_clear_stride = 0; ex.tail_clear_n = 0;
     const int rc = fill_l1(ex, begin_host, end_host, coef_host, n_ranges);
     if (rc != PVD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -1329,12 +1329,15 @@ static uint32_t objective_row_blocks(uint32_t rows, uint32_t cap) {
 }
 
 uint32_t pvd_composite_objective_blocks(uint32_t N, uint32_t rows) { return div_up(N, kBlock / kWave) + objective_row_blocks(rows, 256u); }
+// PVD_OBJECTIVE_FIXED_PARTS: the number of partial sums depends on N alone (the feature rows always take 256 workgroups; those beyond
+// the rows write zeros), so ranks whose sample counts differ leave buffers of ONE size -- which ray-DP all-reduces between the launches
+uint32_t pvd_composite_objective_blocks_fixed(uint32_t N) { return div_up(N, kBlock / kWave) + 256u; }
 
 int pvd_composite_objective_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
                                     const float *bg, float bg_scalar, const float *nears, const float *fars, float depth_eps,
                                     float *weights_sum, float *depth, float *image, const int32_t *budget_dev, const float *img_tea,
                                     const float *fea_stu, const float *fea_tea, const float *col_stu, const float *col_tea, uint32_t rows,
-                                    float *S4, float *rates4_decay, float fea_decay, pvd_stream_t stream) {
+                                    float *S4, float *rates4_decay, float fea_decay, uint32_t flags, pvd_stream_t stream) {
     PVD_REQUIRE(N > 0 && rows > 0);
     PVD_REQUIRE(sigmas && rgbs && deltas && rays && nears && fars && weights_sum && depth && image);
     PVD_REQUIRE(img_tea && fea_stu && fea_tea && col_stu && col_tea && S4);
@@ -1344,7 +1347,7 @@ int pvd_composite_objective_forward(const float *sigmas, const float *rgbs, cons
     ob.ray_blocks = div_up(N, kBlock / kWave);
     ob.partials = S4 + 4;  // the layout pvd_distill_loss_final reduces: S4[0..4) the sums, then one float4 per workgroup
     ob.rates_decay = rates4_decay; ob.fea_decay = fea_decay;
-    const uint32_t blocks = ob.ray_blocks + objective_row_blocks(rows, 256u);
+    const uint32_t blocks = ob.ray_blocks + ((flags & PVD_OBJECTIVE_FIXED_PARTS) ? 256u : objective_row_blocks(rows, 256u));
     hipLaunchKernelGGL((k_composite_fwd_wave<true, true>), dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, sigmas, rgbs, deltas, rays, M, N,
                        weights_sum, depth, image, ep, ob);
     return check_launch();
@@ -1368,7 +1371,8 @@ int pvd_composite_objective_backward(const float *grad_weights_sum, const float 
     ob.ray_blocks = div_up(N, kBlock / kWave);
     ob.coef = coef4; ob.upstream = upstream; ob.g_fea = g_fea; ob.g_col = g_col;
     if (rates4) {  // finish the objective here: the forward launch's partial sums sit at S4 + 4
-        ob.rates = rates4; ob.extra = extra; ob.n_extra = n_extra; ob.nparts = pvd_composite_objective_blocks(N, rows);
+        ob.rates = rates4; ob.extra = extra; ob.n_extra = n_extra;
+        ob.nparts = (flags & PVD_OBJECTIVE_FIXED_PARTS) ? pvd_composite_objective_blocks_fixed(N) : pvd_composite_objective_blocks(N, rows);
         ob.partials = S4 + 4; ob.sums = S4; ob.loss = loss; ob.coef_out = coef4; ob.norms = norms4;
     }
     const uint32_t blocks = ob.ray_blocks + objective_row_blocks(rows, 2048u);

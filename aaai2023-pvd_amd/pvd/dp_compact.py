@@ -145,6 +145,45 @@ class GradCompactor:
             found_inf.masked_fill_(~torch.isfinite(flat.index_select(0, self.idx)).all(), 1.0)
 
 
+class ExchangeLayout:
+    """The compact gradient as it crosses the links (round 6): `chunks` equal chunks of whole groups of four floats, each followed
+    by ONE flag group whose first word is the step's inf flag -- the collective sums the flags with the data, so every rank ends up
+    with the global verdict and GradScaler's check needs neither a launch nor a collective of its own.
+        chunks == 1: one all-reduce of the buffer (every rank updates every row);
+        chunks == world: reduce_scatter -> this rank's AdamW on its chunk's rows -> all_gather of the updated rows (sharded update).
+    The run table walks the set in the optimizer's list order (group j of the touched set = list entry j of FlatAdamW's part-B
+    list), cut at chunk boundaries; `xbuf` / `pbuf` are the persistent gradient / parameter exchange buffers."""
+
+    def __init__(self, compactor, groups, chunks, device, with_params=False):
+        idx = compactor.idx
+        assert idx.numel() % 4 == 0, "the touched set must consist of whole groups of four parameters"
+        g = idx.view(-1, 4)
+        assert bool((g[:, 0] % 4 == 0).all()) and bool((g[:, 3] == g[:, 0] + 3).all()), "the touched set must consist of aligned groups of four"
+        assert groups.numel() == g.shape[0] and bool((groups.long() == (g[:, 0] >> 2)).all()), \
+            "the optimizer's part-B list must be the touched set, group for group"
+        self.n_groups = G = int(g.shape[0])
+        self.chunks = int(chunks)
+        self.gpc = (G + self.chunks - 1) // self.chunks  # groups per chunk
+        self.chunk = 4 * self.gpc + 4                    # floats per chunk (data + the flag group)
+        self.slot = 4 * self.gpc                         # the flag word's offset inside a chunk
+        tables = []
+        for r in range(self.chunks):
+            part = idx[4 * r * self.gpc:4 * min((r + 1) * self.gpc, G)]
+            t = segments_of(part)
+            t[:, 1] += r * self.chunk
+            tables.append(t)
+        self.segs = torch.cat(tables).contiguous()
+        self.xbuf = torch.zeros(self.chunks * self.chunk, dtype=torch.float32, device=device)
+        self.pbuf = torch.zeros_like(self.xbuf) if with_params else None
+
+    def rows_of(self, r):
+        """(first, one past last) list entry of chunk r"""
+        return r * self.gpc, min((r + 1) * self.gpc, self.n_groups)
+
+    def chunk_of(self, buf, r):
+        return buf[r * self.chunk:(r + 1) * self.chunk]
+
+
 SEG_MAX = 4096  # elements per run-table entry = per workgroup
 
 

@@ -183,6 +183,23 @@ class FlatAdamW(torch.optim.Optimizer):
             self._owed_is_carried = False
             self._l1_layout_is("one")
 
+    # ---- ray-DP (round 6): the exchanged compact gradient goes straight into part B of a two-part update (no pass that puts the
+    # summed rows back into flat_g; the gather that filled the buffer zeroed the rows and looked at them: no zero_grad, no check)
+    _compact = None
+
+    def compact_ready(self):
+        """May the coming step() take its gradient from a compact exchange buffer?  Only the two-part form walks the touched set as a
+        list of its own (part B), and only with nothing else pending."""
+        lazy = self._lazy_state() if (self.touched is not None and self._outside_is_zero and not self._cold_dirty and self._cold_bits is not None) else None
+        return bool(lazy is not None and self._two_part_now((lazy[0], lazy[1], None)))
+
+    def take_compact(self, grad, flag, clear, rows, param_out=None):
+        """grad: f32, four floats per list entry of rows = (first, one past last) of the part-B list; flag: f32 [1] view = the
+        step's found_inf (global); clear = (tensor, stride, count): flag words the update's tail zeroes; param_out: the updated rows'
+        copy for a sharded update's all-gather."""
+        self._compact = dict(grad=grad, flag=flag, clear=clear, rows=rows, param_out=param_out)
+        self._checked_by_backward = True  # (FlatGradScaler.step: no check launch -- the gather looked at every value it moved)
+
     touched = None  # set_touched(): the only entries of flat_g anything ever writes (pvd/dp_compact.py), or None = all
     _outside_is_zero = False
 
@@ -302,6 +319,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._checked_by_backward = False  # (a backward before this zero_grad says nothing about the gradients to come)
         self._half_grad = None
         self._half_range_dirty = False
+        self._compact = None
         if self._zeroed_by_step and self.touched is not None and self._outside_is_zero:
             self._zeroed_by_step = False  # the previous step's update zeroed every group it read: the touched set is clean
         elif self.touched is not None and self._outside_is_zero:
@@ -423,6 +441,8 @@ class FlatAdamW(torch.optim.Optimizer):
         # its own buffer
         zero_after = bool(self.zero_in_step and getattr(self, "_half_grad", None) is None
                           and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) >= 3)
+        cg, self._compact = self._compact, None
+        assert cg is None or two, "a compact gradient was handed over (take_compact) but the update is not in its two-part form"
         if two:
             # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
             # the step's record: two buffers taken in turn (part A of step k may still be reading its own while step k + 1 writes), and
@@ -437,8 +457,11 @@ class FlatAdamW(torch.optim.Optimizer):
                                d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                                schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                                amp_update=getattr(self, "amp_update", None), l1_next=(st["buf"], st["scale"]) if st is not None else None,
-                               cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B), snapshot=self._snapshot, zero_after=zero_after,
-                               arrivals=self._tail_in_kernel())
+                               cold_bits=cold, lazy=(lazy[0], lazy[1], self._warm_B if cg is None else self._warm_B[cg["rows"][0]:cg["rows"][1]]),
+                               snapshot=self._snapshot, zero_after=zero_after and cg is None, arrivals=self._tail_in_kernel(),
+                               **({} if cg is None else dict(compact_grad=cg["grad"], compact_param_out=cg["param_out"], tail_clear=cg["clear"])))
+            if cg is not None:
+                zero_after = True  # (the gather that filled the buffer zeroed every touched row behind itself)
             self._part_a_owed = (cold, lazy[0], lazy[1], self._warm_A, getattr(self, "grad_scale", None) is not None,
                                  (st["buf"][4096:], st["scale"]) if st is not None else None, self._snapshot)
             if not self.defer_part_a:
@@ -488,7 +511,7 @@ class FlatGradScaler(torch.amp.GradScaler):
             raise RuntimeError("step() has already been called since the last update().")
         if state["stage"] is OptState.UNSCALED:
             return super().step(optimizer, *args, **kwargs)  # unscale_() was called explicitly: generic path
-        flag = optimizer.inf_flag()
+        flag = optimizer.inf_flag() if optimizer._compact is None else optimizer._compact["flag"]
         if optimizer._checked_by_backward:
             optimizer._checked_by_backward = False  # the backward's own launches looked at every gradient they completed
         else:

@@ -15,10 +15,14 @@ class ObjectiveRide:
     _DistillNormL2 then skips its own sums launch, and in the backward pass leaves coefficients and gradient buffers here for
     the compositing backward launch instead of launching k_sumsq4_bwd (`armed`).  Two launches fewer on the step's chain."""
 
-    def __init__(self, img_t, fea_t, col_t, rates_decay=None, fea_decay=1.0):
+    def __init__(self, img_t, fea_t, col_t, rates_decay=None, fea_decay=1.0, fixed_parts=False):
         """rates_decay (the device-side rates [4]) + fea_decay: the objective is FINISHED by the backward launch as well (no
         k_loss_final between the passes; loss / norms are filled in by the backward pass): the feature rate's per-step decay is
-        then applied by the forward launch."""
+        then applied by the forward launch.
+        fixed_parts (ray-DP): the forward launch leaves a number of partial sums that depends on the ray count alone, the same on every
+        rank; _DistillNormL2 all-reduces the PARTIALS over the ranks and the backward launch finishes the objective from the summed
+        partials like from its own -- one small collective between the two compositing launches and nothing else."""
+        self.fixed_parts = bool(fixed_parts)
         f = lambda t: t.detach().float().contiguous()
         self.img_t, self.fea_t, self.col_t = f(img_t).reshape(-1, 3), f(fea_t), f(col_t)
         self.fea_s = self.col_s = self.S = None
@@ -44,12 +48,16 @@ class _DistillNormL2(Function):
         dev = img_s.device
         args = [t.detach().float().contiguous() for t in (img_s, img_t, fea_s, fea_t, col_s, col_t)]
         exchange = dp is not None and dp.enabled
-        ride = ride if (ride is not None and ride.S is not None and ride.nparts >= 2 and not exchange and not defer) else None
+        ride = ride if (ride is not None and ride.S is not None and ride.nparts >= 2 and not defer
+                        and (not exchange or (ride.fixed_parts and ride.decayed))) else None
         ctx.ride = ride
         if ride is not None:  # the compositing launch already formed the partial sums (ObjectiveRide)
             loss = torch.empty(1, dtype=torch.float32, device=dev)
             coef = torch.empty(4, dtype=torch.float32, device=dev)
             norms = torch.empty(4, dtype=torch.float32, device=dev)
+            if exchange:  # under ray-DP the norms are global: the partial sums of all shards, summed (the same buffer size on every rank)
+                assert ride.rates_decay is rates and any(t.requires_grad for t in (img_s, fea_s, col_s))
+                dp.all_reduce_sum_(ride.S[4:4 + 4 * ride.nparts])
             if ride.decayed and ride.rates_decay is rates and any(t.requires_grad for t in (img_s, fea_s, col_s)):
                 # ... and applied the rate decay: the backward launch finishes the objective (loss / norms / coef filled in THERE)
                 ride.finish = (rates, extra, ride.S, loss, norms)

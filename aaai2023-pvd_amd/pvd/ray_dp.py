@@ -25,27 +25,66 @@ class RayDP:
         self.ingraph = (self.enabled and dist.get_backend(group) == "nccl" and os.environ.get("PVD_DP_INGRAPH", "1") != "0")
 
 
-    def _two_shot_sum_(self, t):
-        """SUM over ranks as reduce-scatter + all-gather built from ALL-TO-ALL exchanges (PVD_DP_EXCHANGE=twoshot, opt-in): rank r
-        receives chunk r of every peer, adds the n chunks in rank order, and sends the sum to every peer.  On a fully connected
-        node every rank then talks to its n - 1 peers at once over its own links -- 2 (S / n) / one link's bandwidth instead of
-        a ring's 2 (n - 1) / n S / (its slowest hop) (tools/scale_model.py) -- and every
-        element is summed by exactly ONE rank, so the replicas receive identical bits by construction."""
+    def _issue(self, run, replay=None):
+        """A collective at this point of the step: recorded as a node of the graph being captured (RCCL, `ingraph`), or run eagerly
+        between two graphs of a segmented capture, or simply run."""
+        if self.capture is not None and self.capture.active and self.ingraph:
+            run()
+        elif self.capture is not None and self.capture.active:
+            self.capture.break_for(run, replay)  # collectives stay out of the graphs: eager, between two replays
+        else:
+            run()
+
+    def _staged(self, *tensors):
+        """gloo (the test backend: several ranks sharing one GPU) moves host memory: stage device tensors through the host."""
+        return self.enabled and dist.get_backend(self.group) == "gloo" and any(t.is_cuda for t in tensors)
+
+    def reduce_scatter_sum_(self, out, inp):
+        """out = this rank's chunk of SUM over ranks of inp (inp.numel() == world_size * out.numel(); `out` may be the rank's own
+        chunk of `inp`, the in-place form).  Every element is summed by exactly one rank."""
+        assert inp.is_contiguous() and out.is_contiguous() and inp.numel() == self.world_size * out.numel()
+        if self._staged(out, inp):
+            def run():
+                h_in, h_out = inp.detach().cpu(), torch.empty(out.shape, dtype=out.dtype)
+                dist.reduce_scatter_tensor(h_out, h_in, op=dist.ReduceOp.SUM, group=self.group)
+                out.copy_(h_out)
+        else:
+            def run():
+                dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+        self._issue(run)
+        return out
+
+    def all_gather_(self, out, inp):
+        """out = concatenation over ranks of inp (`inp` may be the rank's own chunk of `out`)."""
+        assert inp.is_contiguous() and out.is_contiguous() and out.numel() == self.world_size * inp.numel()
+        if self._staged(out, inp):
+            def run():
+                h_in, h_out = inp.detach().cpu(), torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(h_out, h_in, group=self.group)
+                out.copy_(h_out)
+        else:
+            def run():
+                dist.all_gather_into_tensor(out, inp, group=self.group)
+        self._issue(run)
+        return out
+
+    def sharded_sum_(self, t):
+        """SUM over ranks as the standard pair reduce-scatter + all-gather (PVD_DP_EXCHANGE=sharded on a path without the flat
+        optimizer's sharded update -- CPU / gloo tests, the generic optimizers): the bytes of the all-reduce, every element summed by
+        exactly ONE rank, so the replicas receive identical bits by construction."""
         n = self.world_size
-        assert t.is_contiguous(), "the two-shot exchange writes its result through a flat view: a non-contiguous tensor would lose it"
+        assert t.is_contiguous()
         flat = t.reshape(-1)
         chunk = (flat.numel() + n - 1) // n
-        send = flat
+        buf = flat
         if chunk * n != flat.numel():
-            send = torch.zeros(chunk * n, dtype=flat.dtype, device=flat.device)
-            send[:flat.numel()].copy_(flat)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)  # recv[k * chunk : (k + 1) * chunk] = rank k's chunk `rank`
-        red = recv.view(n, chunk)[0].clone()
-        for k in range(1, n):  # rank order: the same sum whichever rank forms it
-            red.add_(recv.view(n, chunk)[k])
-        out = torch.empty_like(send)
-        dist.all_to_all_single(out, red.repeat(n), group=self.group)  # out[k * chunk : ...] = the sum rank k formed
+            buf = torch.zeros(chunk * n, dtype=flat.dtype, device=flat.device)
+            buf[:flat.numel()].copy_(flat)
+        mine = buf[self.rank * chunk:(self.rank + 1) * chunk]
+        red = torch.empty_like(mine)
+        self.reduce_scatter_sum_(red, buf)
+        out = torch.empty_like(buf)
+        self.all_gather_(out, red)
         flat.copy_(out[:flat.numel()])
         return t
 
@@ -53,26 +92,17 @@ class RayDP:
         """overlap: a callable launching device work that does not depend on the result (e.g. replaying the graph of the
         next step's parameter-independent prefix); in a captured step it is issued while the collective is in flight."""
         if self.enabled:
-            # (verified on gloo only, tests/test_dist_gloo.py.  NOT recorded into a graph and not taken in a one-rank world: an attempt to
-            # capture RCCL's all-to-all in a forced one-rank world did not return within ten minutes on the GPU box)
-            two_shot = (os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "twoshot" and self.world_size > 1
-                        and not (self.capture is not None and self.capture.active and self.ingraph)
-                        and t.numel() >= int(os.environ.get("PVD_DP_TWOSHOT_MIN", "65536")))  # (scalars and short buffers: one latency-bound all-reduce)
-            run = (lambda: self._two_shot_sum_(t)) if two_shot else (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
-            if two_shot:
-                overlap = None  # (its exchanges are issued synchronously: the overlap callable would only follow them)
-            if self.capture is not None and self.capture.active and self.ingraph:
-                run()  # recorded as a node of the graph being captured
-            elif self.capture is not None and self.capture.active:
-                replay = None
-                if overlap is not None:
-                    def replay():
-                        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                        overlap()
-                        work.wait()
-                self.capture.break_for(run, replay)  # collectives stay out of the graphs: eager, between two replays
-            else:
-                run()
+            if (os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "sharded" and self.world_size > 1 and overlap is None
+                    and t.numel() >= int(os.environ.get("PVD_DP_SHARDED_MIN", "65536"))):  # (scalars and short buffers: one latency-bound all-reduce)
+                return self.sharded_sum_(t)
+            run = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # noqa: E731
+            replay = None
+            if overlap is not None and self.capture is not None and self.capture.active and not self.ingraph:
+                def replay():
+                    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    overlap()
+                    work.wait()
+            self._issue(run, replay)
         return t
 
     def global_sum(self, local):

@@ -162,9 +162,88 @@ class _TrainerBase:
                 self.optimizer.set_touched(c)
         self.flat.zero_()
 
+    # ---- ray-DP exchange, round 6 form (recorded steps with the flat optimizer's two-part update and a compact set)
+    _xlayouts = None
+    _v2_off = False  # the touched set is not whole aligned groups of four in the optimizer's list order: the classic sequence stays
+    _sharded_stale = False  # moments of the other ranks' rows are out of date on this rank (a sharded update ran)
+
+    def _exchange_mode(self, c):
+        """None = the classic sequence (gather -> all-reduce -> scatter + inf check -> update), else "allreduce" | "sharded":
+        gather (zeroes the rows behind itself, looks at what it moves, raises the buffer's flag words) -> collective(s) -> part B of
+        the update reads the buffer directly.  PVD_DP_EXCHANGE = allreduce (default) | sharded | classic."""
+        mode = os.environ.get("PVD_DP_EXCHANGE", "allreduce")
+        if (mode == "classic" or c is None or self._v2_off or not self.flat_opt or self.device_type != "cuda" or c is not self.optimizer.touched
+                or not self.optimizer._outside_is_zero or os.environ.get("PVD_DP_WIRE", "f32") != "f32"
+                or getattr(self, "_overlap_with_exchange", None) is not None or not self.optimizer.compact_ready()):
+            return None
+        return "sharded" if (mode == "sharded" and (self.dp.world_size > 1 or os.environ.get("PVD_DP_FORCE") == "1")) else "allreduce"
+
+    def _xlayout(self, c, chunks, with_params):
+        from .dp_compact import ExchangeLayout
+        key = (id(c), chunks, with_params)
+        if self._xlayouts is None or self._xlayouts[0] != key:
+            assert not torch.cuda.is_current_stream_capturing(), "the exchange layout is built by the eager warm-up steps"
+            self._xlayouts = (key, ExchangeLayout(c, self.optimizer._warm_B, chunks, self.device, with_params=with_params))
+        return self._xlayouts[1]
+
+    def prepare_exchange(self):
+        """(before a recording, eagerly) build the exchange layout the recorded steps will use."""
+        if not self.dp.enabled or not self.flat_opt:
+            return
+        c = self._grad_compactor()
+        mode = self._exchange_mode(c)
+        if mode is not None:
+            try:
+                self._xlayout(c, self.dp.world_size if mode == "sharded" else 1, mode == "sharded")
+            except AssertionError:
+                self._v2_off = True
+
+    def _exchange_v2(self, c, mode):
+        import pvd_hip
+        o, dp = self.optimizer, self.dp
+        sharded = mode == "sharded"
+        L = self._xlayout(c, dp.world_size if sharded else 1, sharded)
+        pvd_hip.segments_gather_zero_check(self.flat.flat, L.segs, L.xbuf, L.xbuf[L.slot:], L.chunk, L.chunks)
+        clear = (L.xbuf[L.slot:], L.chunk, L.chunks)
+        if not sharded:
+            dp.all_reduce_sum_(L.xbuf)
+            o.take_compact(L.xbuf, L.xbuf[L.slot:L.slot + 1], clear, (0, L.n_groups))
+            return
+        mine = L.chunk_of(L.xbuf, dp.rank)
+        dp.reduce_scatter_sum_(mine, L.xbuf)  # (in place: this rank's chunk of the buffer receives the sum)
+        pmine = L.chunk_of(L.pbuf, dp.rank)
+        o.take_compact(mine, mine[L.slot:L.slot + 1], clear, L.rows_of(dp.rank), param_out=pmine)
+
+        def after_update():
+            dp.all_gather_(L.pbuf, pmine)
+            pvd_hip.segments_op(pvd_hip.SEG_SCATTER, o.flat_p, L.segs, buf=L.pbuf)  # every rank's updated rows into the parameters
+            pvd_hip.note_weights_changed(o.params)
+        self._after_update = after_update
+        self._sharded_stale = True
+
+    def sync_sharded_state(self):
+        """After sharded updates a rank holds current moments only for its own rows: before anything else updates all rows (an eager
+        step, a recording in another form) or reads the optimizer state, every rank's rows are all-gathered -- one pass per moment."""
+        if not self._sharded_stale:
+            return
+        import pvd_hip
+        assert not torch.cuda.is_current_stream_capturing()
+        L, o, dp = self._xlayouts[1], self.optimizer, self.dp
+        o.flush()
+        for buf in (o.flat_m, o.flat_v):
+            pvd_hip.segments_op(pvd_hip.SEG_GATHER, buf, L.segs, buf=L.pbuf)
+            dp.all_gather_(L.pbuf, L.chunk_of(L.pbuf, dp.rank).clone())
+            pvd_hip.segments_op(pvd_hip.SEG_SCATTER, buf, L.segs, buf=L.pbuf)
+        self._sharded_stale = False
+
     def _exchange(self):
         if self.dp.enabled:
             c = self._grad_compactor()
+            mode = self._exchange_mode(c)
+            if mode is not None:
+                return self._exchange_v2(c, mode)
+            if self._sharded_stale and not torch.cuda.is_current_stream_capturing():
+                self.sync_sharded_state()
             ov = getattr(self, "_overlap_with_exchange", None)
             # PVD_DP_WIRE=f16 | bf16 (opt-in, NOT the reference's arithmetic): the gradient crosses the links in 16 bits -- half the
             # bytes of the one exchange that bounds the multi-GPU step (DESIGN section 6).  f16 relies on the loss scale (AMP): an
@@ -194,9 +273,14 @@ class _TrainerBase:
                 if checked:
                     self.optimizer.note_checked_by_backward()
 
+    _after_update = None
+
     def _optimize(self):
         self.scaler.step(self.optimizer)
         self.scaler.update()
+        after, self._after_update = self._after_update, None
+        if after is not None:  # (a sharded update: all-gather of the updated rows)
+            after()
 
     def _backward_and_step(self, loss):
         self._backward(loss)
@@ -378,7 +462,12 @@ class DistillTrainer(_TrainerBase):
             # the teacher's outputs exist already: the stage-3 objective can ride on the student's compositing launches
             # (ObjectiveRide: two launches fewer on the chain)
             ride = None
-            if (self.fused_loss is not None and o.loss_type == "normL2" and not self.dp.enabled and torch.is_grad_enabled()
+            # (under ray-DP too, since round 6: ONE all-reduce of the forward launch's partial sums -- a count that is the same on every
+            # rank, ~20 KB -- sits between the two compositing launches and the backward launch finishes the objective from the summed
+            # partials; PVD_DP_RIDE=0: the four separate objective launches of rounds 1-5)
+            l1_on_host = o.l1_reg_weight > 0.0 and o.model_type == "vm" and not self.flat_opt
+            dp_ride = self.dp.enabled and not l1_on_host and os.environ.get("PVD_DP_RIDE", "1") != "0"
+            if (self.fused_loss is not None and o.loss_type == "normL2" and (not self.dp.enabled or dp_ride) and torch.is_grad_enabled()
                     and self._stage_of(self.global_step) == 3 and out_tea.get("image") is not None
                     and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc * 0.995, o.loss_rate_rgb) > 0.0
                     and torch.is_tensor(getattr(tea, "feature_sigma_color", None)) and torch.is_tensor(getattr(tea, "color_l", None))
@@ -387,9 +476,10 @@ class DistillTrainer(_TrainerBase):
                 from .losses import ObjectiveRide
                 # the objective is finished inside the compositing backward's launch -- never when the L1 value is added to the loss
                 # by the host afterwards (L1 on, VM student, non-flat optimizer: k_loss_final then stays a launch of its own)
-                l1_on_host = o.l1_reg_weight > 0.0 and o.model_type == "vm" and not self.flat_opt
                 fin = not l1_on_host
-                ride = ObjectiveRide(out_tea["image"], tea.feature_sigma_color, tea.color_l, rates_decay=self.rates if fin else None, fea_decay=0.995)
+                ride = ObjectiveRide(out_tea["image"], tea.feature_sigma_color, tea.color_l, rates_decay=self.rates if fin else None, fea_decay=0.995,
+                                     fixed_parts=self.dp.enabled)
+                self.dp_objective_rides = bool(self.dp.enabled)
             out_stu = stu.render(pre["rays_o"], pre["rays_d"], staged=False, bg_color=pre["bg"], perturb=True, force_all_rays=False,
                                  inherited_params=pre["inh"], nears_fars=pre["nf"], premarched=True, objective=ride, **kw)
             self._ride = ride if (ride is not None and ride.S is not None) else None
@@ -515,6 +605,7 @@ class DistillTrainer(_TrainerBase):
         warm = 3
         if self.flat_opt:
             self.optimizer.flush()  # (a part of the previous recording's last update may still be owed: FlatAdamW.carry_last)
+            self.sync_sharded_state()  # (a sharded recording leaves the other ranks' rows' moments behind: current before anything else runs)
         self._replay_owes_part_a = None  # what replay() tells the optimizer afterwards belongs to the recording made below
         self.fused_spans = None
         stage = self._stage_of(self.global_step)
@@ -619,6 +710,12 @@ class DistillTrainer(_TrainerBase):
         if late:
             # ... and the LAST step's deferred part rides on the next replay's first branch instead of trailing the graph
             self.optimizer.carry_last = True
+        if late and self.dp.enabled:
+            # round 6: the recorded steps' exchange feeds part B directly (gather that zeroes and checks -> collective -> update); the
+            # layout is built here, outside the recording, and the steps record no zero_grad of their own after the first
+            self.prepare_exchange()
+            if self._exchange_mode(self._grad_compactor()) is not None:
+                self._fold_launches(True)
         cap = SegmentedCapture(self.device)
         self.dp.capture = cap
         branch = torch.cuda.Stream(self.device)

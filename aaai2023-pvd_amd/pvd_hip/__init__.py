@@ -84,15 +84,16 @@ ENTRY_POINTS = (
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
-    "pvd_composite_objective_blocks", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
+    "pvd_composite_objective_blocks", "pvd_composite_objective_blocks_fixed", "pvd_composite_objective_forward", "pvd_composite_objective_backward",
     "pvd_distill_sumsq", "pvd_distill_loss_final", "pvd_distill_sumsq_backward", "pvd_distill_loss_backward", "pvd_grid_set_variant", "pvd_grid_set_fwd_kernel",
-    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_check_finite_mixed", "pvd_l1_ranges", "pvd_segments_op",
+    "pvd_adamw_step", "pvd_adamw_step_ex", "pvd_adamw_lazy_flush", "pvd_freq_encode", "pvd_mlp_head_forward_fused", "pvd_check_finite", "pvd_check_finite_f16", "pvd_check_finite_mixed", "pvd_l1_ranges", "pvd_segments_op", "pvd_segments_gather_zero_check",
 )
 for _name in ENTRY_POINTS:
     if _name not in ("pvd_status_string", "pvd_last_hip_error"):
         getattr(_lib, _name).restype = ctypes.c_int
 _lib.pvd_march_workspace_bytes.restype = ctypes.c_size_t
 _lib.pvd_composite_objective_blocks.restype = ctypes.c_uint32
+_lib.pvd_composite_objective_blocks_fixed.restype = ctypes.c_uint32
 
 
 class PvdHipError(RuntimeError):
@@ -919,12 +920,16 @@ def composite_rays_train_bg_backward(grad_weights_sum, grad_image, sigmas, rgbs,
 
 
 
-def composite_objective_blocks(N, rows):
+def composite_objective_blocks(N, rows, fixed=False):
+    """partial sums a composite_objective_forward launch leaves; fixed: a count that depends on N alone (ray-DP: every rank's buffer has
+    one size whatever its sample count)"""
+    if fixed:
+        return int(_lib.pvd_composite_objective_blocks_fixed(_u32(N)))
     return int(_lib.pvd_composite_objective_blocks(_u32(N), _u32(rows)))
 
 
 def composite_objective_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar, nears, fars, depth_eps, weights_sum, depth, image,
-                                img_t, fea_s, fea_t, col_s, col_t, S4, budget_dev=None, rates_decay=None, fea_decay=1.0):
+                                img_t, fea_s, fea_t, col_s, col_t, S4, budget_dev=None, rates_decay=None, fea_decay=1.0, fixed_parts=False):
     """pvd_composite_objective_forward: composite_rays_train_bg_forward + the partial sums of the four squared norms of the
     stage-3 objective in one launch (S4: 4 + 4 * composite_objective_blocks(N, rows) floats)."""
     dev = _dev(sigmas, rgbs, deltas, rays, bg, nears, fars, weights_sum, depth, image, budget_dev, img_t, fea_s, fea_t, col_s, col_t, S4)
@@ -934,19 +939,21 @@ def composite_objective_forward(sigmas, rgbs, deltas, rays, M, N, bg, bg_scalar,
     rows = fea_s.shape[0]
     if fea_s.dim() != 2 or fea_s.shape[1] != 16 or fea_t.shape != fea_s.shape or col_s.shape != (rows, 3) or col_t.shape != (rows, 3):
         raise PvdHipError("feature rows must be [rows,16], colour rows [rows,3]")
-    if img_t.numel() != 3 * N or S4.numel() < 4 + 4 * composite_objective_blocks(N, rows):
+    if img_t.numel() != 3 * N or S4.numel() < 4 + 4 * composite_objective_blocks(N, rows, fixed_parts):
         raise PvdHipError("teacher image must be [N,3]; S4 must hold 4 + 4 * composite_objective_blocks floats")
     if budget_dev is not None:
         _want(budget_dev, torch.int32, "budget_dev")
     _call("pvd_composite_objective_forward", dev, _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u32(M), _u32(N), _p(bg), _f32(bg_scalar),
           _p(nears), _p(fars), _f32(depth_eps), _p(weights_sum), _p(depth), _p(image), _p(budget_dev), _p(img_t), _p(fea_s), _p(fea_t),
-          _p(col_s), _p(col_t), _u32(rows), _p(S4), _p(rates_decay), _f32(fea_decay))
+          _p(col_s), _p(col_t), _u32(rows), _p(S4), _p(rates_decay), _f32(fea_decay), _u32(2 if fixed_parts else 0))
 
 
 def composite_objective_backward(grad_ws, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, bg, bg_scalar, grad_sigmas, grad_rgbs,
-                                 img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_fea, g_col, fresh=False, budget_dev=None, finish=None):
+                                 img_t, fea_s, fea_t, col_s, col_t, coef4, upstream, g_fea, g_col, fresh=False, budget_dev=None, finish=None,
+                                 fixed_parts=False):
     """pvd_composite_objective_backward: sumsq_backward + composite_rays_train_bg_backward in one launch.
-    finish = (rates4, extra or None, S4, loss, norms4): the launch also finishes the objective (coef4 becomes an output)."""
+    finish = (rates4, extra or None, S4, loss, norms4): the launch also finishes the objective (coef4 becomes an output);
+    fixed_parts: the forward launch ran with fixed_parts (ray-DP: the partial sums were all-reduced over the ranks in between)."""
     dev = _dev(grad_ws, sigmas, rgbs, deltas, rays, weights_sum, image, bg, grad_sigmas, grad_rgbs, budget_dev, img_t, fea_s, fea_t, col_s,
                col_t, coef4, upstream, g_fea, g_col)
     _f32_all(sigmas=sigmas, rgbs=rgbs, deltas=deltas, weights_sum=weights_sum, image=image, grad_sigmas=grad_sigmas, grad_rgbs=grad_rgbs,
@@ -962,10 +969,11 @@ def composite_objective_backward(grad_ws, sigmas, rgbs, deltas, rays, weights_su
         _f32_all(rates4=rates4, S4=S4, loss=loss, norms4=norms4)
         if extra is not None:
             _want(extra, torch.float32, "extra")
-        if S4.numel() < 4 + 4 * composite_objective_blocks(N, rows):
+        if S4.numel() < 4 + 4 * composite_objective_blocks(N, rows, fixed_parts):
             raise PvdHipError("S4 must be the buffer composite_objective_forward filled")
     _call("pvd_composite_objective_backward", dev, _p(grad_ws), _p(sigmas), _p(rgbs), _p(deltas), _p(rays), _p(weights_sum), _p(image),
-          _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32(1 if fresh else 0), _p(budget_dev), _p(img_t),
+          _u32(M), _u32(N), _p(bg), _f32(bg_scalar), _p(grad_sigmas), _p(grad_rgbs), _u32((1 if fresh else 0) | (2 if fixed_parts else 0)),
+          _p(budget_dev), _p(img_t),
           _p(fea_s), _p(fea_t), _p(col_s), _p(col_t), _u32(rows), _p(coef4), _p(upstream), _p(g_fea), _p(g_col), _p(rates4), _p(extra),
           _u32(extra.numel() if extra is not None else 0), _p(S4), _p(loss), _p(norms4))
 
@@ -1048,7 +1056,9 @@ class _AdamwExtras(ctypes.Structure):  # pvd_adamw_extras, include/pvd_hip.h
                 ("lazy_log", ctypes.c_void_p), ("lazy_count", ctypes.c_void_p), ("lazy_capacity", ctypes.c_uint32),
                 ("warm_groups", ctypes.c_void_p), ("n_warm_groups", ctypes.c_uint32), ("warm_zero_grad_from", ctypes.c_uint32),
                 ("snapshot", ctypes.c_void_p), ("replay", ctypes.c_void_p),
-                ("zero_grad_after", ctypes.c_uint32), ("arrivals", ctypes.c_void_p)]
+                ("zero_grad_after", ctypes.c_uint32), ("arrivals", ctypes.c_void_p),
+                ("compact_grad", ctypes.c_void_p), ("compact_param_out", ctypes.c_void_p), ("tail_clear", ctypes.c_void_p),
+                ("tail_clear_stride", ctypes.c_uint32), ("tail_clear_n", ctypes.c_uint32)]
 
 
 def _u64_array(vals):
@@ -1056,14 +1066,17 @@ def _u64_array(vals):
 
 
 def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None, schedule=None,
-               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None, snapshot=None, replay=None, zero_after=False, arrivals=None):
+               l1_ranges=None, amp_update=None, half_grad=None, l1_next=None, cold_bits=None, lazy=None, snapshot=None, replay=None, zero_after=False, arrivals=None,
+               compact_grad=None, compact_param_out=None, tail_clear=None):
     """schedule: None or (kind, T, param, base_lr [segments] device, sched_step [1] device), kind 1 cosine / 2 exponential.
     l1_ranges: None or list of (begin, end, coef) element ranges of the flat buffer.
     cold_bits: None or int32 [ceil(n / 128)]: bit i set = parameters [4i, 4i+4) have zero gradient and moments, for good.
     snapshot / replay: f32 [4 + segments] device: the two-part update of include/pvd_hip.h (snapshot: this launch records the
     scalars it used; replay: this launch is the deferred part and uses a recorded step's scalars, no tail).
     zero_after: the update zeroes every gradient group it has read (the next step needs no zero_grad launch); arrivals: uint32 [1]
-    device, zero -- the tail's work is done inside the update kernel by the last workgroup to arrive (no tail launch)."""
+    device, zero -- the tail's work is done inside the update kernel by the last workgroup to arrive (no tail launch).
+    compact_grad / compact_param_out (f32 [4 * len(warm list)]) and tail_clear = (f32 tensor, stride, count): ray-DP, see
+    pvd_adamw_extras in include/pvd_hip.h."""
     dev = _dev(p, g, m, v, lr, step, grad_scale, found_inf)
     _f32_all(p=p, g=g, m=m, v=v, lr=lr, step=step)
     ends = _u64_array(segment_ends)
@@ -1136,6 +1149,22 @@ def adamw_step(p, g, m, v, segment_ends, lr, beta1, beta2, eps, weight_decay, st
             b, e = _u64_array([r[0] for r in l1_ranges]), _u64_array([r[1] for r in l1_ranges])
             c = (ctypes.c_float * len(l1_ranges))(*[float(r[2]) for r in l1_ranges])
             ex.n_l1, ex.l1_begin_host, ex.l1_end_host, ex.l1_coef_host = len(l1_ranges), b, e, c
+        for name_, t_ in (("compact_grad", compact_grad), ("compact_param_out", compact_param_out)):
+            if t_ is not None:
+                _dev(t_)
+                _want(t_, torch.float32, name_)
+                if not ex.n_warm_groups or t_.numel() < 4 * ex.n_warm_groups:
+                    raise PvdHipError("%s needs a warm list and four floats per list entry" % name_)
+                setattr(ex, name_, t_.data_ptr())
+        if tail_clear is not None:
+            t_, stride_, count_ = tail_clear
+            _dev(t_)
+            _want(t_, torch.float32, "tail_clear")
+            if count_ < 1 or (count_ - 1) * stride_ >= t_.numel():
+                raise PvdHipError("tail_clear: count words at the given stride must lie inside the tensor")
+            ex.tail_clear, ex.tail_clear_stride, ex.tail_clear_n = t_.data_ptr(), int(stride_), int(count_)
+    elif compact_grad is not None or compact_param_out is not None or tail_clear is not None:
+        raise PvdHipError("compact_grad / compact_param_out / tail_clear need the warm-list form of the update")
     _call("pvd_adamw_step_ex", dev, _p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.numel()), ends, _u32(len(segment_ends)), _p(lr),
           ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_double(weight_decay), _p(step), _p(grad_scale),
           _p(found_inf), ctypes.byref(ex) if ex is not None else _vp(0))
@@ -1196,6 +1225,20 @@ def segments_op(op, flat, segs, buf=None, found_inf=None):
             raise PvdHipError("the inf check needs found_inf")
         _f32_all(found_inf=found_inf)
     _call("pvd_segments_op", dev, ctypes.c_int(op), _p(flat), _p(buf), _p(segs), ctypes.c_uint32(segs.shape[0]), _p(found_inf))
+
+
+def segments_gather_zero_check(flat, segs, buf, slots, slot_stride, n_slots):
+    """pvd_segments_gather_zero_check: buf <- the listed ranges of flat, flat's ranges <- 0, slots[k * slot_stride] <- 1 (k < n_slots)
+    if an inf / nan was moved.  `slots` is a view into the exchange buffer (its first flag word)."""
+    dev = _dev(flat, segs, buf, slots)
+    _f32_all(flat=flat, buf=buf, slots=slots)
+    _want(segs, torch.int32, "segs")
+    if segs.dim() != 2 or segs.shape[1] != 3 or not segs.is_contiguous():
+        raise PvdHipError("segs must be a contiguous [n, 3] int32 tensor")
+    if not (1 <= n_slots <= 64) or (n_slots - 1) * slot_stride >= slots.numel():
+        raise PvdHipError("the flag words must lie inside `slots`")
+    _call("pvd_segments_gather_zero_check", dev, _p(flat), _p(buf), _p(segs), ctypes.c_uint32(segs.shape[0]), _p(slots), _u32(slot_stride),
+          _u32(n_slots))
 
 
 def l1_ranges(p, ranges, scratch, out=None):

@@ -198,12 +198,15 @@ def make_ops(backend, device_type="cuda"):
             ctx.objective = objective if (objective is not None and hasattr(backend, "composite_objective_forward") and N > 0 and M > 0) else None
             if ctx.objective is not None:
                 ob = ctx.objective
-                ob.S = torch.empty(4 + 4 * backend.composite_objective_blocks(N, ob.fea_s.shape[0]), dtype=torch.float32, device=sigmas.device)
+                fixed = bool(getattr(ob, "fixed_parts", False))  # ray-DP: a partial-sum count that is the same on every rank
+                fk = {"fixed_parts": True} if fixed else {}
+                nparts = backend.composite_objective_blocks(N, ob.fea_s.shape[0], **({"fixed": True} if fixed else {}))
+                ob.S = torch.empty(4 + 4 * nparts, dtype=torch.float32, device=sigmas.device)
                 dk = {} if getattr(ob, "rates_decay", None) is None else {"rates_decay": ob.rates_decay, "fea_decay": ob.fea_decay}
                 backend.composite_objective_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum, depth,
-                                                    image, ob.img_t, ob.fea_s, ob.fea_t, ob.col_s, ob.col_t, ob.S, **kw, **dk)
-                ob.decayed = bool(dk)
-                ob.nparts = backend.composite_objective_blocks(N, ob.fea_s.shape[0])
+                                                    image, ob.img_t, ob.fea_s, ob.fea_t, ob.col_s, ob.col_t, ob.S, **kw, **dk, **fk)
+                ob.decayed = "rates_decay" in dk
+                ob.nparts = nparts
             else:
                 backend.composite_rays_train_bg_forward(sigmas, rgbs, deltas, rays, M, N, bg_t, bg_s, nears, fars, depth_eps, weights_sum,
                                                         depth, image, **kw)
@@ -233,7 +236,8 @@ def make_ops(backend, device_type="cuda"):
                 ob.armed = False
                 backend.composite_objective_backward(gws, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, ctx.bg[0], ctx.bg[1], grad_sigmas,
                                                      grad_rgbs, ob.img_t, ob.fea_s, ob.fea_t, ob.col_s, ob.col_t, ob.coef, ob.upstream, ob.g_fea,
-                                                     ob.g_col, fresh=bool(ctx.packed_rays), finish=getattr(ob, "finish", None), **kw)
+                                                     ob.g_col, fresh=bool(ctx.packed_rays), finish=getattr(ob, "finish", None),
+                                                     **({"fixed_parts": True} if getattr(ob, "fixed_parts", False) else {}), **kw)
             elif ctx.packed_rays:
                 backend.composite_rays_train_bg_backward(gws, grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
                                                          ctx.bg[0], ctx.bg[1], grad_sigmas, grad_rgbs, fresh=True, **kw)

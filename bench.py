@@ -805,9 +805,15 @@ def main():
             c = getattr(tr, "_compactor", None)
             compact = c is not None and getattr(c, "agreed", True) and c.fraction < 0.7
             total = tr.flat.flat.numel() * 4 / 1e6
-            out["config"]["exchange"] = "all-reduce of %.1f MB (%s of %.1f MB of fp32 gradients)%s + 16 B of loss sums" % (
-                c.idx.numel() * 4 / 1e6 if compact else total, "touched rows only" if compact else "dense", total,
-                ", next step's prefix replayed underneath" if getattr(tr, "_g_prefix", None) is not None else "")
+            lay = getattr(tr, "_xlayouts", None)
+            form = "all-reduce"
+            if lay is not None:  # round 6: the gather zeroes / checks, the buffer carries the inf flag, part B of the update reads it directly
+                form = ("reduce_scatter -> AdamW on the rank's rows -> all_gather (sharded update)" if lay[1].pbuf is not None else
+                        "all-reduce feeding the update directly (no scatter / check launches)")
+            out["config"]["exchange"] = "%s of %.1f MB (%s of %.1f MB of fp32 gradients)%s + 16 B of loss sums%s" % (
+                form, c.idx.numel() * 4 / 1e6 if compact else total, "touched rows only" if compact else "dense", total,
+                ", next step's prefix replayed underneath" if getattr(tr, "_g_prefix", None) is not None else "",
+                " between the two compositing launches (objective riding on them)" if getattr(tr, "dp_objective_rides", False) else "")
             out["config"]["exchange"] += ("; collectives recorded into the step's HIP graph (1 graph launch per step)" if dp.ingraph else
                                           "; collectives eager between %d graphs" % len(getattr(tr, "_cap").graphs))
         except Exception as e:  # noqa: BLE001

@@ -515,14 +515,21 @@ int pvd_composite_rays_train_bg_backward(const float *grad_weights_sum, const fl
  *            forward launch's partial sums (at S4 + 4) for itself, coef4 becomes an output, workgroup 0 publishes S4[0..3],
  *            loss, norms4 (+ the parameter-only partial sums `extra`) -- so no pvd_distill_loss_final runs between the
  *            passes; the forward launch then applies the feature rate's decay (rates4_decay[1] *= fea_decay, one thread).
+ * Ray data parallelism (the four sums of squares are sums over the RANKS' rows): both launches with flags &
+ *            PVD_OBJECTIVE_FIXED_PARTS -- the number of partial sums then depends on N alone
+ *            (pvd_composite_objective_blocks_fixed(N); workgroups beyond the feature rows write zeros), so every rank leaves
+ *            a buffer of the same size and the host all-reduces (SUM) the PARTIALS S4[4 ..) between the two launches: one
+ *            collective and nothing else between them; the backward launch reduces the summed partials like its own.
  * img_tea [N,3] by ray index, fea_* [rows,16] (column 0 = sigma_l), col_* [rows,3], all f32; rows > 0. */
+#define PVD_OBJECTIVE_FIXED_PARTS 2u
 uint32_t pvd_composite_objective_blocks(uint32_t N, uint32_t rows);
+uint32_t pvd_composite_objective_blocks_fixed(uint32_t N);
 int pvd_composite_objective_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, uint32_t M,
                                     uint32_t N, const float *bg, float bg_scalar, const float *nears, const float *fars,
                                     float depth_eps, float *weights_sum, float *depth, float *image, const int32_t *budget_dev,
                                     const float *img_tea, const float *fea_stu, const float *fea_tea, const float *col_stu,
                                     const float *col_tea, uint32_t rows, float *S4, float *rates4_decay, float fea_decay,
-                                    pvd_stream_t stream);
+                                    uint32_t flags, pvd_stream_t stream);
 int pvd_composite_objective_backward(const float *grad_weights_sum, const float *sigmas, const float *rgbs, const float *deltas,
                                      const int32_t *rays, const float *weights_sum, const float *image, uint32_t M, uint32_t N,
                                      const float *bg, float bg_scalar, float *grad_sigmas, float *grad_rgbs, uint32_t flags,
@@ -651,6 +658,20 @@ typedef struct pvd_adamw_extras {
      *    relaxed atomic when it is done: the last one knows nobody will read them again), and no tail kernel is launched. */
     uint32_t zero_grad_after;
     uint32_t *arrivals;
+    /* Ray data parallelism (new work: the reference has no multi-GPU path, tools/details.md:24).  Only with warm_groups, not
+     * with replay / warm_zero_grad_from / g16:
+     *  compact_grad != NULL (DEVICE f32 [4 * n_warm_groups]): the gradient of list entry j is compact_grad[4 j .. 4 j + 4) -- the
+     *    compact exchange buffer after its collective (pvd_segments_gather_zero_check filled it in list order) -- instead of
+     *    g[4 warm_groups[j] ..): no pass that puts the summed rows back into g.  A SHARDED update passes its slice of the list
+     *    (warm_groups + j0, n_warm_groups = j1 - j0) with the reduce-scattered chunk that belongs to it;
+     *  compact_param_out != NULL (DEVICE f32 [4 * n_warm_groups]): the updated parameters of entry j are ALSO written there (on
+     *    a skipped step: the unchanged ones) -- the chunk a sharded update all-gathers;
+     *  tail_clear (DEVICE f32), tail_clear_stride, tail_clear_n: the tail also zeroes tail_clear[k * tail_clear_stride], k <
+     *    tail_clear_n -- the flag words of the exchange buffer's chunks, so that the next step's gather starts from zeros. */
+    const float *compact_grad;
+    float *compact_param_out;
+    float *tail_clear;
+    uint32_t tail_clear_stride, tail_clear_n;
 } pvd_adamw_extras;
 int pvd_adamw_step_ex(float *p, const float *g, float *m, float *v, uint64_t n, const uint64_t *segment_ends_host,
                       uint32_t n_segments, float *lr, double beta1, double beta2, double eps, double weight_decay,
@@ -684,6 +705,13 @@ int pvd_check_finite_mixed(const float *g, uint64_t n, uint64_t skip_begin, uint
  * Segments whose start, dst and len are multiples of 4 move as float4. */
 int pvd_segments_op(int op, float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *found_inf,
                     pvd_stream_t stream);
+/* Ray-DP, what goes on the wire, in one pass: buf[dst+i] = flat[start+i] (gather), flat[start+i] = 0 (the NEXT step's zero_grad),
+ * and a workgroup that moves an inf / nan stores 1 into slots[k * slot_stride] for every k < n_slots (<= 64) -- one flag word per
+ * chunk of the exchange buffer.  The collective that follows sums the flag words with the data, so after it every rank holds the
+ * step's GLOBAL found_inf in its chunk (GradScaler's inf check + all-reduce of the verdict, with no launch of their own); the
+ * update's tail zeroes the words again (pvd_adamw_extras.tail_clear).  The slots must be zero on entry. */
+int pvd_segments_gather_zero_check(float *flat, float *buf, const uint32_t *segs, uint32_t n_segs, float *slots,
+                                   uint32_t slot_stride, uint32_t n_slots, pvd_stream_t stream);
 
 /* out[0] = sum_r coef[r] * sum_{i in [begin[r], end[r])} |p[i]|  (value of the L1 regulariser; scratch: 1024 floats).
  * out == NULL: only the 1024 partial sums are left in scratch (for pvd_distill_loss_final's `extra`). */

@@ -85,9 +85,11 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
     _same_training(*runs)
 
 
-def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1"):
+def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1", exchange=None, ride="1"):
     os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", PVD_DP_INGRAPH="1" if ingraph else "0", PVD_DP_PIPELINE=pipeline,
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PVD_DP_RIDE=ride)
+    if exchange is not None:
+        os.environ["PVD_DP_EXCHANGE"] = exchange
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -115,7 +117,12 @@ def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1")
         assert getattr(w.trainer, "_g_prefix", None) is not None
     losses = [float(w.step()[1]["rgb"]) for _ in range(40 // steps_per_graph)]
     torch.cuda.synchronize()
-    torch.save({"losses": losses}, out_path)
+    o = w.trainer.optimizer
+    # the deterministic quantities of the run (bit for bit, whatever the float atomics do to the losses)
+    torch.save({"losses": losses, "step_count": float(o.step_count), "lr": o.lr_dev.cpu(), "scale": float(w.trainer.scaler.get_scale()),
+                "global_step": int(w.trainer.global_step),
+                "exchange_mode": (w.trainer._xlayouts[1].chunks if getattr(w.trainer, "_xlayouts", None) else None),
+                "rode": bool(getattr(w.trainer, "dp_objective_rides", False))}, out_path)
     dist.destroy_process_group()
 
 
@@ -147,3 +154,27 @@ def test_rccl_in_graph_with_the_next_prefix_forked_under_the_exchange(tmp_path):
         assert len(losses) == 10 and all(l == l for l in losses) and losses[-1] < losses[0]
         runs.append(losses)
     _same_training(*runs)
+
+
+@pytest.mark.timeout(1500)
+def test_rccl_in_graph_round6_exchange_forms(tmp_path):
+    """Round 6, in a one-rank RCCL world with everything recorded into the graph (four steps per graph, forked prefix): the
+    objective riding on the compositing launches with ONE 16-byte all-reduce between them, the gather that zeroes / checks and
+    feeds part B of the update directly, and the sharded form (reduce_scatter_tensor -> AdamW on the rank's rows -> all_gather_into_tensor
+    -> parameters) all CAPTURE and REPLAY under RCCL and train like rounds 1-5's sequence; step count, learning rates, loss scale
+    are equal bit for bit."""
+    runs = {}
+    for name, exchange, ride in (("classic", "classic", "0"), ("allreduce", "allreduce", "1"), ("sharded", "sharded", "1")):
+        out = str(tmp_path / ("r6_%s.pt" % name))
+        mp.spawn(_rccl_worker, args=(_free_port(), out, True, 4, "2", exchange, ride), nprocs=1, join=True)
+        runs[name] = torch.load(out)
+        losses = runs[name]["losses"]
+        assert len(losses) == 10 and all(l == l for l in losses) and losses[-1] < losses[0]
+    assert runs["classic"]["exchange_mode"] is None and not runs["classic"]["rode"]
+    assert runs["allreduce"]["exchange_mode"] == 1 and runs["allreduce"]["rode"]
+    assert runs["sharded"]["exchange_mode"] == 1 and runs["sharded"]["rode"]  # (one rank: one chunk, through reduce_scatter / all_gather)
+    for name in ("allreduce", "sharded"):
+        _same_training(runs["classic"]["losses"], runs[name]["losses"])
+        for k in ("step_count", "scale", "global_step"):
+            assert runs["classic"][k] == runs[name][k], (name, k, runs["classic"][k], runs[name][k])
+        assert torch.equal(runs["classic"]["lr"], runs[name]["lr"])

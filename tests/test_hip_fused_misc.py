@@ -954,18 +954,29 @@ def test_objective_riding_on_the_compositing_launches_equals_the_separate_launch
     outs = []
     extra = torch.rand(8192, device=dev, generator=g) * 1e-3  # partial sums of a parameter-only term (the L1 regulariser's value)
     # separate launches; riding with k_loss_final between the passes; riding with the objective finished by the backward launch
-    for riding in (None, "final", "finish"):
+    class OneRankWorld:  # ray-DP's interface as _DistillNormL2 uses it; a world of one rank sums nothing
+        enabled, calls = True, []
+
+        def all_reduce_sum_(self, t, overlap=None):
+            self.calls.append(int(t.numel()))
+            return t
+    # ... and (round 6) riding under ray-DP: a partial-sum count that depends on N alone, the partials all-reduced between the launches
+    for riding in (None, "final", "finish", "dp"):
         sig, rgb, fea, col = [t.clone().requires_grad_(True) for t in (sig0, rgb0, fea0, col0)]
         r4 = rates.clone()
         ride = None
         if riding:
-            ride = ObjectiveRide(img_t, fea_t, col_t, rates_decay=r4 if riding == "finish" else None, fea_decay=0.995)
+            ride = ObjectiveRide(img_t, fea_t, col_t, rates_decay=r4 if riding in ("finish", "dp") else None, fea_decay=0.995,
+                                 fixed_parts=riding == "dp")
             assert ride.with_student(fea, col)
         ws, depth, img = raymarching.composite_rays_train_bg(sig, rgb, deltas, rays, bg, nears, fars, 1e-6, True, **({"objective": ride} if riding else {}))
         assert (ride is not None and ride.S is not None and ride.nparts >= 2) == bool(riding)
-        loss, norms = distill_loss_normL2(img.view(1, N, 3), img_t, fea, fea_t, col, col_t, r4, None, fea_decay=0.995, extra=extra,
-                                          **({"ride": ride} if riding else {}))
-        assert (ride is not None and ride.finish is not None) == (riding == "finish")
+        loss, norms = distill_loss_normL2(img.view(1, N, 3), img_t, fea, fea_t, col, col_t, r4, OneRankWorld() if riding == "dp" else None,
+                                          fea_decay=0.995, extra=extra, **({"ride": ride} if riding else {}))
+        assert (ride is not None and ride.finish is not None) == (riding in ("finish", "dp"))
+        if riding == "dp":  # ONE collective, over the partials: (rays / 4 workgroups + 256) float4 entries whatever the sample count
+            assert OneRankWorld.calls == [4 * ((N + 3) // 4 + 256)] and ride.nparts == (N + 3) // 4 + 256
+            OneRankWorld.calls.clear()
         (loss * 3.0).backward()  # (finish: loss / norms are filled in by the backward launch)
         outs.append((img.detach(), ws.detach(), depth.detach(), float(loss), norms.clone(), sig.grad, rgb.grad, fea.grad, col.grad, r4.clone()))
     a = outs[0]
