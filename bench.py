@@ -431,6 +431,8 @@ def main():
                     help="after the timed region: this many more steps in one synchronised window (`sustained`); 0 = skip")
     ap.add_argument("--no-psnr", action="store_true", help="skip the staged distillation run + held-out PSNR (`psnr`, ~12 s, outside the timed region)")
     ap.add_argument("--psnr-schedule", type=str, default="3000,500,1500,6000", help="teacher steps, end of stage 1, end of stage 2, total distillation steps")
+    ap.add_argument("--occupancy", type=int, choices=[1, 5, 15], default=5,
+                    help="SURVEY 8(d)'s occupancy sweep: ~1 / ~5 (the metric's scene) / ~15 %% of the 128^3 cells occupied (ChairScene(thicken = 0 / 0.08 / 0.2))")
     ap.add_argument("--workload", choices=["distill", "teacher"], default="distill",
                     help="distill = BASELINE.json's metric (configs[2]); teacher = hash teacher training step (configs[1], single GPU)")
     args = ap.parse_args()
@@ -482,7 +484,8 @@ def main():
     opt = PVDConfig(num_rays=args.rays, model_type=args.student, teacher_type=args.teacher, fp16=not args.fp32, bound=args.bound, dt_gamma=args.dt_gamma,
                     data_type=args.data_type)
     dp = RayDP()
-    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp, scene_scale=args.scene_scale)
+    w = DistillWorkload(hip_ops(), dev, opt, teacher_pretrain_steps=args.teacher_pretrain, seed=0, dp=dp, scene_scale=args.scene_scale,
+                        thicken={1: 0.0, 5: 0.08, 15: 0.2}[args.occupancy])
     if dp.enabled:  # replicas must start bit-identical (teacher pre-training uses float atomics)
         for m in (w.tea, w.stu):
             for t in list(m.parameters()) + list(m.buffers()):
@@ -655,6 +658,45 @@ def main():
                 torch.cuda.synchronize()
             return ev_a.elapsed_time(ev_b) / n_launch * 1e3
 
+        def sol_probe(xyzs):
+            """The lookup's gather-only speed of light on THESE sample rows (tools/probes/hash_sol.hip, sol_gather variant 1): the product
+            kernel's index code, lane mapping and therefore address stream, all 14 levels' gathers in flight, no blend, no head, 4 B
+            written per lane -- what the memory system charges for the gathers alone at this launch size."""
+            import ctypes
+            lib = ctypes.CDLL(os.path.join(REPO, "tools", "probes", "libhash_sol.so"))
+            enc = w.tea.encoder
+            emb16 = enc.embeddings.detach().half().contiguous()
+            x01 = ((xyzs.float() + opt.bound) / (2 * opt.bound)).contiguous()
+            offs = enc.offsets.cpu().numpy().astype(np.int32)
+            S = np.float32(np.log2(enc.per_level_scale))
+            scales = (np.exp2(np.arange(14, dtype=np.float32) * S) * np.float32(enc.base_resolution) - np.float32(1)).astype(np.float32)
+            sink = torch.zeros(2 * x01.shape[0], dtype=torch.int32, device=dev)
+
+            def run():
+                rc = lib.sol_gather(ctypes.c_int(1), ctypes.c_void_p(x01.data_ptr()), ctypes.c_void_p(emb16.data_ptr()), offs.ctypes.data_as(ctypes.c_void_p),
+                                    scales.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(x01.shape[0]), ctypes.c_void_p(sink.data_ptr()),
+                                    ctypes.c_uint32(0xFFFFFFFF), ctypes.c_uint32(0), ctypes.c_uint32(0),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                assert rc == 0, rc
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(per_graph):
+                        run()
+                g.replay()
+                ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev_a.record(side)
+                for _ in range(reps):
+                    g.replay()
+                ev_b.record(side)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            return ev_a.elapsed_time(ev_b) / n_launch * 1e3
+
         # WHICH cameras: the launch's duration depends on the batch's camera (the hash keeps x-neighbours in one cache line, so
         # rays that run along x coalesce and rays that run along y or z do not: 21.7 us vs 32 us on the same box,
         # tools/probe_alone_vs_history.py).  `alone` = cameras of the TIMED REGION (what "the kernel's average launch duration
@@ -672,12 +714,17 @@ def main():
             next_cam = (first + args.steps) % P  # the batch right behind the timed region: what rounds 1-3 measured on (one camera)
         else:
             timed_cams, epoch_cams, next_cam = [None], [], None
-        per_cam = {}
+        per_cam, sol_cam, sol_err = {}, {}, None
         B = None
         for cam in list(timed_cams) + [c for c in epoch_cams + ([next_cam] if next_cam is not None else []) if c not in timed_cams]:
             xyzs, dirs = samples_of_pose(cam)
             per_cam[cam] = time_alone(xyzs, dirs)
             B = int(xyzs.shape[0])
+            if cam in timed_cams and sol_err is None and opt.fp16:
+                try:
+                    sol_cam[cam] = sol_probe(xyzs)
+                except Exception as e:  # noqa: BLE001  (the probe library is a tool: never lose the line to it)
+                    sol_err = "%s: %s" % (type(e).__name__, str(e)[:160])
         if saved is not None:
             st.copy_(saved)
         us_alone = float(np.mean([per_cam[c] for c in timed_cams]))
@@ -693,6 +740,18 @@ def main():
                  "cameras": [c for c in timed_cams], "us_per_camera": [per_cam[c] for c in timed_cams],
                  "timing": "HIP events on the launch stream around %d back-to-back launches (HIP graphs of %d) per camera, nothing else on the "
                            "chip, right after the timed region, on the sample rows of %d cameras of the timed region" % (n_launch, per_graph, len(timed_cams))}
+        # the speed of light of the lookup at THIS launch size on THESE rows (VERDICT r5 "next" 3): `frac` = fraction of 8 TB/s the
+        # gather-only probe reaches; the product kernel's fraction OF that figure is `alone.frac_of_sol` / roofline.frac_of_sol
+        sol = {"error": sol_err} if sol_err else None
+        if sol_cam and sol_err is None:
+            us_sol = float(np.mean([sol_cam[c] for c in timed_cams]))
+            sol = {"us_per_launch": us_sol, "achieved": gbs(us_sol), "frac": gbs(us_sol) / HBM_PEAK_GBS, "cameras": [c for c in timed_cams],
+                   "us_per_camera": [sol_cam[c] for c in timed_cams],
+                   "what": "gather-only probe (tools/probes/hash_sol.hip, all 14 levels in flight): the product kernel's index code, lane mapping "
+                           "and address stream on the same sample rows and the same f16 table -- no blend, no LDS tile, no head; timed like `alone`",
+                   "why_below_peak": "every fine-level corner pair is its own 128-byte line (8 useful bytes) and each of the 8 non-coherent XCD L2s "
+                                     "pulls its own copy of every 2 MB level through the fabric: DESIGN.md (the roofline kernel), profiles/r06_hash_sol_table.txt"}
+            alone["frac_of_sol"] = us_sol / us_alone
         alone_epoch = None
         if us_epoch is not None:
             alone_epoch = {"us_per_launch": us_epoch, "achieved": gbs(us_epoch), "frac": gbs(us_epoch) / HBM_PEAK_GBS, "cameras": epoch_cams,
@@ -752,6 +811,7 @@ def main():
                 "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": bps * Bh, "bytes_per_sample": bps,
                 "bytes_per_sample_fused": 552 if fused else None,
                 "samples_per_launch": Bh, "us_per_launch": head["us_per_launch"], "launches": head.get("launches"),
+                "sol": sol, "frac_of_sol": (sol["us_per_launch"] / head["us_per_launch"]) if (sol and "us_per_launch" in sol) else None,
                 "alone": alone, "alone_epoch": alone_epoch,
                 "alone_next_batch": (None if next_cam is None else {"camera": next_cam, "us_per_launch": per_cam[next_cam], "frac": gbs(per_cam[next_cam]) / HBM_PEAK_GBS,
                                                                     "what": "rounds 1-3's protocol: ONE camera, the batch right behind the timed region"}),
@@ -763,6 +823,8 @@ def main():
         roof = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     samples = int(w.stu.step_counter[:, 0].float().mean().item())
+    bits = w.stu.density_bitfield
+    occupied = float(sum(int(((bits >> k) & 1).sum()) for k in range(8))) / float(bits.numel() * 8)
     total_rays = args.steps * global_rays
     out = {
         "metric": "train rays/s (%s->%s chair distillation step)" % (opt.teacher_type, opt.model_type),
@@ -778,8 +840,8 @@ def main():
         "dtype": "f32" if args.fp32 else "f16 tables+MLP (AMP, as the reference forces) / f32 marcher+compositor",
         "data": "synthetic (analytic chair-like scene, 800x800 Blender-style cameras at r=3.2; no dataset offline)",
         "config": {"workload": "distill %s->%s, synthetic chair, %s cameras, stage 3 (rgb + feature/sigma/colour losses), %d rays/GPU/step, "
-                               "occupancy 128^3 ~5%% occupied, max_steps 1024, teacher pre-trained %d steps%s" % (
-                                   args.teacher, args.student, args.data_type, args.rays, args.teacher_pretrain,
+                               "occupancy 128^3 %.1f%% occupied, max_steps 1024, teacher pre-trained %d steps%s" % (
+                                   args.teacher, args.student, args.data_type, args.rays, 100.0 * occupied, args.teacher_pretrain,
                                    "" if (args.bound == 1.0 and args.dt_gamma == 0.0) else "; bound %g (%d cascades), dt_gamma %g, scene scale %g"
                                    % (args.bound, w.stu.cascade, args.dt_gamma, args.scene_scale)),
                    "rays_per_gpu": args.rays, "parallelism": "ray-dp%d" % world, "launch": launch_mode,
@@ -792,6 +854,9 @@ def main():
                    "untimed_steps_beyond_warmup": (0 if args.eager else 3 * (2 if two_recordings else 1)) + untimed_extra,
                    "capture_fallback": (not args.eager) and not launch_mode.startswith("hipGraph replay"),  # True = the step fell back to eager launches (~5x the ms)
                    "samples_per_step_per_gpu": samples,
+                   # rays/s depends on the scene through the samples a ray generates: the transferable figure is samples/s
+                   "occupied_fraction": occupied, "samples_per_ray": samples / float(args.rays),
+                   "samples_per_s": samples * world * args.steps / elapsed,
                    "padded_rows_per_step": int(w.stu.mean_count) + 128 - int(w.stu.mean_count) % 128,
                    "teacher_psnr_db": w.teacher_psnr,
                    "psnr_student_vs_teacher_db": float(psnr(pred_stu.detach(), pred_tea.detach())) if pred_stu is not None else None,

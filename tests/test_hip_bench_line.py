@@ -51,6 +51,11 @@ def test_single_gpu_line_carries_the_contract():
     # the headline figure is the kernel's duration INSIDE the replayed step, stamped by the launch itself (live, not quoted)
     assert r["in_step"]["timing"].startswith("LIVE") and r["in_step"]["launches"] >= 20 and r["in_step"]["us_per_launch"] > 0
     assert abs(r["us_per_launch"] - r["in_step"]["us_per_launch"]) < 1e-9 and "live" in r["where"]
+    # the lookup's speed of light on the same rows (gather-only probe), and the product kernel's fraction of it
+    assert "error" not in r["sol"], r["sol"]
+    assert 0 < r["sol"]["frac"] < 1 and r["sol"]["us_per_launch"] > 0 and 0 < r["frac_of_sol"] < 1.5
+    assert abs(r["alone"]["frac_of_sol"] - r["sol"]["us_per_launch"] / r["alone"]["us_per_launch"]) < 1e-9
+    assert 0.01 < cfg["occupied_fraction"] < 0.2 and cfg["samples_per_ray"] > 1 and cfg["samples_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     su = d["sustained"]  # a second, longer synchronised window behind the timed one

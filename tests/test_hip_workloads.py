@@ -21,15 +21,15 @@ def _cpu_state(model):
     return {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
 
 
-def _pair(scene_scale=1.0, **opt_kw):
+def _pair(scene_scale=1.0, thicken=0.08, **opt_kw):
     from oracle_ops import oracle_ops
     from pvd.config import PVDConfig
     from pvd.ops import hip_ops
     from pvd.workload import DistillWorkload
     opt_kw = dict(dict(num_rays=512, iters=200, fp16=False), **opt_kw)
     torch.manual_seed(0)
-    gpu = DistillWorkload(hip_ops(), torch.device(DEV), PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale)
-    cpu = DistillWorkload(oracle_ops(), "cpu", PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale)
+    gpu = DistillWorkload(hip_ops(), torch.device(DEV), PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale, thicken=thicken)
+    cpu = DistillWorkload(oracle_ops(), "cpu", PVDConfig(**opt_kw), teacher_pretrain_steps=0, seed=0, scene_scale=scene_scale, thicken=thicken)
     with torch.no_grad():  # weights away from their initialisation (a density field that is not ~constant)
         g = torch.Generator(device=DEV).manual_seed(3)
         for n, p in gpu.tea.named_parameters():

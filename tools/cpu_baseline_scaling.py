@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Why does bench.py's cpu_baseline LOSE throughput from 16 to 128 threads (14.8 k rays/s at 16 threads,
 3.3 k on all 128 physical cores)?  The CPU step is two thread pools working in turn: the oracle's C kernels (OpenMP: march,
-grid / SH encoders, compositing) and PyTorch-CPU (MLP GEMMs, VM grid_sample, autograd, AdamW).  This tool pins them SEPARATELY
-(oracle.set_num_threads vs torch.set_num_threads) and times (a) the whole distillation step for every pair of counts, (b) the
-oracle kernels alone and the torch pieces alone at every count, so the piece that collapses is named.
+grid / SH encoders, compositing) and PyTorch-CPU (MLP GEMMs, VM grid_sample, autograd, AdamW).  This tool times (a) the whole
+distillation step by thread count and (b) the oracle kernels (called directly on preallocated buffers) and the torch pieces alone
+at every count, so the piece that collapses is named.  (The first version pinned the two separately and found that it cannot be done:
+both run on ONE libgomp whose thread count is a single global setting.)
 
     python tools/cpu_baseline_scaling.py [--rays 4096] [--steps 3]        # CPU only, no GPU needed"""
 import argparse
@@ -50,22 +51,23 @@ def main():
     print("host: %d logical cpus; %d rays/step; mean_count %d; torch intra-op default %d, oracle default %d" % (
         ncpu, a.rays, w.stu.mean_count, torch.get_num_threads(), oracle.num_threads()))
 
-    # ---- (a) the whole step, oracle threads x torch threads
-    print("\n(a) whole distillation step, ms (median of %d): rows = oracle (OpenMP) threads, columns = torch threads" % a.steps)
-    print("%8s " % "" + " ".join("%9d" % c for c in counts))
-    grid = {}
-    for no in counts:
-        row = []
-        for nt in counts:
-            oracle.set_num_threads(no)
-            torch.set_num_threads(nt)
-            ms = timed(w.step, a.steps) * 1e3
-            grid[(no, nt)] = ms
-            row.append(ms)
-        print("%8d " % no + " ".join("%9.1f" % v for v in row), flush=True)
-    best = min(grid, key=grid.get)
-    print("best: oracle %d x torch %d threads = %.1f ms = %.0f rays/s; all-%d x all-%d = %.1f ms = %.0f rays/s" % (
-        best[0], best[1], grid[best], a.rays / grid[best] * 1e3, ncpu, ncpu, grid[(ncpu, ncpu)], a.rays / grid[(ncpu, ncpu)] * 1e3))
+    # ---- (a) the whole step.  FINDING of the first run of this tool (profiles/r06_cpu_baseline_scaling.txt): the two "pools" are ONE --
+    # PyTorch-CPU and the oracle library both run on the process's libgomp, whose thread count is a single global setting:
+    # whichever of torch.set_num_threads / omp_set_num_threads is called LAST decides for both (the rows of a 2-D table came out
+    # identical).  So the table is one-dimensional, and the order below (torch first, the oracle's setter last) is what takes effect.
+    def set_threads(n):
+        torch.set_num_threads(n)
+        oracle.set_num_threads(n)
+
+    print("\n(a) whole distillation step by thread count (one shared OpenMP runtime), median of %d" % a.steps)
+    whole = {}
+    for n in counts:
+        set_threads(n)
+        whole[n] = timed(w.step, a.steps) * 1e3
+        print("%8d threads %9.1f ms %9.0f rays/s" % (n, whole[n], a.rays / whole[n] * 1e3), flush=True)
+    best = min(whole, key=whole.get)
+    print("best: %d threads = %.1f ms = %.0f rays/s; %d threads = %.1f ms = %.0f rays/s" % (
+        best, whole[best], a.rays / whole[best] * 1e3, ncpu, whole[ncpu], a.rays / whole[ncpu] * 1e3))
 
     # ---- (b) the pieces alone
     rm = w.stu.rm
@@ -73,22 +75,34 @@ def main():
     o, d = r_o.contiguous().view(-1, 3), r_d.contiguous().view(-1, 3)
     nears, fars = rm.near_far_from_aabb(o, d, w.stu.aabb_train, w.stu.min_near)
 
-    def march():
-        return rm.march_rays_train(o, d, w.stu.bound, w.stu.density_bitfield, w.stu.cascade, w.stu.grid_size, nears, fars, None, -1, False, 128,
-                                   True, 0, 1024)
-    xyzs, dirs, deltas, rays = march()
+    xyzs, dirs, deltas, rays = rm.march_rays_train(o, d, w.stu.bound, w.stu.density_bitfield, w.stu.cascade, w.stu.grid_size, nears, fars, None, -1,
+                                                   False, 128, True, 0, 1024)
     M = xyzs.shape[0]
     enc = w.tea.encoder
     x01 = ((xyzs + w.tea.bound) / (2 * w.tea.bound)).contiguous()
     sig = torch.rand(M)
     rgb = torch.rand(M, 3)
 
+    # the oracle's C kernels called directly on preallocated buffers (through the autograd wrappers a piece also times the wrapper's
+    # single-threaded torch work -- zero fills, the [L,B,C] -> [B,LC] permute -- which hid the kernels' own scaling in the first run)
+    import oracle_backend as ob
+    N = o.shape[0]
+    bufs = dict(xyzs=torch.zeros(M, 3), dirs=torch.zeros(M, 3), deltas=torch.zeros(M, 2), rays=torch.zeros(N, 3, dtype=torch.int32),
+                counter=torch.zeros(2, dtype=torch.int32), enc=torch.empty(14, M, 2), ws=torch.empty(N), depth=torch.empty(N), img=torch.empty(N, 3))
+    emb, offsets = enc.embeddings.detach().contiguous(), enc.offsets
+    S = float(torch.log2(torch.tensor(float(enc.per_level_scale))))
+    bit = w.stu.density_bitfield.contiguous()
+
+    def march():
+        bufs["counter"].zero_()
+        ob.march_rays_train(o, d, bit, float(w.stu.bound), 0.0, 1024, N, int(w.stu.cascade), int(w.stu.grid_size), M, nears, fars, bufs["xyzs"],
+                            bufs["dirs"], bufs["deltas"], bufs["rays"], bufs["counter"], True)
+
     def grid_fwd():
-        with torch.no_grad():
-            return enc(xyzs, bound=w.tea.bound)
+        ob.grid_encode_forward(x01, emb, offsets, bufs["enc"], M, 3, 2, 14, S, int(enc.base_resolution), False, None, 0, False)
 
     def composite():
-        return rm.composite_rays_train(sig, rgb, deltas, rays)
+        ob.composite_rays_train_forward(sig, rgb, deltas, rays, M, N, bufs["ws"], bufs["depth"], bufs["img"])
 
     def teacher_fwd():
         with torch.no_grad():
@@ -117,13 +131,12 @@ def main():
               ("oracle: composite fwd", composite, "omp"), ("mixed: hash teacher forward (oracle grid+SH, torch MLP)", teacher_fwd, "both"),
               ("torch: VM student fwd+bwd (grid_sample x12, MLP)", student_fwd_bwd, "torch"), ("torch: 32-64-64-3 MLP fwd+bwd", mlp_fwd_bwd, "torch"),
               ("torch: AdamW over the student (%.1f M params)" % (sum(p.numel() for p in opt_params) / 1e6), adamw.step, "torch")]
-    print("\n(b) the pieces alone, ms (median of %d); the OTHER pool pinned to 1 thread (mixed: both pools move together)" % a.steps)
+    print("\n(b) the pieces alone by thread count, ms (median of %d)" % a.steps)
     print("%-58s " % "" + " ".join("%8d" % c for c in counts))
     for name, fn, pool in pieces:
         row = []
         for n in counts:
-            oracle.set_num_threads(n if pool in ("omp", "both") else 1)
-            torch.set_num_threads(n if pool in ("torch", "both") else 1)
+            set_threads(n)
             row.append(timed(fn, a.steps) * 1e3)
         print("%-58s " % name + " ".join("%8.1f" % v for v in row), flush=True)
 

@@ -82,6 +82,21 @@ def split(blocks, row_mask=0xFFFFFFFF):
     assert rc == 0, rc
 
 
+stage = torch.zeros(28 * 2 * M, dtype=torch.int32, device=dev)  # 7 levels x 4 y-z corners x (2 lanes per sample): 224 B/sample
+
+
+def split7(what, blocks, row_mask=0xFFFFFFFF):
+    rc = lib.sol_split7(ctypes.c_int(what), p(x01), p(emb16), offs.ctypes.data_as(ctypes.c_void_p), scales.ctypes.data_as(ctypes.c_void_p),
+                        ctypes.c_uint32(M), p(out), p(stage), ctypes.c_uint32(row_mask), ctypes.c_uint32(blocks),
+                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+
+
+def split7_pipeline(blocks):
+    split7(1, blocks)
+    split7(2, 0)
+
+
 def stream(blocks):
     rc = lib.sol_stream(p(stream_src), ctypes.c_size_t(ALG), p(out), ctypes.c_uint32(blocks), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
@@ -123,6 +138,13 @@ ROWS = [
     ("split map, all-hit tables, 2904 wg", lambda: split(2904, row_mask=ALL_HIT), None),
     ("gather levels 0-6 only", lambda: gather(7), None),
     ("gather levels 7-13 only", lambda: gather(8), None),
+    ("gather levels 7-13 only, all-hit", lambda: gather(8, row_mask=ALL_HIT), None),
+    ("split map: levels 7-13, pair-owned rows, 2904 wg", lambda: split7(0, 2904), None),
+    ("split map: levels 7-13, pair-owned rows, 1456 wg", lambda: split7(0, 1456), None),
+    ("split map 7-13 + staging writes (224 B/sample), 2904 wg", lambda: split7(1, 2904), None),
+    ("split map 7-13 + staging writes (224 B/sample), 1456 wg", lambda: split7(1, 1456), None),
+    ("blend side: gather 0-6 + read staged 7-13", lambda: split7(2, 0), None),
+    ("SPLIT PIPELINE: split 7-13 + staging, then blend side", lambda: split7_pipeline(1456), ALG),
     ("gather G=7, 64-sample workgroups", lambda: gather(9), ALG),
     ("gather G=14, 64-sample workgroups", lambda: gather(15), ALG),
     ("gather G=7, 256-sample workgroups", lambda: gather(10), ALG),
@@ -174,12 +196,12 @@ if args.pmc:
     print("samples_per_launch", M)
 else:
     print("samples per launch: %d   algorithmic bytes (516 B/sample): %.2f MB" % (M, ALG / 1e6))
-    print("%-42s %9s %10s %8s" % ("row", "us/launch", "GB/s @516", "of 8TB/s"))
+    print("%-56s %9s %10s %8s" % ("row", "us/launch", "GB/s @516", "of 8TB/s"))
     for name, fn, nbytes in ROWS:
         if args.rows and args.rows not in name:
             continue
         us = timed(fn)
         if nbytes:
-            print("%-42s %9.2f %10.0f %8.3f" % (name, us, nbytes / us / 1e3, nbytes / us / 1e3 / 8000.0))
+            print("%-56s %9.2f %10.0f %8.3f" % (name, us, nbytes / us / 1e3, nbytes / us / 1e3 / 8000.0))
         else:
-            print("%-42s %9.2f" % (name, us))
+            print("%-56s %9.2f" % (name, us))

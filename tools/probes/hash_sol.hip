@@ -28,6 +28,7 @@ struct SolArgs {
     uint32_t *out;         // [2 M]
     uint32_t row_mask;     // 0xffffffff: the real tables
     uint32_t chunk_perm;   // 1: chunk c is processed by workgroup slot (c % 8) * ceil(n / 8) + c / 8 (XCD-contiguous ranges)
+    uint32_t *stage;       // split map with staging: corner values [(level, corner)][2 M] (round 6), or nullptr
 };
 
 template <int FLAVOUR>
@@ -170,7 +171,12 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_gather(SolArgs a) {
 // b runs on XCD b % 8: pair (b % 8) >> 1; the pair's two XCDs take alternate chunks).  An L2 then holds a quarter of every fine
 // level (2 MB in all).  Four passes over the samples' index arithmetic, a quarter of the loads each; what a product kernel would
 // still have to add: the corner values written to a staging buffer and read back by the blending pass.
-template <uint32_t TILE>
+// Round 6 (VERDICT r5 "next" 3): the level range is a parameter (levels [L0, L0 + NL): 10-13 as in round 5, 7-13 = every level that
+// is larger than an L2's share), and with a.stage the owning pair WRITES each corner value it loaded to the staging buffer the
+// blending pass reads back -- what a bit-exact product needs: the reference blends corner by corner in f16 in a fixed order, so the
+// pairs can only deliver VALUES, and a sample's 8 corners of a level hash to rows of different pairs (different XCDs: LDS cannot carry
+// them, the staging goes through memory).
+template <uint32_t TILE, uint32_t L0, uint32_t NL>
 __global__ void __launch_bounds__(2 * TILE) k_sol_split(SolArgs a) {
     const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
     const uint32_t nchunks = (a.M + TILE - 1) / TILE;
@@ -186,10 +192,11 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_split(SolArgs a) {
             for (uint32_t d = 0; d < 3; d++) inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
         }
         uint32_t acc = 0;
-        uint32_t v[4][4];
+        uint32_t v[NL][4];
+        bool mine[NL][4];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t level = 10u + j;
+        for (uint32_t j = 0; j < NL; j++) {
+            const uint32_t level = L0 + j;
             const uint32_t off0 = (uint32_t)a.offs[level];
             const float scale = a.scale[level];
             Level3 lv;
@@ -203,25 +210,87 @@ __global__ void __launch_bounds__(2 * TILE) k_sol_split(SolArgs a) {
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t r = row[k] & a.row_mask;
-                v[j][k] = (((r >> 10) & 3u) == pair) ? table[r] : 0u;
+                mine[j][k] = ((r >> 10) & 3u) == pair;
+                v[j][k] = mine[j][k] ? table[r] : 0u;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.stage) {  // the owner's values to the staging planes: plane (j, k), element 2 b + xb
+            if (b < a.M) {
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++)
+                for (uint32_t j = 0; j < NL; j++)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) acc += v[j][k];
-        if (b < a.M && acc == 0x12345678u) a.out[2 * b + xb] = acc;  // (keeps the loads; the staging write is not part of this probe)
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (mine[j][k]) a.stage[(size_t)(j * 4u + k) * 2u * a.M + 2u * b + xb] = v[j][k];
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < NL; j++)
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) acc += v[j][k];
+            if (b < a.M && acc == 0x12345678u) a.out[2 * b + xb] = acc;  // (keeps the loads)
+        }
+    }
+}
+
+// ... and the blending pass's memory side: the coarse levels [0, L0) gathered as the product does, the NL fine levels' corner values
+// read back from the staging planes (coalesced), one dword written per lane
+template <uint32_t TILE, uint32_t L0, uint32_t NL>
+__global__ void __launch_bounds__(2 * TILE) k_sol_blend_side(SolArgs a) {
+    const uint32_t xb = threadIdx.x & 1u, s_local = threadIdx.x >> 1;
+    const uint32_t nchunks = (a.M + TILE - 1) / TILE;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t b = chunk * TILE + s_local;
+        float x01[3] = {0.f, 0.f, 0.f};
+        bool inside = b < a.M;
+        if (inside) {
+            const Pos3 p = *reinterpret_cast<const Pos3 *>(a.xyz + (size_t)b * 3);
+            x01[0] = p.x; x01[1] = p.y; x01[2] = p.z;
+            for (uint32_t d = 0; d < 3; d++) inside = inside && !(x01[d] < 0.0f) && !(x01[d] > 1.0f);
+        }
+        uint32_t acc = 0;
+        uint32_t v[L0][4];
+        issue<L0, 0>(a, 0u, L0, x01, inside, xb, v);
+        uint32_t w[NL][4];
+        const uint32_t bb = b < a.M ? b : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < NL; j++)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) w[j][k] = a.stage[(size_t)(j * 4u + k) * 2u * a.M + 2u * bb + xb];
+        acc = fold<L0, 0>(0u, L0, v, acc);
+#pragma unroll
+        for (uint32_t j = 0; j < NL; j++)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) acc += w[j][k];
+        if (b < a.M) a.out[2 * b + xb] = acc;
     }
 }
 
 extern "C" int sol_split(const float *xyz, const void *grid, const int32_t *offs_host, const float *scale_host, uint32_t M, uint32_t *out,
                          uint32_t row_mask, uint32_t blocks, void *stream) {
     SolArgs a;
-    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = 0;
+    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = 0; a.stage = nullptr;
     for (int i = 0; i < 15; i++) a.offs[i] = offs_host[i];
     for (int i = 0; i < 14; i++) a.scale[i] = scale_host[i];
-    hipLaunchKernelGGL((k_sol_split<128>), dim3(blocks & ~7u), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_sol_split<128, 10, 4>), dim3(blocks & ~7u), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// levels 7-13; what: 0 = the pair-owned gathers alone, 1 = + staging writes (stage: 28 planes of 2 M dwords), 2 = the blending pass's
+// memory side (coarse levels gathered + staged values read back)
+extern "C" int sol_split7(int what, const float *xyz, const void *grid, const int32_t *offs_host, const float *scale_host, uint32_t M, uint32_t *out,
+                          uint32_t *stage, uint32_t row_mask, uint32_t blocks, void *stream) {
+    SolArgs a;
+    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = 0;
+    a.stage = what == 0 ? nullptr : stage;
+    for (int i = 0; i < 15; i++) a.offs[i] = offs_host[i];
+    for (int i = 0; i < 14; i++) a.scale[i] = scale_host[i];
+    if (what == 2) {
+        const uint32_t nchunks = (M + 127u) / 128u;
+        hipLaunchKernelGGL((k_sol_blend_side<128, 7, 7>), dim3(blocks ? blocks : nchunks), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((k_sol_split<128, 7, 7>), dim3(blocks & ~7u), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return (int)hipGetLastError();
 }
 
@@ -249,7 +318,7 @@ static int launch(const SolArgs &a, uint32_t blocks, hipStream_t s) {
 extern "C" int sol_gather(int variant, const float *xyz, const void *grid, const int32_t *offs_host, const float *scale_host, uint32_t M,
                           uint32_t *out, uint32_t row_mask, uint32_t chunk_perm, uint32_t blocks, void *stream) {
     SolArgs a;
-    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = chunk_perm;
+    a.xyz = xyz; a.grid = (const uint32_t *)grid; a.M = M; a.out = out; a.row_mask = row_mask; a.chunk_perm = chunk_perm; a.stage = nullptr;
     for (int i = 0; i < 15; i++) a.offs[i] = offs_host[i];
     for (int i = 0; i < 14; i++) a.scale[i] = scale_host[i];
     hipStream_t s = (hipStream_t)stream;

@@ -1,49 +1,72 @@
 #!/usr/bin/env python3
-"""The arithmetic behind DESIGN section 10.4: weak-scaling efficiency of the ray-DP step on N GPUs of one node from MEASURED single-box
-quantities and an ASSUMED ring all-reduce bus bandwidth -- nothing here is a measurement of more than one GPU.
+"""The arithmetic behind DESIGN's multi-GPU section: weak-scaling efficiency of the ray-DP step on N GPUs of one node from MEASURED
+single-box quantities and ASSUMED link rates -- nothing here is a measurement of more than one GPU (every gpurun box has one).
 
-  step_1        the plain single-GPU step (bench.py, N = 1)                                          [ms]
-  step_dp       the ray-DP recording in a one-rank RCCL world (PVD_DP_FORCE=1 PVD_DP_PIPELINE=2):    [ms]
-                what every rank executes besides waiting for the exchange
-  bytes         the compact gradient that crosses the links (touched rows, fp32)                     [MB]
-  ring all-reduce of B bytes over N ranks: 2 (N - 1) / N * B / busbw + 2 (N - 1) * hop latency
-  efficiency    step_1 / (step_dp + t_AR - hidden), hidden = what of the exchange an overlap could cover
+  step_1       the plain single-GPU step (bench.py, N = 1)                                                         [ms]
+  step_ar      the ray-DP recording, all-reduce form, in a one-rank RCCL world (PVD_DP_FORCE=1 PVD_DP_PIPELINE=2):  [ms]
+               what every rank executes besides waiting for the wire (profiles/r06_dp_one_rank_forms.txt)
+  step_sh      the same with the sharded update (PVD_DP_EXCHANGE=sharded); at N ranks its AdamW part B walks 1/N of the
+               touched rows: step_sh - part_b * (1 - 1/N)
+  bytes        the compact gradient that crosses the links (touched rows, fp32)                                    [MB]
+  wire, ring   2 (N - 1) / N * B / busbw + 2 (N - 1) hops          (all-reduce; reduce-scatter + all-gather: the same bytes, one more launch)
+  wire, direct reduce-scatter then all-gather on a fully connected node, every GPU sending B / N to each peer over its own xGMI link
+               at once: 2 * (B / N) / (one direction of one link) + two latencies     (/opt/skills guide: 7 links x ~153 GB/s per GPU)
+  efficiency   step_1 / (step_form(N) + wire)          -- the exchange is NOT overlapped with anything (it sits between the table
+               scatter and the update: both ends are on the step's critical chain)
 
-  python tools/scale_model.py [--step1 0.272] [--step-dp 0.316] [--mb 13.3] [--hop-us 4]"""
+  python tools/scale_model.py [--step1 0.2727] [--step-ar 0.2788] [--step-sh 0.2877] [--part-b-us 31.8] [--mb 13.3]"""
 import argparse
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--step1", type=float, default=0.272)
-ap.add_argument("--step-dp", type=float, default=0.316)
+ap.add_argument("--step1", type=float, default=0.2727)
+ap.add_argument("--step-ar", type=float, default=0.2788)
+ap.add_argument("--step-sh", type=float, default=0.2877)
+ap.add_argument("--step-classic", type=float, default=0.3143, help="rounds 1-5's sequence on the same box, for the table's first row")
+ap.add_argument("--part-b-us", type=float, default=31.8, help="AdamW part B over all touched rows (profiles/r06_dp_one_rank_timeline.txt)")
 ap.add_argument("--mb", type=float, default=13.3)
 ap.add_argument("--hop-us", type=float, default=4.0)
+ap.add_argument("--link-gbs", type=float, default=76.8, help="one direction of one xGMI link")
+ap.add_argument("--lat-us", type=float, default=6.0, help="latency of one direct collective")
 a = ap.parse_args()
 
 
-def t_ar_us(n, mb, busbw_gbs):
-    return 2.0 * (n - 1) / n * mb * 1e6 / (busbw_gbs * 1e9) * 1e6 + 2 * (n - 1) * a.hop_us
+def t_ring_us(n, mb, busbw_gbs, launches=1):
+    return 2.0 * (n - 1) / n * mb * 1e6 / (busbw_gbs * 1e9) * 1e6 + 2 * (n - 1) * a.hop_us + (launches - 1) * a.lat_us
 
 
-def t_direct_us(n, mb, link_gbs=76.8, lat_us=6.0):
-    """two-shot all-reduce on a fully connected node: reduce-scatter then all-gather, every GPU sends B / n to each
-    of its n - 1 peers over its own link at the same time: 2 x (B / n) / link bandwidth (one direction of one xGMI link) + two latencies"""
-    return 2.0 * (mb * 1e6 / n) / (link_gbs * 1e9) * 1e6 + 2 * lat_us
+def t_direct_us(n, mb):
+    return 2.0 * (mb * 1e6 / n) / (a.link_gbs * 1e9) * 1e6 + 2 * a.lat_us
 
 
-print("step_1 %.3f ms, ray-DP recording %.3f ms, %.1f MB on the wire in fp32, %.0f us per ring hop" % (a.step1, a.step_dp, a.mb, a.hop_us))
-print("%-44s %8s %8s %8s" % ("", "N = 2", "N = 4", "N = 8"))
-for label, mb, hidden in (("fp32 wire, exchange not overlapped (shipped)", a.mb, 0.0),
-                          ("16-bit wire (PVD_DP_WIRE, opt-in)", a.mb / 2, 0.0),
-                          ("fp32 wire, two of three buckets under the scatter", a.mb, 66.0),
-                          ("16-bit wire + bucket overlap", a.mb / 2, 66.0)):
-    for bw in (100.0, 150.0, 200.0):
-        eff = []
-        for n in (2, 4, 8):
-            t = max(t_ar_us(n, mb, bw) - hidden, 0.0)
-            eff.append(a.step1 * 1e3 / (a.step_dp * 1e3 + t))
-        print("%-44s %8.2f %8.2f %8.2f   (bus bandwidth %3.0f GB/s: t_AR(8) = %3.0f us)" % (label, eff[0], eff[1], eff[2], bw, t_ar_us(8, mb, bw)))
+def step_sharded_ms(n):
+    return a.step_sh - a.part_b_us * 1e-3 * (1.0 - 1.0 / n)
 
-for label, mb, hidden in (("direct two-shot over all 7 links, fp32", a.mb, 0.0), ("direct two-shot, 16-bit wire", a.mb / 2, 0.0),
-                          ("direct two-shot, fp32, bucket overlap", a.mb, 66.0)):
-    eff = [a.step1 * 1e3 / (a.step_dp * 1e3 + max(t_direct_us(n, mb) - hidden, 0.0)) for n in (2, 4, 8)]
-    print("%-44s %8.2f %8.2f %8.2f   (76.8 GB/s per link and direction: t_AR(8) = %3.0f us)" % (label, eff[0], eff[1], eff[2], t_direct_us(8, mb)))
+
+print("measured on one MI355X: step_1 %.4f ms; one-rank RCCL recording: classic %.4f, all-reduce form %.4f, sharded form %.4f ms "
+      "(its AdamW part B: %.1f us over all rows); %.1f MB on the wire in fp32" % (a.step1, a.step_classic, a.step_ar, a.step_sh, a.part_b_us, a.mb))
+print("assumed: ring hop %.0f us; direct exchange over %d-1 links at %.1f GB/s per link and direction, %.0f us per collective" % (
+    a.hop_us, 8, a.link_gbs, a.lat_us))
+print("%-66s %7s %7s %7s" % ("form of the step, wire model", "N = 2", "N = 4", "N = 8"))
+rows = []
+for bw in (100.0, 150.0, 200.0):
+    rows.append(("rounds 1-5 sequence (classic), ring all-reduce at %3.0f GB/s" % bw,
+                 [a.step1 / (a.step_classic + t_ring_us(n, a.mb, bw) * 1e-3) for n in (2, 4, 8)], "t_wire(8) = %3.0f us" % t_ring_us(8, a.mb, bw)))
+for bw in (100.0, 150.0, 200.0, 300.0):
+    rows.append(("all-reduce form (default), ring at %3.0f GB/s bus bandwidth" % bw,
+                 [a.step1 / (a.step_ar + t_ring_us(n, a.mb, bw) * 1e-3) for n in (2, 4, 8)], "t_wire(8) = %3.0f us" % t_ring_us(8, a.mb, bw)))
+for bw in (150.0, 300.0):
+    rows.append(("sharded update, reduce_scatter + all_gather as rings at %3.0f GB/s" % bw,
+                 [a.step1 / (step_sharded_ms(n) + t_ring_us(n, a.mb, bw, launches=2) * 1e-3) for n in (2, 4, 8)],
+                 "t_wire(8) = %3.0f us" % t_ring_us(8, a.mb, bw, launches=2)))
+rows.append(("all-reduce form, direct exchange over all links",
+             [a.step1 / (a.step_ar + t_direct_us(n, a.mb) * 1e-3) for n in (2, 4, 8)], "t_wire(8) = %3.0f us" % t_direct_us(8, a.mb)))
+rows.append(("sharded update, direct reduce_scatter + all_gather",
+             [a.step1 / (step_sharded_ms(n) + t_direct_us(n, a.mb) * 1e-3) for n in (2, 4, 8)], "t_wire(8) = %3.0f us" % t_direct_us(8, a.mb)))
+rows.append(("sharded update, direct, 16-bit wire (PVD_DP_WIRE: all-reduce form only today)",
+             [a.step1 / (step_sharded_ms(n) + t_direct_us(n, a.mb / 2) * 1e-3) for n in (2, 4, 8)], "t_wire(8) = %3.0f us" % t_direct_us(8, a.mb / 2)))
+for label, eff, note in rows:
+    print("%-66s %7.2f %7.2f %7.2f   (%s)" % (label, eff[0], eff[1], eff[2], note))
+# the bound no schedule of an un-overlapped fp32 exchange of this size beats: all 7 links of a GPU busy in both phases, zero recording tax
+floor = 2.0 * (7.0 / 8.0) * a.mb * 1e6 / (7 * a.link_gbs * 1e9) * 1e6
+print("bound at N = 8: 2 x 7/8 x %.1f MB over 7 x %.1f GB/s = %.0f us on the wire -> %.2f with no recording tax at all; 0.85 needs <= %.0f us of "
+      "wire + tax per step" % (a.mb, a.link_gbs, floor, a.step1 / (a.step1 + floor * 1e-3), (a.step1 / 0.85 - a.step1) * 1e3))
