@@ -2182,27 +2182,11 @@ int pvd_infer_image_vm(const float *rays_o, const float *rays_d, const float *ne
                                   depth, image_out, s);
     if (prc != PVD_OK) return prc;
     // 128 sample rows per local round, shaded through a 64-row feature tile in two passes: 47 KB of LDS and (by launch bounds) 168
-    // VGPRs = THREE workgroups per CU.  PVD_INFER_VM_ROWS (measurement): 128 = the feature tile holds all 128 rows (67 KB, ~190 VGPRs:
-    // two per CU), 64 = 64-row rounds (three per CU)
-    static int rows = -1;
-    if (rows < 0) { const char *e = getenv("PVD_INFER_VM_ROWS"); rows = e ? atoi(e) : 0; }
+    // VGPRs = THREE workgroups per CU (a 128-row feature tile -- 67 KB, ~190 VGPRs, two per CU -- and 64-row rounds were measured and
+    // removed: profiles/r05_render_vm.txt)
     uint32_t blocks = div_up(N, 64u);
-    const uint32_t cap = rows == 128 ? 512u : 768u;
-    if (blocks > cap) blocks = cap;  // persistent
-    if (rows == 64) {
-        hipLaunchKernelGGL((k_infer_vm_persistent<64, 64, 64, 3>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<64, 64>()), s, a, tb, q);
-    } else if (rows == 128) {
-        static bool attr_set = false;
-        if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_infer_vm_persistent<64, 128, 128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)infer_vm_persistent_lds_bytes<128, 128>()) != hipSuccess)
-                return PVD_ERR_LAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128, 128, 1>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<128, 128>()), s, a, tb, q);
-    } else {
-        hipLaunchKernelGGL((k_infer_vm_persistent<64, 128, 64, 3>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<128, 64>()), s, a, tb, q);
-    }
+    if (blocks > 768u) blocks = 768u;  // persistent
+    hipLaunchKernelGGL((k_infer_vm_persistent<64, 128, 64, 3>), dim3(blocks), dim3(kHeadBlock), (infer_vm_persistent_lds_bytes<128, 64>()), s, a, tb, q);
     return check_launch();
 }
 

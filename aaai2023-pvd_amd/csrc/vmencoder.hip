@@ -433,15 +433,6 @@ static uint32_t pick_chunk(uint32_t M, bool backward) {
     // A wave walks its run of samples serially, and every step that moves a window waits for a memory round trip
     // (load of the entering texels / the atomics' addresses): the launch lasts as long as ONE wave's chain, so runs
     // are kept short as long as the chip is not oversubscribed several times; longer runs only buy window reuse.
-    // PVD_VM_CHUNK_FWD / PVD_VM_CHUNK_BWD override (measurement).
-    static int env_f = -1, env_b = -1;
-    if (env_f < 0) {
-        const char *f = getenv("PVD_VM_CHUNK_FWD"), *b = getenv("PVD_VM_CHUNK_BWD");
-        env_f = f ? atoi(f) : 0;
-        env_b = b ? atoi(b) : 0;
-    }
-    const int forced = backward ? env_b : env_f;
-    if (forced >= 1 && forced <= 64) return (uint32_t)forced;
     if (backward) {  // three factor sets per run (blockIdx.y): long runs merge the most atomics; keep >= 3072 waves
         uint32_t chunk = 64;
         while (chunk > 16 && 3ull * M / chunk < 3072ull) chunk >>= 1;

@@ -464,9 +464,9 @@ class DistillTrainer(_TrainerBase):
             ride = None
             # (under ray-DP too, since round 6: ONE all-reduce of the forward launch's partial sums -- a count that is the same on every
             # rank, ~20 KB -- sits between the two compositing launches and the backward launch finishes the objective from the summed
-            # partials; PVD_DP_RIDE=0: the four separate objective launches of rounds 1-5)
+            # partials; PVD_DP_EXCHANGE=classic keeps the four separate objective launches of rounds 1-5)
             l1_on_host = o.l1_reg_weight > 0.0 and o.model_type == "vm" and not self.flat_opt
-            dp_ride = self.dp.enabled and not l1_on_host and os.environ.get("PVD_DP_RIDE", "1") != "0"
+            dp_ride = self.dp.enabled and not l1_on_host and os.environ.get("PVD_DP_EXCHANGE", "allreduce") != "classic"
             if (self.fused_loss is not None and o.loss_type == "normL2" and (not self.dp.enabled or dp_ride) and torch.is_grad_enabled()
                     and self._stage_of(self.global_step) == 3 and out_tea.get("image") is not None
                     and min(o.loss_rate_color, o.loss_rate_sigma, self.loss_rate_fea_sc * 0.995, o.loss_rate_rgb) > 0.0

@@ -449,10 +449,6 @@ def grid_set_fwd_kernel(lanes_per_sample=2, persistent_blocks=4096):
     return rc
 
 
-if os.environ.get("PVD_GRID_LPS"):  # A/B knob: PVD_GRID_LPS=2 [PVD_GRID_PERSIST=4096]
-    grid_set_fwd_kernel(int(os.environ["PVD_GRID_LPS"]), int(os.environ.get("PVD_GRID_PERSIST", "0")))
-
-
 # --------------------------------------------------------------------------- _shencoder
 def sh_encode_forward(inputs, outputs, B, D, C, calc_grad_inputs, dy_dx):
     dev = _dev(inputs, outputs, dy_dx)

@@ -85,9 +85,9 @@ def test_two_ranks_segmented_graph_capture(tmp_path):
     _same_training(*runs)
 
 
-def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1", exchange=None, ride="1"):
+def _rccl_worker(rank, port, out_path, ingraph, steps_per_graph=1, pipeline="1", exchange=None):
     os.environ.update(PVD_DP_FORCE="1", PVD_DP_OVERLAP="1", PVD_DP_INGRAPH="1" if ingraph else "0", PVD_DP_PIPELINE=pipeline,
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PVD_DP_RIDE=ride)
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if exchange is not None:
         os.environ["PVD_DP_EXCHANGE"] = exchange
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
@@ -164,9 +164,9 @@ def test_rccl_in_graph_round6_exchange_forms(tmp_path):
     -> parameters) all CAPTURE and REPLAY under RCCL and train like rounds 1-5's sequence; step count, learning rates, loss scale
     are equal bit for bit."""
     runs = {}
-    for name, exchange, ride in (("classic", "classic", "0"), ("allreduce", "allreduce", "1"), ("sharded", "sharded", "1")):
+    for name in ("classic", "allreduce", "sharded"):
         out = str(tmp_path / ("r6_%s.pt" % name))
-        mp.spawn(_rccl_worker, args=(_free_port(), out, True, 4, "2", exchange, ride), nprocs=1, join=True)
+        mp.spawn(_rccl_worker, args=(_free_port(), out, True, 4, "2", name), nprocs=1, join=True)
         runs[name] = torch.load(out)
         losses = runs[name]["losses"]
         assert len(losses) == 10 and all(l == l for l in losses) and losses[-1] < losses[0]

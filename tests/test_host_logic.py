@@ -339,3 +339,26 @@ def test_carried_prefix_keeps_views_and_copies_storage_by_storage():
     bad["inh"][0] = torch.rand(9, 3)
     with pytest.raises(AssertionError):
         c.store(bad)
+
+
+def test_every_environment_switch_is_registered():
+    """aaai2023-pvd_amd/pvd/knobs.py is the one place a reader finds the PVD_* switches: every name the product sources (Python and
+    the C side's getenv) or bench.py read must be in it, and it must not list names nothing reads."""
+    import os
+    import re
+    from pvd import knobs
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.join(REPO, "aaai2023-pvd_amd")
+    read = set()
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py") and not path.endswith(os.path.join("pvd", "knobs.py")):
+                src = open(path).read()
+                read |= set(re.findall(r'environ(?:\.get|\.setdefault)?[\(\[]\s*"(PVD_[A-Z0-9_]+)"', src))
+            elif f.endswith((".hip", ".h")):
+                read |= set(re.findall(r'getenv\("(PVD_[A-Z0-9_]+)"\)', open(path).read()))
+    read |= set(re.findall(r'environ(?:\.get|\.setdefault)?[\(\[]\s*"(PVD_[A-Z0-9_]+)"', open(os.path.join(REPO, "bench.py")).read()))
+    assert read - set(knobs.ALL) == set(), "unregistered switches: %s" % sorted(read - set(knobs.ALL))
+    assert set(knobs.ALL) - read == set(), "registered but read by nothing: %s" % sorted(set(knobs.ALL) - read)
+    assert len(knobs.PRODUCTION) <= 8
