@@ -128,6 +128,18 @@ class BlenderScene:
         return out
 
 
+    def update_error(self, batch, error):
+        """reference: the error-map update at the end of train_step (distill_mutual/utils.py:1120-1129, --error_map): the per-ray error
+        [B, N] of the batch `self.batch()` returned goes into the frames' maps as an EMA at the cells the rays were drawn from,
+        and the updated rows are PUT BACK (indexing with a list copies)."""
+        if self.error_map is None or "inds_coarse" not in batch:
+            return
+        from .scene import update_error_map
+        idx = torch.as_tensor(batch["index"], dtype=torch.long, device=self.error_map.device)
+        rows = update_error_map(self.error_map[idx], batch["inds_coarse"].to(self.error_map.device), error.reshape(len(idx), -1))
+        self.error_map[idx] = rows
+
+
 def training_target(images, generator=None, bg_radius=-1):
     """Ground-truth pixels and the background they were blended over (reference train_step, utils.py:980-1001):
     RGB images train against a white background; RGBA images against a random colour per ray, blended by alpha."""

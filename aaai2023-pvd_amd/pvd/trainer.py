@@ -833,7 +833,9 @@ class TeacherTrainer(_TrainerBase):
         super().__init__(opt, model, lr, device, fp16, dp, exp_decay=True)
         self.model.train()
 
-    def train_step(self, rays_o, rays_d, gt_rgb, bg_color):
+    def train_step(self, rays_o, rays_d, gt_rgb, bg_color, error_sink=None):
+        """error_sink (optional): called with the step's per-ray error [.., N] (mean over the channels of the squared difference, detached)
+        -- what --error_map feeds back into the data provider's sampling weights (utils.py:1120-1129; BlenderScene.update_error)."""
         o, m = self.opt, self.model
         if m.cuda_ray and self.global_step % o.update_extra_interval == 0:
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
@@ -843,9 +845,12 @@ class TeacherTrainer(_TrainerBase):
             out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                            dt_gamma=o.dt_gamma, max_steps=o.max_steps, num_steps=o.num_steps, upsample_steps=o.upsample_steps)
             pred = out["image"]
-            loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
+            sq = (pred.float() - gt_rgb.float()) ** 2
+            loss = self.dp.global_mean(sq)
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
                 loss = loss + self._l1_term()
+        if error_sink is not None:
+            error_sink(sq.detach().mean(-1))
         self._backward_and_step(loss)
         return loss.detach(), pred
 

@@ -303,13 +303,27 @@ def teacher_workload(args, dev):
         # a Blender-format scene on disk through the reference-shaped reader (pvd/provider.py <- distill_mutual/provider.py:133-326):
         # frames + cameras from transforms_train.json, ground truth = the PNGs' pixels blended over a random background by their alpha
         from pvd.provider import BlenderScene, training_target
-        scene = BlenderScene(args.data_root, "train", scale=opt.scale, device=dev, num_rays=opt.num_rays)
+        scene = BlenderScene(args.data_root, "train", scale=opt.scale, device=dev, num_rays=opt.num_rays, error_map=args.error_map)
+        if args.error_map:
+            # the reference's --error_map loop (utils.py:1120-1129): every step draws its pixels by the frame's current map and feeds the
+            # per-ray error back -- the batch depends on the previous step's result, so these steps run eagerly, outside the timed blocks
+            args.eager = True
+            em_losses = []
+            for it in range(32):
+                b = scene.batch([it % len(scene)], generator=w.gen)
+                gt, bg = training_target(b["images"], generator=w.gen)
+                l, _ = tr.train_step(b["rays_o"], b["rays_d"], gt, bg, error_sink=lambda e, b=b: scene.update_error(b, e))
+                em_losses.append(float(l))
+            data_note = "; --error_map: 32 eager steps drew their pixels by the per-frame error map (map range %.3g .. %.3g after them)" % (
+                float(scene.error_map.min()), float(scene.error_map.max()))
+        else:
+            data_note = ""
         for it in range(16):
             b = scene.batch([it % len(scene)], generator=w.gen)
             gt, bg = training_target(b["images"], generator=w.gen)
             batches.append((b["rays_o"], b["rays_d"], gt, bg))
         data = "Blender-format scene read by pvd/provider.py from %s: %d train views of %dx%d (tools/make_blender_scene.py: the synthetic chair written to disk)" % (
-            args.data_root, len(scene), scene.W, scene.H)
+            args.data_root, len(scene), scene.W, scene.H) + data_note
     else:
         for it in range(16):
             r = get_rays(w.poses[it % len(w.poses)][None], BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=w.gen)
@@ -426,6 +440,8 @@ def main():
     ap.add_argument("--teacher", type=str, default="hash", help="teacher model type (configs[3]: mlp)")
     ap.add_argument("--data-root", type=str, default=None,
                     help="--workload teacher: train from a Blender-format scene on disk (transforms_train.json + PNGs) through pvd/provider.py")
+    ap.add_argument("--error-map", action="store_true",
+                    help="--workload teacher --data-root: sample pixels by the per-image error map and update it every step (the reference's --error_map; eager steps)")
     ap.add_argument("--scene-scale", type=float, default=1.0, help="scale of the synthetic scene (with --bound > 1)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="after the timed region: this many more steps in one synchronised window (`sustained`); 0 = skip")
@@ -767,7 +783,7 @@ def main():
         # profiles/, is kept next to it as the outside view of the same quantity when it was taken on this build of the kernel
         # (under the profiler the graph's kernels overlap less, so that figure is the shorter one).
         in_step = None
-        rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r05_in_step.json", "r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
+        rec_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r06_in_step.json", "r05_in_step.json", "r04_in_step.json", "r03_in_step.json")) if os.path.exists(q)), None)
         if fused and rec_path:
             rec = json.load(open(rec_path))
             if rec.get("source_sha16") == kernel_source_sha16():
@@ -790,7 +806,7 @@ def main():
         # always in the object
         head = in_step if in_step is not None else alone
         traffic, traffic_note = None, "no PMC pass recorded for this build of the kernel"
-        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
+        pmc_path = next((q for q in (os.path.join(REPO, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"))
                          if os.path.exists(q)), None)
         if pmc_path:  # FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of THIS kernel source
             pmc = json.load(open(pmc_path))
@@ -816,7 +832,7 @@ def main():
                 "alone_next_batch": (None if next_cam is None else {"camera": next_cam, "us_per_launch": per_cam[next_cam], "frac": gbs(per_cam[next_cam]) / HBM_PEAK_GBS,
                                                                     "what": "rounds 1-3's protocol: ONE camera, the batch right behind the timed region"}),
                 "in_step": in_step, "in_step_rocprof": in_step_rocprof if in_step_rocprof is not in_step else None,
-                "rederive": "python tools/roofline_from_profile.py  (profiles/r05_kernel_populations.txt + r05_bench_profiled_line.json + r05_kernel_stats.csv)"}
+                "rederive": "python tools/roofline_from_profile.py  (profiles/r06_kernel_populations.txt + r06_bench_profiled_line.json + r06_kernel_stats.csv)"}
     except LookupError as e:
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "note": str(e)}
     except Exception as e:  # noqa: BLE001  (never lose the throughput line to the roofline measurement)

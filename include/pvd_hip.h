@@ -273,7 +273,12 @@ typedef struct pvd_head_dw_rider {
      * here): pvd_vm_backward_rider's launch stores 1 into it when an incoming gradient value it reads (grad_sigma_feat,
      * grad_color_prod) or a sum it adds into gW* is inf / nan -- GradScaler's inf check of everything this launch completes (the
      * twelve table gradients are sums of those values times finite interpolation weights and table entries; the four weight
-     * gradients), folded into the launch, so that the step's chain has no separate check between the scatter and the update. */
+     * gradients), folded into the launch, so that the step's chain has no separate check between the scatter and the update.
+     * LIMIT of the folded check (it looks at the launch's INPUTS and the weight-gradient sums, not at the table gradients it writes): it
+     * is GradScaler's check exactly when finite inputs imply finite table gradients -- finite table entries, and no fp32 overflow of a
+     * product or of the accumulated sums (under AMP the inputs are loss-scaled f16-range values times weights in [0, 1] and table
+     * entries: orders of magnitude below 3e38).  A caller that cannot promise finite tables runs pvd_check_finite / pvd_segments_op(3) on
+     * the gradients instead (the harness: PVD_INF_CHECK_RIDE=0; under ray-DP the exchange's gather looks at the written values). */
     float *found_inf;
 } pvd_head_dw_rider;
 int pvd_vm_backward_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,

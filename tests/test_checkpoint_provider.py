@@ -203,3 +203,30 @@ def test_blender_scene_reader(tmp_path, alpha):
     assert (half.H, half.W) == (6, 8)
     blocks = (images.astype(np.float32) / 255).reshape(3, 6, 2, 8, 2, -1).mean(axis=(2, 4))
     assert np.abs(half.images.numpy() - blocks).max() <= 1.01 / 255  # 8-bit result: the rounding of the average
+
+
+def test_error_map_sampling_loop_feeds_back(tmp_path):
+    """--error_map end to end on the provider side (the update used to be unwired): batches carry `index` / `inds_coarse`,
+    BlenderScene.update_error puts the EMA rows BACK into the frame's map (utils.py:1120-1129), untouched frames and cells keep
+    their weights, and the next draw of that frame follows the updated map."""
+    from pvd.provider import BlenderScene
+    root = str(tmp_path)
+    _write_scene(root, alpha=True, H=256, W=256)
+    sc = BlenderScene(root, "train", scale=0.8, num_rays=64, error_map=True)
+    assert sc.error_map.shape == (3, 128 * 128) and float(sc.error_map.min()) == 1.0
+    g = torch.Generator().manual_seed(3)
+    b = sc.batch([1], generator=g)
+    assert b["index"] == [1] and b["inds_coarse"].shape == (1, 64)
+    err = torch.zeros(1, 64)  # "these rays are already perfect": their cells drop to 0.1, everything else keeps weight 1
+    sc.update_error(b, err)
+    row = sc.error_map[1]
+    assert torch.allclose(row[b["inds_coarse"][0]], torch.full((64,), 0.1)) and int((row != 1.0).sum()) == len(set(b["inds_coarse"][0].tolist()))
+    assert float(sc.error_map[0].min()) == 1.0 and float(sc.error_map[2].min()) == 1.0
+    # a very wrong batch on the same frame: its cells now weigh 0.1 * old + 0.9 * 50
+    b2 = sc.batch([1], generator=g)
+    sc.update_error(b2, torch.full((1, 64), 50.0))
+    hot = set(b2["inds_coarse"][0].tolist())
+    assert all(float(sc.error_map[1, c]) > 40.0 for c in hot)
+    # ... and the next draw of that frame concentrates on them (64 draws without replacement from weights ~45 vs ~1 over 16 k cells)
+    b3 = sc.batch([1], generator=g)
+    assert len(hot & set(b3["inds_coarse"][0].tolist())) >= 8

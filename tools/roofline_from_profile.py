@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Re-derive bench.py's `roofline` figures from the committed rocprofv3 evidence, without a GPU:
 
-    python tools/roofline_from_profile.py [profiles/r05_kernel_populations.txt] [profiles/r05_bench_profiled_line.json] [profiles/r05_kernel_stats.csv]
+    python tools/roofline_from_profile.py [profiles/r06_kernel_populations.txt] [profiles/r06_bench_profiled_line.json] [profiles/r06_kernel_stats.csv]
 
   kernel_populations.txt   tools/kernel_populations.py over the kernel trace of `rocprofv3 --kernel-trace --stats -- python bench.py
                            <the driver's arguments>`: the launches of the roofline kernel split into those that have the chip to
@@ -21,9 +21,9 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(REPO, "profiles")
-pops = sys.argv[1] if len(sys.argv) > 1 else os.path.join(P, "r05_kernel_populations.txt")
-line = sys.argv[2] if len(sys.argv) > 2 else os.path.join(P, "r05_bench_profiled_line.json")
-stats = sys.argv[3] if len(sys.argv) > 3 else os.path.join(P, "r05_kernel_stats.csv")
+pops = sys.argv[1] if len(sys.argv) > 1 else os.path.join(P, "r06_kernel_populations.txt")
+line = sys.argv[2] if len(sys.argv) > 2 else os.path.join(P, "r06_bench_profiled_line.json")
+stats = sys.argv[3] if len(sys.argv) > 3 else os.path.join(P, "r06_kernel_stats.csv")
 
 d = json.loads([l for l in open(line).read().splitlines() if l.startswith("{")][-1])
 r = d["roofline"]
