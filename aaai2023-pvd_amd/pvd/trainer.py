@@ -367,7 +367,9 @@ class _TrainerBase:
         self.dp.capture = None
         self._fold_launches(False)
         self._graph_zeroes = False
+        self._after_update = None  # (a sharded update recorded half way: its all-gather belongs to a step that never ran)
         if self.flat_opt:
+            self.optimizer._compact = None  # an exchange buffer handed over to an update that never came
             self.optimizer._half_grad = None  # a half-precision table gradient handed over by a backward whose update never came
             self.optimizer._part_a_owed = None  # (a two-part update recorded half way: nothing of it ran)
             self.optimizer.end_two_part(failed=True)

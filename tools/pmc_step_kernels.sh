@@ -6,7 +6,7 @@ mkdir -p "$GRAFT_REPO_ROOT/gpurun_out/$OUT"
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 : > gpurun_out/$OUT/pmc_step_kernels.csv
-for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCC_REQ_sum TCC_MISS_sum"; do
+for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCC_REQ_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
   (cd /tmp && rm -rf /tmp/pmcs_$n && timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 5 --teacher-pretrain 20 --no-cpu-baseline --no-psnr --sustained-steps 0 --eager > /tmp/pmcs_$n.log 2>&1)
   f=$(find /tmp/pmcs_$n -name "*counter_collection.csv" | head -1)
