@@ -188,10 +188,13 @@ class FlatAdamW(torch.optim.Optimizer):
     _compact = None
 
     def compact_ready(self):
-        """May the coming step() take its gradient from a compact exchange buffer?  Only the two-part form walks the touched set as a
-        list of its own (part B), and only with nothing else pending."""
+        """May the coming step() take its gradient from a compact exchange buffer?  The update must walk the touched set as a LIST of its
+        own: part B of the two-part form, or the single launch of a model whose warm groups ARE the touched set (no L1-only rows, no
+        moments still decaying elsewhere: the Plenoxel student) -- and nothing else may be pending."""
         lazy = self._lazy_state() if (self.touched is not None and self._outside_is_zero and not self._cold_dirty and self._cold_bits is not None) else None
-        return bool(lazy is not None and self._two_part_now((lazy[0], lazy[1], None)))
+        if lazy is None or getattr(self, "_half_grad", None) is not None or getattr(self, "_warm_B", None) is None or self._warm_B.numel() == 0:
+            return False
+        return bool(self._two_part_now((lazy[0], lazy[1], None)) or (not self.two_part and self._warm_A.numel() == 0))
 
     def take_compact(self, grad, flag, clear, rows, param_out=None):
         """grad: f32, four floats per list entry of rows = (first, one past last) of the part-B list; flag: f32 [1] view = the
@@ -442,7 +445,8 @@ class FlatAdamW(torch.optim.Optimizer):
         zero_after = bool(self.zero_in_step and getattr(self, "_half_grad", None) is None
                           and self.touched is not None and self._outside_is_zero and cold is not None and lazy is not None and len(lazy) >= 3)
         cg, self._compact = self._compact, None
-        assert cg is None or two, "a compact gradient was handed over (take_compact) but the update is not in its two-part form"
+        assert cg is None or two or (lazy is not None and len(lazy) >= 3 and self._warm_A.numel() == 0), \
+            "a compact gradient was handed over (take_compact) but the update does not walk the touched set as a list of its own"
         if two:
             # part B (what the backward may have written) + the tail, which records the scalars this step used; part A is owed
             # the step's record: two buffers taken in turn (part A of step k may still be reading its own while step k + 1 writes), and
@@ -471,8 +475,12 @@ class FlatAdamW(torch.optim.Optimizer):
                                d["eps"], d["weight_decay"], self.step_count, getattr(self, "grad_scale", None), getattr(self, "found_inf", None),
                                schedule=getattr(self, "_schedule", None), l1_ranges=getattr(self, "_l1", None),
                                amp_update=getattr(self, "amp_update", None), half_grad=getattr(self, "_half_grad", None),
-                               l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold, lazy=lazy, zero_after=zero_after,
-                               arrivals=self._tail_in_kernel())
+                               l1_next=(st["buf"], st["scale"]) if st is not None else None, cold_bits=cold,
+                               lazy=lazy if cg is None else (lazy[0], lazy[1], self._warm_B[cg["rows"][0]:cg["rows"][1]]),
+                               zero_after=zero_after and cg is None, arrivals=self._tail_in_kernel(),
+                               **({} if cg is None else dict(compact_grad=cg["grad"], compact_param_out=cg["param_out"], tail_clear=cg["clear"])))
+            if cg is not None:
+                zero_after = True  # (the exchange's gather zeroed every touched row behind itself)
         self._zeroed_by_step = zero_after
         self._half_grad = None
         self._half_range_dirty = False

@@ -712,9 +712,10 @@ class DistillTrainer(_TrainerBase):
         if late:
             # ... and the LAST step's deferred part rides on the next replay's first branch instead of trailing the graph
             self.optimizer.carry_last = True
-        if late and self.dp.enabled:
-            # round 6: the recorded steps' exchange feeds part B directly (gather that zeroes and checks -> collective -> update); the
-            # layout is built here, outside the recording, and the steps record no zero_grad of their own after the first
+        if self.dp.enabled and self.flat_opt:
+            # round 6: the recorded steps' exchange feeds the update directly (gather that zeroes and checks -> collective -> part B, or
+            # the single launch of a student without deferred rows); the layout is built here, outside the recording, and the steps
+            # record no zero_grad of their own after the first
             self.prepare_exchange()
             if self._exchange_mode(self._grad_compactor()) is not None:
                 self._fold_launches(True)

@@ -102,8 +102,11 @@ def test_teacher_block_graph_follows_the_eager_run_across_grid_updates():
                 losses.append(float(loss))
                 counts.append(int(tea.mean_count))
         assert tr.global_step == 64 and tr.scheduler.last_epoch == 64
-        runs.append((losses, counts, float(tr.optimizer.lr_dev[0])))
-    (la, ca, lra), (lb, cb, lrb) = runs
+        runs.append((losses, counts, float(tr.optimizer.lr_dev[0]), float(tr.optimizer.step_count), float(tr.scaler.get_scale())))
+    (la, ca, lra, sa, sca), (lb, cb, lrb, sb, scb) = runs
+    # the deterministic quantities bit for bit: a missed or doubled update, a skipped step or a schedule tick out of place
+    # shows here whatever the float atomics do to the losses
+    assert sa == sb and sa >= 60.0 and sca == scb, (sa, sb, sca, scb)
     assert np.allclose(la[:16], lb[:16], rtol=1e-3)  # the eager prefix is the same run (up to the order of the scatter-add atomics)
     # (atomics and update_extra_state's random cells: same statistics, not the same bits)
     assert np.allclose(la[16:], lb[16:], rtol=0.15), (la[16:], lb[16:])  # (0.08 failed once in ~5 runs at 0.092: one batch's loss after 64 steps)

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out_path):
+def _worker(rank, world, port, mode, out_path, student="vm"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PVD_DP_EXCHANGE=mode)
     for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
         if p not in sys.path:
@@ -43,15 +43,21 @@ def _worker(rank, world, port, mode, out_path):
     from pvd.trainer import RayDP
     from pvd.workload import DistillWorkload
     dp = RayDP()
-    w = DistillWorkload(hip_ops(), dev, PVDConfig(num_rays=1024, resolution0=64, iters=300), teacher_pretrain_steps=0, seed=0, dp=dp)
+    kw = dict(resolution0=64) if student == "vm" else dict(model_type="tensors", plenoxel_res="[64,64,64]")
+    w = DistillWorkload(hip_ops(), dev, PVDConfig(num_rays=1024, iters=300, **kw), teacher_pretrain_steps=0, seed=0, dp=dp)
     tr = w.trainer
     o = tr.optimizer
     tr.scaler.scale(torch.zeros((), device=dev))  # (creates the device-side loss scale)
-    tr._l1_term(partials_only=True)               # the L1 regulariser folded into the update: rows that are warm without a gradient
+    if student == "vm":
+        tr._l1_term(partials_only=True)           # the L1 regulariser folded into the update: rows that are warm without a gradient
     tr._zero_grads()                              # builds the compactor / touched set, one full clear
     c = tr._grad_compactor()
     assert c is not None and c is o.touched and c.fraction < 0.7
-    assert o.begin_two_part(defer=False)          # the update in its two-part form, eagerly (part A right behind part B)
+    if student == "vm":
+        assert o.begin_two_part(defer=False)      # the update in its two-part form, eagerly (part A right behind part B)
+    else:  # the Plenoxel student has no deferred rows: ONE launch whose warm list is the touched set (built by a first, gradient-free step)
+        o.step()
+        assert not o.begin_two_part(defer=False) and o._warm_A.numel() == 0 and o._warm_B.numel() * 4 == c.idx.numel()
     assert (tr._exchange_mode(c) is None) == (mode == "classic") and (mode == "classic" or tr._exchange_mode(c) == mode)
     scales, skipped = [], []
     for k in range(6):
@@ -85,15 +91,16 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(1200)
-def test_exchange_forms_leave_the_same_bits(tmp_path):
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("student", ["vm", "tensors"])
+def test_exchange_forms_leave_the_same_bits(tmp_path, student):
     res = {}
     for mode in ("classic", "allreduce", "sharded"):
         out = str(tmp_path / ("x_%s.pt" % mode))
-        mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), mode, out, student), nprocs=2, join=True)
         res[mode] = torch.load(out)
     ref = res["classic"]
-    assert float(ref["step"]) == 5.0  # six steps, one skipped
+    assert float(ref["step"]) == (5.0 if student == "vm" else 6.0)  # six steps, one skipped (+ the Plenoxel run's gradient-free first step)
     for mode in ("allreduce", "sharded"):
         for name in ("p", "m", "v", "step", "lr"):
             assert torch.equal(ref[name], res[mode][name]), "%s: %s differs from the classic sequence (max abs %g)" % (
