@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of one 800 x 800 inference render (640 000 rays) of the hash teacher, the VM student and the Plenoxel student: the reference-shaped loop
 (one device-to-host read-back per round) vs the rounds whose state stays on the device (pvd_infer_*) vs -- hash model -- the
-whole loop as one persistent launch (pvd_infer_image_hash / pvd_infer_image_vm / pvd_infer_image_plenoxel; PVD_INFER_VM_ROWS=64|128)."""
+whole loop as one persistent launch (pvd_infer_image_hash / pvd_infer_image_vm / pvd_infer_image_plenoxel)."""
 import os
 import sys
 import time

@@ -8,12 +8,10 @@ timeout 1200 python -m pytest tests/test_hip_dp_exchange.py -x -q 2>&1 | tail -2
 timeout 1500 python -m pytest tests/test_hip_dp_graph.py -q 2>&1 | tail -25 | tee $OUT/t_dp_graph.log
 timeout 900 python -m pytest tests/test_hip_fused_misc.py tests/test_hip_graph.py -q 2>&1 | tail -8 | tee $OUT/t_misc.log
 for m in classic allreduce sharded; do
-  r=1; [ $m = classic ] && r=0
-  PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 PVD_DP_EXCHANGE=$m PVD_DP_RIDE=$r timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_dp1_$m.json 2>> $OUT/bench.err
+  # (PVD_DP_EXCHANGE=classic implies the separate objective launches since the knob PVD_DP_RIDE was folded into it)
+  PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 PVD_DP_EXCHANGE=$m timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_dp1_$m.json 2>> $OUT/bench.err
   python -c "import json;d=json.load(open('$OUT/bench_dp1_$m.json'));print('$m', d['ms_per_step'], d['sustained']['ms_per_step'], d['config'].get('exchange'))" | tee -a $OUT/dp1_modes.txt
 done
-PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 PVD_DP_EXCHANGE=classic PVD_DP_RIDE=1 timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_dp1_classic_ride.json 2>> $OUT/bench.err
-python -c "import json;d=json.load(open('$OUT/bench_dp1_classic_ride.json'));print('classic+ride', d['ms_per_step'], d['sustained']['ms_per_step'])" | tee -a $OUT/dp1_modes.txt
 timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_single.json 2>> $OUT/bench.err
 python -c "import json;d=json.load(open('$OUT/bench_single.json'));print('single', d['ms_per_step'], d['sustained']['ms_per_step'])" | tee -a $OUT/dp1_modes.txt
 (cd /tmp && rm -rf /tmp/prof_dp && PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dp -o b -- python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-psnr --sustained-steps 0 > /tmp/prof_dp.log 2>&1)

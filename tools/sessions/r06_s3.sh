@@ -8,8 +8,8 @@ line() { grep '^{' "$1" | tail -1; }
 timeout 900 python -m pytest tests/test_hip_fused_misc.py -q -k "objective" 2>&1 | tail -4 | tee $OUT/t_ride.log
 timeout 1500 python -m pytest tests/test_hip_dp_graph.py -q 2>&1 | tail -6 | tee $OUT/t_dp_graph.log
 for m in classic allreduce sharded; do
-  r=1; [ $m = classic ] && r=0
-  PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 PVD_DP_EXCHANGE=$m PVD_DP_RIDE=$r timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_dp1_$m.txt 2>> $OUT/bench.err
+  # (PVD_DP_EXCHANGE=classic implies the separate objective launches since the knob PVD_DP_RIDE was folded into it)
+  PVD_DP_FORCE=1 PVD_DP_PIPELINE=2 PVD_DP_EXCHANGE=$m timeout 600 python bench.py --no-cpu-baseline --no-psnr > $OUT/bench_dp1_$m.txt 2>> $OUT/bench.err
   line $OUT/bench_dp1_$m.txt > $OUT/bench_dp1_$m.json
   python -c "import json;d=json.load(open('$OUT/bench_dp1_$m.json'));print('$m', d['ms_per_step'], d['sustained']['ms_per_step'])" | tee -a $OUT/dp1_modes.txt
 done
