@@ -163,6 +163,7 @@ class ExchangeLayout:
             "the optimizer's part-B list must be the touched set, group for group"
         self.n_groups = G = int(g.shape[0])
         self.chunks = int(chunks)
+        assert G >= self.chunks, "fewer touched groups than chunks: every rank of a sharded update needs rows of its own"
         self.gpc = (G + self.chunks - 1) // self.chunks  # groups per chunk
         self.chunk = 4 * self.gpc + 4                    # floats per chunk (data + the flag group)
         self.slot = 4 * self.gpc                         # the flag word's offset inside a chunk
