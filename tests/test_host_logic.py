@@ -362,3 +362,37 @@ def test_every_environment_switch_is_registered():
     assert read - set(knobs.ALL) == set(), "unregistered switches: %s" % sorted(read - set(knobs.ALL))
     assert set(knobs.ALL) - read == set(), "registered but read by nothing: %s" % sorted(set(knobs.ALL) - read)
     assert len(knobs.PRODUCTION) <= 8
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 8])
+def test_exchange_layout_covers_every_touched_group_once(chunks):
+    """pvd/dp_compact.py: ExchangeLayout (the ray-DP exchange buffer of round 6) on a synthetic touched set -- every group of four lands at
+    its list position inside its chunk, no run crosses a chunk boundary or reaches a flag group, the chunks' row ranges tile the list."""
+    import types
+    from pvd.dp_compact import ExchangeLayout, segments_of
+    g = torch.Generator().manual_seed(chunks)
+    n_groups_total = 5000
+    keep = torch.rand(n_groups_total, generator=g) < 0.3
+    keep[100:1400] = True  # a long run (cut into several table entries)
+    groups = keep.nonzero().squeeze(1)
+    idx = (groups[:, None] * 4 + torch.arange(4)).reshape(-1)
+    c = types.SimpleNamespace(idx=idx, segs=segments_of(idx))
+    L = ExchangeLayout(c, groups.to(torch.int32), chunks, torch.device("cpu"), with_params=chunks > 1)
+    G = groups.numel()
+    assert L.n_groups == G and L.chunk == 4 * L.gpc + 4 and L.slot == 4 * L.gpc and L.xbuf.numel() == chunks * L.chunk
+    assert (L.pbuf is not None) == (chunks > 1)
+    # gather by the table (what k_segments<5> does) == list order inside the chunked layout
+    flat = torch.arange(4 * n_groups_total, dtype=torch.float32) + 1.0
+    buf = torch.zeros_like(L.xbuf)
+    covered = torch.zeros(L.xbuf.numel(), dtype=torch.int32)
+    for start, dst, length in L.segs.tolist():
+        buf[dst:dst + length] = flat[start:start + length]
+        covered[dst:dst + length] += 1
+        assert dst // L.chunk == (dst + length - 1) // L.chunk and (dst + length - 1) % L.chunk < L.slot  # inside one chunk's data
+    assert int(covered.max()) == 1 and int(covered.sum()) == 4 * G
+    rows = [L.rows_of(r) for r in range(chunks)]
+    assert rows[0][0] == 0 and rows[-1][1] == G and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    for r, (lo, hi) in enumerate(rows):
+        want = flat[idx[4 * lo:4 * hi]]
+        assert torch.equal(L.chunk_of(buf, r)[:4 * (hi - lo)], want)
+        assert float(L.chunk_of(buf, r)[4 * (hi - lo):].abs().max()) == 0.0  # padding and the flag group stay untouched
