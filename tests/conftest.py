@@ -27,7 +27,7 @@ for p in (REPO, PKG, os.path.dirname(os.path.abspath(__file__))):
 
 # kernel-level oracle parity, then step / workload parity, then behaviour; graph recorders last (and isolated)
 ORDER = [
-    "test_hip_parity.py", "test_hip_edges.py", "test_hip_golden.py", "test_hip_vm.py", "test_hip_plenoxel.py", "test_hip_occupancy.py",
+    "test_hip_reference_kernels.py", "test_hip_parity.py", "test_hip_edges.py", "test_hip_golden.py", "test_hip_vm.py", "test_hip_plenoxel.py", "test_hip_occupancy.py",
     "test_hip_head.py", "test_hip_mlp_frozen.py", "test_hip_infer_rounds.py",
     "test_hip_golden_step.py", "test_hip_fullsize.py", "test_hip_render_parity.py", "test_hip_workloads.py",
     "test_hip_fused_misc.py", "test_hip_bench_line.py",

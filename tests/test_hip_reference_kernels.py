@@ -1,0 +1,168 @@
+"""libpvd_hip.so against the REFERENCE'S OWN KERNELS, on the GPU:
+  * the fixture tests/golden/reference_kernels.npz (the reference's raymarching.cu / shencoder.cu, built for gfx950 by
+    oracle/build_ref.py, run by tests/golden/make_golden_ref_kernels.py) through the product's operator API;
+  * LIVE, when oracle/_ref travelled with the tree: the reference's kernels and the product's on fresh inputs at the metric's size
+    (4096 rays), side by side on this GPU.
+Bars: marcher / near-far / Morton / packbits bit for bit (north_star: "bit-exact occupancy / sample indices"), compositing and SH
+within 1e-6 / 1e-4 (north_star: RGB / sigma within 1e-4)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+PATH = os.path.join(HERE, "golden", "reference_kernels.npz")
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _by_ray(rays, xyzs, deltas, N):
+    rays, xyzs, deltas = rays.cpu().numpy(), xyzs.cpu().numpy(), deltas.cpu().numpy()
+    counts = np.zeros(N, np.int32)
+    parts = {}
+    for idx, off, num in rays:
+        counts[idx] = num
+        parts[int(idx)] = (xyzs[off:off + num], deltas[off:off + num])
+    order = [parts[i] for i in range(N) if i in parts]
+    return counts, np.concatenate([p[0] for p in order]), np.concatenate([p[1] for p in order])
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not os.path.exists(PATH):
+        pytest.skip("fixture not generated yet")
+    return dict(np.load(PATH))
+
+
+def test_fixture_marcher_and_integer_kernels_bit_for_bit(G):
+    import raymarching as RM
+    n, f = RM.near_far_from_aabb(T(G["nf_o"]), T(G["nf_d"]), T(G["nf_aabb"]), 0.2)
+    assert np.array_equal(n.cpu().numpy(), G["nf_nears"]) and np.array_equal(f.cpu().numpy(), G["nf_fars"])
+    assert np.array_equal(RM.morton3D(T(G["mo_coords"])).cpu().numpy(), G["mo_idx"])
+    assert np.array_equal(RM.morton3D_invert(T(G["mo_idx"])).cpu().numpy(), G["mo_back"])
+    assert np.array_equal(RM.packbits(T(G["pb_grid"]).view(1, -1), 10.0).cpu().numpy().reshape(-1), G["pb_bits"])
+    pol = RM.polar_from_ray(T(G["nf_o"]), T(G["nf_d"]), 2.0).cpu().numpy()
+    assert np.array_equal(np.isnan(pol), np.isnan(G["polar"])) and np.nanmax(np.abs(pol - G["polar"])) <= 5e-7
+    for tag in ("a", "b"):
+        bound, C, dtg = float(G["m%s_cfg" % tag][0]), int(G["m%s_cfg" % tag][1]), float(G["m%s_cfg" % tag][2])
+        o, d = G["m%s_o" % tag], G["m%s_d" % tag]
+        for perturb in (0, 1):
+            cnt = G["m%s%d_counts" % (tag, perturb)]
+            M = int(cnt.sum()) + 128
+            x, dd, dl, rays = RM.march_rays_train(T(o), T(d), bound, T(G["m%s_bits" % tag]), C, 128, T(G["m%s_nears" % tag]), T(G["m%s_fars" % tag]), None, M,
+                                                  bool(perturb), -1, False, dtg, 1024)
+            c, xs, ls = _by_ray(rays, x, dl, o.shape[0])
+            assert np.array_equal(c, cnt), (tag, perturb)
+            assert np.array_equal(xs, G["m%s%d_xyzs" % (tag, perturb)]) and np.array_equal(ls, G["m%s%d_deltas" % (tag, perturb)]), (tag, perturb)
+
+
+def test_fixture_compositing_sh_and_inference_trio(G):
+    import pvd_hip
+    import raymarching as RM
+    sig, rgb = T(G["cp_sig"]).requires_grad_(True), T(G["cp_rgb"]).requires_grad_(True)
+    ws, dep, img = RM.composite_rays_train(sig, rgb, T(G["cp_deltas"]), T(G["cp_rays"]))
+    ((ws * T(G["cp_gws"])).sum() + (img * T(G["cp_gimg"])).sum()).backward()
+    assert np.abs(ws.detach().cpu().numpy() - G["cp_ws"]).max() <= 1e-6 and np.abs(img.detach().cpu().numpy() - G["cp_image"]).max() <= 1e-6
+    assert np.abs(dep.detach().cpu().numpy() - G["cp_depth"]).max() <= 2e-6
+    assert np.abs(rgb.grad.cpu().numpy() - G["cp_grgb"]).max() <= 1e-6
+    assert np.abs(sig.grad.cpu().numpy() - G["cp_gsig"]).max() <= 5e-6 * np.abs(G["cp_gsig"]).max() + 1e-9
+    NS = G["sh_dirs"].shape[0]
+    for deg in range(1, 9):
+        out = torch.empty(NS, deg * deg, device=DEV)
+        dy = torch.empty(NS, 3 * deg * deg, device=DEV)
+        pvd_hip.sh_encode_forward(T(G["sh_dirs"]), out, NS, 3, deg, True, dy)
+        gi = torch.zeros(NS, 3, device=DEV)
+        pvd_hip.sh_encode_backward(T(G["sh%d_g" % deg]), T(G["sh_dirs"]), NS, 3, deg, T(G["sh%d_dy" % deg]), gi)
+        assert np.abs(out.cpu().numpy() - G["sh%d_out" % deg]).max() <= 5e-6, deg
+        assert np.abs(dy.cpu().numpy() - G["sh%d_dy" % deg]).max() <= 5e-5, deg
+        assert np.abs(gi.cpu().numpy() - G["sh%d_gi" % deg]).max() <= 2e-5 * (1 + np.abs(G["sh%d_gi" % deg]).max()), deg
+    alive = np.arange(1024, dtype=np.int32)
+    for perturb in (0, 1):
+        x, dd, dl = RM.march_rays(1024, 4, T(alive), T(G["inf_nears"].copy()), T(G["inf_o"]), T(G["inf_d"]), 1.0, T(G["inf_bits"]), 1, 128, T(G["inf_nears"]),
+                                  T(G["inf_fars"]), -1, perturb, 0, 1024)
+        assert np.array_equal(x.cpu().numpy(), G["inf%d_xyzs" % perturb]) and np.array_equal(dl.cpu().numpy(), G["inf%d_deltas" % perturb])
+    rt, ws, dep, img = T(G["inf_nears"].copy()), torch.zeros(1024, device=DEV), torch.zeros(1024, device=DEV), torch.zeros(1024, 3, device=DEV)
+    al = T(alive.copy())
+    RM.composite_rays(1024, 4, al, rt, T(G["inf_sig"]), T(G["inf_rgb"]), T(G["inf1_deltas"]), ws, dep, img)
+    assert np.array_equal(al.cpu().numpy(), G["inf_alive_after"]) and np.array_equal(rt.cpu().numpy(), G["inf_t_after"])
+    assert np.abs(ws.cpu().numpy() - G["inf_ws"]).max() <= 1e-6 and np.abs(dep.cpu().numpy() - G["inf_depth"]).max() <= 2e-6
+    assert np.abs(img.cpu().numpy() - G["inf_image"]).max() <= 1e-6
+
+
+def _ref_modules():
+    sys.path.insert(0, REPO)
+    from oracle.build_ref import available, load_module
+    if set(available()) != {"_raymarching_ref", "_shencoder_ref"}:
+        pytest.skip("oracle/_ref did not travel with the tree (built by oracle/build_ref.py where /root/reference exists)")
+    return load_module("_raymarching_ref"), load_module("_shencoder_ref")
+
+
+@pytest.mark.parametrize("perturb", [0, 1])
+def test_live_marcher_at_the_metrics_size_equals_the_reference_kernel(perturb):
+    """4096 rays of a training camera through the chair's occupancy grid: kernel_march_rays_train of the reference (hipcc build of its own
+    source) and pvd_march_rays_train side by side -- per ray the same count, positions and steps, bit for bit (~9e4 samples)."""
+    rm, _ = _ref_modules()
+    import raymarching as RM
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, packbits_torch, synthetic_poses
+    poses = torch.from_numpy(synthetic_poses(np.random.RandomState(0))).to(DEV)
+    bits = packbits_torch(ChairScene().density_grid(128, 1.0, 1, device=DEV), 10.0)
+    r = get_rays(poses[3:4], BLENDER_INTRINSICS, 800, 800, 4096, generator=torch.Generator(device=DEV).manual_seed(7))
+    o, d = r["rays_o"].reshape(-1, 3).contiguous(), r["rays_d"].reshape(-1, 3).contiguous()
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0], device=DEV)
+    n_ref, f_ref = torch.empty(4096, device=DEV), torch.empty(4096, device=DEV)
+    rm.near_far_from_aabb(o, d, aabb, 4096, 0.2, n_ref, f_ref)
+    nears, fars = RM.near_far_from_aabb(o, d, aabb, 0.2)
+    assert torch.equal(nears, n_ref) and torch.equal(fars, f_ref)
+    M = 4096 * 64
+    xr, dr, lr = torch.zeros(M, 3, device=DEV), torch.zeros(M, 3, device=DEV), torch.zeros(M, 2, device=DEV)
+    rr = torch.empty(4096, 3, dtype=torch.int32, device=DEV)
+    cr = torch.zeros(2, dtype=torch.int32, device=DEV)
+    rm.march_rays_train(o, d, bits, 1.0, 0.0, 1024, 4096, 1, 128, M, nears, fars, xr, dr, lr, rr, cr, perturb)
+    torch.cuda.synchronize()
+    xh, dh, lh, rh = RM.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, None, M, bool(perturb), -1, False, 0, 1024)
+    c_ref, x_ref, l_ref = _by_ray(rr, xr, lr, 4096)
+    c_hip, x_hip, l_hip = _by_ray(rh, xh, lh, 4096)
+    assert int(cr[0]) == int(c_ref.sum()) > 60000
+    assert np.array_equal(c_ref, c_hip) and np.array_equal(x_ref, x_hip) and np.array_equal(l_ref, l_hip)
+
+
+def test_live_compositing_and_sh_equal_the_reference_kernels():
+    rm, sh = _ref_modules()
+    import pvd_hip
+    import raymarching as RM
+    g = torch.Generator(device=DEV).manual_seed(11)
+    N = 4096
+    counts = torch.randint(0, 64, (N,), device=DEV, generator=g, dtype=torch.int32)
+    offs = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+    rays = torch.stack([torch.arange(N, device=DEV, dtype=torch.int32), offs, counts], 1).contiguous()
+    M = int(counts.sum())
+    sig = torch.exp(torch.rand(M, device=DEV, generator=g) * 9 - 2)
+    rgb = torch.rand(M, 3, device=DEV, generator=g)
+    deltas = torch.rand(M, 2, device=DEV, generator=g) * 0.01 + 1e-3
+    ws_r, dep_r, img_r = torch.empty(N, device=DEV), torch.empty(N, device=DEV), torch.empty(N, 3, device=DEV)
+    rm.composite_rays_train_forward(sig, rgb, deltas, rays, M, N, ws_r, dep_r, img_r)
+    gws, gimg = torch.randn(N, device=DEV, generator=g), torch.randn(N, 3, device=DEV, generator=g)
+    gs_r, gr_r = torch.zeros(M, device=DEV), torch.zeros(M, 3, device=DEV)
+    rm.composite_rays_train_backward(gws, gimg, sig, rgb, deltas, rays, ws_r, img_r, M, N, gs_r, gr_r)
+    s2, c2 = sig.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+    ws, dep, img = RM.composite_rays_train(s2, c2, deltas, rays)
+    ((ws * gws).sum() + (img * gimg).sum()).backward()
+    assert (ws - ws_r).abs().max().item() <= 2e-6 and (img - img_r).abs().max().item() <= 2e-6 and (dep - dep_r).abs().max().item() <= 2e-6
+    assert (c2.grad - gr_r).abs().max().item() <= 2e-6
+    assert (s2.grad - gs_r).abs().max().item() <= 1e-5 * gs_r.abs().max().item() + 1e-9
+    B = 100000
+    dirs = torch.randn(B, 3, device=DEV, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    for deg in (3, 4):  # the two degrees the models use (network.py:126-130)
+        o_r, dy_r = torch.empty(B, deg * deg, device=DEV), torch.empty(B, 3 * deg * deg, device=DEV)
+        sh.sh_encode_forward(dirs, o_r, B, 3, deg, True, dy_r)
+        o_h, dy_h = torch.empty(B, deg * deg, device=DEV), torch.empty(B, 3 * deg * deg, device=DEV)
+        pvd_hip.sh_encode_forward(dirs, o_h, B, 3, deg, True, dy_h)
+        assert (o_h - o_r).abs().max().item() <= 2e-6 and (dy_h - dy_r).abs().max().item() <= 1e-5
