@@ -6,9 +6,12 @@ numpy-facing ctypes binding of ``oracle/libpvd_oracle.so`` (built from
 this package, and only as the checker / timed CPU baseline.  The product
 (``aaai2023-pvd_amd/``) never imports it.
 
-PARITY STATUS: "parity unpinned by the reference" (no reference tests or golden
-vectors exist and its CUDA sources cannot be built here); see
-``oracle/pvd_oracle.h`` for what pins the oracle instead.
+PARITY STATUS (round 6): marcher, compositor, Morton / packbits, SH encoder and the
+inference trio are pinned by the reference's OWN kernels (``oracle/build_ref.py``
+builds raymarching.cu / shencoder.cu for gfx950 the way the reference builds them;
+``tests/golden/reference_kernels.npz``, ``tests/test_oracle_ref_kernels.py``); the
+grid encoder is "parity unpinned by the reference" (its source does not build on
+HIP); see ``oracle/pvd_oracle.h``.
 """
 import ctypes
 import os

@@ -3,8 +3,9 @@
  *
  * Plain C restatement of the reference's CUDA kernels; citations are to
  * /root/reference/<file>:<line>.  Build: oracle/Makefile (gcc -O2
- * -ffp-contract=off, OpenMP optional).  PARITY UNPINNED BY THE REFERENCE --
- * see pvd_oracle.h for what pins it instead.
+ * -ffp-contract=off, OpenMP optional).  Parity: pinned by the reference's own
+ * raymarching / SH kernels built for gfx950 (oracle/_ref, round 6); the grid
+ * encoder is PARITY UNPINNED BY THE REFERENCE -- see pvd_oracle.h.
  */
 #include "pvd_oracle.h"
 

@@ -18,8 +18,9 @@ without its CUDA extensions --
     arithmetic in those fixtures is the oracle's, not the reference's).
   * the reference's `composite_rays_train` autograd wrapper (raymarching/raymarching.py:292-357:
     allocation, saved tensors, which gradients exist) the same way, forward + backward.
-The reference's kernels themselves cannot be built here (no cuda.h, stand-ins are not allowed), so
-kernel arithmetic is NOT pinned by these fixtures ("parity unpinned", see oracle/pvd_oracle.h).
+Kernel arithmetic is NOT pinned by THESE fixtures; since round 6 the reference's own raymarching / SH kernels are built for gfx950
+(oracle/build_ref.py) and pin it through tests/golden/make_golden_ref_kernels.py -> reference_kernels.npz (the grid encoder's source
+does not build on HIP: "parity unpinned by the reference", see oracle/pvd_oracle.h).
 Only data (inputs + expected outputs) is written; no reference source is copied.
 """
 import os
