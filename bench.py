@@ -188,6 +188,39 @@ def cpu_baseline_teacher(tea_gpu, opt, topt, steps, num_rays):
                          "and occupancy grid as the GPU run, no grid update inside the sample")
 
 
+def gpu_reference_step(opt, steps=10):
+    """(reported baseline, next to cpu_baseline) the metric's step through the REFERENCE'S OWN native code + PyTorch on this GPU: oracle/_ref =
+    raymarching.cu / shencoder.cu of the reference built for gfx950 (oracle/build_ref.py), bound under this repo's restatement of the
+    reference's host code in its generic form (the reference's autograd wrappers, F.grid_sample, nn.Linear under autocast, torch AdamW +
+    GradScaler, eager launches); the hash teacher's lookup is this repo's generic encoder kernel (gridencoder.cu does not build on HIP).
+    None when oracle/_ref did not travel with the tree."""
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from oracle.build_ref import available
+        if set(available()) != {"_raymarching_ref", "_shencoder_ref"}:
+            return None
+        from bench_reference_kernels_step import reference_kernel_ops
+        from pvd.config import PVDConfig
+        from pvd.workload import DistillWorkload
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ropt = PVDConfig(**{**opt.__dict__})
+        torch.manual_seed(0)
+        w = DistillWorkload(reference_kernel_ops(), dev, ropt, teacher_pretrain_steps=0, seed=0)
+        for _ in range(3):
+            w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"value": opt.num_rays / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "kind": "reference kernels (hipcc build of the reference's raymarching.cu / "
+                "shencoder.cu) + PyTorch-ROCm eager, generic host code; hash lookup: this repo's generic encoder kernel",
+                "sample": "%d eager steps x %d rays after 3 warm-up steps, same scene / models / AMP as the timed run" % (steps, opt.num_rays)}
+    except Exception as e:  # noqa: BLE001  (never lose the line to a reported baseline)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def psnr_run(dev, student, teacher_steps, stage1, stage2, steps, oracle_check=True, dp=None, num_rays=None):
     """The metric's second half, OUTSIDE the timed region: a whole (short) distillation run through the three stages of the
     reference schedule (main_distill_mutual.py:387-396, scaled: stage 1 feature loss only, stage 2 + sigma / colour, stage 3 + RGB)
@@ -901,8 +934,10 @@ def main():
             out["config"]["exchange"] = "unknown (%s)" % type(e).__name__
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
+        out["gpu_reference"] = gpu_reference_step(opt)
     else:
         out["cpu_baseline"] = None
+        out["gpu_reference"] = None
     out["psnr"] = None
     if rank == 0 and world == 1 and not args.no_psnr and not args.eager and args.student == "vm" and args.bound == 1.0:
         try:

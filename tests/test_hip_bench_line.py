@@ -58,6 +58,8 @@ def test_single_gpu_line_carries_the_contract():
     assert 0.01 < cfg["occupied_fraction"] < 0.2 and cfg["samples_per_ray"] > 1 and cfg["samples_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    gr = d["gpu_reference"]  # the reference's own kernels + PyTorch on this GPU (None when oracle/_ref did not travel)
+    assert gr is None or ("error" not in gr and 0 < gr["value"] < d["value"]), gr
     su = d["sustained"]  # a second, longer synchronised window behind the timed one
     assert su["steps"] == 40 and su["ms_per_step"] > 0 and abs(su["vs_timed"] - su["ms_per_step"] / d["ms_per_step"]) < 1e-9
     q = d["psnr"]  # the metric's second half, outside the timed region: staged distillation run + held-out views
