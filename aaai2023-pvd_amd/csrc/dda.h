@@ -12,7 +12,7 @@ constexpr float kSqrt3 = 1.7320508075688772f;  // SQRT3(), raymarching.cu:21
 
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, Cf, Hf, cell_hi;
+    float bound, dt_gamma, dt_min, dt_max, dt_const, rH, Cf, Hf, cell_hi;
     uint32_t H, H3;
     const uint8_t *grid;
     // wave-uniform fast paths with identical results: one cascade (level is always 0) and a power-of-two H
@@ -28,6 +28,10 @@ struct Dda {
         bound = bound_; dt_gamma = dt_gamma_;
         dt_min = 2 * kSqrt3 / (float)max_steps;
         dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H_;
+        // the step of a march with dt_gamma == 0: clamp(0, dt_min, dt_max) = fminf(dt_max, fmaxf(dt_min, 0)) (:36-38, :368) -- dt_min
+        // unless max_steps is so small that dt_min exceeds dt_max (max_steps < H / 2^(C-1)): then dt_max (round 6, found against the
+        // reference's own kernel)
+        dt_const = clampf(0.0f, dt_min, dt_max);
         rH = 1.0f / (float)H_;
         Cf = (float)C; Hf = (float)H_; cell_hi = (float)(H_ - 1);
         H = H_; H3 = H_ * H_ * H_;
@@ -66,24 +70,28 @@ struct Dda {
 
         // nearest cell via fp64 temporaries, as the reference source promotes (:377-379)
         int nx, ny, nz;
+        // x * mip_rbound + 1 is ONE fused operation in the reference's builds (v_fma in the ISA of its own kernel compiled for gfx950,
+        // oracle/_ref; nvcc contracts it too): exact product, hence no change, for a power-of-two mip_bound; decides knife-edge cells
+        // for others (bound 1.5: 2 rays of 2048 differed by a sample before round 6)
         if (pow2_h) {
-            nx = (int)clampf((x * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
-            ny = (int)clampf((y * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
-            nz = (int)clampf((z * mip_rbound + 1.0f) * half_h, 0.0f, cell_hi);
+            nx = (int)clampf(fmaf(x, mip_rbound, 1.0f) * half_h, 0.0f, cell_hi);
+            ny = (int)clampf(fmaf(y, mip_rbound, 1.0f) * half_h, 0.0f, cell_hi);
+            nz = (int)clampf(fmaf(z, mip_rbound, 1.0f) * half_h, 0.0f, cell_hi);
         } else {
             const double Hd = (double)H;
-            nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
-            ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
-            nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * Hd), 0.0f, cell_hi);
+            nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * Hd), 0.0f, cell_hi);
+            ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * Hd), 0.0f, cell_hi);
+            nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * Hd), 0.0f, cell_hi);
         }
 
         const uint32_t index = (uint32_t)level * H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
         const bool occ = (grid[index >> 3] >> (index & 7u)) & 1u;
         if (occ) return true;
 
-        const float tx = (((nx + 0.5f + 0.5f * sign1f(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-        const float ty = (((ny + 0.5f + 0.5f * sign1f(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-        const float tz = (((nz + 0.5f + 0.5f * sign1f(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+        // (...) * mip_bound - x: contracted likewise
+        const float tx = fmaf(((nx + 0.5f + 0.5f * sign1f(dx)) * rH * 2 - 1), mip_bound, -x) * rdx;
+        const float ty = fmaf(((ny + 0.5f + 0.5f * sign1f(dy)) * rH * 2 - 1), mip_bound, -y) * rdy;
+        const float tz = fmaf(((nz + 0.5f + 0.5f * sign1f(dz)) * rH * 2 - 1), mip_bound, -z) * rdz;
         const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         if (SKIP_TARGET_ONLY) {  // the wave-parallel marcher resolves the skip itself
             t_next = tt;
@@ -106,7 +114,9 @@ __device__ __forceinline__ float ray_t0(float near, float dt_min, uint32_t pertu
     Pcg32 g;
     g.seed(seed);
     g.advance(n);
-    return near + dt_min * g.next_float();
+    // `t0 += dt_min * rng.next_float()` (:353, :751) is ONE fused operation in the reference's builds (v_fmac_f32 in the ISA of its own
+    // kernels compiled for gfx950, oracle/_ref; nvcc contracts it too): about one ray in 2000 lands an ulp away otherwise
+    return fmaf(dt_min, g.next_float(), near);
 }
 
 

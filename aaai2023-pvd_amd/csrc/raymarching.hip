@@ -322,7 +322,7 @@ __device__ __forceinline__ uint32_t march_ray_wave(const Dda &r, float t0, float
         const uint32_t bb = __float_as_uint(t_base);
         const bool fast = !grows && lat_c != 0 && bb + 64u * lat_c < (((bb >> 23) + 1u) << 23);
         const float t = grows ? lattice_points_gamma(t_base, lane, r.dt_gamma, r.dt_min, r.dt_max, far)
-                              : (fast ? __uint_as_float(bb + lane * lat_c) : lattice_advance(t_base, r.dt_min, lane));
+                              : (fast ? __uint_as_float(bb + lane * lat_c) : lattice_advance(t_base, r.dt_const, lane));
         const float t_after = t + clampf(t * r.dt_gamma, r.dt_min, r.dt_max);
         const bool valid = t < far;
         float x = 0, y = 0, z = 0, dtp = 0, tt = 0;
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(kBlock) k_march_write_records(const float *__r
     for (uint32_t c = 0; c < rr.n; c++) {
         const uint64_t emit_mask = rr.chunk[c].mask;
         const float t = r.dt_gamma != 0.0f ? lattice_points_gamma(rr.chunk[c].t_base, lane, r.dt_gamma, r.dt_min, r.dt_max, 3.0e38f)
-                                           : lattice_advance(rr.chunk[c].t_base, r.dt_min, lane);
+                                           : lattice_advance(rr.chunk[c].t_base, r.dt_const, lane);
         const float t_after = t + clampf(t * r.dt_gamma, r.dt_min, r.dt_max);
         const uint64_t below = emit_mask & ((1ull << lane) - 1ull);
         const int prev_lane = below ? 63 - __clzll((long long)below) : 0;

@@ -299,9 +299,12 @@ static inline int dda_probe(const dda_t *r, float t, float *px, float *py, float
 
     /* nearest cell: double temporaries then float clamp then trunc (:377-379) */
     const float hi = (float)(r->H - 1);
-    const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * (double)r->H), 0.0f, hi);
-    const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * (double)r->H), 0.0f, hi);
-    const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * (double)r->H), 0.0f, hi);
+    /* x * mip_rbound + 1 is a float expression the reference's compilers contract (checked in the ISA of the reference's own kernel built
+     * for gfx950, oracle/_ref; nvcc's -fmad=true does the same): a fused multiply-add.  For a power-of-two mip_bound the product is
+     * exact and nothing changes; for others (bound 1.5) it decides knife-edge cells (round 6: 2 rays of 2048 differed without it). */
+    const int nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)r->H), 0.0f, hi);
+    const int ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)r->H), 0.0f, hi);
+    const int nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)r->H), 0.0f, hi);
 
     const uint32_t index = (uint32_t)level * r->H * r->H * r->H + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
     const int occ = (r->grid[index >> 3] >> (index & 7u)) & 1;
@@ -310,9 +313,10 @@ static inline int dda_probe(const dda_t *r, float t, float *px, float *py, float
     if (occ) return 1;
 
     /* distance to the exit face of this cell (:393-397) */
-    const float tx = (((nx + 0.5f + 0.5f * sign1f(r->dx)) * r->rH * 2 - 1) * mip_bound - x) * r->rdx;
-    const float ty = (((ny + 0.5f + 0.5f * sign1f(r->dy)) * r->rH * 2 - 1) * mip_bound - y) * r->rdy;
-    const float tz = (((nz + 0.5f + 0.5f * sign1f(r->dz)) * r->rH * 2 - 1) * mip_bound - z) * r->rdz;
+    /* (...) * mip_bound - x: contracted likewise (exact product for a power-of-two mip_bound) */
+    const float tx = fmaf(((nx + 0.5f + 0.5f * sign1f(r->dx)) * r->rH * 2 - 1), mip_bound, -x) * r->rdx;
+    const float ty = fmaf(((ny + 0.5f + 0.5f * sign1f(r->dy)) * r->rH * 2 - 1), mip_bound, -y) * r->rdy;
+    const float tz = fmaf(((nz + 0.5f + 0.5f * sign1f(r->dz)) * r->rH * 2 - 1), mip_bound, -z) * r->rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do { /* always at least one step (:399-401) */
         t += clampf(t * r->dt_gamma, r->dt_min, r->dt_max);
@@ -341,7 +345,7 @@ void pvdo_march_rays_train(const float *rays_o, const float *rays_d, const uint8
             pcg32_t g;
             pcg_seed(&g, 42u, 1u);
             pcg_advance(&g, (uint64_t)n);
-            t0 += r.dt_min * pcg_next_float(&g);
+            t0 = fmaf(r.dt_min, pcg_next_float(&g), t0);  /* `t0 += dt_min * rng.next_float()` is ONE fused operation in the reference's build (v_fmac_f32 in oracle/_ref's ISA; nvcc contracts it too) */
         }
         float t = t0;
         uint32_t num = 0;
@@ -479,7 +483,7 @@ void pvdo_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_aliv
             pcg32_t g;
             pcg_seed(&g, (uint64_t)perturb, 1u);
             pcg_advance(&g, (uint64_t)n);
-            t += r.dt_min * pcg_next_float(&g);
+            t = fmaf(r.dt_min, pcg_next_float(&g), t);  /* fused, as above (:751) */
         }
         float last_t = t;
         float *px = xyzs + 3 * (size_t)n * n_step, *pd = dirs + 3 * (size_t)n * n_step, *pl = deltas + 2 * (size_t)n * n_step;

@@ -269,3 +269,50 @@ def test_live_distillation_step_through_the_reference_kernels_matches_the_produc
         scale = gr[n].abs().max().item()
         assert scale > 0, n
         assert (gh[n] - gr[n]).abs().max().item() / scale <= 1e-3, (n, (gh[n] - gr[n]).abs().max().item() / scale)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (cascades, bound, dt_gamma, max_steps, occupied fraction of a RANDOM bitfield, perturb)
+    (1, 1.0, 0.0, 1024, 0.30, 1), (1, 1.0, 0.0, 64, 0.30, 0), (2, 2.0, 1.0 / 128, 1024, 0.10, 1), (3, 4.0, 1.0 / 256, 512, 0.05, 1),
+    (2, 1.5, 0.0, 1024, 0.50, 0), (1, 1.0, 1.0 / 64, 1024, 0.02, 1),
+])
+def test_live_marcher_on_random_occupancy_grids_equals_the_reference_kernel(cfg):
+    """Beyond the chair: random bitfields (no spatial structure: the skip logic's worst case), one to three cascades, power-of-two and
+    non-power-of-two bounds, constant and distance-proportional steps, a coarse step (max_steps 64: dt_min = 2 sqrt(3) / 64), jitter on / off --
+    kernel_march_rays_train of the reference and pvd_march_rays_train agree per ray, bit for bit; the inference march on the same grids too."""
+    rm, _ = _ref_modules()
+    import raymarching as RM
+    C, bound, dtg, max_steps, frac, perturb = cfg
+    g = torch.Generator(device=DEV).manual_seed(int(1000 * frac) + C)
+    H = 128
+    bits = (torch.rand(C * H ** 3 // 8, 8, device=DEV, generator=g) < frac)
+    bits = (bits.to(torch.uint8) << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8).contiguous()
+    N = 2048
+    o = torch.randn(N, 3, device=DEV, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (bound * 2.5)
+    tgt = (torch.rand(N, 3, device=DEV, generator=g) - 0.5) * bound
+    d = tgt - o
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    o = o.contiguous()
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, device=DEV)
+    nears, fars = RM.near_far_from_aabb(o, d, aabb, 0.2)
+    n_r, f_r = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    rm.near_far_from_aabb(o, d, aabb, N, 0.2, n_r, f_r)
+    assert torch.equal(nears, n_r) and torch.equal(fars, f_r)
+    M = N * max_steps
+    xr, dr, lr = torch.zeros(M, 3, device=DEV), torch.zeros(M, 3, device=DEV), torch.zeros(M, 2, device=DEV)
+    rr = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+    cr = torch.zeros(2, dtype=torch.int32, device=DEV)
+    rm.march_rays_train(o, d, bits, bound, dtg, max_steps, N, C, H, M, nears, fars, xr, dr, lr, rr, cr, perturb)
+    torch.cuda.synchronize()
+    xh, dh, lh, rh = RM.march_rays_train(o, d, bound, bits, C, H, nears, fars, None, M, bool(perturb), -1, False, dtg, max_steps)
+    c_ref, x_ref, l_ref = _by_ray(rr, xr, lr, N)
+    c_hip, x_hip, l_hip = _by_ray(rh, xh, lh, N)
+    assert int(c_ref.sum()) > 1000 and int(c_ref.max()) <= max_steps  # (max_steps also sets the step: dt_min = 2 sqrt(3) / max_steps, raymarching.cu:346)
+    assert np.array_equal(c_ref, c_hip) and np.array_equal(x_ref, x_hip) and np.array_equal(l_ref, l_hip)
+    # the inference march from the same starting points: 4 steps per ray
+    alive = torch.arange(N, dtype=torch.int32, device=DEV)
+    xi_r, di_r, li_r = torch.zeros(N * 4, 3, device=DEV), torch.zeros(N * 4, 3, device=DEV), torch.zeros(N * 4, 2, device=DEV)
+    rm.march_rays(N, 4, alive, nears.clone(), o, d, bound, dtg, max_steps, C, H, bits, nears, fars, xi_r, di_r, li_r, perturb)
+    xi_h, di_h, li_h = RM.march_rays(N, 4, alive, nears.clone(), o, d, bound, bits, C, H, nears, fars, -1, perturb, dtg, max_steps)
+    assert torch.equal(xi_r, xi_h) and torch.equal(li_r, li_h)

@@ -144,7 +144,7 @@ def _bruteforce_walk(o, d, near, far, bits, t0):
 def test_march_samples_match_bruteforce_fixed_step_walk(perturb):
     """dt_gamma = 0, bound = 1: an independent numpy walk in float32 reproduces, per ray, num_steps AND every sample's
     clamped position, dt and `t - last_t` (bit for bit), with and without the per-ray start jitter
-    t0 = near + dt_min * pcg32{42}.advance(n).next_float() (raymarching.cu:346-352; the generator is pinned by its published
+    t0 = fma(dt_min, pcg32{42}.advance(n).next_float(), near) (raymarching.cu:346-352; the generator is pinned by its published
     known-answer vector above)."""
     o, d, bits, _ = _scene(256, 1)
     aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
@@ -160,7 +160,7 @@ def test_march_samples_match_bruteforce_fixed_step_walk(perturb):
         t0 = f32(n[ray])
         if perturb:
             _, noise = oracle.pcg32_stream(42, ray, 1)
-            t0 = f32(t0 + f32(dt * f32(noise[0])))
+            t0 = f32(np.float64(t0) + np.float64(dt) * np.float64(noise[0]))  # fmaf(dt_min, rnd, near): fused in the reference's builds (oracle/_ref's ISA)
         walk = _bruteforce_walk(o[ray], d[ray], n[ray], f[ray], bits, t0)
         s, c = int(rays[ray, 1]), int(rays[ray, 2])
         assert c == len(walk), ray
@@ -201,7 +201,7 @@ def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_ste
         level = max(lvl_pos, lvl_dt)
         mip_bound = min(f32(1 << level), bound)
         mip_rbound = f32(1) / mip_bound
-        v = ((p * mip_rbound).astype(np.float32) + f32(1)).astype(np.float32)
+        v = (p.astype(np.float64) * np.float64(mip_rbound) + 1.0).astype(np.float32)  # fmaf(x, mip_rbound, 1): ONE rounding, as the reference's builds fuse it
         cell = np.clip((0.5 * v.astype(np.float64) * H).astype(np.float32), 0, H - 1).astype(np.int32)
         m = level * H ** 3 + int(oracle.morton3D(cell[None])[0])
         if (bits[m // 8] >> (m % 8)) & 1:
@@ -212,7 +212,7 @@ def _bruteforce_walk_general(o, d, far, bits, t0, bound, C, H, dt_gamma, max_ste
             sgn = np.copysign(f32(1), d).astype(np.float32)
             a = (cell.astype(np.float32) + f32(0.5) + (f32(0.5) * sgn).astype(np.float32)).astype(np.float32)
             face = (((a * rH).astype(np.float32) * f32(2)).astype(np.float32) - f32(1)).astype(np.float32)
-            txyz = (((face * mip_bound).astype(np.float32) - p).astype(np.float32) * rd).astype(np.float32)
+            txyz = ((face.astype(np.float64) * np.float64(mip_bound) - p.astype(np.float64)).astype(np.float32) * rd).astype(np.float32)  # fmaf(face, mip_bound, -x) * rd
             tt = f32(t + max(f32(0), txyz.min()))
             while True:
                 t = f32(t + step_of(t))
@@ -243,7 +243,7 @@ def test_march_samples_match_bruteforce_walk_with_cascades_and_growing_steps(bou
             assert rays[ray, 2] == 0
             continue
         _, noise = oracle.pcg32_stream(42, ray, 1)
-        t0 = f32(f32(n[ray]) + f32(dt_min * f32(noise[0])))
+        t0 = f32(np.float64(n[ray]) + np.float64(dt_min) * np.float64(noise[0]))  # fmaf(dt_min, rnd, near): fused in the reference's builds
         walk = _bruteforce_walk_general(o[ray], d[ray], f[ray], bits, t0, bound, C, H, dt_gamma)
         s, c = int(rays[ray, 1]), int(rays[ray, 2])
         assert c == len(walk), (ray, c, len(walk))
