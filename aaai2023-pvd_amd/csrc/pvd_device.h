@@ -2,8 +2,10 @@
 //
 // Canonical floating-point mode (see DESIGN.md "Arithmetic contract"): the library is
 // built with -ffp-contract=off, so a product is rounded before it is added unless the
-// source says fmaf().  fmaf() is used exactly where nvcc's default -fmad=true contracts
-// the reference source AND the value feeds an integer decision (o + t*d in the marchers,
+// source says fmaf().  fmaf() is used exactly where the reference's compilers contract
+// the reference source AND the value feeds an integer decision or a position (o + t*d, the
+// start jitter, x*mip_rbound + 1 and (..)*mip_bound - x in the marchers -- the last three
+// found in round 6 against the reference's own kernels built for gfx950, oracle/_ref --,
 // x*scale + 0.5 and acc += w*v in the grid encoder); the CPU oracle mirrors this, which is
 // what makes HIP-vs-oracle bit-exact for the marcher and the encoder forward.
 #pragma once

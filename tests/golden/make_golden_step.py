@@ -7,7 +7,7 @@ Everything that is Python / torch in the reference on that path is the reference
 the stage gating, which model marches and which inherits, `sigmas * density_scale`, the background mix, the four loss terms
 with their rates and the 0.995 decay, the VM L1 term, and autograd through all of it.  The native operators underneath
 (march_rays_train, composite_rays_train, grid_encode, sh_encode) are the CPU oracle standing in for the reference's CUDA
-extensions (they cannot be built here: no cuda.h, stand-ins are not allowed), exactly as in make_golden.py, and `Tensor.cuda()` is
+extensions here on the CPU (their kernels only run on a GPU: oracle/build_ref.py + make_golden_ref_kernels.py pin those), exactly as in make_golden.py, and `Tensor.cuda()` is
 made the identity for the run (the wrappers call it; there is no GPU here) -- so this pins the repo's renderer / trainer
 restatement, not kernel arithmetic.
 
