@@ -64,7 +64,8 @@ def compare(a, which=("A", "B", "C")):
     dev = torch.device("cuda:0")
 
     def config():
-        return PVDConfig(model_type=a.student, iters=a.steps, stage_iters={"stage1": a.stage1, "stage2": a.stage2}, fp16=True)
+        return PVDConfig(model_type=a.student, teacher_type=getattr(a, "teacher_type", "hash"), iters=a.steps,
+                         stage_iters={"stage1": a.stage1, "stage2": a.stage2}, fp16=True)
 
     # the teacher and the student's initial state: made once, by the product
     torch.manual_seed(0)
@@ -124,12 +125,13 @@ def main():
     ap.add_argument("--stage2", type=int, default=1500)
     ap.add_argument("--steps", type=int, default=6000)
     ap.add_argument("--student", default="vm")
+    ap.add_argument("--teacher-type", default="hash", help="mlp: no grid encoder anywhere -- every native call of run A is the reference's own code")
     a = ap.parse_args()
     from pvd.trainer import psnr
     runs, teacher_psnr = compare(a)
-    print("hash -> %s distillation on the synthetic chair, fp16 AMP, 4096 rays/step, one MI355X; teacher: %d steps on the analytic scene "
+    print("%s -> %s distillation on the synthetic chair, fp16 AMP, 4096 rays/step, one MI355X; teacher: %d steps on the analytic scene "
           "(last-batch PSNR %.2f dB); schedule: stage 1 to %d, stage 2 to %d, stage 3 to %d; 4 held-out 200x200 views, inference path"
-          % (a.student, a.teacher, teacher_psnr or float("nan"), a.stage1, a.stage2, a.steps))
+          % (a.teacher_type, a.student, a.teacher, teacher_psnr or float("nan"), a.stage1, a.stage2, a.steps))
     print("%-58s %7s %9s %20s %16s %16s" % ("run", "steps", "wall s", "student vs teacher dB", "student vs GT dB", "teacher vs GT dB"))
     for name, rows, _, dt, steps in runs:
         m = rows.mean(0)
