@@ -118,8 +118,54 @@ def compare(a, which=("A", "B", "C")):
     return [run(table[k][0], table[k][1](), table[k][2]) for k in which], teacher_psnr
 
 
+def compare_teacher_training(a):
+    """configs[1]: the hash (or mlp / vm) model trained on the analytic scene's pixels for a.teacher steps through both stacks -- same
+    initial weights (seeded constructor), same batches -- then 4 held-out views against the ground truth."""
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    from pvd.trainer import psnr
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    rows = []
+    for name, ops in (("A  reference kernels + PyTorch (eager)", reference_kernel_ops()), ("B  libpvd_hip.so (eager)", hip_ops())):
+        seed = int(getattr(a, "seed", 0))
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed(1234 + seed)
+        opt = PVDConfig(model_type="vm", teacher_type=a.teacher_type, fp16=True)
+        t0 = time.perf_counter()
+        w = DistillWorkload(ops, dev, opt, teacher_pretrain_steps=a.teacher, seed=seed)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        poses = torch.from_numpy(synthetic_poses(np.random.RandomState(123))[:4]).to(dev)
+        res = 200
+        intr = tuple(v * res / 800.0 for v in BLENDER_INTRINSICS)
+        w.tea.eval()
+        vals, imgs = [], []
+        with torch.no_grad():
+            for pose in poses:
+                r = get_rays(pose[None], intr, res, res, -1)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    t_img = w.tea.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, max_steps=1024)["image"]
+                gt = w.target(r["rays_o"], r["rays_d"], torch.ones(1, res * res, 3, device=dev))
+                vals.append(float(psnr(t_img, gt)))
+                imgs.append(t_img.float())
+        rows.append((name, np.array(vals), torch.stack(imgs), dt, w.teacher_psnr))
+        del w
+        torch.cuda.empty_cache()
+    print("%s model trained on the analytic chair's pixels (configs[1]), %d steps x 4096 rays, fp16 AMP, one MI355X; 4 held-out 200x200 views, inference path"
+          % (a.teacher_type, a.teacher))
+    print("%-44s %9s %22s %18s" % ("run", "wall s", "last training batch dB", "held-out vs GT dB"))
+    for name, v, _, dt, last in rows:
+        print("%-44s %9.1f %22.3f %18.3f   per view %s" % (name, dt, last, v.mean(), np.array2string(v, precision=2)))
+    print("difference of the means: B - A  %+.3f dB;  the two models' renders against each other: %.2f dB"
+          % (rows[1][1].mean() - rows[0][1].mean(), float(psnr(rows[1][2], rows[0][2]))))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0, help="(--teacher-training) initial weights and batches")
+    ap.add_argument("--teacher-training", action="store_true", help="configs[1] instead: train the teacher-type model through both stacks")
     ap.add_argument("--teacher", type=int, default=3000)
     ap.add_argument("--stage1", type=int, default=500)
     ap.add_argument("--stage2", type=int, default=1500)
@@ -127,6 +173,8 @@ def main():
     ap.add_argument("--student", default="vm")
     ap.add_argument("--teacher-type", default="hash", help="mlp: no grid encoder anywhere -- every native call of run A is the reference's own code")
     a = ap.parse_args()
+    if a.teacher_training:
+        return compare_teacher_training(a)
     from pvd.trainer import psnr
     runs, teacher_psnr = compare(a)
     print("%s -> %s distillation on the synthetic chair, fp16 AMP, 4096 rays/step, one MI355X; teacher: %d steps on the analytic scene "
