@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 m = make_model(hip_ops(), PVDConfig(model_type="hash"), "hash", True, dev).eval()
 m.encoder.embeddings.data.uniform_(-0.3, 0.3)
 xs = [(samples(4096, pose=p) * 2 - 1).contiguous() for p in range(20)]
-for K in (1, 2, 5, 10, 20):
+for K in (1, 2, 3, 4, 5, 8, 10, 20):
     x = torch.cat(xs[:K]).contiguous()
     d = torch.randn_like(x)
     d = d / d.norm(dim=-1, keepdim=True)
