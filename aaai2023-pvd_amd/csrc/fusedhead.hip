@@ -32,6 +32,7 @@
 #include "infer_persistent.h"
 #include "grid_lookup.h"
 #include "head_dw_reduce.h"
+#include "head_pack.h"
 #include "vm_lookup.h"
 
 #include <stdlib.h>
@@ -44,7 +45,6 @@ typedef half_t h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kHeadBlock = 256;  // 4 independent waves sharing the weights in LDS
-constexpr int kPad = 4;               // halfs of LDS row padding
 
 __device__ __forceinline__ f4 mfma(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
@@ -135,7 +135,6 @@ struct HeadArgs {
     float *feat16;  // [M][16]  feature_sigma_color
 };
 
-constexpr int KIND_HASH = 0, KIND_VM = 1;
 
 // the 4 SH values k = 4*hi + j of a degree-4 basis for direction d (all 16 computed, 4 kept)
 __device__ __forceinline__ h4 sh_frag(float x, float y, float z, uint32_t hi) {
@@ -261,59 +260,13 @@ __device__ __forceinline__ void copy_image_dma_static(half_t *__restrict__ lds, 
     }
 }
 
-// the packed image: [HeadLds<KIND>][HeadLdsT<KIND>], exactly the backward kernel's LDS contents.  One image element per
-// thread and ONE round of loads: the ten matrices (five weights, plain and transposed) used to be ten loops one after the
-// other, i.e. ten dependent memory round trips for 43 k elements (7.6 us in the step's timeline).
-struct PackSeg {
-    int begin;        // first image element (halfs) of this matrix
-    int rows_dst, stride;  // destination rows and row stride (cols_pad + kPad, or rows_pad + kPad when transposed)
-    const float *src;
-    int rows, cols, rows_pad, cols_pad, row0, col_split, transposed;
-};
-
-__device__ __forceinline__ float pack_value(const PackSeg &g, int local) {
-    const int dr = local / g.stride, dc = local - dr * g.stride;
-    const int r = g.transposed ? dc : dr, c = g.transposed ? dr : dc;  // logical (padded) row / column of the weight
-    if (r >= g.rows_pad || c >= g.cols_pad) return 0.f;                // row padding
-    const int sr = r - g.row0;
-    int sc = c;
-    if (g.col_split >= 0) {
-        if (c == g.col_split) return 0.f;
-        if (c > g.col_split) sc = c - 1;
-    }
-    return (sr >= 0 && sr < g.rows && sc < g.cols) ? g.src[(size_t)sr * g.cols + sc] : 0.f;
-}
-
+// the packed image: [HeadLds<KIND>][HeadLdsT<KIND>], exactly the backward kernel's LDS contents (head_pack.h: shared with the VM
+// lookup's forward launch, which can carry the pack in extra workgroups)
 template <int KIND>
 __global__ void __launch_bounds__(256) k_head_pack(HeadArgs a, half_t *__restrict__ image) {
-    // (matrix, rows, cols, rows_pad, cols_pad, row0, col_split) in the order HeadLds / HeadLdsT carve them
-    PackSeg seg[10];
-    int n = 0, pos = 0;
-    auto add = [&](const float *src, int rows, int cols, int rows_pad, int cols_pad, int row0, int split, int transposed) {
-        const int rows_dst = transposed ? cols_pad : rows_pad, stride = (transposed ? rows_pad : cols_pad) + kPad;
-        seg[n++] = PackSeg{pos, rows_dst, stride, src, rows, cols, rows_pad, cols_pad, row0, split, transposed};
-        pos += rows_dst * stride;
-    };
-    for (int t = 0; t < 2; t++) {
-        if (KIND == KIND_HASH) {
-            add(a.Wa1, 64, 28, 64, 32, 0, -1, t);
-            add(a.Wa2, 16, 64, 16, 64, 0, -1, t);
-        } else {
-            add(a.Wa1, 15, 144, 16, 144, 1, -1, t);  // zero row 0
-        }
-        add(a.Wc1, 64, 31, 64, 32, 0, 16, t);  // zero column 16
-        add(a.Wc2, 64, 64, 64, 64, 0, -1, t);
-        add(a.Wc3, 3, 64, 16, 64, 0, -1, t);
-    }
-    const int total = pos;  // == HeadLds<KIND>::halfs + HeadLdsT<KIND>::halfs
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        PackSeg g = seg[0];  // (unrolled selection: the segment table stays in scalar registers, no indexed private array)
-#pragma unroll
-        for (int q = 1; q < 10; q++)
-            if (q < n && i >= seg[q].begin) g = seg[q];
-        image[i] = (half_t)pack_value(g, i - g.begin);
-    }
+    head_pack_elements<KIND>(a.Wa1, a.Wa2, a.Wc1, a.Wc2, a.Wc3, image, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
+static_assert(kVmImageHalfs == HeadLds<KIND_VM>::halfs + HeadLdsT<KIND_VM>::halfs, "head_pack.h: the VM image's size");
 
 // the global-memory inputs of one tile.  Loaded one tile AHEAD of their use: at one wave per SIMD (the backward) nothing
 // else hides the ~2k-cycle round trip, which was a quarter of the 17.5k cycles per tile.

@@ -8,7 +8,7 @@ void set_last_error(hipError_t e) { g_last_error = e; }
 
 extern "C" {
 
-int pvd_abi_version(void) { return 5; }  // 2: pvd_adamw_extras gained snapshot / replay; 3: + warm_zero_grad_from, zero_grad_after, arrivals; 4: pvd_head_dw_rider.found_inf; 5: pvd_adamw_extras.compact_grad / compact_param_out / tail_clear, pvd_composite_objective_forward(arrive), pvd_segments_gather_zero_check
+int pvd_abi_version(void) { return 6; }  // 2: pvd_adamw_extras gained snapshot / replay; 3: + warm_zero_grad_from, zero_grad_after, arrivals; 4: pvd_head_dw_rider.found_inf; 5: pvd_adamw_extras.compact_grad / compact_param_out / tail_clear, pvd_composite_objective_forward(arrive), pvd_segments_gather_zero_check; 6: pvd_vm_forward_pack_rider
 
 const char *pvd_status_string(int status) {
     switch (status) {

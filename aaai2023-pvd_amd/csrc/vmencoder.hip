@@ -19,6 +19,7 @@
 // consecutive samples that hit the same texel are merged in registers before touching memory.
 #include "pvd_device.h"
 #include "head_dw_reduce.h"
+#include "head_pack.h"
 #include "vm_lookup.h"
 
 #include <stdlib.h>
@@ -306,7 +307,14 @@ __device__ __forceinline__ void walk_move(PlaneWin<GRAD> &pw, LineWin<GRAD> &lw,
 template <typename T>
 __global__ void __launch_bounds__(kVmBlock) k_vm_fwd(const float *__restrict__ xyz, uint32_t M, uint32_t chunk, VmTables tb,
                                                      float *__restrict__ sigma_feat, T *__restrict__ color_prod,
-                                                     const int32_t *__restrict__ rows_dev) {
+                                                     const int32_t *__restrict__ rows_dev, pvd_head_pack_rider pk = pvd_head_pack_rider{},
+                                                     uint32_t lookup_blocks = 0xFFFFFFFFu) {
+    if (blockIdx.x >= lookup_blocks) {  // the VM head's packed weight image riding on this launch: head_pack.h
+        static_assert(kVmBlock == 256, "the pack workgroups stride by 256 threads");
+        head_pack_elements<KIND_VM>(pk.Wa1, nullptr, pk.Wc1, pk.Wc2, pk.Wc3, reinterpret_cast<_Float16 *>(pk.image),
+                                    (int)((blockIdx.x - lookup_blocks) * kVmBlock + threadIdx.x), (int)((gridDim.x - lookup_blocks) * kVmBlock));
+        return;
+    }
     if (rows_dev) M = min(M, (uint32_t)max(*rows_dev, 0));  // inference rounds: the row count lives on the device
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kVmBlock + threadIdx.x) >> 6;
@@ -449,24 +457,44 @@ using namespace pvd;
 
 extern "C" {
 
-int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
-                   float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
-                   pvd_stream_t stream) {
-    if (M == 0) return PVD_OK;
+static int vm_forward_impl(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                           float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
+                           const pvd_head_pack_rider *pack, pvd_stream_t stream) {
     if (!xyz || !aabb_host || !tables_host || !res_host || !sigma_feat || !color_prod) return PVD_ERR_INVALID;
     VmTables tb;
     const int rc = fill_tables(tb, tables_host, res_host, aabb_host, texel_stride_host);
     if (rc != PVD_OK) return rc;
     const uint32_t chunk = pick_chunk(M, false);
     const uint32_t waves = div_up(M, chunk);
-    const dim3 grid(div_up(waves * 64u, kVmBlock)), block(kVmBlock);
+    const uint32_t lookup_blocks = div_up(waves * 64u, kVmBlock);
+    // the rider's workgroups come LAST in the grid (dispatched behind the lookup's: they fill the launch's tail), one element each
+    const uint32_t pack_blocks = pack ? div_up((uint32_t)kVmImageHalfs, kVmBlock) : 0u;
+    const dim3 grid(lookup_blocks + pack_blocks), block(kVmBlock);
+    const pvd_head_pack_rider pk = pack ? *pack : pvd_head_pack_rider{};
     if (prod_dtype == PVD_F32)
-        hipLaunchKernelGGL((k_vm_fwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (float *)color_prod, rows_dev);
+        hipLaunchKernelGGL((k_vm_fwd<float>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (float *)color_prod, rows_dev, pk,
+                           lookup_blocks);
     else if (prod_dtype == PVD_F16)
-        hipLaunchKernelGGL((k_vm_fwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (half_t *)color_prod, rows_dev);
+        hipLaunchKernelGGL((k_vm_fwd<half_t>), grid, block, 0, (hipStream_t)stream, xyz, M, chunk, tb, sigma_feat, (half_t *)color_prod, rows_dev, pk,
+                           lookup_blocks);
     else
         return PVD_ERR_UNSUPPORTED;
     return check_launch();
+}
+
+int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                   float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
+                   pvd_stream_t stream) {
+    if (M == 0) return PVD_OK;
+    return vm_forward_impl(xyz, M, aabb_host, tables_host, res_host, sigma_feat, color_prod, prod_dtype, rows_dev, texel_stride_host, nullptr, stream);
+}
+
+int pvd_vm_forward_pack_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
+                              float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
+                              const pvd_head_pack_rider *pack, pvd_stream_t stream) {
+    if (!pack || !pack->Wa1 || !pack->Wc1 || !pack->Wc2 || !pack->Wc3 || !pack->image || M == 0)
+        return PVD_ERR_INVALID;  // (an owed image cannot be dropped: with no rows there is no launch to ride on)
+    return vm_forward_impl(xyz, M, aabb_host, tables_host, res_host, sigma_feat, color_prod, prod_dtype, rows_dev, texel_stride_host, pack, stream);
 }
 
 static int vm_backward_impl(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,

@@ -291,14 +291,27 @@ def vm_head_train(model, sigma_raw, prod, d, head_dw=None):
                               head_dw)
 
 
-def prepack_train_image(model):
-    """Pack NOW, on the caller's stream, the weight image the next vm_head_train forward of `model` will use (the trainer
-    issues this next to the marcher, on a parallel branch of the captured step).  The weights must not change in between."""
-    if getattr(model, "model_type", None) != "vm":
-        return False
+def train_image_buffer(model):
+    """the VM model's own buffer for the training head's packed weight image"""
     buf = getattr(model, "_train_image_buf", None)
     if buf is None:
         buf = model._train_image_buf = torch.empty(pvd_hip.head_image_halfs(KIND_VM), dtype=torch.float16, device=model.basis_mat.weight.device)
+    return buf
+
+
+def pack_rides_on_lookup():
+    """The training head's weight image is packed by extra workgroups of the VM lookup's forward launch (network.py; round 6).
+    PVD_HEAD_DW_RIDE=0 -- the switch of the head's riders on the lookup's launches -- makes it a launch again (tests)."""
+    return os.environ.get("PVD_HEAD_DW_RIDE", "1") != "0"
+
+
+def prepack_train_image(model):
+    """Pack NOW, on the caller's stream, the weight image the next vm_head_train forward of `model` will use (the trainer
+    issues this next to the marcher, on a parallel branch of the captured step).  The weights must not change in between.
+    Nothing to do (False) when the pack rides on the lookup's launch."""
+    if getattr(model, "model_type", None) != "vm" or pack_rides_on_lookup():
+        return False
+    buf = train_image_buffer(model)
     pvd_hip.head_pack_weights(KIND_VM, model.basis_mat.weight.detach(), None, model.color_net[0].weight.detach(),
                               model.color_net[1].weight.detach(), model.color_net[2].weight.detach(), image=buf)
     model._train_image_ready = buf

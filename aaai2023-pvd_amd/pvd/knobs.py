@@ -28,7 +28,7 @@ TEST = {
     "PVD_ADAMW_LAZY": ("1", "0 = decay the cold parameter groups every step instead of logging and replaying the decays -- bit-identical"),
     "PVD_TOUCHED_SET": ("1", "0 = zero / check the whole gradient buffer instead of the rows the occupancy grid lets a sample touch -- same training"),
     "PVD_INF_CHECK_RIDE": ("1", "0 = GradScaler's inf check as a launch of its own instead of riding on the table scatter / the exchange"),
-    "PVD_HEAD_DW_RIDE": ("1", "0 = the heads' weight-gradient reduction as its own launch instead of extra workgroups of the table scatter"),
+    "PVD_HEAD_DW_RIDE": ("1", "0 = the VM head's riders on the lookup's launches as launches of their own: the weight-gradient reduction (extra workgroups of the table scatter) and the f16 weight image (extra workgroups of the lookup's forward)"),
     "PVD_MLP_FUSED": ("1", "0 = the frozen NeRF-MLP teacher layer by layer instead of pvd_mlp_head_forward_fused"),
     "PVD_INFER_PERSISTENT": ("1", "0 = inference as rounds (march / forward / composite / compact launches) instead of one persistent launch -- bit-identical images"),
     "PVD_INFER_DEVICE_ROUNDS": ("1", "0 = the reference-shaped host loop with a read-back per round"),

@@ -322,8 +322,18 @@ class NeRFNetwork(NeRFRenderer):
                 if head_dw is not None and getattr(self, "_inf_check_in_backward", None) is not None:
                     # (trainer) the scaler's inf check of this model's gradients rides on the same launch: (flag, note)
                     head_dw["found_inf"] = self._inf_check_in_backward
+                if head_dw is not None and hasattr(fh, "train_image_buffer") and fh.pack_rides_on_lookup() and "_train_image_ready" not in self.__dict__:
+                    # ... and so does the head's packed f16 weight image, on the lookup's FORWARD launch (nothing between the update
+                    # and the head's forward but the lookup: no pack launch, no wait for one packed on another stream)
+                    head_dw["pack"] = (self.basis_mat.weight, self.color_net[0].weight, self.color_net[1].weight, self.color_net[2].weight,
+                                       fh.train_image_buffer(self))
                 sraw, prod = self.ops.vm_encode(x, self._aabb(), *self.sigma_mat, *self.sigma_vec, *self.color_mat, *self.color_vec,
                                                 *(() if head_dw is None else (head_dw,)))
+                if head_dw is not None:
+                    head_dw.pop("pack", None)  # (a lookup that did not take it: the head packs for itself)
+                    packed = head_dw.pop("packed", None)
+                    if packed is not None:
+                        self._train_image_ready = packed
                 out = fh.vm_head_train(self, sraw, prod, d, head_dw=head_dw if prod.requires_grad else None)
             elif self.model_type == "hash" and hasattr(fh, "hash_head_train") and not x.requires_grad:
                 out = fh.hash_head_train(self, x, d)  # teacher training / hash student

@@ -80,7 +80,7 @@ ENTRY_POINTS = (
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
     "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
-    "pvd_vm_forward", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_infer_image_plenoxel", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
+    "pvd_vm_forward", "pvd_vm_forward_pack_rider", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_infer_image_plenoxel", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
     "pvd_head_backward", "pvd_head_backward_workspace_floats", "pvd_head_image_halfs", "pvd_head_pack_weights",
     "pvd_composite_rays_train_bg_forward", "pvd_composite_rays_train_bg_backward",
@@ -511,13 +511,34 @@ def _rows_dev(rows_dev, dev):
     return _p(rows_dev)
 
 
-def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=None):
-    """tables: 12 channels-last factor tensors (physical [H][W][R] / [L][R]); see include/pvd_hip.h."""
+class _HeadPackRider(ctypes.Structure):  # pvd_head_pack_rider, include/pvd_hip.h
+    _fields_ = [("Wa1", ctypes.c_void_p), ("Wc1", ctypes.c_void_p), ("Wc2", ctypes.c_void_p), ("Wc3", ctypes.c_void_p), ("image", ctypes.c_void_p)]
+
+
+def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=None, pack=None):
+    """tables: 12 channels-last factor tensors (physical [H][W][R] / [L][R]); see include/pvd_hip.h.
+    pack = (basis_mat.weight, color_net.0/1/2.weight, image): the VM head's packed weight image is written by extra workgroups of this
+    launch (pvd_vm_forward_pack_rider) -- what head_pack_weights(KIND_VM, ..., image=image) would write."""
     dev, aabb, resa = _vm_common(xyz, aabb_host, tables, res)
     _dev(sigma_feat, color_prod)
     _want(sigma_feat, torch.float32, "sigma_feat")
     dt = _table_dtype(color_prod, "color_prod")
     strides, _ = _vm_texel_strides(tables)
+    if pack is not None:
+        Wa1, Wc1, Wc2, Wc3, image = pack
+        _dev(xyz, Wa1, Wc1, Wc2, Wc3, image)
+        for w, shape in ((Wa1, (15, 144)), (Wc1, (64, 31)), (Wc2, (64, 64)), (Wc3, (3, 64))):
+            _want(w, torch.float32, "head weight")
+            if tuple(w.shape) != shape or not w.is_contiguous():
+                raise PvdHipError("pack rider: head weight of shape %s, contiguous, expected" % (shape,))
+        _want(image, torch.float16, "image")
+        if image.numel() != head_image_halfs(1) or not image.is_contiguous() or xyz.shape[0] == 0:
+            raise PvdHipError("pack rider: image of head_image_halfs(1) halfs and at least one row expected")
+        rider = _HeadPackRider(Wa1.data_ptr(), Wc1.data_ptr(), Wc2.data_ptr(), Wc3.data_ptr(), image.data_ptr())
+        _check(_invoke("pvd_vm_forward_pack_rider", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat),
+                       _p(color_prod), _int(dt), _rows_dev(rows_dev, dev), strides, ctypes.byref(rider), meta=(xyz.shape[0], dt)),
+               "pvd_vm_forward_pack_rider")
+        return
     _check(_invoke("pvd_vm_forward", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat), _p(color_prod),
                    _int(dt), _rows_dev(rows_dev, dev), strides, meta=(xyz.shape[0], dt)), "pvd_vm_forward")
 

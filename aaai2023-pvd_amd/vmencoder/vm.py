@@ -59,7 +59,14 @@ def make_vm_encode(backend, device_type="cuda"):
             half = torch.is_autocast_enabled(device_type)
             sigma_feat = torch.empty(M, dtype=torch.float32, device=xyz.device)
             color_prod = torch.empty(M, 144, dtype=torch.float16 if half else torch.float32, device=xyz.device)
-            backend.vm_forward(xyz, aabb_host, tabs, res, sigma_feat, color_prod)
+            # "pack" in the hand-over dict: (basis_mat.weight, color_net.0/1/2.weight, image) -- the VM head's packed weight image is
+            # written by extra workgroups of this lookup's launch (pvd_hip.vm_forward(pack=)); "packed" tells the head it is there
+            pack = ctx.head_dw.pop("pack", None) if ctx.head_dw is not None else None
+            if pack is not None and M > 0:
+                backend.vm_forward(xyz, aabb_host, tabs, res, sigma_feat, color_prod, pack=tuple(t.detach() for t in pack))
+                ctx.head_dw["packed"] = pack[-1]
+            else:
+                backend.vm_forward(xyz, aabb_host, tabs, res, sigma_feat, color_prod)
             ctx.save_for_backward(xyz, *tabs)
             ctx.aabb_host, ctx.res = aabb_host, res
             ctx.leaves = tables  # the Parameter objects themselves (to reach their .grad buffers)

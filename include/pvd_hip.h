@@ -254,6 +254,20 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
                    const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev,
                    const uint32_t *texel_stride_host, pvd_stream_t stream);
 
+/* (ABI 6) The VM head's packed weight image riding on the lookup's launch: pvd_vm_forward_pack_rider = pvd_vm_forward + what
+ * pvd_head_pack_weights(kind 1, Wa1 = basis_mat, Wc1..3 = color_net, image) writes, in extra workgroups at the end of the same grid.
+ * In a training step the head's forward follows the lookup and both read the weights the update has just written: with the pack on
+ * the lookup's launch the step's dependent chain has neither a pack launch nor a cross-stream wait for one.  The image
+ * (pvd_head_image_halfs(1) halfs) is complete when the launch is; it must not be in use by another stream meanwhile.  M == 0 is
+ * PVD_ERR_INVALID (no launch to ride on: call pvd_head_pack_weights). */
+typedef struct pvd_head_pack_rider {
+    const float *Wa1, *Wc1, *Wc2, *Wc3; /* DEVICE fp32 masters: basis_mat [15][144], color_net [64][31], [64][64], [3][64] */
+    void *image;                        /* DEVICE f16 [pvd_head_image_halfs(1)] */
+} pvd_head_pack_rider;
+int pvd_vm_forward_pack_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
+                              const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev,
+                              const uint32_t *texel_stride_host, const pvd_head_pack_rider *pack, pvd_stream_t stream);
+
 /* grad_tables_host[12]: HOST array of DEVICE pointers laid out like tables_host, f32, accumulated into
  * with atomics (zero-filled by the caller, or a gradient buffer to accumulate into). */
 int pvd_vm_backward(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,

@@ -16,7 +16,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
-    assert len(syms) == 71, syms
+    assert len(syms) == 72, syms
     for must in ("pvd_march_rays_train", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
                  "pvd_grid_encode_forward", "pvd_grid_encode_backward", "pvd_sh_encode_forward", "pvd_near_far_from_aabb"):
         assert must in syms
@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib_built):
     for s in declared_symbols():
         assert hasattr(lib, s), "libpvd_hip.so does not export %s" % s
     lib.pvd_abi_version.restype = ctypes.c_int
-    assert lib.pvd_abi_version() == 5
+    assert lib.pvd_abi_version() == 6
     lib.pvd_status_string.restype = ctypes.c_char_p
     assert lib.pvd_status_string(-2) and lib.pvd_status_string(0) == b"ok"
 

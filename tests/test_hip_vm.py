@@ -165,3 +165,59 @@ def test_vm_non_cubic_tables_and_incoherent_order():
     gh = torch.autograd.grad((sig_h * gs).sum() + (prod_h.float() * gp).sum(), params)
     for a, b in zip(gh, gr):
         assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("M", [1, 4097, 92928])
+def test_head_weight_image_packed_on_the_lookup_launch_is_the_pack_kernels_image(M):
+    """pvd_vm_forward_pack_rider (ABI 6): the VM head's f16 weight image written by extra workgroups of the lookup's forward launch --
+    the same bits as pvd_head_pack_weights, and a lookup that is the plain launch's, for one row, a ragged and the metric's row count;
+    then a training forward + backward of the model with the rider on (default) and off: identical outputs and gradients."""
+    import os
+    import pvd_hip
+    from vmencoder.vm import to_channels_last_param
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    res = [300, 300, 300]
+    mats = [to_channels_last_param(torch.randn(1, R, 300, 300, device=dev, generator=g) * 0.1) for R in (16, 16, 16)]
+    vecs = [to_channels_last_param(torch.randn(1, R, 300, 1, device=dev, generator=g) * 0.1) for R in (16, 16, 16)]
+    cmats = [to_channels_last_param(torch.randn(1, 48, 300, 300, device=dev, generator=g) * 0.1) for _ in range(3)]
+    cvecs = [to_channels_last_param(torch.randn(1, 48, 300, 1, device=dev, generator=g) * 0.1) for _ in range(3)]
+    tabs = mats + vecs + cmats + cvecs
+    x = (torch.rand(M, 3, device=dev, generator=g) * 2 - 1).contiguous()
+    aabb = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    Wa1, Wc1, Wc2, Wc3 = (torch.randn(*s, device=dev, generator=g) for s in ((15, 144), (64, 31), (64, 64), (3, 64)))
+    want = pvd_hip.head_pack_weights(1, Wa1, None, Wc1, Wc2, Wc3)
+    s0, p0 = torch.empty(M, device=dev), torch.empty(M, 144, dtype=torch.float16, device=dev)
+    pvd_hip.vm_forward(x, aabb, tabs, res, s0, p0)
+    image = torch.full((pvd_hip.head_image_halfs(1),), float("nan"), dtype=torch.float16, device=dev)
+    s1, p1 = torch.empty(M, device=dev), torch.empty(M, 144, dtype=torch.float16, device=dev)
+    pvd_hip.vm_forward(x, aabb, tabs, res, s1, p1, pack=(Wa1, Wc1, Wc2, Wc3, image))
+    assert torch.equal(image.view(torch.int16), want[:image.numel()].view(torch.int16))
+    assert torch.equal(s0, s1) and torch.equal(p0.view(torch.int16), p1.view(torch.int16))
+    with pytest.raises(pvd_hip.PvdHipError):
+        pvd_hip.vm_forward(x[:0], aabb, tabs, res, s1[:0], p1[:0], pack=(Wa1, Wc1, Wc2, Wc3, image))
+    if M != 4097:
+        return
+    # the model's training forward + backward, rider on / off
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import make_model
+    outs = []
+    for ride in ("1", "0"):
+        os.environ["PVD_HEAD_DW_RIDE"] = ride
+        try:
+            torch.manual_seed(0)
+            m = make_model(hip_ops(), PVDConfig(model_type="vm", stage_iters={"stage1": -1, "stage2": -1}), "vm", False, dev).train()
+            m.args.global_step = 0
+            d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(9)), dim=-1)
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, rgb = m(x * 0.9, d)
+                ((sigma * 1e-3).sum() + rgb.float().sum() + m.feature_sigma_color.sum()).backward()
+            assert ("_train_image_buf" in m.__dict__) == (ride == "1")
+            outs.append([sigma.detach().clone(), rgb.detach().float().clone()] + [p.grad.detach().float().clone() for p in m.parameters() if p.grad is not None])
+        finally:
+            os.environ.pop("PVD_HEAD_DW_RIDE", None)
+    assert len(outs[0]) == len(outs[1]) > 4
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2:], outs[1][2:]):
+        assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-30)  # (table gradients: atomics' order)
