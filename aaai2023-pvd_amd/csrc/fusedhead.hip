@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(256) k_head_pack(HeadArgs a, half_t *__restric
     head_pack_elements<KIND>(a.Wa1, a.Wa2, a.Wc1, a.Wc2, a.Wc3, image, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 static_assert(kVmImageHalfs == HeadLds<KIND_VM>::halfs + HeadLdsT<KIND_VM>::halfs, "head_pack.h: the VM image's size");
+static_assert(kHashImageHalfs == HeadLds<KIND_HASH>::halfs + HeadLdsT<KIND_HASH>::halfs, "head_pack.h: the hash image's size");
 
 // the global-memory inputs of one tile.  Loaded one tile AHEAD of their use: at one wave per SIMD (the backward) nothing
 // else hides the ~2k-cycle round trip, which was a quarter of the 17.5k cycles per tile.
@@ -1647,7 +1648,7 @@ __global__ void __launch_bounds__(kHeadBlock, OCC) k_head_bwd(HeadBwdArgs a) {
     auto load_grad = [&](size_t b, bool valid) {
         TileGrad q = {0.f, 0.f, 0.f, 0.f, zero};
         if (valid) {
-            q.feat = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);
+            if (a.g_feat16) q.feat = *reinterpret_cast<const f4 *>(a.g_feat16 + b * 16 + 4 * hi);  // (NULL: no gradient reaches the feature rows)
             if (hi == 0) {
                 q.r = a.g_rgb[3 * b]; q.g = a.g_rgb[3 * b + 1]; q.bl = a.g_rgb[3 * b + 2]; q.sig = a.g_sigma[b];
                 if (a.g_rgb2) { q.r += a.g_rgb2[3 * b]; q.g += a.g_rgb2[3 * b + 1]; q.bl += a.g_rgb2[3 * b + 2]; }
@@ -2180,7 +2181,7 @@ static int head_backward_impl(int kind, const void *x0, const float *sigma_raw, 
                               pvd_head_dw_rider *defer, pvd_stream_t stream) {
     if (defer) { defer->partials = nullptr; defer->nblocks = 0; }
     if (M == 0) return PVD_OK;
-    if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_feat16 || !g_x0 || !gWa1 || !gWc1 || !gWc2 || !gWc3 ||
+    if (!x0 || !dirs || !Wa1 || !Wc1 || !Wc2 || !Wc3 || !g_sigma || !g_rgb || !g_x0 || !gWa1 || !gWc1 || !gWc2 || !gWc3 ||
         !workspace)
         return PVD_ERR_INVALID;
     HeadBwdArgs a;

@@ -11,6 +11,7 @@
 // the [L,B,C] store is a fully coalesced C*sizeof(T)-per-lane write.  One feature vector
 // (C elements) is one global load / one packed atomic.
 #include "grid_lookup.h"
+#include "head_pack.h"
 
 namespace pvd {
 
@@ -87,6 +88,8 @@ static LevelSchedule make_schedule(const LevelScales &sc, uint32_t L, uint32_t n
 }
 
 static thread_local InputAffine g_input_affine = {false, 0.f, 1.f};
+// (pvd_grid_encode_forward_affine_pack) the hash head's packed weight image riding on the next forward launch of this thread
+static thread_local pvd_head_pack_rider g_pack_rider = {};
 
 // reference: kernel_grid, gridencoder.cu:75-224
 template <typename T, uint32_t D, uint32_t C>
@@ -304,15 +307,21 @@ template <uint32_t LPS>
 __global__ void __launch_bounds__(kGridBlock) k_grid_fwd_lps(const float *__restrict__ inputs, const uint32_t *__restrict__ grid,
                                                              const int32_t *__restrict__ offsets, uint32_t *__restrict__ outputs,
                                                              uint32_t B, uint32_t L, LevelScales scales, LpsSchedule sched,
-                                                             uint32_t gridtype, bool align_corners, uint32_t level_mask, InputAffine aff) {
+                                                             uint32_t gridtype, bool align_corners, uint32_t level_mask, InputAffine aff,
+                                                             pvd_head_pack_rider pk = pvd_head_pack_rider{}, uint32_t lookup_blocks = 0xFFFFFFFFu) {
     constexpr uint32_t D = 3;
     constexpr uint32_t SPB = kGridBlock / LPS;  // samples per workgroup pass
     constexpr uint32_t NL = 8 / LPS;            // loads per lane
+    if (blockIdx.x >= lookup_blocks) {  // the hash head's packed weight image riding on this launch (head_pack.h), at the end of the grid
+        head_pack_elements<KIND_HASH>(pk.Wa1, pk.Wa2, pk.Wc1, pk.Wc2, pk.Wc3, reinterpret_cast<_Float16 *>(pk.image),
+                                      (int)((blockIdx.x - lookup_blocks) * kGridBlock + threadIdx.x), (int)((gridDim.x - lookup_blocks) * kGridBlock));
+        return;
+    }
     const uint32_t q = threadIdx.x & (LPS - 1);
     const uint32_t xb = q & 1u, yq = (q >> 1) & 1u;
     const uint32_t s_in_block = threadIdx.x / LPS;
     uint32_t step, end;
-    uint32_t i = sched.first(blockIdx.x, gridDim.x, step, end);
+    uint32_t i = sched.first(blockIdx.x, lookup_blocks == 0xFFFFFFFFu ? gridDim.x : lookup_blocks, step, end);
     // the position of the NEXT item's sample is loaded while this item's gathers are in flight (a wave otherwise pays two
     // dependent memory round trips per item: position, then corners)
     auto fetch = [&](uint32_t item, uint32_t &level, uint32_t &b, Pos3 &p) {
@@ -640,7 +649,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_bwd_coarse(const T *__restr
 __global__ void __launch_bounds__(kGridBlock) k_grid_bwd_lps2(const uint32_t *__restrict__ grad, const float *__restrict__ inputs,
                                                               const int32_t *__restrict__ offsets, half_t *__restrict__ grad_grid, uint32_t B,
                                                               uint32_t L, LevelScales scales, uint32_t gridtype, bool align_corners,
-                                                              uint32_t level_mask) {
+                                                              uint32_t level_mask, InputAffine aff) {
     constexpr uint32_t D = 3;
     const uint32_t level = blockIdx.y;
     if (level >= L) return;
@@ -654,7 +663,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_bwd_lps2(const uint32_t *__
     index.init((uint32_t)offsets[level + 1] - off0, (uint32_t)ceil((double)scale) + 1u, gridtype, align_corners);
     float frac[D];
     uint32_t cell[D];
-    const bool live = b < B && locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell);
+    const bool live = b < B && locate<D>(inputs + (size_t)b * D, scale, align_corners, frac, cell, aff);
     float g0 = 0.f, g1 = 0.f;
     if (live) {
         half_t gv[2];
@@ -738,7 +747,12 @@ static int launch_fwd(const float *inputs, const void *emb, const int32_t *offse
         const bool affine = g_grid_affine && blocks >= 8;
         if (affine) blocks &= ~7u;
         const LpsSchedule sched = make_lps_schedule(sc, nullptr, L, nb, affine, g_grid_hash_rows);
-        if (lps == 2)
+        if (lps == 2 && g_pack_rider.image) {
+            const pvd_head_pack_rider pk = g_pack_rider;
+            g_pack_rider = pvd_head_pack_rider{};  // (taken)
+            hipLaunchKernelGGL((k_grid_fwd_lps<2>), dim3(blocks + div_up((uint32_t)kHashImageHalfs, kGridBlock)), dim3(kGridBlock), 0, s, inputs,
+                               (const uint32_t *)emb, offsets, (uint32_t *)outputs, B, L, sc, sched, gridtype, align, g_grid_level_mask, aff, pk, blocks);
+        } else if (lps == 2)
             hipLaunchKernelGGL((k_grid_fwd_lps<2>), dim3(blocks), dim3(kGridBlock), 0, s, inputs, (const uint32_t *)emb, offsets, (uint32_t *)outputs,
                                B, L, sc, sched, gridtype, align, g_grid_level_mask, aff);
         else
@@ -769,9 +783,10 @@ static int launch_bwd(const void *grad, const float *inputs, const int32_t *offs
     const LevelScales sc = make_scales(L, S, H);
     if (g_grid_bwd_lps && !calc && D == 3 && C == 2 && sizeof(T) == 2) {
         hipLaunchKernelGGL(k_grid_bwd_lps2, dim3(div_up(2u * B, kGridBlock), L), dim3(kGridBlock), 0, s, (const uint32_t *)grad, inputs, offsets,
-                           (half_t *)grad_emb, B, L, sc, gridtype, align, g_grid_level_mask);
+                           (half_t *)grad_emb, B, L, sc, gridtype, align, g_grid_level_mask, g_input_affine);
         return check_launch();
     }
+    if (g_input_affine.on) return PVD_ERR_UNSUPPORTED;  // (pvd_grid_encode_backward_affine: the f16 / D 3 / C 2 scatter only)
     // levels whose cells are wider than a few marching steps go through the run-merging kernel
     uint32_t n_coarse = 0;
     if (g_grid_coarse_scale > 0.f)
@@ -884,6 +899,28 @@ int pvd_grid_encode_forward_affine(const float *inputs, float in_add, float in_d
     return rc;
 }
 
+__global__ void __launch_bounds__(256) k_grid_pack_only(pvd_head_pack_rider pk) {
+    head_pack_elements<KIND_HASH>(pk.Wa1, pk.Wa2, pk.Wc1, pk.Wc2, pk.Wc3, reinterpret_cast<_Float16 *>(pk.image), (int)(blockIdx.x * 256 + threadIdx.x),
+                                  (int)(gridDim.x * 256));
+}
+
+int pvd_grid_encode_forward_affine_pack(const float *inputs, float in_add, float in_div, const void *embeddings, const int32_t *offsets,
+                                        void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                        int align_corners, int dtype, const pvd_head_pack_rider *pack, pvd_stream_t stream) {
+    if (!pack || pack->kind != 0 || !pack->Wa1 || !pack->Wa2 || !pack->Wc1 || !pack->Wc2 || !pack->Wc3 || !pack->image) return PVD_ERR_INVALID;
+    g_pack_rider = *pack;
+    const int rc = pvd_grid_encode_forward_affine(inputs, in_add, in_div, embeddings, offsets, outputs, B, D, C, L, S, H, gridtype, align_corners,
+                                                  dtype, stream);
+    if (g_pack_rider.image) {  // the launch that ran (another kernel variant, B == 0, an error) did not take it: pack in a launch of its own
+        const pvd_head_pack_rider pk = g_pack_rider;
+        g_pack_rider = pvd_head_pack_rider{};
+        if (rc != PVD_OK) return rc;
+        hipLaunchKernelGGL(k_grid_pack_only, dim3(div_up((uint32_t)kHashImageHalfs, 256u)), dim3(256), 0, (hipStream_t)stream, pk);
+        return check_launch();
+    }
+    return rc;
+}
+
 int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
                              void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
@@ -899,6 +936,18 @@ int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *
         return bwd_t<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs != 0, dy_dx, grad_inputs,
                              gridtype, align_corners != 0, (hipStream_t)stream);
     return PVD_ERR_UNSUPPORTED;
+}
+
+int pvd_grid_encode_backward_affine(const void *grad, const float *inputs, float in_add, float in_div, const void *embeddings,
+                                    const int32_t *offsets, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream) {
+    if (!(in_div != 0.f)) return PVD_ERR_INVALID;
+    if (!(dtype == PVD_F16 && D == 3 && C == 2)) return PVD_ERR_UNSUPPORTED;
+    g_input_affine = {true, in_add, in_div};
+    const int rc = pvd_grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype,
+                                            align_corners, dtype, stream);
+    g_input_affine = {false, 0.f, 1.f};
+    return rc;
 }
 
 }  // extern "C"

@@ -15,6 +15,10 @@ constexpr int KIND_HASH = 0, KIND_VM = 1;
 constexpr int kVmImageHalfs = (16 * (144 + kPad) + 64 * (32 + kPad) + 64 * (64 + kPad) + 16 * (64 + kPad)) +
                               (144 * (16 + kPad) + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad));
 
+// halfs of the hash head's image
+constexpr int kHashImageHalfs = (64 * (32 + kPad) + 16 * (64 + kPad) + 64 * (32 + kPad) + 64 * (64 + kPad) + 16 * (64 + kPad)) +
+                                (32 * (64 + kPad) + 64 * (16 + kPad) + 32 * (64 + kPad) + 64 * (64 + kPad) + 64 * (16 + kPad));
+
 // One image element per thread and ONE round of loads: the ten matrices (five weights, plain and transposed) used to be ten loops one
 // after the other, i.e. ten dependent memory round trips for 43 k elements (7.6 us in the step's timeline).
 struct PackSeg {

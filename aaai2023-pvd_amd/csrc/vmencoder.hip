@@ -492,7 +492,7 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
 int pvd_vm_forward_pack_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host, const uint32_t *res_host,
                               float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev, const uint32_t *texel_stride_host,
                               const pvd_head_pack_rider *pack, pvd_stream_t stream) {
-    if (!pack || !pack->Wa1 || !pack->Wc1 || !pack->Wc2 || !pack->Wc3 || !pack->image || M == 0)
+    if (!pack || pack->kind != 1 || !pack->Wa1 || !pack->Wc1 || !pack->Wc2 || !pack->Wc3 || !pack->image || M == 0)
         return PVD_ERR_INVALID;  // (an owed image cannot be dropped: with no rows there is no launch to ride on)
     return vm_forward_impl(xyz, M, aabb_host, tables_host, res_host, sigma_feat, color_prod, prod_dtype, rows_dev, texel_stride_host, pack, stream);
 }

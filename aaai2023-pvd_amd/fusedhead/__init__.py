@@ -325,6 +325,23 @@ def _grid_dims(enc):
     return L, C, float(np.log2(enc.per_level_scale))
 
 
+_ZERO_CACHE = {}
+
+
+def _zeros_cached(dev, *shape):
+    """A zero-filled f32 buffer that is only ever READ (an absent upstream gradient handed to a kernel): allocated and filled once per
+    shape instead of once per step.  While a graph is being recorded a fresh buffer is made (a cached one must not live in a graph's pool)."""
+    if torch.cuda.is_current_stream_capturing():
+        hit = _ZERO_CACHE.get((dev, shape))
+        return hit if hit is not None else torch.zeros(*shape, dtype=torch.float32, device=dev)
+    hit = _ZERO_CACHE.get((dev, shape))
+    if hit is None:
+        if len(_ZERO_CACHE) > 16:
+            _ZERO_CACHE.clear()
+        hit = _ZERO_CACHE[(dev, shape)] = torch.zeros(*shape, dtype=torch.float32, device=dev)
+    return hit
+
+
 class _HashHeadTrain(torch.autograd.Function):
     """(x01 [M,3] in [0,1], embeddings [rows,2] f32, dirs, sigma_net.{0,1}.weight, color_net.{0,1,2}.weight) ->
     (sigma, rgb, feature_sigma_color): grid lookup + MFMA head forward, MFMA head + grid scatter backward.
@@ -332,15 +349,28 @@ class _HashHeadTrain(torch.autograd.Function):
     gradient table from the atomics (grid.py:105-123), widened to f32 when it reaches the parameter."""
 
     @staticmethod
-    def forward(ctx, x01, emb, dirs, Ws0, Ws1, Wc1, Wc2, Wc3, offsets, S, H, gridtype, align, smin, cmax):
+    def forward(ctx, x01, emb, dirs, Ws0, Ws1, Wc1, Wc2, Wc3, offsets, S, H, gridtype, align, smin, cmax, aff=None):
+        """aff = (in_add, in_div): x01 holds positions in [-bound, bound] and both grid kernels map them while they read them
+        (pvd_grid_encode_forward_affine / _backward_affine: GridEncoder.forward's two elementwise launches and their tensor are gone)."""
         M = x01.shape[0]
         dev = x01.device
         x01, dirs = x01.float().contiguous(), dirs.float().contiguous()
         emb16 = emb.detach().to(torch.float16)
         enc = torch.empty(14, M, 2, dtype=torch.float16, device=dev)
-        pvd_hip.grid_encode_forward(x01, emb16, offsets, enc, M, 3, 2, 14, S, H, False, enc, gridtype, align)
+        image = None
+        if aff is None:
+            pvd_hip.grid_encode_forward(x01, emb16, offsets, enc, M, 3, 2, 14, S, H, False, enc, gridtype, align)
+        elif M > 0 and pack_rides_on_lookup():
+            # ... and the head's packed weight image is written by extra workgroups of the lookup's launch (no pack launch in between)
+            image = torch.empty(pvd_hip.head_image_halfs(KIND_HASH), dtype=torch.float16, device=dev)
+            pvd_hip.grid_encode_forward_affine_pack(x01, aff[0], aff[1], emb16, offsets, enc, M, 3, 2, 14, S, H, gridtype, align,
+                                                    (Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(), image))
+        else:
+            pvd_hip.grid_encode_forward_affine(x01, aff[0], aff[1], emb16, offsets, enc, M, 3, 2, 14, S, H, gridtype, align)
+        ctx.aff = aff
         sigma, rgb, feat = _outputs(M, dev)
-        image = pvd_hip.head_pack_weights(KIND_HASH, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach())
+        if image is None:
+            image = pvd_hip.head_pack_weights(KIND_HASH, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach())
         pvd_hip.head_forward(KIND_HASH, enc, None, dirs, M, Ws0.detach(), Ws1.detach(), Wc1.detach(), Wc2.detach(), Wc3.detach(),
                              smin, smin, cmax, sigma, rgb, feat, image=image)
         ctx.image = image
@@ -358,10 +388,10 @@ class _HashHeadTrain(torch.autograd.Function):
         emb = ctx.emb
         M = x01.shape[0]
         dev = x01.device
-        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        zeros = lambda *s: _zeros_cached(dev, *s)  # (teacher training: no gradient reaches the feature rows)
         g_sigma = g_sigma.float().contiguous() if g_sigma is not None else zeros(M)
         g_rgb = g_rgb.float().contiguous() if g_rgb is not None else zeros(M, 3)
-        g_feat = g_feat.float().contiguous() if g_feat is not None else zeros(M, 16)
+        g_feat = g_feat.float().contiguous() if g_feat is not None else None  # (NULL to the kernel: read as zeros)
         g_enc = torch.empty(14, M, 2, dtype=torch.float16, device=dev)
         ws = torch.empty(pvd_hip.head_backward_workspace_floats(KIND_HASH, M), dtype=torch.float32, device=dev)
         direct = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.leaves)
@@ -373,7 +403,10 @@ class _HashHeadTrain(torch.autograd.Function):
             S, H, gridtype, align = ctx.grid
             g16 = torch.zeros(emb.shape, dtype=torch.float16, device=dev)
             dummy = g16[:1]
-            pvd_hip.grid_encode_backward(g_enc, x01, g16, offsets, g16, M, 3, 2, 14, S, H, False, dummy, dummy, gridtype, align)
+            if ctx.aff is None:
+                pvd_hip.grid_encode_backward(g_enc, x01, g16, offsets, g16, M, 3, 2, 14, S, H, False, dummy, dummy, gridtype, align)
+            else:
+                pvd_hip.grid_encode_backward_affine(g_enc, x01, ctx.aff[0], ctx.aff[1], g16, offsets, g16, M, 3, 2, 14, S, H, gridtype, align)
             taker = getattr(emb, "_pvd_half_grad_taker", None)  # FlatAdamW: adds the f16 table inside its update kernel
             if emb.is_leaf and taker is not None and taker(emb, g16):
                 pass
@@ -382,7 +415,7 @@ class _HashHeadTrain(torch.autograd.Function):
             else:
                 g_emb = g16.float()
         gw = (None,) * 5 if direct else tuple(grads)
-        return (None, g_emb, None) + gw + (None,) * 7
+        return (None, g_emb, None) + gw + (None,) * 8
 
 
 def hash_head_train(model, x, d):
@@ -390,7 +423,7 @@ def hash_head_train(model, x, d):
     _, _, S = _grid_dims(enc)
     a = model.args
     bound = model.bound
-    x01 = (x.float() + bound) / (2 * bound)  # GridEncoder.forward's mapping (grid.py:211)
-    return _HashHeadTrain.apply(x01, enc.embeddings, d, model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight,
+    # GridEncoder.forward's mapping (grid.py:211), x01 = (x + bound) / (2 bound): inside the two grid kernels, the same two operations
+    return _HashHeadTrain.apply(x.float(), enc.embeddings, d, model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight,
                                 model.color_net[1].weight, model.color_net[2].weight, enc.offsets, S, enc.base_resolution, enc.gridtype_id,
-                                enc.align_corners, a.sigma_clip_min, a.sigma_clip_max)
+                                enc.align_corners, a.sigma_clip_min, a.sigma_clip_max, (float(bound), float(2 * bound)))

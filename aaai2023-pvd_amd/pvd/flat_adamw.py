@@ -318,16 +318,30 @@ class FlatAdamW(torch.optim.Optimizer):
     def note_checked_by_backward(self):
         self._checked_by_backward = True
 
-    def zero_grad(self, set_to_none=False):
+    _fp32_range_still_zero = None  # (lo, hi): the fp32 gradient range of a parameter whose gradient arrived in half precision, untouched since the last zero_grad
+
+    def zero_grad(self, set_to_none=False, full=False):
+        """full = True: zero the whole buffer whatever the last step is known to have left (the FIRST zero_grad of a recording: what
+        the host knows then describes the last executed step, not the state every replay will start from)."""
         self._checked_by_backward = False  # (a backward before this zero_grad says nothing about the gradients to come)
         self._half_grad = None
         self._half_range_dirty = False
         self._compact = None
+        still_zero, self._fp32_range_still_zero = self._fp32_range_still_zero, None
         if self._zeroed_by_step and self.touched is not None and self._outside_is_zero:
             self._zeroed_by_step = False  # the previous step's update zeroed every group it read: the touched set is clean
         elif self.touched is not None and self._outside_is_zero:
             self._zeroed_by_step = False
             self.touched.zero(self.flat_g)
+        elif still_zero is not None and not full and self.touched is None:
+            # the hash table's gradient went to the update in half precision (accept_half_grad) and nothing wrote its fp32 range since
+            # the last zero_grad: 42 MB of zeros need no second fill -- only what lies outside the range (the heads) is cleared
+            self._zeroed_by_step = False
+            lo, hi = still_zero
+            if lo > 0:
+                self.flat_g[:lo].zero_()
+            if hi < self.flat_g.numel():
+                self.flat_g[hi:].zero_()
         else:
             self._zeroed_by_step = False
             self.flat_g.zero_()
@@ -482,6 +496,10 @@ class FlatAdamW(torch.optim.Optimizer):
             if cg is not None:
                 zero_after = True  # (the exchange's gather zeroed every touched row behind itself)
         self._zeroed_by_step = zero_after
+        hg = getattr(self, "_half_grad", None)
+        # (every zero_grad leaves the whole buffer zero; a step whose table gradient was taken in half precision and whose fp32 range
+        # nobody wrote leaves that range zero)
+        self._fp32_range_still_zero = (hg[0], hg[1]) if (hg is not None and not self._half_range_dirty) else None
         self._half_grad = None
         self._half_range_dirty = False
         pvd_hip.note_weights_changed(self.params)  # the kernel rewrites the parameters without bumping their autograd versions

@@ -154,7 +154,7 @@ class FlatGrads:
         # grads to share one memory layout, and autograd then accumulates without a re-layout
         return torch.as_strided(self.flat, p.size(), p.stride(), storage_offset=off)
 
-    def zero_(self):
+    def zero_(self, full=False):
         self.flat.zero_()
         # re-attach: optimizers / zero_grad(set_to_none) may have dropped the views
         off = 0
@@ -170,8 +170,8 @@ class _FlatOptGrads:
     def __init__(self, opt):
         self.opt, self.flat, self.params = opt, opt.flat_g, opt.params
 
-    def zero_(self):
-        self.opt.zero_grad()
+    def zero_(self, full=False):
+        self.opt.zero_grad(full=full)
 
 
 def _make_loss(kind, dp):

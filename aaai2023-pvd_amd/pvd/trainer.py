@@ -152,15 +152,16 @@ class _TrainerBase:
             self._compactor = c
         return c if (c.fraction < 0.7 and c.agreed) else None
 
-    def _zero_grads(self):
+    def _zero_grads(self, first_in_recording=False):
         """zero_grad.  With the flat optimizer and a frozen occupancy grid only the rows a sample can touch are ever
         written (the same set the compact exchange moves), so after one full clear only those are cleared and
-        inf-checked (FlatAdamW.set_touched); PVD_TOUCHED_SET=0 turns that off."""
+        inf-checked (FlatAdamW.set_touched); PVD_TOUCHED_SET=0 turns that off.  first_in_recording: the first zero_grad recorded
+        into a graph clears everything (FlatAdamW.zero_grad(full=True))."""
         if self.flat_opt:
             c = self._grad_compactor() if os.environ.get("PVD_TOUCHED_SET", "1") != "0" else None
             if c is not self.optimizer.touched:
                 self.optimizer.set_touched(c)
-        self.flat.zero_()
+        self.flat.zero_(full=first_in_recording)
 
     # ---- ray-DP exchange, round 6 form (recorded steps with the flat optimizer's two-part update and a compact set)
     _xlayouts = None
@@ -324,8 +325,8 @@ class _TrainerBase:
             self._fold_launches(True)
         try:
             with cap:
-                for _ in range(max(1, int(steps_per_graph))):
-                    self._zero_grads()
+                for k_rec in range(max(1, int(steps_per_graph))):
+                    self._zero_grads(first_in_recording=k_rec == 0)
                     self._static_out = body()
                     if os.environ.get("PVD_TEST_FAIL_IN_CAPTURE") == "1":  # exercises the callers' eager fallback
                         raise RuntimeError("forced failure inside the capture (PVD_TEST_FAIL_IN_CAPTURE)")
@@ -747,7 +748,7 @@ class DistillTrainer(_TrainerBase):
                                 self.optimizer.run_part_a()  # what the previous step's update still owes
                                 if k == 0:
                                     self.optimizer.run_carried_part_a(scaled)  # ... and the previous replay's last step
-                        self._zero_grads()
+                        self._zero_grads(first_in_recording=k == 0)
                         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                             self._static_out = self.compute_loss(None, None, None, pre=pre)
                         self._backward(self._static_out[0])
@@ -848,14 +849,21 @@ class TeacherTrainer(_TrainerBase):
             out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                            dt_gamma=o.dt_gamma, max_steps=o.max_steps, num_steps=o.num_steps, upsample_steps=o.upsample_steps)
             pred = out["image"]
-            sq = (pred.float() - gt_rgb.float()) ** 2
-            loss = self.dp.global_mean(sq)
+            loss = self._mse(pred, gt_rgb)
             if o.l1_reg_weight > 0.0 and o.model_type == "vm":
                 loss = loss + self._l1_term()
         if error_sink is not None:
-            error_sink(sq.detach().mean(-1))
+            error_sink(((pred.detach().float() - gt_rgb.float()) ** 2).mean(-1))
         self._backward_and_step(loss)
         return loss.detach(), pred
+
+    def _mse(self, pred, gt):
+        """mean over rays and channels of the squared difference (just_train_tea/utils.py:573-581: MSELoss(reduction='none'), .mean(-1),
+        .mean()).  One GPU: the library's fused form -- two launches forward, one backward, where subtract / square / mean and their
+        three autograd nodes were six."""
+        if self.dp.enabled or not pred.is_cuda:
+            return self.dp.global_mean((pred.float() - gt.float()) ** 2)
+        return torch.nn.functional.mse_loss(pred.float(), gt.float())
 
     # ---- a whole block of steps between two occupancy-grid updates as ONE captured graph
     def _block_body(self, batches):
@@ -869,7 +877,7 @@ class TeacherTrainer(_TrainerBase):
                 out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
                                dt_gamma=o.dt_gamma, max_steps=o.max_steps, num_steps=o.num_steps, upsample_steps=o.upsample_steps)
                 pred = out["image"]
-                loss = self.dp.global_mean((pred.float() - gt_rgb.float()) ** 2)
+                loss = self._mse(pred, gt_rgb)
                 if o.l1_reg_weight > 0.0 and o.model_type == "vm":
                     loss = loss + self._l1_term()
             return loss, pred
@@ -892,7 +900,7 @@ class TeacherTrainer(_TrainerBase):
                 out = m.render(b[0], b[1], staged=False, bg_color=b[3], perturb=True, force_all_rays=False, inherited_params=inh,
                                nears_fars=nf, premarched=True, own_march=True, num_steps=o.num_steps, upsample_steps=o.upsample_steps, **kw)
                 pred = out["image"]
-                loss = self.dp.global_mean((pred.float() - b[2].float()) ** 2)
+                loss = self._mse(pred, b[2])
                 if o.l1_reg_weight > 0.0 and o.model_type == "vm":
                     loss = loss + self._l1_term()
             return loss, pred
@@ -907,10 +915,12 @@ class TeacherTrainer(_TrainerBase):
                 marched = march(batches[0])
                 try:
                     for k in range(K):
-                        self._zero_grads()
+                        self._zero_grads(first_in_recording=k == 0)
                         self._static_out = loss_of(batches[k], marched)
                         nxt = None
                         if k + 1 < K:
+                            # (where this fork sits does not matter to the step: at its start, here, or between the head's backward
+                            # and the table scatter -- 0.599 / 0.599 / 0.600 ms, profiles/r06_teacher_launch_diet.txt)
                             branch.wait_stream(main)
                             with torch.cuda.stream(branch):
                                 nxt = march(batches[k + 1])

@@ -78,7 +78,7 @@ ENTRY_POINTS = (
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
-    "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_backward",
+    "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_forward_affine_pack", "pvd_grid_encode_backward", "pvd_grid_encode_backward_affine",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_forward_pack_rider", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_infer_image_plenoxel", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
@@ -437,6 +437,41 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     _check(status, "pvd_grid_encode_backward")
 
 
+def grid_encode_forward_affine_pack(inputs, in_add, in_div, embeddings, offsets, outputs, B, D, C, L, S, H, gridtype, align_corners, pack):
+    """grid_encode_forward_affine + the HASH head's packed weight image written by extra workgroups of the same launch.
+    pack = (sigma_net.0.weight, sigma_net.1.weight, color_net.0/1/2.weight, image)."""
+    dev = _dev(inputs, embeddings, offsets, outputs, *pack)
+    _want(inputs, torch.float32, "inputs"), _want(offsets, torch.int32, "offsets")
+    dt = _table_dtype(embeddings, "embeddings")
+    _want(outputs, embeddings.dtype, "outputs")
+    Wa1, Wa2, Wc1, Wc2, Wc3, image = pack
+    for w, shape in ((Wa1, (64, 28)), (Wa2, (16, 64)), (Wc1, (64, 31)), (Wc2, (64, 64)), (Wc3, (3, 64))):
+        _want(w, torch.float32, "head weight")
+        if tuple(w.shape) != shape:
+            raise PvdHipError("pack rider: head weight of shape %s expected" % (shape,))
+    _want(image, torch.float16, "image")
+    if image.numel() != head_image_halfs(0):
+        raise PvdHipError("pack rider: image of head_image_halfs(0) halfs expected")
+    rider = _HeadPackRider(0, Wa1.data_ptr(), Wa2.data_ptr(), Wc1.data_ptr(), Wc2.data_ptr(), Wc3.data_ptr(), image.data_ptr())
+    status = _invoke("pvd_grid_encode_forward_affine_pack", dev, _p(inputs), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets), _p(outputs),
+                     _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), _u32(gridtype), _int(int(bool(align_corners))), _int(dt),
+                     ctypes.byref(rider), meta=(B, D, C, L, dt))
+    if status == -2:
+        raise PvdHipError("GridEncoding: C must be 1, 2, 4, or 8.")
+    _check(status, "pvd_grid_encode_forward_affine_pack")
+
+
+def grid_encode_backward_affine(grad, inputs, in_add, in_div, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners):
+    """grid_encode_backward (no grad_inputs) on x01 = (inputs + in_add) / in_div, mapped inside the kernel; f16 table, D 3, C 2 only."""
+    dev = _dev(grad, inputs, embeddings, offsets, grad_embeddings)
+    _want(inputs, torch.float32, "inputs"), _want(offsets, torch.int32, "offsets")
+    dt = _table_dtype(grad_embeddings, "grad_embeddings")
+    _want(grad, grad_embeddings.dtype, "grad")
+    _check(_invoke("pvd_grid_encode_backward_affine", dev, _p(grad), _p(inputs), _f32(in_add), _f32(in_div), _p(embeddings), _p(offsets),
+                   _p(grad_embeddings), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), _u32(gridtype), _int(int(bool(align_corners))),
+                   _int(dt), meta=(B, D, C, L, dt)), "pvd_grid_encode_backward_affine")
+
+
 def grid_set_variant(v):
     return int(_lib.pvd_grid_set_variant(_int(int(v))))
 
@@ -512,7 +547,8 @@ def _rows_dev(rows_dev, dev):
 
 
 class _HeadPackRider(ctypes.Structure):  # pvd_head_pack_rider, include/pvd_hip.h
-    _fields_ = [("Wa1", ctypes.c_void_p), ("Wc1", ctypes.c_void_p), ("Wc2", ctypes.c_void_p), ("Wc3", ctypes.c_void_p), ("image", ctypes.c_void_p)]
+    _fields_ = [("kind", ctypes.c_int), ("Wa1", ctypes.c_void_p), ("Wa2", ctypes.c_void_p), ("Wc1", ctypes.c_void_p), ("Wc2", ctypes.c_void_p),
+                ("Wc3", ctypes.c_void_p), ("image", ctypes.c_void_p)]
 
 
 def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=None, pack=None):
@@ -534,7 +570,7 @@ def vm_forward(xyz, aabb_host, tables, res, sigma_feat, color_prod, rows_dev=Non
         _want(image, torch.float16, "image")
         if image.numel() != head_image_halfs(1) or not image.is_contiguous() or xyz.shape[0] == 0:
             raise PvdHipError("pack rider: image of head_image_halfs(1) halfs and at least one row expected")
-        rider = _HeadPackRider(Wa1.data_ptr(), Wc1.data_ptr(), Wc2.data_ptr(), Wc3.data_ptr(), image.data_ptr())
+        rider = _HeadPackRider(1, Wa1.data_ptr(), None, Wc1.data_ptr(), Wc2.data_ptr(), Wc3.data_ptr(), image.data_ptr())
         _check(_invoke("pvd_vm_forward_pack_rider", dev, _p(xyz), _u32(xyz.shape[0]), aabb, _host_ptr_array(tables), resa, _p(sigma_feat),
                        _p(color_prod), _int(dt), _rows_dev(rows_dev, dev), strides, ctypes.byref(rider), meta=(xyz.shape[0], dt)),
                "pvd_vm_forward_pack_rider")
@@ -866,9 +902,9 @@ def head_backward(kind, x0, sigma_raw, dirs, M, Wa1, Wa2, Wc1, Wc2, Wc3, clip_si
     receives what vm_backward(..., head_dw=dict) needs to run it inside the table scatter's launch (pvd_head_backward_defer)."""
     dev = _dev(x0, sigma_raw, dirs, Wa1, Wa2, Wc1, Wc2, Wc3, g_sigma, g_rgb, g_feat16, g_sigma_raw, g_x0, workspace)
     _want(x0, torch.float16, "x0"), _want(g_x0, torch.float16, "g_x0")
-    _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb, g_feat16=g_feat16,
+    _f32_all(dirs=dirs, Wa1=Wa1, Wc1=Wc1, Wc2=Wc2, Wc3=Wc3, g_sigma=g_sigma, g_rgb=g_rgb,
              gWa1=gWa1, gWc1=gWc1, gWc2=gWc2, gWc3=gWc3, workspace=workspace)
-    for t in (sigma_raw, Wa2, g_sigma_raw, gWa2):
+    for t in (sigma_raw, Wa2, g_sigma_raw, gWa2, g_feat16):  # (g_feat16 None: no gradient reaches the feature rows)
         if t is not None:
             _want(t, torch.float32, "head_backward argument")
     for t in (gWa1, gWa2, gWc1, gWc2, gWc3):

@@ -212,6 +212,25 @@ int pvd_grid_encode_forward_affine(const float *inputs, float in_add, float in_d
                                    const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                    float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                    pvd_stream_t stream);
+/* (ABI 6) ... and its backward: pvd_grid_encode_backward (no grad_inputs) reading the positions through the same mapping, so that a
+ * training step needs no normalised copy of them at all.  dtype PVD_F16, D = 3, C = 2 (the PVD table's scatter) only: anything else
+ * is PVD_ERR_UNSUPPORTED. */
+/* (ABI 6) a head's packed f16 weight image riding on a lookup's forward launch (see pvd_vm_forward_pack_rider below) */
+typedef struct pvd_head_pack_rider {
+    int kind;                                 /* 1: VM head (pvd_vm_forward_pack_rider); 0: hash head (pvd_grid_encode_forward_affine_pack) */
+    const float *Wa1, *Wa2, *Wc1, *Wc2, *Wc3; /* DEVICE fp32 masters, as pvd_head_pack_weights takes them (Wa2: hash head only, else NULL) */
+    void *image;                              /* DEVICE f16 [pvd_head_image_halfs(kind)] */
+} pvd_head_pack_rider;
+/* (ABI 6) pvd_grid_encode_forward_affine + the HASH head's packed weight image (pvd_head_pack_weights, kind 0) written by extra workgroups
+ * at the end of the same grid (the f16 / D 3 / C 2 lookup; any other variant packs in a launch of its own behind the lookup): the
+ * teacher-training / hash-student step then has no pack launch between the lookup and the head's forward.  pack->kind must be 0. */
+int pvd_grid_encode_forward_affine_pack(const float *inputs, float in_add, float in_div, const void *embeddings,
+                                        const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                        float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                        const pvd_head_pack_rider *pack, pvd_stream_t stream);
+int pvd_grid_encode_backward_affine(const void *grad, const float *inputs, float in_add, float in_div, const void *embeddings,
+                                    const int32_t *offsets, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                    float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype, pvd_stream_t stream);
 
 int pvd_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,
                              const int32_t *offsets, void *grad_embeddings,
@@ -260,10 +279,6 @@ int pvd_vm_forward(const float *xyz, uint32_t M, const float *aabb_host, const v
  * the lookup's launch the step's dependent chain has neither a pack launch nor a cross-stream wait for one.  The image
  * (pvd_head_image_halfs(1) halfs) is complete when the launch is; it must not be in use by another stream meanwhile.  M == 0 is
  * PVD_ERR_INVALID (no launch to ride on: call pvd_head_pack_weights). */
-typedef struct pvd_head_pack_rider {
-    const float *Wa1, *Wc1, *Wc2, *Wc3; /* DEVICE fp32 masters: basis_mat [15][144], color_net [64][31], [64][64], [3][64] */
-    void *image;                        /* DEVICE f16 [pvd_head_image_halfs(1)] */
-} pvd_head_pack_rider;
 int pvd_vm_forward_pack_rider(const float *xyz, uint32_t M, const float *aabb_host, const void *const *tables_host,
                               const uint32_t *res_host, float *sigma_feat, void *color_prod, int prod_dtype, const int32_t *rows_dev,
                               const uint32_t *texel_stride_host, const pvd_head_pack_rider *pack, pvd_stream_t stream);
@@ -431,7 +446,8 @@ int pvd_head_pack_weights(int kind, const float *Wa1, const float *Wa2, const fl
  *                         reads as `grad`); gWa1 = sigma_net.0 [64][28], gWa2 = sigma_net.1 [16][64];
  *                         sigma_raw / g_sigma_raw unused (NULL).
  *   gWc1 [64][31], gWc2 [64][64], gWc3 [3][64]: color_net.
- * g_sigma [M], g_rgb [M][3], g_feat16 [M][16]: incoming gradients (f32) of pvd_head_forward's three outputs.
+ * g_sigma [M], g_rgb [M][3], g_feat16 [M][16]: incoming gradients (f32) of pvd_head_forward's three outputs; g_feat16 may be NULL
+ *   (ABI 6: no gradient reaches feature_sigma_color -- a model trained on pixels alone -- read as zeros).
  * g_rgb2 [M][3] or NULL: a second gradient of the rgb output (it feeds both the compositing and the colour term of the
  *   distillation objective, utils.py:1158-1176), added while loading instead of by a separate elementwise launch.
  * workspace: pvd_head_backward_workspace_floats(kind, M) floats of scratch (per-wave dW partials).

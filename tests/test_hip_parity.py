@@ -351,6 +351,64 @@ def test_grid_encode_forward_affine_is_the_mapped_forward(hip, dev, dtype, bound
                           np.ascontiguousarray(ref).view(np.uint16 if dtype == np.float16 else np.uint32))
 
 
+@pytest.mark.parametrize("B", [1, 4097, 92928])
+def test_grid_encode_forward_affine_pack_is_lookup_plus_the_pack_kernels_image(hip, dev, B):
+    """pvd_grid_encode_forward_affine_pack (ABI 6): the same lookup bit for bit, and the hash head's f16 weight image as
+    pvd_head_pack_weights writes it -- also when the launch that runs is not the two-lanes-per-sample kernel (the image then comes from a
+    launch of its own behind the lookup)."""
+    rng = np.random.RandomState(8)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19)
+    emb = _table(offs[-1], C, rng, np.float16)
+    x = rng.uniform(-1.02, 1.02, (B, D)).astype(np.float32)
+    W = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev) for s in ((64, 28), (16, 64), (64, 31), (64, 64), (3, 64))]
+    want = hip.head_pack_weights(0, *W)
+    ref = torch.empty(L, B, C, dtype=torch.float16, device=dev)
+    hip.grid_encode_forward_affine(t(x, dev), 1.0, 2.0, t(emb, dev), t(offs, dev), ref, B, D, C, L, S, H, 0, False)
+    try:
+        for variant in ((2, 4096), (4, 4096), (0, 0)):  # lanes per sample, persistent workgroups (0: the generic kernel)
+            hip.grid_set_fwd_kernel(*variant)
+            out = torch.empty(L, B, C, dtype=torch.float16, device=dev)
+            image = torch.full((hip.head_image_halfs(0),), float("nan"), dtype=torch.float16, device=dev)
+            hip.grid_encode_forward_affine_pack(t(x, dev), 1.0, 2.0, t(emb, dev), t(offs, dev), out, B, D, C, L, S, H, 0, False, (*W, image))
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), variant
+            assert torch.equal(image.view(torch.int16), want[:image.numel()].view(torch.int16)), variant
+    finally:
+        hip.grid_set_fwd_kernel()
+
+
+@pytest.mark.parametrize("bound", [1.0, 2.0, 1.5])
+def test_grid_encode_backward_affine_is_the_mapped_backward(hip, dev, bound):
+    """pvd_grid_encode_backward_affine(x, bound, 2*bound) (ABI 6) against pvd_grid_encode_backward((x + bound) / (2*bound)) and the oracle on the
+    mapped positions: the same rows and weights (f16 atomics: order-dependent rounding, the existing backward bar), identical where a row
+    receives ONE contribution; f32 tables / other shapes are refused."""
+    rng = np.random.RandomState(6)
+    L, H, D, C = 14, 16, 3, 2
+    pls = np.exp2(np.log2(2048 / H) / (L - 1))
+    S = float(np.log2(pls))
+    offs = _offsets(D, L, pls, H, 19)
+    B = 20000
+    x = rng.uniform(-1.05 * bound, 1.05 * bound, (B, D)).astype(np.float32)
+    x[:4] = [[-bound] * 3, [bound] * 3, [0, 0, 0], [bound, -bound, 0.5 * bound]]
+    x01 = ((x + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+    grad = (rng.standard_normal((L, B, C)) * 0.05).astype(np.float16)
+    g_a = torch.zeros(int(offs[-1]), C, dtype=torch.float16, device=dev)
+    g_p = torch.zeros(int(offs[-1]), C, dtype=torch.float16, device=dev)
+    dummy = g_p[:1]
+    hip.grid_encode_backward_affine(t(grad, dev), t(x, dev), bound, 2 * bound, g_a, t(offs, dev), g_a, B, D, C, L, S, H, 0, False)
+    hip.grid_encode_backward(t(grad, dev), t(x01, dev), g_p, t(offs, dev), g_p, B, D, C, L, S, H, False, dummy, dummy, 0, False)
+    a, p = g_a.float().cpu().numpy(), g_p.float().cpu().numpy()
+    scale = np.abs(p).max()
+    assert scale > 0 and np.abs(a - p).max() <= 2e-2 * scale
+    ref = oracle.grid_encode_backward(grad, x01, np.zeros((int(offs[-1]), C), np.float16), offs, S, H)[0].astype(np.float32)
+    assert np.abs(a - ref).max() <= 2e-2 * max(np.abs(ref).max(), 1e-30)
+    g32 = torch.zeros(int(offs[-1]), C, dtype=torch.float32, device=dev)
+    with pytest.raises(hip.PvdHipError):
+        hip.grid_encode_backward_affine(t(grad.astype(np.float32), dev), t(x, dev), bound, 2 * bound, g32, t(offs, dev), g32, B, D, C, L, S, H, 0, False)
+
+
 @pytest.mark.parametrize("degree", list(range(1, 9)))
 def test_sh_encode(hip, dev, degree):
     rng = np.random.RandomState(degree)
