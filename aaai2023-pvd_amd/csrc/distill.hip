@@ -194,7 +194,41 @@ __global__ void __launch_bounds__(kLossBlock) k_loss_final_bwd(const float *__re
 
 using namespace pvd;
 
+namespace pvd {
+// Mean squared error of two images and its gradient in ONE launch of one workgroup (the teacher's objective, just_train_tea/utils.py:
+// 573-581: MSELoss(reduction='none'), .mean(-1), .mean() -- 12 288 elements): loss = sum (a - b)^2 / n, d = 2 (a - b) / n.  The library's
+// formulation is four to six launches of ~5 us each (elementwise, mean, and their autograd nodes) on the step's dependent chain.
+constexpr uint32_t kMseBlock = 1024;
+__global__ void __launch_bounds__(kMseBlock) k_mse(const float *__restrict__ a, const float *__restrict__ b, uint32_t n, float *__restrict__ loss,
+                                                   float *__restrict__ d) {
+    __shared__ float sh[kMseBlock / 64];
+    const float k = 2.0f / (float)n;
+    float acc = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += kMseBlock) {
+        const float e = a[i] - b[i];
+        acc += e * e;
+        d[i] = k * e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+#pragma unroll
+        for (uint32_t w = 0; w < kMseBlock / 64; w++) r += sh[w];
+        loss[0] = r / (float)n;
+    }
+}
+}  // namespace pvd
+
 extern "C" {
+
+int pvd_mse_forward(const float *pred, const float *target, uint32_t n, float *loss, float *dloss_dpred, pvd_stream_t stream) {
+    if (!pred || !target || !loss || !dloss_dpred || n == 0) return PVD_ERR_INVALID;
+    hipLaunchKernelGGL(k_mse, dim3(1), dim3(kMseBlock), 0, (hipStream_t)stream, pred, target, n, loss, dloss_dpred);
+    return check_launch();
+}
 
 static uint32_t sumsq_blocks(uint32_t n_img, uint32_t M) {
     uint32_t blocks = div_up(M * 4u > n_img ? M * 4u : n_img, kLossBlock);

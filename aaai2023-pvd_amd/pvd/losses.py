@@ -120,3 +120,27 @@ def distill_loss_normL2(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp=None
     defer=True: the returned loss / norms tensors are filled in by the BACKWARD pass (one launch fewer per training step);
     only for callers that look at them after loss.backward()."""
     return _DistillNormL2.apply(img_s, img_t, fea_s, fea_t, col_s, col_t, rates, dp, float(fea_decay), extra, bool(defer), ride)
+
+
+class _FusedMSE(torch.autograd.Function):
+    """mean((pred - target)^2) with its gradient formed in the forward's one launch (pvd_mse_forward); the backward is one multiply by
+    the upstream gradient.  The teacher's objective (just_train_tea/utils.py:573-581)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        import pvd_hip
+        p, t = pred.float().contiguous(), target.float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        d = torch.empty_like(p)
+        pvd_hip.mse_forward(p, t, loss.view(1), d)
+        ctx.save_for_backward(d)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g, None
+
+
+def mse_fused(pred, target):
+    return _FusedMSE.apply(pred, target)

@@ -7,6 +7,11 @@ import types
 import torch
 
 
+def _mse_loss():
+    from .losses import mse_fused
+    return mse_fused
+
+
 def _distill_loss():
     from .losses import distill_loss_normL2
     return distill_loss_normL2
@@ -59,4 +64,4 @@ def hip_ops():
         return pvd_hip.freq_encode(x, bands, include_input, out_dtype, row_stride)
 
     return types.SimpleNamespace(freq_encode=freq_encode, make_batch=make_batch, occupancy=pvd_hip.occupancy_backend, raymarching=raymarching, GridEncoder=gridencoder.GridEncoder, SHEncoder=shencoder.SHEncoder,
-                                 vm_encode=vmencoder.vm_encode, vm_encode_infer=vmencoder.vm_encode_infer, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")
+                                 vm_encode=vmencoder.vm_encode, vm_encode_infer=vmencoder.vm_encode_infer, plenoxel=plenoxel, get_rays=get_rays_fused, fused_head=fusedhead, distill_loss=_distill_loss(), mse_loss=_mse_loss(), flat_adamw=_flat_adamw(), device_type="cuda", name="hip")

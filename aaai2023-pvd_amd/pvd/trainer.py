@@ -859,10 +859,13 @@ class TeacherTrainer(_TrainerBase):
 
     def _mse(self, pred, gt):
         """mean over rays and channels of the squared difference (just_train_tea/utils.py:573-581: MSELoss(reduction='none'), .mean(-1),
-        .mean()).  One GPU: the library's fused form -- two launches forward, one backward, where subtract / square / mean and their
-        three autograd nodes were six."""
+        .mean()).  One GPU: one launch forward (value + gradient), one multiply backward, where subtract / square / mean and their
+        three autograd nodes were six (the library's mse_loss: two + two)."""
         if self.dp.enabled or not pred.is_cuda:
             return self.dp.global_mean((pred.float() - gt.float()) ** 2)
+        fused = getattr(self.model.ops, "mse_loss", None)
+        if fused is not None and pred.dtype == torch.float32:
+            return fused(pred, gt)  # value and gradient in one launch, one multiply backward (pvd_mse_forward)
         return torch.nn.functional.mse_loss(pred.float(), gt.float())
 
     # ---- a whole block of steps between two occupancy-grid updates as ONE captured graph

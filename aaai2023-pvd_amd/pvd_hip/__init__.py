@@ -78,7 +78,7 @@ ENTRY_POINTS = (
     "pvd_near_far_from_aabb", "pvd_polar_from_ray", "pvd_morton3D", "pvd_morton3D_invert", "pvd_packbits",
     "pvd_march_rays_train", "pvd_march_rays_train_ws", "pvd_march_workspace_bytes", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
     "pvd_march_rays", "pvd_composite_rays", "pvd_compact_rays", "pvd_infer_round_begin", "pvd_infer_compact", "pvd_infer_march", "pvd_infer_composite", "pvd_occ_sample", "pvd_occ_update", "pvd_occ_finish", "pvd_occ_sample_replay", "pvd_occ_update_ordered",
-    "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_forward_affine_pack", "pvd_grid_encode_backward", "pvd_grid_encode_backward_affine",
+    "pvd_mse_forward", "pvd_grid_encode_forward", "pvd_grid_encode_forward_affine", "pvd_grid_encode_forward_affine_pack", "pvd_grid_encode_backward", "pvd_grid_encode_backward_affine",
     "pvd_sh_encode_forward", "pvd_sh_encode_backward",
     "pvd_vm_forward", "pvd_vm_forward_pack_rider", "pvd_vm_backward", "pvd_infer_image_vm", "pvd_infer_image_plenoxel", "pvd_vm_backward_rider", "pvd_head_backward_defer", "pvd_plenoxel_forward", "pvd_plenoxel_backward", "pvd_get_rays", "pvd_make_ray_batch",
     "pvd_head_forward", "pvd_hash_head_forward_fused", "pvd_hash_head_forward_fused_span", "pvd_infer_image_hash",
@@ -1040,6 +1040,15 @@ def _distill_shapes(img_s, img_t, fea_s, fea_t, col_s, col_t):
     if img_s.numel() != img_t.numel():
         raise PvdHipError("student and teacher images differ in size")
     return M, fea_s.shape[1]
+
+
+def mse_forward(pred, target, loss, dloss):
+    """loss[0] = mean((pred - target)^2), dloss = 2 (pred - target) / n: one launch (pvd_mse_forward)."""
+    dev = _dev(pred, target, loss, dloss)
+    _f32_all(pred=pred, target=target, loss=loss, dloss=dloss)
+    if pred.numel() != target.numel() or dloss.numel() != pred.numel() or pred.numel() == 0:
+        raise PvdHipError("mse_forward: pred, target and dloss of one (non-empty) size expected")
+    _call("pvd_mse_forward", dev, _p(pred), _p(target), _u32(pred.numel()), _p(loss), _p(dloss))
 
 
 def distill_sumsq(img_s, img_t, fea_s, fea_t, col_s, col_t, S4, reduce=True, rates_decay=None, fea_decay=1.0):

@@ -573,6 +573,11 @@ int pvd_composite_objective_backward(const float *grad_weights_sum, const float 
                                      const float *upstream, float *g_fea, float *g_col, const float *rates4, const float *extra,
                                      uint32_t n_extra, float *S4, float *loss, float *norms4, pvd_stream_t stream);
 
+/* (ABI 6) The teacher's objective -- torch code in the reference: MSELoss(reduction='none'), .mean(-1), .mean(),
+ * just_train_tea/utils.py:573-581 -- and its gradient in one launch: loss[0] = sum (pred - target)^2 / n, dloss_dpred[i] =
+ * 2 (pred[i] - target[i]) / n (the caller multiplies by the upstream gradient, e.g. the loss scale).  n = rays x 3. */
+int pvd_mse_forward(const float *pred, const float *target, uint32_t n, float *loss, float *dloss_dpred, pvd_stream_t stream);
+
 /* Stage-3 distillation objective with loss_type = normL2 (distill_mutual/utils.py:941-952, 1109-1189):
  *   S4 = { |I_tea - I_stu|^2, |F_stu - F_tea|^2, |F_stu[:,0] - F_tea[:,0]|^2, |c_stu - c_tea|^2 }  (sums over all rows)
  *   loss = sum_i rates4[i] * sqrt(S4[i]) + sum(extra);  coef4[i] = rates4[i] / sqrt(S4[i])  (0 if S4[i] == 0)

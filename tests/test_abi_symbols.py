@@ -16,7 +16,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
-    assert len(syms) == 74, syms
+    assert len(syms) == 75, syms
     for must in ("pvd_march_rays_train", "pvd_composite_rays_train_forward", "pvd_composite_rays_train_backward",
                  "pvd_grid_encode_forward", "pvd_grid_encode_backward", "pvd_sh_encode_forward", "pvd_near_far_from_aabb"):
         assert must in syms

@@ -993,3 +993,22 @@ def test_objective_riding_on_the_compositing_launches_equals_the_separate_launch
         x, y = outs[1][k], outs[2][k]
         assert (x == y) if isinstance(x, float) else torch.equal(x, y), k
     assert float(a[5].abs().max()) > 0 and float(a[7].abs().max()) > 0
+
+
+@pytest.mark.parametrize("n_rays", [1, 4096, 5000])
+def test_fused_mse_matches_the_library_formulation(n_rays):
+    """pvd_mse_forward (ABI 6): the teacher's objective mean((pred - gt)^2) and its gradient in one launch, against the reference's
+    formulation -- MSELoss(reduction='none'), .mean(-1), .mean() (just_train_tea/utils.py:573-581) -- value and gradient, with an
+    upstream gradient (the loss scale)."""
+    from pvd.losses import mse_fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(n_rays)
+    pred = torch.rand(1, n_rays, 3, device=dev, generator=g, requires_grad=True)
+    gt = torch.rand(1, n_rays, 3, device=dev, generator=g)
+    ref_in = pred.detach().clone().requires_grad_(True)
+    ref = torch.nn.MSELoss(reduction="none")(ref_in, gt).mean(-1).mean()
+    ref.backward(gradient=torch.tensor(65536.0, device=dev))
+    out = mse_fused(pred, gt)
+    out.backward(gradient=torch.tensor(65536.0, device=dev))
+    assert out.shape == ref.shape and abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert (pred.grad - ref_in.grad).abs().max().item() <= 2e-6 * ref_in.grad.abs().max().item()
