@@ -105,6 +105,79 @@ class RayDP:
             self._issue(run, replay)
         return t
 
+    def broadcast_(self, t, src=0):
+        """t = rank `src`'s t on every rank (never part of a recorded step: occupancy upkeep and evaluation run between the graphs)."""
+        if not self.enabled or self.world_size == 1:
+            return t
+        assert t.is_contiguous()
+        if self._staged(t):
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def sync_occupancy(self, model, src=0):
+        """SURVEY 8(e), occupancy state: the replicas march on ONE occupancy grid.  `update_extra_state` draws random cells and
+        jitter (renderer.py:691-693,708-722 of the reference), so after an update every rank takes rank `src`'s density grid,
+        bitfield, running mean and sweep count (8.4 MB + 256 KiB every 16 steps); `mean_count` -- the size of a rank's OWN sample
+        buffer -- stays per rank.  The device-side update needs it as much as the torch one: its list of occupied cells is
+        compacted with atomics, so the list's order -- and with it which occupied cells a draw lands on -- differs from run to
+        run even on bit-identical replicas (tests/test_hip_dp_eval_occupancy.py).  Returns True if this rank's grid was
+        already rank src's (the occupancy epoch, which invalidates recorded steps and the exchange's row set, moves only if not)."""
+        if not self.enabled or not getattr(model, "cuda_ray", False):
+            return True
+        grid, bits = model.density_grid, model.density_bitfield
+        before = (grid.clone(), bits.clone())
+        self.broadcast_(grid, src)
+        self.broadcast_(bits, src)
+        md = model.mean_density
+        scal = torch.tensor([float(md), float(model.iter_density)], dtype=torch.float64, device=grid.device)
+        self.broadcast_(scal, src)
+        if self.rank != src:
+            if torch.is_tensor(md):
+                md.fill_(float(scal[0]))
+            else:
+                model.mean_density = float(scal[0])
+            model.iter_density = int(scal[1])
+        same = torch.equal(before[0], grid) and torch.equal(before[1], bits)
+        if not same:
+            model.note_occupancy_changed()
+        return same
+
+    def render_sharded(self, model, rays_o, rays_d, **render_kw):
+        """SURVEY 8(e), evaluation: the N rays of one image [1, N, 3] (row-major pixels, so a slice is a band of image rows) are cut
+        into world_size contiguous slices of ceil(N / G) rays -- the last one padded with copies of the image's last ray, so that
+        every rank renders and gathers the same shape --, rank r renders slice r through `model.render(staged=True)` and ONE
+        all-gather of [ceil(N / G), 4] (rgb, depth) leaves the whole image on every rank.  The reference gathers whole per-rank
+        predictions the same way (distill_mutual/utils.py:1243-1258: all_gather of preds / preds_depth).  Rays are independent in
+        the inference path, so the result has the bits of a one-rank render (tests/test_dist_gloo.py, tests/test_hip_dp_exchange.py).
+        A per-ray `bg_color` [1, N, 3] is sliced with the rays."""
+        if not self.enabled or self.world_size == 1:
+            out = model.render(rays_o, rays_d, staged=True, **render_kw)
+            return {"image": out["image"], "depth": out["depth"]}
+        assert rays_o.dim() == 3 and rays_o.shape[0] == 1 and rays_o.shape == rays_d.shape, "one image per call: [1, N, 3]"
+        N, G = rays_o.shape[1], self.world_size
+        per = (N + G - 1) // G
+        lo = min(self.rank * per, N)
+        hi = min(lo + per, N)
+
+        def piece(t):  # this rank's band, padded to `per` rays with the image's last ray
+            part = t[:, lo:hi]
+            if hi - lo < per:
+                part = torch.cat([part, t[:, N - 1:N].expand(-1, per - (hi - lo), -1)], dim=1)
+            return part.contiguous()
+        kw = dict(render_kw)
+        bg = kw.get("bg_color")
+        if torch.is_tensor(bg) and bg.dim() == 3 and bg.shape[1] == N:
+            kw["bg_color"] = piece(bg)
+        out = model.render(piece(rays_o), piece(rays_d), staged=True, **kw)
+        mine = torch.cat([out["image"].reshape(per, 3).float(), out["depth"].reshape(per, 1).float()], dim=1).contiguous()
+        everyone = torch.empty(G * per, 4, dtype=torch.float32, device=mine.device)
+        self.all_gather_(everyone, mine)
+        return {"image": everyone[:N, :3].reshape(1, N, 3), "depth": everyone[:N, 3].reshape(1, N)}
+
     def global_sum(self, local):
         """Value = sum over ranks, gradient = gradient of the local term (d total / d local = 1)."""
         if not self.enabled:

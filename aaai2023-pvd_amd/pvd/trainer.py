@@ -842,8 +842,7 @@ class TeacherTrainer(_TrainerBase):
         -- what --error_map feeds back into the data provider's sampling weights (utils.py:1120-1129; BlenderScene.update_error)."""
         o, m = self.opt, self.model
         if m.cuda_ray and self.global_step % o.update_extra_interval == 0:
-            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
-                m.update_extra_state()
+            self._update_occupancy()
         self._zero_grads()
         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
             out = m.render(rays_o, rays_d, staged=False, bg_color=bg_color, perturb=True, force_all_rays=False,
@@ -856,6 +855,14 @@ class TeacherTrainer(_TrainerBase):
             error_sink(((pred.detach().float() - gt_rgb.float()) ** 2).mean(-1))
         self._backward_and_step(loss)
         return loss.detach(), pred
+
+    def _update_occupancy(self):
+        """update_extra_state (just_train_tea/utils.py:841-846), and under ray-DP the replicas agree on rank 0's grid afterwards
+        (the update draws random cells; RayDP.sync_occupancy)."""
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
+            self.model.update_extra_state()
+        if self.dp.enabled:
+            self.dp.sync_occupancy(self.model)
 
     def _mse(self, pred, gt):
         """mean over rays and channels of the squared difference (just_train_tea/utils.py:573-581: MSELoss(reduction='none'), .mean(-1),
@@ -975,8 +982,7 @@ class TeacherTrainer(_TrainerBase):
         """The occupancy-grid update (eager: it sizes the next block's budget) followed by one replay = 16 training steps."""
         o, m = self.opt, self.model
         assert self.global_step % o.update_extra_interval == 0
-        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16 and self.device_type == "cuda"):
-            m.update_extra_state()
+        self._update_occupancy()
         aligned = m.mean_count + (128 - m.mean_count % 128)
         if getattr(m, "budget_exceeded", False) or aligned < 0.6 * m.sample_alloc:
             # the scene needs more rows than were captured (or far fewer: the padding rows cost time): capture again

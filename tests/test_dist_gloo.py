@@ -302,3 +302,156 @@ def test_ray_dp_step_with_the_sharded_exchange(tmp_path, monkeypatch):
     mp.spawn(_worker, args=(2, _free_port(), two, OPT_COMPACT, True), nprocs=2, join=True)
     a, b = torch.load(ref), torch.load(two)
     assert torch.equal(a["flat"], b["flat"]) and a["loss"] == b["loss"]
+
+
+# ---- evaluation split over the ranks, occupancy state agreed after an update
+
+def _thicken(model):
+    """an untrained VM student is empty space (sigma features of +-0.1): scale its sigma factors so that the picture shows something"""
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("sigma_"):
+                p.mul_(8.0)
+
+
+def _eval_worker(rank, world, port, out_path, res):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    from pvd.trainer import RayDP
+    dp = RayDP()
+    w = _make(OPT, dp=dp)
+    _thicken(w.stu)
+    pose = torch.from_numpy(synthetic_poses(np.random.RandomState(7))[:1])
+    r = get_rays(pose, tuple(v * res / 800.0 for v in BLENDER_INTRINSICS), res, res, -1)
+    N = res * res
+    bg = torch.rand(1, N, 3, generator=torch.Generator().manual_seed(3))  # a per-ray background travels with its rays
+    w.stu.eval()
+    with torch.no_grad():
+        out = dp.render_sharded(w.stu, r["rays_o"], r["rays_d"], bg_color=bg, perturb=False, max_steps=1024)
+    assert out["image"].shape == (1, N, 3) and out["depth"].shape == (1, N)
+    both = torch.cat([out["image"].reshape(-1), out["depth"].reshape(-1)])
+    everyone = [torch.empty_like(both) for _ in range(world)]
+    dist.all_gather(everyone, both)
+    # the whole image, the same bits, on every rank (bits: the depth of a ray that misses the box is NaN, as in the reference --
+    # (inf - inf) / 0 in run_cuda's normalisation, renderer.py:539)
+    assert all(torch.equal(everyone[0].view(torch.int32), e.view(torch.int32)) for e in everyone)
+    if rank == 0:
+        torch.save({"image": out["image"], "depth": out["depth"]}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_evaluation_render_split_over_the_ranks_is_the_one_rank_image(tmp_path, world):
+    """RayDP.render_sharded (the reference all-gathers per-rank predictions, distill_mutual/utils.py:1243-1258): bands of an
+    image rendered by 2 / 3 ranks and all-gathered equal the image one process renders -- 25 x 25 pixels, so the last band is padded
+    (625 = 2 x 313 - 1 = 3 x 209 - 2) and the padding must not show."""
+    _setup_paths()
+    res = 25
+    out = str(tmp_path / "eval.pt")
+    mp.spawn(_eval_worker, args=(world, _free_port(), out, res), nprocs=world, join=True)
+    got = torch.load(out)
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    w = _make(OPT)
+    _thicken(w.stu)
+    pose = torch.from_numpy(synthetic_poses(np.random.RandomState(7))[:1])
+    r = get_rays(pose, tuple(v * res / 800.0 for v in BLENDER_INTRINSICS), res, res, -1)
+    bg = torch.rand(1, res * res, 3, generator=torch.Generator().manual_seed(3))
+    w.stu.eval()
+    with torch.no_grad():
+        want = w.stu.render(r["rays_o"], r["rays_d"], staged=True, bg_color=bg, perturb=False, max_steps=1024)
+    assert float(torch.nan_to_num(want["depth"], nan=0.0).max()) > 0 and float((want["image"] - bg).abs().max()) > 0.05  # the object is in the picture
+    # (CPU: the library's matrix products may block a band differently from the whole image -- rounding, not bits; the GPU form of
+    # this test asserts equality)
+    assert (got["image"] - want["image"].float()).abs().max().item() <= 1e-5
+    assert torch.equal(torch.isnan(got["depth"]), torch.isnan(want["depth"]))  # (rays that miss the box)
+    assert (torch.nan_to_num(got["depth"], nan=0.0) - torch.nan_to_num(want["depth"].float(), nan=0.0)).abs().max().item() <= 1e-5
+
+
+TEA_OPT = dict(num_rays=256, resolution0=24, iters=50, fp16=False, model_type="vm", teacher_type="vm", update_extra_interval=16,
+               stage_iters={"stage1": -1, "stage2": -1})
+
+
+def _teacher_and_batch(dp=None):
+    from oracle_ops import oracle_ops
+    from pvd.config import PVDConfig
+    from pvd.scene import BLENDER_INTRINSICS, ChairScene, get_rays, synthetic_poses
+    from pvd.trainer import TeacherTrainer
+    from pvd.workload import AnalyticTarget, install_occupancy, make_model
+    opt = PVDConfig(**TEA_OPT)
+    torch.manual_seed(0)
+    m = make_model(oracle_ops(), opt, "vm", True, torch.device("cpu"), teacher_variant=True)
+    scene = ChairScene()
+    install_occupancy(m, scene, opt)
+    m.mean_count = 0  # (first block: the marcher sizes its buffers exactly)
+    tr = TeacherTrainer(opt, m, "cpu", fp16=False, dp=dp)
+    gen = torch.Generator().manual_seed(11)
+    pose = torch.from_numpy(synthetic_poses(np.random.RandomState(0))[:1])
+    r = get_rays(pose, BLENDER_INTRINSICS, 800, 800, opt.num_rays, generator=gen)
+    bg = torch.rand(1, opt.num_rays, 3, generator=gen)
+    gt = AnalyticTarget(oracle_ops(), scene, m)(r["rays_o"], r["rays_d"], bg)
+    return m, tr, (r["rays_o"], r["rays_d"], gt, bg)
+
+
+def _teacher_worker(rank, world, port, out_path):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from pvd.trainer import RayDP
+    dp = RayDP()
+    m, tr, (o, d, gt, bg) = _teacher_and_batch(dp)
+    half = o.shape[1] // world
+    sl = slice(rank * half, (rank + 1) * half)
+    torch.manual_seed(100 + rank)  # the occupancy update's random cells and jitter differ from rank to rank ...
+    assert tr.global_step % tr.opt.update_extra_interval == 0
+    loss, _ = tr.train_step(o[:, sl].contiguous(), d[:, sl].contiguous(), gt[:, sl].contiguous(), bg[:, sl].contiguous())
+    state = torch.cat([m.density_grid.reshape(-1), m.density_bitfield.reshape(-1).float(),
+                       torch.tensor([float(m.mean_density), float(m.iter_density)])])
+    everyone = [torch.empty_like(state) for _ in range(world)]
+    dist.all_gather(everyone, state)
+    assert all(torch.equal(everyone[0], e) for e in everyone)  # ... and every rank marches on rank 0's grid all the same
+    params = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    gp = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(gp, params)
+    assert all(torch.equal(gp[0], t) for t in gp)
+    if rank == 0:
+        torch.save({"loss": float(loss), "flat": tr.flat.flat.clone(), "grid": m.density_grid.clone(), "bits": m.density_bitfield.clone()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_teacher_step_on_two_ranks_agrees_on_the_occupancy_grid_and_equals_one_process(tmp_path):
+    """Teacher training under ray-DP (occupancy state): the step that updates the occupancy grid, on two ranks whose
+    random streams differ.  After it every rank holds rank 0's grid / bitfield / running mean (RayDP.sync_occupancy), the replicas'
+    parameters are identical, and loss and gradient are those of one process that ran rank 0's update and rendered both shards."""
+    _setup_paths()
+    out = str(tmp_path / "tea.pt")
+    mp.spawn(_teacher_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    m, tr, (o, d, gt, bg) = _teacher_and_batch()
+    torch.manual_seed(100)  # rank 0's stream
+    m.update_extra_state()
+    assert torch.equal(m.density_grid, got["grid"]) and torch.equal(m.density_bitfield, got["bits"])
+    tr.flat.zero_()
+    half = o.shape[1] // 2
+    errs = []
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        out_r = m.render(o[:, sl].contiguous(), d[:, sl].contiguous(), staged=False, bg_color=bg[:, sl].contiguous(), perturb=True,
+                         force_all_rays=False, dt_gamma=0, max_steps=1024)
+        errs.append((out_r["image"].float() - gt[:, sl].float()) ** 2)
+    mse = torch.cat(errs, dim=1).mean()
+    l1 = tr._l1_term() if (tr.opt.l1_reg_weight > 0.0) else torch.zeros(())
+    (mse + l1).backward()
+    # a rank's reported loss carries 1/G of the parameter-only L1 term (its gradients are summed over ranks)
+    assert abs((float(mse.detach()) + float(l1.detach()) / 2) - got["loss"]) <= 1e-5 * abs(got["loss"]), (float(mse), float(l1), got["loss"])
+    flat = tr.flat.flat
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - got["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - got["flat"]).abs().max().item(), scale)

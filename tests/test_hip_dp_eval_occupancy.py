@@ -1,0 +1,137 @@
+"""SURVEY 8(e)'s two non-gradient bullets on the GPU, two ranks (gloo, sharing cuda:0):
+
+  * evaluation: an image rendered as bands by the ranks and all-gathered (RayDP.render_sharded; the reference all-gathers per-rank
+    predictions, distill_mutual/utils.py:1243-1258) has the BITS of the one-rank render -- through the persistent inference launch
+    of the hash teacher and of the VM student, with a band boundary inside an image row and a padded last band;
+  * occupancy state: `update_extra_state` (device-side: csrc/occupancy.hip) on both ranks, bit-identical replicas, the same call
+    count: the grids may STILL differ (the list of occupied cells is compacted with atomics, its order decides which occupied
+    cells are re-queried) -- RayDP.sync_occupancy leaves rank 0's grid, bitfield and running mean everywhere, moves the occupancy
+    epoch only on a rank whose grid changed, and a second call finds nothing to do."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _paths():
+    for p in (REPO, os.path.join(REPO, "aaai2023-pvd_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _workload(dp=None, pretrain=30):
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.workload import DistillWorkload
+    dev = torch.device("cuda:0")
+    return DistillWorkload(hip_ops(), dev, PVDConfig(num_rays=1024, iters=300, resolution0=64), teacher_pretrain_steps=pretrain, seed=0, dp=dp)
+
+
+def _image_rays(res, dev):
+    from pvd.scene import BLENDER_INTRINSICS, get_rays, synthetic_poses
+    pose = torch.from_numpy(synthetic_poses(np.random.RandomState(7))[:1]).to(dev)
+    return get_rays(pose, tuple(v * res / 800.0 for v in BLENDER_INTRINSICS), res, res, -1)
+
+
+def _bits(t):
+    return t.float().contiguous().view(torch.int32)
+
+
+def _worker(rank, world, port, out_path, res):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _paths()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    import pvd_hip
+    from pvd.trainer import RayDP
+    dp = RayDP()
+    w = _workload(dp)
+    for m in (w.tea, w.stu):  # replicas start bit-identical (teacher pre-training uses float atomics), as bench.py does
+        for t in list(m.parameters()) + list(m.buffers()):
+            d = t.data
+            if not d.is_contiguous():
+                d = d.permute(0, 2, 3, 1) if d.dim() == 4 else d.permute(0, 2, 3, 4, 1)
+            dp.broadcast_(d, src=0)
+        pvd_hip.note_weights_changed(list(m.parameters()))
+        m.eval()
+    r = _image_rays(res, dev)
+    res_out = {}
+    with torch.no_grad():
+        for name, m in (("tea", w.tea), ("stu", w.stu)):
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = dp.render_sharded(m, r["rays_o"], r["rays_d"], bg_color=1, perturb=False, max_steps=1024)
+                one = m.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, max_steps=1024)
+            assert out["image"].shape == (1, res * res, 3) and out["depth"].shape == (1, res * res)
+            # the bands, gathered, are the image this very rank renders alone
+            assert torch.equal(_bits(out["image"]), _bits(one["image"])), name
+            assert torch.equal(_bits(out["depth"]), _bits(one["depth"])), name
+            res_out[name] = (out["image"].cpu(), out["depth"].cpu())
+            both = torch.cat([_bits(out["image"]).reshape(-1), _bits(out["depth"]).reshape(-1)]).cpu()
+            ev = [torch.empty_like(both) for _ in range(world)]
+            dist.all_gather(ev, both)
+            assert all(torch.equal(ev[0], e) for e in ev), name
+
+    # ---- occupancy: the device-side update on both ranks, then the agreement
+    tea = w.tea
+    tea.train()
+    tea.iter_density = 20  # (a partial update: random cells + occupied cells)
+    with torch.autocast("cuda", dtype=torch.float16):
+        tea.update_extra_state()
+    def everyone_equal():
+        state = torch.cat([tea.density_grid.reshape(-1).float(), tea.density_bitfield.reshape(-1).float(),
+                           torch.tensor([float(tea.mean_density), float(tea.iter_density)], device=dev)]).cpu()
+        ev = [torch.empty_like(state) for _ in range(world)]
+        dist.all_gather(ev, state)
+        return all(torch.equal(ev[0], e) for e in ev)
+    epoch = tea.occ_epoch
+    agreed_by_itself = everyone_equal()
+    same = dp.sync_occupancy(tea)
+    assert rank != 0 or same  # rank 0 keeps its own
+    assert tea.occ_epoch == epoch + (0 if same else 1)
+    assert everyone_equal()
+    assert agreed_by_itself or rank == 0 or not same  # (if the updates disagreed, rank 1 was the one that changed)
+    epoch = tea.occ_epoch
+    assert dp.sync_occupancy(tea) and tea.occ_epoch == epoch  # nothing left to do
+    if rank == 1:  # a replica that drifted: put right by the broadcast, and it knows
+        tea.density_grid[0, 12345] += 1.0
+        tea.density_bitfield[77] ^= 0x5A
+    same = dp.sync_occupancy(tea)
+    assert same == (rank == 0) and tea.occ_epoch == epoch + (0 if rank == 0 else 1)
+    assert everyone_equal()
+    res_out["updates_agreed_by_themselves"] = bool(agreed_by_itself)
+    if rank == 0:
+        torch.save(res_out, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1800)
+def test_sharded_evaluation_has_the_bits_of_the_one_rank_render_and_replicas_agree_on_the_grid(tmp_path):
+    res = 75  # 5625 rays = 2 x 2813 - 1: the band boundary falls inside an image row and the last band is padded
+    out = str(tmp_path / "eval.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, res), nprocs=2, join=True)
+    got = torch.load(out)
+    print("device-side occupancy updates of two identical replicas agreed by themselves:", got["updates_agreed_by_themselves"])
+    for name in ("tea", "stu"):
+        img, depth = got[name]
+        assert torch.isfinite(img).all()
+    # the trained teacher shows the chair: not a blank picture
+    assert float((got["tea"][0] - 1.0).abs().max()) > 0.2 and float(torch.nan_to_num(got["tea"][1], nan=0.0).max()) > 0.1
