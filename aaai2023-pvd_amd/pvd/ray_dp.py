@@ -124,7 +124,8 @@ class RayDP:
         bitfield, running mean and sweep count (8.4 MB + 256 KiB every 16 steps); `mean_count` -- the size of a rank's OWN sample
         buffer -- stays per rank.  The device-side update needs it as much as the torch one: its list of occupied cells is
         compacted with atomics, so the list's order -- and with it which occupied cells a draw lands on -- differs from run to
-        run even on bit-identical replicas (tests/test_hip_dp_eval_occupancy.py).  Returns True if this rank's grid was
+        run even on bit-identical replicas, and a cell drawn twice keeps whichever density was written last, as with the
+        reference's `tmp_grid[cas, indices] = sigmas` on a GPU (tests/test_hip_dp_eval_occupancy.py).  Returns True if this rank's grid was
         already rank src's (the occupancy epoch, which invalidates recorded steps and the exchange's row set, moves only if not)."""
         if not self.enabled or not getattr(model, "cuda_ray", False):
             return True
