@@ -934,6 +934,31 @@ def main():
                                           "; collectives eager between %d graphs" % len(getattr(tr, "_cap").graphs))
         except Exception as e:  # noqa: BLE001
             out["config"]["exchange"] = "unknown (%s)" % type(e).__name__
+        # the exchange's collective ALONE on a buffer of the step's size, every rank in step (barrier, then 20 back-to-back calls between
+        # two synchronisations; MAX over ranks): what the wire costs next to ms_per_step(N) - ms_per_step(1).  Informational.
+        try:
+            if world > 1:
+                c = getattr(w.trainer, "_compactor", None)
+                compact = c is not None and getattr(c, "agreed", True) and c.fraction < 0.7
+                n_el = int(c.idx.numel()) if compact else int(w.trainer.flat.flat.numel())
+                scratch = torch.zeros(n_el, dtype=torch.float32, device=dev)
+                reps = 20
+                for _ in range(3):
+                    dp.all_reduce_sum_(scratch)
+                dist.barrier()
+                torch.cuda.synchronize()
+                tx = time.perf_counter()
+                for _ in range(reps):
+                    dp.all_reduce_sum_(scratch)
+                torch.cuda.synchronize()
+                us = torch.tensor([(time.perf_counter() - tx) / reps * 1e6], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(us, op=dist.ReduceOp.MAX)
+                out["config"]["exchange_alone"] = {
+                    "collective": "sharded pair (reduce_scatter + all_gather)" if os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "sharded" else "all_reduce",
+                    "backend": backend, "bytes": n_el * 4, "us_per_call": float(us[0]),
+                    "bus_GBps": 2.0 * (world - 1) / world * n_el * 4 / (float(us[0]) * 1e-6) / 1e9}
+        except Exception as e:  # noqa: BLE001
+            out["config"]["exchange_alone"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps, args.rays)
         out["gpu_reference"] = gpu_reference_step(opt)

@@ -102,6 +102,9 @@ def test_two_ranks_as_the_driver_launches_them(strong):
     assert "all-reduce" in d["config"]["exchange"] and math.isfinite(d["config"]["loss"]) and d["config"]["capture_fallback"] is False
     assert d["cpu_baseline"] is None and d["psnr"] is None  # rank 0 at N = 1 only
     assert d["sustained"]["steps"] == 40
+    xa = d["config"]["exchange_alone"]  # the collective alone on a buffer of the step's size (MAX over ranks): the wire's share of a step
+    assert "error" not in xa, xa
+    assert xa["collective"] == "all_reduce" and xa["backend"] == "gloo" and xa["bytes"] > 0 and xa["us_per_call"] > 0 and xa["bus_GBps"] > 0
 
 
 def test_gpus_flag_alone_spawns_the_ranks():
