@@ -690,10 +690,10 @@ class DistillTrainer(_TrainerBase):
         torch.cuda.synchronize()
         # Two-part AdamW (FlatAdamW.two_part, PVD_ADAMW_SPLIT=late, the default; =0: one launch): the update behind the table scatter
         # covers only what the backward can have written (touched rows, the heads); the L1-only / still-decaying rows -- half of the
-        # update's bytes, read by nothing but their own update -- are updated ONE STEP LATER at the END of the next step's branch,
-        # next to the head backward and the table scatter, which wait on the matrix cores and on the memory side's atomic units, not
-        # on HBM: 0.280 vs 0.296 ms/step (profiles/r04_adamw_late_ab.txt; at the START of the branch it measured slower than one
-        # launch, profiles/r03_adamw_split_ab.txt).  Bit-identical parameters and moments (tests/test_hip_graph.py).  The objective
+        # update's bytes, read by nothing but their own update -- are updated ONE STEP LATER on the next step's branch (between its
+        # march and its teacher forward since round 6; at the end of the branch before), next to the head backward and the table
+        # scatter, which wait on the matrix cores and on the memory side's atomic units, not on HBM: 0.280 vs 0.296 ms/step
+        # (profiles/r04_adamw_late_ab.txt; at the START of the branch it measured slower than one launch, profiles/r03_adamw_split_ab.txt).  Bit-identical parameters and moments (tests/test_hip_graph.py).  The objective
         # does not wait for it: the L1 VALUE it reports counts those rows one step late.  Under ray-DP with the collectives in the
         # graph the deferred rows are the ones no sample reaches -- not part of the exchange, updated from the step's scalars,
         # which are the same on every rank -- and the deferred part then runs under the exchange.
@@ -741,13 +741,18 @@ class DistillTrainer(_TrainerBase):
                                 packed = torch.cuda.Event()
                                 packed.record(branch)
                                 self.model_stu._before_head = lambda packed=packed: main.wait_event(packed)
-                            pre_next = self.prefetch(batch_fn)
-                            if k + 1 == K:  # for the next replay
-                                carried.store(pre_next)
+                            marched = self.prefetch_march(batch_fn)
                             if late:
+                                # BETWEEN the march and the teacher's forward: the deferred part (HBM streaming) then runs next to the
+                                # student's head backward and the teacher's lookup next to the table scatter, instead of the lookup on
+                                # the head backward (46 -> 42 us) and the deferred part on the scatter: 0.2683 -> 0.2650 ms/step; at the
+                                # START of the branch 0.286 (profiles/r06_part_a_position_ab.txt).  No dependency edge either way.
                                 self.optimizer.run_part_a()  # what the previous step's update still owes
                                 if k == 0:
                                     self.optimizer.run_carried_part_a(scaled)  # ... and the previous replay's last step
+                            pre_next = self.prefetch_teacher(marched)
+                            if k + 1 == K:  # for the next replay
+                                carried.store(pre_next)
                         self._zero_grads(first_in_recording=k == 0)
                         with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                             self._static_out = self.compute_loss(None, None, None, pre=pre)
