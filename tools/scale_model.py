@@ -14,14 +14,14 @@ single-box quantities and ASSUMED link rates -- nothing here is a measurement of
   efficiency   step_1 / (step_form(N) + wire)          -- the exchange is NOT overlapped with anything (it sits between the table
                scatter and the update: both ends are on the step's critical chain)
 
-  python tools/scale_model.py [--step1 0.2727] [--step-ar 0.2788] [--step-sh 0.2877] [--part-b-us 31.8] [--mb 13.3]"""
+  python tools/scale_model.py [--step1 0.2643] [--step-ar 0.2726] [--step-sh 0.2808] [--part-b-us 31.8] [--mb 13.3]"""
 import argparse
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--step1", type=float, default=0.2727)
-ap.add_argument("--step-ar", type=float, default=0.2788)
-ap.add_argument("--step-sh", type=float, default=0.2877)
-ap.add_argument("--step-classic", type=float, default=0.3143, help="rounds 1-5's sequence on the same box, for the table's first row")
+ap.add_argument("--step1", type=float, default=0.2643)
+ap.add_argument("--step-ar", type=float, default=0.2726)
+ap.add_argument("--step-sh", type=float, default=0.2808)
+ap.add_argument("--step-classic", type=float, default=0.3086, help="rounds 1-5's sequence on the same box, for the table's first row")
 ap.add_argument("--part-b-us", type=float, default=31.8, help="AdamW part B over all touched rows (profiles/r06_dp_one_rank_timeline.txt)")
 ap.add_argument("--mb", type=float, default=13.3)
 ap.add_argument("--hop-us", type=float, default=4.0)
