@@ -120,3 +120,20 @@ def test_gpus_flag_alone_spawns_the_ranks():
     assert len(lines) == 1, out[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "ray-dp2" and d["scaling"] == "weak" and d["value"] > 0
+
+
+@pytest.mark.parametrize("name,extra", [
+    ("configs[3] mlp->tensors, llff cameras", ["--teacher", "mlp", "--student", "tensors", "--data-type", "llff", "--teacher-pretrain", "0"]),
+    ("configs[4] hash->hash, bound 2, tank cameras", ["--student", "hash", "--data-type", "tank", "--bound", "2", "--dt-gamma", "0.00390625", "--scene-scale", "1.9"]),
+])
+def test_the_eight_gpu_configurations_in_their_two_rank_form(name, extra):
+    """BASELINE configs[3] and configs[4] are quoted on 8 GPUs with ray-DP: their N > 1 recording (exchange of the Plenoxel volume's /
+    the hash table's gradient -- the latter arrives in half precision and is widened for the exchange --, loss sums, MAX over ranks,
+    one line) on two ranks sharing the GPU over gloo, as the driver launches them."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", *COMMON, *extra]
+    d = _line(cmd, env={"PVD_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "ray-dp2" and d["scaling"] == "weak", name
+    assert d["value"] > 0 and math.isfinite(d["config"]["loss"]) and d["config"]["capture_fallback"] is False, name
+    assert "error" not in d["config"]["exchange_alone"] and d["config"]["exchange_alone"]["bytes"] > 0, name
+    assert abs(d["value"] - 10 * 2048 / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]

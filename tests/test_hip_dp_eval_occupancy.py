@@ -135,3 +135,54 @@ def test_sharded_evaluation_has_the_bits_of_the_one_rank_render_and_replicas_agr
         assert torch.isfinite(img).all()
     # the trained teacher shows the chair: not a blank picture
     assert float((got["tea"][0] - 1.0).abs().max()) > 0.2 and float(torch.nan_to_num(got["tea"][1], nan=0.0).max()) > 0.1
+
+
+def _hash_student_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _paths()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    import pvd_hip
+    from pvd.config import PVDConfig
+    from pvd.ops import hip_ops
+    from pvd.trainer import RayDP
+    from pvd.workload import DistillWorkload
+    dp = RayDP()
+    w = DistillWorkload(hip_ops(), dev, PVDConfig(num_rays=1024, iters=300, model_type="hash"), teacher_pretrain_steps=20, seed=0, dp=dp)
+    for m in (w.tea, w.stu):
+        for t in list(m.parameters()) + list(m.buffers()):
+            dp.broadcast_(t.data, src=0)
+        pvd_hip.note_weights_changed(list(m.parameters()))
+    p0 = torch.cat([p.detach().reshape(-1).float() for p in w.stu.parameters()]).clone()
+    losses = []
+    for _ in range(4):  # eager steps: every rank its own rays, the table's gradient leaves the backward in half precision
+        loss, info, _, _ = w.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    tr = w.trainer
+    if getattr(tr, "flat_opt", False):
+        tr.optimizer.flush()
+    params = torch.cat([p.detach().reshape(-1).float() for p in w.stu.parameters()]).cpu()
+    both = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(both, params)
+    assert all(torch.equal(both[0], t) for t in both), "replicas of the hash student differ after four ray-DP steps"
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    moved = (params - p0.cpu()).abs()
+    table = w.stu.encoder.embeddings.detach().float().cpu().reshape(-1)
+    assert float(moved.max()) > 0 and float((table - p0.cpu()[:table.numel()]).abs().max()) >= 0  # (the step did update something)
+    if rank == 0:
+        torch.save({"losses": losses, "moved": float(moved.max()), "moved_rows": int((moved > 0).sum())}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1800)
+def test_hash_student_replicas_stay_identical_under_ray_dp(tmp_path):
+    """BASELINE configs[4] (hash -> hash on 8 GPUs): the hash table's gradient leaves the scatter in HALF precision and, under ray-DP, is
+    widened into the fp32 bucket so that the exchange sees it (pvd/trainer.py).  Two ranks with different rays: after four steps
+    the replicas' parameters are the same bits -- i.e. every rank applied the SUMMED gradient, the table's included."""
+    out = str(tmp_path / "hash_dp.pt")
+    mp.spawn(_hash_student_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["moved"] > 0 and got["moved_rows"] > 1000, got
