@@ -48,7 +48,7 @@ OPT = dict(num_rays=256, resolution0=24, iters=50, fp16=False, model_type="vm",
            loss_rate_fea_sc=0.0, loss_rate_color=0.0, loss_rate_sigma=0.0)  # rgb norm + L1 reg: independent of row padding
 
 
-def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False, skew_rank=None):
+def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False, skew_rank=None, stu_scale=None):
     OPT = opt_kw or globals()["OPT"]
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -71,6 +71,10 @@ def _worker(rank, world, port, out_path, opt_kw=None, expect_compact=False, skew
 
     # --- the real trainer: every rank renders its half of the rays
     w = _make(OPT, dp=dp)
+    if stu_scale is not None:  # (a hash student takes over EVERY tensor of a hash teacher: make it a different model)
+        with torch.no_grad():
+            for p in w.stu.parameters():
+                p.mul_(stu_scale)
     if skew_rank is not None and rank == skew_rank:
         # a replica whose occupancy grid differs (must never happen; if it does the ranks must notice instead of hanging in
         # a collective with different buffer sizes): one more occupied byte -> a different footprint mask on this rank only
@@ -455,3 +459,44 @@ def test_teacher_step_on_two_ranks_agrees_on_the_occupancy_grid_and_equals_one_p
     scale = flat.abs().max().item()
     assert scale > 0
     assert (flat - got["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - got["flat"]).abs().max().item(), scale)
+
+
+OPT_HASH = dict(num_rays=256, iters=50, fp16=False, model_type="hash", loss_rate_fea_sc=0.0, loss_rate_color=0.0, loss_rate_sigma=0.0, l1_reg_weight=0.0)
+
+
+@pytest.mark.timeout(900)
+def test_ray_dp_hash_student_two_ranks_equals_single_process(tmp_path):
+    """BASELINE configs[4]'s student (hash table + sigma / colour MLPs) under ray-DP: two ranks on their halves of the rays against one
+    process on both shards -- the global rgb norm, and the gradient of EVERY parameter (the table's scatter-add result included)."""
+    _setup_paths()
+    out = str(tmp_path / "dph.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, OPT_HASH, False, None, 1.5), nprocs=2, join=True)
+    dp_res = torch.load(out)
+    w = _make(OPT_HASH)
+    with torch.no_grad():
+        for p in w.stu.parameters():
+            p.mul_(1.5)
+    base = _make(OPT_HASH)
+    rays_o, rays_d, bg = base.next_batch()
+    tr, stu, tea = w.trainer, w.stu, w.tea
+    tr.opt.global_step = tr.global_step
+    tr.flat.zero_()
+    diffs = []
+    half = OPT_HASH["num_rays"] // 2
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        o, d, b = rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous()
+        out_s = stu.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024)
+        with torch.no_grad():
+            out_t = tea.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False,
+                               inherited_params=out_s["inherited_params"], dt_gamma=0, max_steps=1024)
+        diffs.append(out_t["image"] - out_s["image"])
+    l_rgb = torch.norm(torch.cat(diffs, dim=1))
+    (l_rgb * tr.opt.loss_rate_rgb).backward()
+    assert abs(float(l_rgb.detach()) - dp_res["rgb"]) <= 1e-5 * abs(dp_res["rgb"]), (float(l_rgb), dp_res["rgb"])
+    flat = tr.flat.flat
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
+    n_table = stu.encoder.embeddings.numel()
+    assert n_table > 0 and float(dp_res["flat"].abs().max()) > 0
