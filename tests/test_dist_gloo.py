@@ -500,3 +500,40 @@ def test_ray_dp_hash_student_two_ranks_equals_single_process(tmp_path):
     assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
     n_table = stu.encoder.embeddings.numel()
     assert n_table > 0 and float(dp_res["flat"].abs().max()) > 0
+
+
+OPT_TENSORS = dict(num_rays=256, iters=50, fp16=False, model_type="tensors", plenoxel_res="[32,32,32]", loss_rate_fea_sc=0.0, loss_rate_color=0.0,
+                   loss_rate_sigma=0.0, l1_reg_weight=0.0)
+
+
+@pytest.mark.timeout(900)
+def test_ray_dp_plenoxel_student_two_ranks_equals_single_process(tmp_path):
+    """BASELINE configs[3]'s student (the Plenoxel volume) under ray-DP with the compact exchange (only voxels under occupied cells cross
+    the links): two ranks on their halves of the rays against one process on both shards."""
+    _setup_paths()
+    out = str(tmp_path / "dpt.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, OPT_TENSORS, True), nprocs=2, join=True)
+    dp_res = torch.load(out)
+    w = _make(OPT_TENSORS)
+    base = _make(OPT_TENSORS)
+    rays_o, rays_d, bg = base.next_batch()
+    tr, stu, tea = w.trainer, w.stu, w.tea
+    tr.opt.global_step = tr.global_step
+    tr.flat.zero_()
+    diffs = []
+    half = OPT_TENSORS["num_rays"] // 2
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        o, d, b = rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), bg[:, sl].contiguous()
+        out_s = stu.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024)
+        with torch.no_grad():
+            out_t = tea.render(o, d, staged=False, bg_color=b, perturb=True, force_all_rays=False,
+                               inherited_params=out_s["inherited_params"], dt_gamma=0, max_steps=1024)
+        diffs.append(out_t["image"] - out_s["image"])
+    l_rgb = torch.norm(torch.cat(diffs, dim=1))
+    (l_rgb * tr.opt.loss_rate_rgb).backward()
+    assert abs(float(l_rgb.detach()) - dp_res["rgb"]) <= 1e-5 * abs(dp_res["rgb"]), (float(l_rgb), dp_res["rgb"])
+    flat = tr.flat.flat
+    scale = flat.abs().max().item()
+    assert scale > 0
+    assert (flat - dp_res["flat"]).abs().max().item() <= 2e-5 * scale, ((flat - dp_res["flat"]).abs().max().item(), scale)
