@@ -12,6 +12,8 @@ PRODUCTION = {
     "PVD_DP_EXCHANGE": ("allreduce", "ray-DP gradient exchange: allreduce (gather that zeroes / checks -> all-reduce -> the update reads the buffer) | "
                                      "sharded (reduce_scatter -> AdamW on the rank's rows -> all_gather) | classic (rounds 1-5's sequence, incl. the objective's "
                                      "four separate launches): pvd/trainer.py, pvd/ray_dp.py"),
+    "PVD_DP_HASH_WIRE": ("f16", "f16 | f32: a hash student's table gradient under ray-DP crosses the links as the half-precision table the scatter wrote "
+                                "(the reference's arithmetic for this gradient; 21 MB) or widened into the fp32 bucket first (42 MB; rounds 1-5)"),
     "PVD_DP_WIRE": ("f32", "f32 | f16 | bf16: width of the gradient on the wire (classic form only; measured -0.3 dB PSNR: opt-in)"),
     "PVD_STEPS_PER_GRAPH": ("", "bench.py: steps recorded per hipGraph launch (default: the largest of 20/10/5/4/2 dividing --steps)"),
     "PVD_HW_QUEUES": ("", "keep = do not set GPU_MAX_HW_QUEUES=2 at import (an integrator who owns that variable); the forked schedule is then refused "

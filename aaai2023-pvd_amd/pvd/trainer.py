@@ -75,9 +75,12 @@ class _TrainerBase:
             model._inf_check_in_backward = (self.optimizer.inf_flag(), self.optimizer.note_checked_by_backward)
         else:
             model.__dict__.pop("_inf_check_in_backward", None)  # (an earlier trainer's: its flag is not this one's)
-        if self.flat_opt and not self.dp.enabled and model.model_type == "hash":
-            # the hash table's f16 scatter-add result goes straight into the update kernel (under ray-DP it is widened into
-            # the fp32 buffer first, so that the exchange sees it)
+        if self.flat_opt and model.model_type == "hash" and (not self.dp.enabled or os.environ.get("PVD_DP_HASH_WIRE", "f16") == "f16"):
+            # the hash table's f16 scatter-add result goes straight into the update kernel.  Under ray-DP it crosses the links AS IT IS
+            # (_exchange: the half table summed in half precision, the heads' fp32 gradients next to it): 21 instead of 42 MB per
+            # step, and the arithmetic the reference has for this gradient -- ONE half-precision table that every sample of the batch
+            # adds into (gridencoder.cu:297-304, grid.py:105-123).  PVD_DP_HASH_WIRE=f32: widened into the fp32 bucket first
+            # (rounds 1-5).
             model.encoder.embeddings._pvd_half_grad_taker = self.optimizer.accept_half_grad
         if self.flat_opt:
             self.flat = _FlatOptGrads(self.optimizer)
@@ -251,7 +254,19 @@ class _TrainerBase:
             # overflow on the wire is an inf in the gradient, which the scaler's check (it runs after the exchange) answers by
             # skipping the step and halving the scale, as for any other overflow; bf16 keeps fp32's range at 8 bits of mantissa.
             wire = {"f16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("PVD_DP_WIRE", "f32"))
-            if c is None:
+            hg = getattr(self.optimizer, "_half_grad", None) if self.flat_opt else None
+            if c is None and hg is not None and not self.optimizer._half_range_dirty and wire is None:
+                # a hash model: the table's gradient is the half-precision buffer the update will read; its fp32 range holds zero_grad's
+                # zeros and stays at home.  Two collectives: the half table (SUM in half precision: an overflow is an inf the scaler's
+                # check -- it follows the exchange -- answers like any other), and the rest of the fp32 bucket (the heads).
+                lo, hi, g16 = hg
+                self.dp.all_reduce_sum_(g16, overlap=ov)
+                flat = self.flat.flat
+                if lo > 0:
+                    self.dp.all_reduce_sum_(flat[:lo])
+                if hi < flat.numel():
+                    self.dp.all_reduce_sum_(flat[hi:])
+            elif c is None:
                 if wire is None:
                     self.dp.all_reduce_sum_(self.flat.flat, overlap=ov)  # one bucket, SUM (losses are already global objectives)
                 else:

@@ -926,8 +926,15 @@ def main():
             if lay is not None:  # round 6: the gather zeroes / checks, the buffer carries the inf flag, part B of the update reads it directly
                 form = ("reduce_scatter -> AdamW on the rank's rows -> all_gather (sharded update)" if lay[1].pbuf is not None else
                         "all-reduce feeding the update directly (no scatter / check launches)")
+            emb = getattr(getattr(w.stu, "encoder", None), "embeddings", None)
+            half_table = (not compact and lay is None and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None
+                          and os.environ.get("PVD_DP_WIRE", "f32") == "f32")
+            if half_table:  # a hash student: the table's gradient crosses as the half-precision table the scatter wrote, the heads' in fp32
+                moved, what = emb.numel() * 2 / 1e6 + (total - emb.numel() * 4 / 1e6), "the hash table's gradient in half precision as the scatter wrote it + the heads' fp32 gradients, instead"
+            else:
+                moved, what = (c.idx.numel() * 4 / 1e6 if compact else total), ("touched rows only" if compact else "dense")
             out["config"]["exchange"] = "%s of %.1f MB (%s of %.1f MB of fp32 gradients)%s + 16 B of loss sums%s" % (
-                form, c.idx.numel() * 4 / 1e6 if compact else total, "touched rows only" if compact else "dense", total,
+                form, moved, what, total,
                 ", next step's prefix replayed underneath" if getattr(tr, "_g_prefix", None) is not None else "",
                 " between the two compositing launches (objective riding on them)" if getattr(tr, "dp_objective_rides", False) else "")
             out["config"]["exchange"] += ("; collectives recorded into the step's HIP graph (1 graph launch per step)" if dp.ingraph else
@@ -941,7 +948,13 @@ def main():
                 c = getattr(w.trainer, "_compactor", None)
                 compact = c is not None and getattr(c, "agreed", True) and c.fraction < 0.7
                 n_el = int(c.idx.numel()) if compact else int(w.trainer.flat.flat.numel())
+                emb = getattr(getattr(w.stu, "encoder", None), "embeddings", None)
+                half_table = (not compact and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None
+                              and os.environ.get("PVD_DP_WIRE", "f32") == "f32" and getattr(w.trainer, "_xlayouts", None) is None)
                 scratch = torch.zeros(n_el, dtype=torch.float32, device=dev)
+                if half_table:  # (the hash table's half-precision gradient: the bulk of a hash student's exchange)
+                    n_el = int(emb.numel())
+                    scratch = torch.zeros(n_el, dtype=torch.float16, device=dev)
                 reps = 20
                 for _ in range(3):
                     dp.all_reduce_sum_(scratch)
@@ -955,8 +968,8 @@ def main():
                 dist.all_reduce(us, op=dist.ReduceOp.MAX)
                 out["config"]["exchange_alone"] = {
                     "collective": "sharded pair (reduce_scatter + all_gather)" if os.environ.get("PVD_DP_EXCHANGE", "allreduce") == "sharded" else "all_reduce",
-                    "backend": backend, "bytes": n_el * 4, "us_per_call": float(us[0]),
-                    "bus_GBps": 2.0 * (world - 1) / world * n_el * 4 / (float(us[0]) * 1e-6) / 1e9}
+                    "backend": backend, "bytes": n_el * scratch.element_size(), "us_per_call": float(us[0]),
+                    "bus_GBps": 2.0 * (world - 1) / world * n_el * scratch.element_size() / (float(us[0]) * 1e-6) / 1e9}
         except Exception as e:  # noqa: BLE001
             out["config"]["exchange_alone"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -175,6 +175,28 @@ def _hash_student_worker(rank, world, port, out_path):
     moved = (params - p0.cpu()).abs()
     table = w.stu.encoder.embeddings.detach().float().cpu().reshape(-1)
     assert float(moved.max()) > 0 and float((table - p0.cpu()[:table.numel()]).abs().max()) >= 0  # (the step did update something)
+    # ---- the exchange itself, deterministically: a synthetic half-precision table gradient per rank (no atomics), the heads' fp32 gradients = rank + 1
+    emb = w.stu.encoder.embeddings
+    o = tr.optimizer
+    tr._zero_grads()
+    tables = [(torch.randn(emb.shape, generator=torch.Generator(device=dev).manual_seed(100 + r), device=dev) * 0.01).half() for r in range(world)]
+    mine = tables[rank].clone()
+    assert o.accept_half_grad(emb, mine), "the hash table's gradient is taken in half precision under ray-DP too (PVD_DP_HASH_WIRE=f16)"
+    lo, hi, _ = o._half_grad
+    assert hi - lo == emb.numel()
+    o.flat_g[:lo] = float(rank + 1)
+    o.flat_g[hi:] = float(rank + 1)
+    tr._exchange()
+    torch.cuda.synchronize()
+    want = tables[0].clone()
+    for r in range(1, world):
+        want += tables[r]  # half + half, rounded once: what a half-precision all-reduce of two ranks leaves
+    assert torch.equal(mine, want), "the half table was not summed in half precision over the ranks"
+    assert float(o.flat_g[lo:hi].abs().max()) == 0.0, "the table's fp32 range stays zero_grad's zeros (nothing is widened into it)"
+    heads = torch.cat([o.flat_g[:lo], o.flat_g[hi:]])
+    assert heads.numel() > 0 and bool((heads == float(sum(range(1, world + 1)))).all()), "the heads' fp32 gradients are summed next to it"
+    o._half_grad = None
+    tr._zero_grads()
     if rank == 0:
         torch.save({"losses": losses, "moved": float(moved.max()), "moved_rows": int((moved > 0).sum())}, out_path)
     dist.barrier()
@@ -183,9 +205,11 @@ def _hash_student_worker(rank, world, port, out_path):
 
 @pytest.mark.timeout(1800)
 def test_hash_student_replicas_stay_identical_under_ray_dp(tmp_path):
-    """BASELINE configs[4] (hash -> hash on 8 GPUs): the hash table's gradient leaves the scatter in HALF precision and, under ray-DP, is
-    widened into the fp32 bucket so that the exchange sees it (pvd/trainer.py).  Two ranks with different rays: after four steps
-    the replicas' parameters are the same bits -- i.e. every rank applied the SUMMED gradient, the table's included."""
+    """BASELINE configs[4] (hash -> hash on 8 GPUs): the hash table's gradient leaves the scatter in HALF precision and crosses the
+    links as it is (21 instead of 42 MB; the reference's arithmetic for this gradient is ONE half table every sample adds into), the
+    heads' fp32 gradients next to it (pvd/trainer.py: _exchange).  Two ranks with different rays: after four steps the replicas'
+    parameters are the same bits -- every rank applied the SUMMED gradient, the table's included; then the exchange alone on
+    synthetic gradients: the half tables' sum in half precision, the fp32 table range untouched, the heads summed."""
     out = str(tmp_path / "hash_dp.pt")
     mp.spawn(_hash_student_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
