@@ -255,17 +255,22 @@ class _TrainerBase:
             # skipping the step and halving the scale, as for any other overflow; bf16 keeps fp32's range at 8 bits of mantissa.
             wire = {"f16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("PVD_DP_WIRE", "f32"))
             hg = getattr(self.optimizer, "_half_grad", None) if self.flat_opt else None
-            if c is None and hg is not None and not self.optimizer._half_range_dirty and wire is None:
+            if c is None and hg is not None:
                 # a hash model: the table's gradient is the half-precision buffer the update will read; its fp32 range holds zero_grad's
                 # zeros and stays at home.  Two collectives: the half table (SUM in half precision: an overflow is an inf the scaler's
-                # check -- it follows the exchange -- answers like any other), and the rest of the fp32 bucket (the heads).
+                # check -- it follows the exchange -- answers like any other), and the rest of the fp32 bucket (the heads: a few KB,
+                # always fp32 -- PVD_DP_WIRE has nothing to narrow here).  After a second backward before the step the fp32 range
+                # carries that backward's gradient (FlatAdamW.accept_half_grad refused it): then the whole bucket crosses as well.
                 lo, hi, g16 = hg
                 self.dp.all_reduce_sum_(g16, overlap=ov)
                 flat = self.flat.flat
-                if lo > 0:
-                    self.dp.all_reduce_sum_(flat[:lo])
-                if hi < flat.numel():
-                    self.dp.all_reduce_sum_(flat[hi:])
+                if self.optimizer._half_range_dirty:
+                    self.dp.all_reduce_sum_(flat)
+                else:
+                    if lo > 0:
+                        self.dp.all_reduce_sum_(flat[:lo])
+                    if hi < flat.numel():
+                        self.dp.all_reduce_sum_(flat[hi:])
             elif c is None:
                 if wire is None:
                     self.dp.all_reduce_sum_(self.flat.flat, overlap=ov)  # one bucket, SUM (losses are already global objectives)

@@ -927,8 +927,7 @@ def main():
                 form = ("reduce_scatter -> AdamW on the rank's rows -> all_gather (sharded update)" if lay[1].pbuf is not None else
                         "all-reduce feeding the update directly (no scatter / check launches)")
             emb = getattr(getattr(w.stu, "encoder", None), "embeddings", None)
-            half_table = (not compact and lay is None and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None
-                          and os.environ.get("PVD_DP_WIRE", "f32") == "f32")
+            half_table = not compact and lay is None and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None
             if half_table:  # a hash student: the table's gradient crosses as the half-precision table the scatter wrote, the heads' in fp32
                 moved, what = emb.numel() * 2 / 1e6 + (total - emb.numel() * 4 / 1e6), "the hash table's gradient in half precision as the scatter wrote it + the heads' fp32 gradients, instead"
             else:
@@ -949,8 +948,7 @@ def main():
                 compact = c is not None and getattr(c, "agreed", True) and c.fraction < 0.7
                 n_el = int(c.idx.numel()) if compact else int(w.trainer.flat.flat.numel())
                 emb = getattr(getattr(w.stu, "encoder", None), "embeddings", None)
-                half_table = (not compact and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None
-                              and os.environ.get("PVD_DP_WIRE", "f32") == "f32" and getattr(w.trainer, "_xlayouts", None) is None)
+                half_table = not compact and emb is not None and getattr(emb, "_pvd_half_grad_taker", None) is not None and getattr(w.trainer, "_xlayouts", None) is None
                 scratch = torch.zeros(n_el, dtype=torch.float32, device=dev)
                 if half_table:  # (the hash table's half-precision gradient: the bulk of a hash student's exchange)
                     n_el = int(emb.numel())
